@@ -1,0 +1,123 @@
+/*
+ * msq.h -- C ABI of libmsq_hip.so, the MI355X (gfx950) native back end of the
+ * MicroScopiQ outlier-aware microscaling quant/dequant + mixed-precision Linear
+ * hot path.
+ *
+ * Drop-in boundary.  The reference routes its native work through the pybind
+ * module `custom_extensions.funcs` (number_system/mx/custom_extensions.py:19,
+ * number_system/mx/cpp/funcs.cpp:218-226) when `custom_cuda=True`
+ * (elemwise_ops.py:117-129, mx_ops.py:363-422).  Each entry point below names
+ * the reference interface it replaces.  Entry points marked NEW have no
+ * reference counterpart (the reference is fake-quant only) and
+ * are specified by the fake-quant maths of utils/quant.py:147-266.
+ *
+ * Conventions (reference: cpp/funcs.h:11-13, cpp/mx.cu:25-26, common.cuh:211-219)
+ *   - plain pointers + sizes, no torch types; all buffers are DEVICE memory,
+ *     contiguous, owned and allocated by the caller; the library never
+ *     allocates, frees or synchronises (graph-capture safe);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns an int status: MSQ_OK or a negative MSQ_ERR_*;
+ *     the reference's AT_ASSERTM / exit() paths become error codes, never exit;
+ *     msq_last_error() returns a thread-local message for the last failure;
+ *   - stateless and re-entrant; rounding-mode ints are the reference's
+ *     RoundingMode {nearest=0 (half away), floor=1, even=2} (formats.py:15-18);
+ *   - tensors are described as [pre, axis_len, post] with the quantisation
+ *     blocks running along the middle axis (a 2-D weight [O,I] with the
+ *     reference harness' axes=[0] is pre=1, axis_len=O, post=I; axes=[-1] is
+ *     pre=O, axis_len=I, post=1).
+ */
+#ifndef MSQ_H
+#define MSQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSQ_OK 0
+#define MSQ_ERR_BAD_ARG (-1)
+#define MSQ_ERR_UNSUPPORTED (-2)
+#define MSQ_ERR_LAUNCH (-3)
+
+/* rounding modes: formats.py:15-18 == cpp/common.cuh:130-134 */
+#define MSQ_RD_NEAREST 0
+#define MSQ_RD_FLOOR 1
+#define MSQ_RD_EVEN 2
+
+/* element formats: ids 1..10 are the reference's ElemFormat values (formats.py:25-38);
+ * posit ids are an extension: MSQ_FMT_POSIT(n, es). */
+#define MSQ_FMT_INT8 1
+#define MSQ_FMT_INT4 2
+#define MSQ_FMT_INT2 3
+#define MSQ_FMT_FP8_E5M2 4
+#define MSQ_FMT_FP8_E4M3 5
+#define MSQ_FMT_FP6_E3M2 6
+#define MSQ_FMT_FP6_E2M3 7
+#define MSQ_FMT_FP4_E2M1 8
+#define MSQ_FMT_FP16 9
+#define MSQ_FMT_BF16 10
+#define MSQ_FMT_POSIT(n, es) (0x100 | ((n) << 2) | (es))
+
+/* outlier quantiser variants */
+#define MSQ_VARIANT_QUANT 0 /* utils/quant.py:147-266 (canonical) */
+#define MSQ_VARIANT_MXOPS 1 /* number_system/mx/mx_ops.py:210-330 (used by MXLinear) */
+
+/* status bits written to *status_flag by the outlier kernels */
+#define MSQ_STATUS_NAN 1 /* one of the reference's NaN asserts (utils/quant.py:225-250) would fire */
+
+int msq_version(void);
+const char* msq_last_error(void);
+
+/* formats.py:65-129 _get_format_params (host, no GPU needed).  kind: 0 float/int, 1 posit. */
+int msq_format_id(const char* name);
+int msq_format_params(int fmt, int* ebits, int* mbits, int* emax, float* max_norm, float* min_norm,
+                      int* kind);
+
+/* replaces quantize_elemwise_func_cuda (cpp/funcs.cpp:183-200, cpp/elemwise.cu:12-75).
+ * dtype: 0 = f32, 1 = f16, 2 = bf16 (the reference supports f32 and f16). */
+int msq_quantize_elemwise(const void* in, void* out, int64_t n, int dtype, int bits, int exp_bits,
+                          float max_norm, int rmode, int saturate_normals, int allow_denorm,
+                          void* stream);
+
+/* replaces quantize_mx_func_cuda (cpp/funcs.cpp:138-159, cpp/mx.cu:13-72):
+ * max_values is [pre, post] = max |.| over the whole axis (the caller has already
+ * reshaped to blocks, mx_ops.py:397-415). */
+int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_t pre,
+                    int64_t axis_len, int64_t post, int scale_bits, int elem_ebits, int elem_mbits,
+                    float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
+
+/* replaces quantize_mx_by_tile_func_cuda (cpp/funcs.cpp:161-181, cpp/mx.cu:76-170):
+ * tiles of tile_size along the axis, ragged last tile NOT padded, shared scale from
+ * the max biased exponent computed in-kernel (single pass). */
+int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                            int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                            float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
+
+/* replace reduce_sum_inner_dim / reduce_max_inner_dim (cpp/funcs.cpp:203-215, cpp/reduce.cu:19-93):
+ * out[outer] = sum / max over the innermost `inner` elements. */
+int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream);
+int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream);
+
+/* NEW -- the MicroScopiQ fake-quant (utils/quant.py:147-266 quantize_mx_outlier_v1 and
+ * :23-146 quantize_mx_outlier_hessian; variant 1 = mx_ops.py:210-330) fused into one
+ * read + one write.  Optional outputs (NULL to skip):
+ *   mask  uint8 [pre,axis_len,post]  (utils/quant.py:460-495 _extract_outlier_indices)
+ *   e_in / e_out  float [pre,nblk,post] clamped shared exponents (NaN kept)
+ *   num_outliers  int8 [ceil(nblk/block)*post] (utils/quant.py:66; needs pre == 1)
+ *   status_flag   int (device): MSQ_STATUS_* bits OR-ed in
+ *   workspace     device scratch of msq_outlier_workspace_bytes() bytes (variant 1 only, else NULL)
+ * in/out dtype: 0 = f32 (bit-exact vs the reference), 1 = f16, 2 = bf16 (computed in f32). */
+int64_t msq_outlier_workspace_bytes(int64_t pre, int64_t axis_len, int64_t post, int block, int variant);
+int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in, float* e_out,
+                          int8_t* num_outliers, int* status_flag, void* workspace,
+                          int64_t workspace_bytes, int dtype, int64_t pre,
+                          int64_t axis_len, int64_t post, int block, int inlier_fmt,
+                          int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits,
+                          float std_dev, int rmode, int flush_fp32_subnorms, int variant,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

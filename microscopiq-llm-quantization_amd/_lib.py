@@ -1,0 +1,88 @@
+"""ctypes binding of libmsq_hip.so (include/msq.h).
+
+The HIP library is the product path: if it is missing or a call fails this module
+raises -- there is no CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmsq_hip.so")
+_lib = None
+
+MSQ_OK = 0
+DTYPE_ID = {"torch.float32": 0, "torch.float16": 1, "torch.bfloat16": 2}
+
+_i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+_SIGS = {
+    "msq_version": (C.c_int, []),
+    "msq_last_error": (C.c_char_p, []),
+    "msq_format_id": (C.c_int, [C.c_char_p]),
+    "msq_format_params": (C.c_int, [_i32] + [C.POINTER(_i32)] * 3 + [C.POINTER(_f32)] * 2 + [C.POINTER(_i32)]),
+    "msq_quantize_elemwise": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "msq_quantize_mx": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "msq_quantize_mx_by_tile": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "msq_reduce_sum_inner": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "msq_reduce_max_inner": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "msq_outlier_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
+    "msq_outlier_fakequant": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64,
+                                        _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+}
+
+
+class MsqError(RuntimeError):
+    pass
+
+
+def so_path():
+    return _SO
+
+
+def lib():
+    """Load libmsq_hip.so; raise loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise MsqError(
+                f"{_SO} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
+                f"{os.path.join(_HERE, 'csrc')}). There is no CPU fallback.")
+        L = C.CDLL(_SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)        # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != MSQ_OK:
+        msg = lib().msq_last_error()
+        raise MsqError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def format_id(name):
+    fid = lib().msq_format_id(str(name).lower().encode())
+    if fid < 0:
+        raise Exception("Undefined elem format", name)      # formats.py:47
+    return fid
+
+
+def format_params(fmt_id):
+    e, m, ex, kind = _i32(), _i32(), _i32(), _i32()
+    mx, mn = _f32(), _f32()
+    check(lib().msq_format_params(fmt_id, C.byref(e), C.byref(m), C.byref(ex), C.byref(mx), C.byref(mn),
+                                  C.byref(kind)), "msq_format_params")
+    return e.value, m.value, ex.value, mx.value, mn.value, kind.value
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,669 @@
+// msq_quant.hip -- gfx950 kernels for the quant/dequant half of the hot path and
+// their C-ABI entry points (include/msq.h).  HBM-bound byte/bit work: one read and
+// one write per element, wave64-coalesced, block statistics kept in registers.
+//
+// Compiled with -ffp-contract=off: the fp32 results must match the reference's
+// CPU arithmetic bit for bit (see msq_device.h).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+#include "msq_host.h"
+
+using namespace msq;
+
+// ===========================================================================
+// dtype helpers
+// ===========================================================================
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static MSQ_D float ld(const float* p, int64_t i) { return p[i]; }
+    static MSQ_D void st(float* p, int64_t i, float v) { p[i] = v; }
+};
+template <> struct IO<__half> {
+    static MSQ_D float ld(const __half* p, int64_t i) { return __half2float(p[i]); }
+    static MSQ_D void st(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
+};
+template <> struct IO<__hip_bfloat16> {
+    static MSQ_D float ld(const __hip_bfloat16* p, int64_t i) { return __bfloat162float(p[i]); }
+    static MSQ_D void st(__hip_bfloat16* p, int64_t i, float v) { p[i] = __float2bfloat16(v); }
+};
+
+// ===========================================================================
+// elementwise quantise (replaces cpp/elemwise.cuh:17-38).  Grid-stride, 4 elements
+// per lane per step for f32 (16-byte accesses), HBM-bound.
+// ===========================================================================
+__global__ void __launch_bounds__(256)
+k_elemwise_f32(const float* __restrict__ in, float* __restrict__ out, int64_t n, int bits, int ebits,
+               float max_norm, int rmode, int saturate, int allow_denorm) {
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x = quant_bits(v.x, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+        v.y = quant_bits(v.y, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+        v.z = quant_bits(v.z, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+        v.w = quant_bits(v.w, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    const int64_t tail = nvec << 2;
+    const int64_t t = tail + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = quant_bits(in[t], bits, ebits, max_norm, rmode, saturate, allow_denorm);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_elemwise_16(const T* __restrict__ in, T* __restrict__ out, int64_t n, int bits, int ebits,
+              float max_norm, int rmode, int saturate, int allow_denorm) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        IO<T>::st(out, i, quant_bits(IO<T>::ld(in, i), bits, ebits, max_norm, rmode, saturate, allow_denorm));
+}
+
+// ===========================================================================
+// MX shared scale with the native semantics (cpp/shared_exp.cuh:14-53): NaN scale on
+// overflow, 2^-emax floor, subnormal/NaN scale mantissa bit.
+// ===========================================================================
+MSQ_D float mx_shared_scale(int shared_exp, int scale_bits, float elem_max_norm) {
+    const int elem_emax = (int)((f2u(elem_max_norm) >> 23) & 0xFF) - 127;
+    if (shared_exp != 255) shared_exp -= elem_emax;
+    const int emax = scale_bits != 0 ? (1 << (scale_bits - 1)) - 1 : 255;
+    const int ub = shared_exp - 127;
+    if (ub > emax) shared_exp = 255;
+    if (ub < -emax) shared_exp = 127 - emax;
+    const uint32_t mant = (shared_exp == 0 || shared_exp == 255) ? (1u << 22) : 0u;
+    return u2f(((uint32_t)shared_exp << 23) | mant);
+}
+
+// quantize_mx with precomputed max values (replaces cpp/mx.cuh:15-53)
+__global__ void __launch_bounds__(256)
+k_mx_maxvals(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ maxv,
+             int64_t total, int64_t axis_len, int64_t post, int scale_bits, int ebits, int mbits,
+             float max_norm, int flush, int rmode) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t q = i % post;
+        const int64_t p = i / (post * axis_len);
+        const int se = (int)((f2u(maxv[p * post + q]) >> 23) & 0xFF);
+        const bool fl = (se == 0) && flush;
+        const float scale = mx_shared_scale(se, scale_bits, max_norm);
+        const float si = fl ? 0.f : in[i] / scale;
+        out[i] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+    }
+}
+
+// quantize_mx_by_tile (replaces cpp/mx.cuh:63-170).  One kernel for both layouts:
+//  post > 1 : one lane per (tile, q) column, lanes run along q -> every row access of
+//             the wave is one coalesced segment; the tile lives in registers (<= 128)
+//             or is re-read (L2-resident) for larger tiles.
+//  post == 1: TS lanes of the wave share a tile (tile innermost, power of two <= 64):
+//             max biased exponent by a DPP/shuffle butterfly inside the wave.
+template <int TS>
+__global__ void __launch_bounds__(256)
+k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t total, int scale_bits,
+                int ebits, int mbits, float max_norm, int flush, int rmode) {
+    // axis_len % TS == 0, TS power of two <= 64: element i belongs to tile i / TS
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float v = (i < total) ? in[i] : 0.f;
+    int se = (int)((f2u(v) >> 23) & 0xFF);
+#pragma unroll
+    for (int m = TS / 2; m > 0; m >>= 1) {
+        const int o = __shfl_xor(se, m, 64);
+        se = o > se ? o : se;
+    }
+    const bool fl = (se == 0) && flush;
+    const float scale = mx_shared_scale(se, scale_bits, max_norm);
+    const float si = fl ? 0.f : v / scale;
+    if (i < total) out[i] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+}
+
+__global__ void __launch_bounds__(256)
+k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len,
+                  int64_t post, int tile, int64_t ntiles, int scale_bits, int ebits, int mbits,
+                  float max_norm, int flush, int rmode) {
+    const int64_t total = pre * ntiles * post;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t q = t % post;
+        const int64_t ti = (t / post) % ntiles;
+        const int64_t p = t / (post * ntiles);
+        const int64_t a0 = ti * tile;
+        int64_t a1 = a0 + tile; a1 = a1 > axis_len ? axis_len : a1;
+        const int64_t base = (p * axis_len) * post + q;
+        int se = 0;
+        for (int64_t a = a0; a < a1; ++a) {
+            const int e = (int)((f2u(in[base + a * post]) >> 23) & 0xFF);
+            se = e > se ? e : se;
+        }
+        const bool fl = (se == 0) && flush;
+        const float scale = mx_shared_scale(se, scale_bits, max_norm);
+        for (int64_t a = a0; a < a1; ++a) {
+            const float si = fl ? 0.f : in[base + a * post] / scale;
+            out[base + a * post] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+        }
+    }
+}
+
+// ===========================================================================
+// inner-dim reductions (replace cpp/reduce.cuh:154-210): one wave per row,
+// 16-byte loads, wave64 shuffle tree; rows of any length >= 1.
+// ===========================================================================
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256)
+k_reduce_inner(const float* __restrict__ in, float* __restrict__ out, int64_t outer, int64_t inner) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= outer) return;
+    const float* r = in + row * inner;
+    float acc = IS_MAX ? -__builtin_inff() : 0.f;
+    const bool al = ((reinterpret_cast<uintptr_t>(r) & 15) == 0);
+    int64_t j = 0;
+    if (al) {
+        const int64_t nv = inner >> 2;
+        for (int64_t v = lane; v < nv; v += 64) {
+            const float4 x = reinterpret_cast<const float4*>(r)[v];
+            if (IS_MAX) { acc = fmaxf(acc, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w))); }
+            else { acc += (x.x + x.y) + (x.z + x.w); }
+        }
+        j = nv << 2;
+    }
+    for (int64_t k = j + lane; k < inner; k += 64) {
+        if (IS_MAX) acc = fmaxf(acc, r[k]); else acc += r[k];
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const float o = __shfl_xor(acc, m, 64);
+        acc = IS_MAX ? fmaxf(acc, o) : acc + o;
+    }
+    if (lane == 0) out[row] = acc;
+}
+
+// ===========================================================================
+// MicroScopiQ outlier-aware fake-quant, one block per lane.
+// ===========================================================================
+struct OutlierArgs {
+    Fmt fi, fo;
+    int in_sb, out_sb;
+    float k;          // std_dev as fp32 (python scalar * fp32 tensor)
+    int rmode, flush, variant;
+    int64_t pre, axis_len, post, nblk;
+    uint8_t* mask;
+    float* e_in;
+    float* e_out;
+    int8_t* n_out;
+    int* status;
+    const float* vmean;   // variant 1 statistics [pre, BS, post]
+    const float* vstd;
+};
+
+// per-block maths on a register-resident block.  a[] in, result written back to a[];
+// mk[] receives the 0/1 mask.  Returns status bits.
+template <int BS>
+MSQ_D int outlier_block(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
+                        const OutlierArgs& A, int order, const float* vmean, const float* vstd,
+                        int64_t vstride) {
+    int status = 0;
+    float lo, hi;
+    if (A.variant == 0) {
+        float ab[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(a[b]);
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        const float mean = s / (float)BS;                    // utils/quant.py:477
+        const float sd = std_welford<BS>(ab, 0);             // :478
+        const float ks = A.k * sd;
+        lo = mean - ks; hi = mean + ks;                      // :489-490
+    }
+#pragma unroll
+    for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
+    float mx_in = 0.f;
+    float inl[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        if (A.variant != 0) {
+            const float mean = vmean[b * vstride], sd = vstd[b * vstride];
+            const float ks = A.k * sd;
+            lo = mean - ks; hi = mean + ks;
+        }
+        const bool m = (a[b] < lo) || (a[b] > hi);           // :492 on the SIGNED value
+        mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
+        const float mf = m ? 1.f : 0.f;
+        inl[b] = a[b] * (1.0f - mf);                         // :192
+        a[b] = a[b] * mf;                                    // :193 (a[] now holds the outlier part)
+        const float t = __builtin_fabsf(inl[b]);
+        mx_in = (t > mx_in || t != t) ? t : mx_in;
+    }
+    float se_in = shared_exp_of_max(mx_in);                  // :196-198
+    const bool fl = A.flush && !(se_in > -127.f);            // :201-202
+    se_in = se_in - (float)A.fi.emax;                        // :207
+    se_in = clamp_scale_exp(se_in, A.in_sb, A.variant);      // :208-211
+    const float sc_in = exp2f_int(se_in);
+    const float rc_in = exp2f_int(-se_in);                   // x / 2^e == x * 2^-e exactly
+    float mx_out = 0.f;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        float v = inl[b];
+        if (fl) v = v * 0.f;
+        v = v * rc_in;                                       // :214
+        a[b] = a[b] * sc_in;                                 // :216
+        v = quant_elem(v, A.fi, A.rmode);                    // :218-221
+        v = v * sc_in;                                       // :224
+        if (v != v || a[b] != a[b]) status |= MSQ_STATUS_NAN; // :225-226
+        inl[b] = v;
+        const float t = __builtin_fabsf(a[b]);
+        mx_out = (t > mx_out || t != t) ? t : mx_out;
+    }
+    float se_out = shared_exp_of_max(mx_out);                // :229-231
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    se_out = se_out - (float)A.fo.emax;                      // :237
+    se_out = clamp_scale_exp(se_out, A.out_sb, A.variant);   // :239-242
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;          // :244
+    const float sc_out = exp2f_int(se_out);
+    const float rc_out = exp2f_int(-se_out);
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        float o = a[b] * rc_out;                             // :247
+        if (o != o) status |= MSQ_STATUS_NAN;                // :250
+        o = quant_elem(o, A.fo, A.rmode);                    // :252-255
+        o = (o * sc_out) * rc_in;                            // :258
+        a[b] = inl[b] + o;                                   // :262
+    }
+    se_in_o = se_in; se_out_o = se_out;
+    return status;
+}
+
+template <int BS>
+MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS + 31) / 32], float se_in,
+                                float se_out, int status, int64_t p, int64_t nb, int64_t q) {
+    if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
+    if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
+    if (A.n_out && A.pre == 1 && (nb % BS) == 0) {           // utils/quant.py:66
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < (BS + 31) / 32; ++w) c += __builtin_popcount(mkw[w]);
+        A.n_out[(nb / BS) * A.post + q] = (int8_t)c;
+    }
+    if (status && A.status) atomicOr(A.status, status);
+}
+
+// --- layout A: post > 1.  lane <-> (p, nb, q), q fastest: each of the BS row reads
+// of a wave is one contiguous 256-byte segment.
+template <int BS, typename T>
+__global__ void __launch_bounds__(256)
+k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
+    const int64_t total = A.pre * A.nblk * A.post;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = t % A.post;
+    const int64_t nb = (t / A.post) % A.nblk;
+    const int64_t p = t / (A.post * A.nblk);
+    const int64_t a0 = nb * BS;
+    const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    float a[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+        a[b] = (a0 + b < A.axis_len) ? IO<T>::ld(in, base + (int64_t)b * A.post) : 0.f;   // zero padding, :563-583
+    int order;
+    {   // torch's summation order for this column (oracle/msq_oracle.c sum_order_for)
+        const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
+        order = (q < lim) ? 0 : 2;
+    }
+    uint32_t mkw[(BS + 31) / 32];
+    float se_in, se_out;
+    const float* vm = A.vmean ? A.vmean + (p * BS) * A.post + q : nullptr;
+    const float* vs = A.vstd ? A.vstd + (p * BS) * A.post + q : nullptr;
+    const int status = outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        if (a0 + b < A.axis_len) {
+            IO<T>::st(out, base + (int64_t)b * A.post, a[b]);
+            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+    }
+    outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, q);
+}
+
+// --- layout B: post == 1 (block contiguous).  A wave owns 64 consecutive blocks.
+// When axis_len % BS == 0 they are one contiguous run of 64*BS floats: the wave
+// streams it with 16-byte coalesced accesses and transposes through LDS (row stride
+// BS+4 floats: conflict-free ds_read_b128 for 16-lane groups) so that each lane ends
+// up with its own block in registers; results go back the same way.
+template <int BS, typename T>
+__global__ void __launch_bounds__(256)
+k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
+    constexpr int LDS_STRIDE = BS + 4;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nblocks = A.pre * A.nblk;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;      // first block of this wave
+    if (g0 >= nblocks) return;
+    const bool fast = (A.axis_len % BS == 0) && (g0 + 64 <= nblocks) && (sizeof(T) == 4);
+    float a[BS];
+    const int64_t g = g0 + lane;
+    const int64_t p = g / A.nblk, nb = g % A.nblk;
+    const int64_t a0 = nb * BS;
+    const int64_t base = p * A.axis_len + a0;
+    float* tl = tile[wv];
+    if (fast) {
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + g0 * BS);
+#pragma unroll
+        for (int t = 0; t < BS / 4; ++t) {
+            const int f = lane + 64 * t;                         // float4 index inside the 64xBS tile
+            const int row = f / (BS / 4), c4 = f % (BS / 4);
+            *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+#pragma unroll
+        for (int c = 0; c < BS / 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
+            a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+            a[b] = (g < nblocks && a0 + b < A.axis_len) ? IO<T>::ld(in, base + b) : 0.f;
+    }
+    uint32_t mkw[(BS + 31) / 32];
+    float se_in, se_out;
+    int status = 0;
+    if (g < nblocks) {
+        const float* vm = A.vmean ? A.vmean + p * BS : nullptr;
+        const float* vs = A.vstd ? A.vstd + p * BS : nullptr;
+        status = outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+    }
+    if (fast) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < BS / 4; ++c)
+            *reinterpret_cast<float4*>(tl + lane * LDS_STRIDE + c * 4) =
+                make_float4(a[c * 4 + 0], a[c * 4 + 1], a[c * 4 + 2], a[c * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + g0 * BS);
+#pragma unroll
+        for (int t = 0; t < BS / 4; ++t) {
+            const int f = lane + 64 * t;
+            const int row = f / (BS / 4), c4 = f % (BS / 4);
+            dst[f] = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c4 * 4);
+        }
+    } else if (g < nblocks) {
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+            if (a0 + b < A.axis_len) IO<T>::st(out, base + b, a[b]);
+    }
+    if (g < nblocks) {
+        if (A.mask) {
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+                if (a0 + b < A.axis_len) A.mask[base + b] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+        outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, 0);
+    }
+}
+
+// variant 1 statistics (mx_ops.py:62-66,248): mean / unbiased std of the SIGNED values
+// over the block-count axis, one lane per (p, b, q).
+__global__ void __launch_bounds__(256)
+k_mxops_stats(const float* __restrict__ in, float* __restrict__ vmean, float* __restrict__ vstd,
+              int64_t pre, int64_t axis_len, int64_t post, int bs, int64_t nblk, int* status) {
+    const int64_t total = pre * bs * post;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = t % post;
+    const int b = (int)((t / post) % bs);
+    const int64_t p = t / (post * bs);
+    const int64_t cols = (int64_t)bs * post, col = (int64_t)b * post + q;
+    const int64_t lim = (cols >= 8) ? (cols / 32) * 32 : (cols / 4) * 4;
+    const int order = (cols == 1) ? 1 : ((col < lim) ? 0 : 2);
+    auto ld = [&](int64_t nb) -> float {
+        const int64_t ai = nb * bs + b;
+        return ai < axis_len ? in[(p * axis_len + ai) * post + q] : 0.f;
+    };
+    float s;
+    if (order == 0) {                       // cascade, step 16 (nblk < 65536)
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        int64_t i = 0;
+        while (i + 16 <= nblk) {
+            for (int j = 0; j < 16; ++j, ++i) acc0 += ld(i);
+            acc1 += acc0; acc0 = 0.f;
+            if ((i & (15 << 4)) == 0) { acc2 += acc1; acc1 = 0.f;
+                if ((i & (15 << 8)) == 0) { acc3 += acc2; acc2 = 0.f; } }
+        }
+        for (; i < nblk; ++i) acc0 += ld(i);
+        acc0 += acc1; acc0 += acc2; acc0 += acc3;
+        s = acc0;
+    } else if (order == 2) {                // ilp4
+        const int64_t S = nblk / 4;
+        float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+        int64_t i = 0;
+        while (i + 16 <= S) {
+            for (int j = 0; j < 16; ++j, ++i) for (int k = 0; k < 4; ++k) a0[k] += ld(i * 4 + k);
+            for (int k = 0; k < 4; ++k) { a1[k] += a0[k]; a0[k] = 0.f; }
+            if ((i & (15 << 4)) == 0) for (int k = 0; k < 4; ++k) { a2[k] += a1[k]; a1[k] = 0.f; }
+        }
+        for (; i < S; ++i) for (int k = 0; k < 4; ++k) a0[k] += ld(i * 4 + k);
+        for (int k = 0; k < 4; ++k) { a0[k] += a1[k]; a0[k] += a2[k]; }
+        for (int64_t r = S * 4; r < nblk; ++r) a0[0] += ld(r);
+        a0[0] += a0[1]; a0[0] += a0[2]; a0[0] += a0[3];
+        s = a0[0];
+    } else {                                // inner8 can only happen for bs*post == 1
+        s = 0.f;
+        for (int64_t i = 0; i < nblk; ++i) s += ld(i);
+    }
+    double mean = 0.0, m2 = 0.0;
+    for (int64_t i = 0; i < nblk; ++i) {
+        const double d = (double)ld(i);
+        const double delta = d - mean;
+        mean = mean + delta / (double)(i + 1);
+        m2 = m2 + delta * (d - mean);
+    }
+    double den = (double)nblk - 1.0; den = den < 0 ? 0 : den;
+    const float sd = (float)__builtin_sqrt(m2 / den);
+    vmean[t] = s / (float)nblk;
+    vstd[t] = sd;
+    if (sd != sd && status) atomicOr(status, MSQ_STATUS_NAN);   // mx_ops.py:66 assert
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return MSQ_ERR_LAUNCH;
+    }
+    return MSQ_OK;
+}
+static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+template <typename T>
+static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
+    const int64_t nthreads = A.pre * A.nblk * A.post;
+#define MSQ_OL(BS)                                                                                      \
+    case BS:                                                                                            \
+        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T>), dim3(grid_for(nthreads, 256)),   \
+                                            dim3(256), 0, st, (const T*)in, (T*)out, A);                \
+        else hipLaunchKernelGGL((k_outlier_strided<BS, T>), dim3(grid_for(nthreads, 256)), dim3(256),   \
+                                0, st, (const T*)in, (T*)out, A);                                       \
+        break;
+    switch (block) { MSQ_OL(8) MSQ_OL(16) MSQ_OL(32) MSQ_OL(64) MSQ_OL(128)
+        default: return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
+    }
+#undef MSQ_OL
+    return MSQ_OK;
+}
+
+extern "C" {
+
+int msq_version(void) { return 100; }
+const char* msq_last_error(void) { return g_err; }
+
+int msq_format_id(const char* name) { return msq_host::format_id(name); }
+
+int msq_format_params(int fmt, int* ebits, int* mbits, int* emax, float* max_norm, float* min_norm, int* kind) {
+    msq_host::FmtInfo f;
+    if (!msq_host::format_info(fmt, &f)) return fail(MSQ_ERR_BAD_ARG, "msq_format_params: unknown format id");
+    if (ebits) *ebits = f.ebits;
+    if (mbits) *mbits = f.mbits;
+    if (emax) *emax = f.emax;
+    if (max_norm) *max_norm = f.max_norm;
+    if (min_norm) *min_norm = f.min_norm;
+    if (kind) *kind = f.kind;
+    return MSQ_OK;
+}
+
+int msq_quantize_elemwise(const void* in, void* out, int64_t n, int dtype, int bits, int exp_bits,
+                          float max_norm, int rmode, int saturate_normals, int allow_denorm, void* stream) {
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_elemwise: null buffer");
+    if (bits > 24 || bits < 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_elemwise: bits must be in [2,24]");  // funcs.cpp:193
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_elemwise: bad rounding mode");
+    if (n == 0) return MSQ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)
+            return fail(MSQ_ERR_BAD_ARG, "msq_quantize_elemwise: f32 buffers must be 16-byte aligned");
+        const int g = grid_for((n + 3) / 4, 256, 2048 * 4);
+        hipLaunchKernelGGL(k_elemwise_f32, dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, n, bits,
+                           exp_bits, max_norm, rmode, saturate_normals, allow_denorm);
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL(k_elemwise_16<__half>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
+                           (const __half*)in, (__half*)out, n, bits, exp_bits, max_norm, rmode,
+                           saturate_normals, allow_denorm);
+    } else if (dtype == 2) {
+        hipLaunchKernelGGL(k_elemwise_16<__hip_bfloat16>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
+                           (const __hip_bfloat16*)in, (__hip_bfloat16*)out, n, bits, exp_bits, max_norm,
+                           rmode, saturate_normals, allow_denorm);
+    } else return fail(MSQ_ERR_UNSUPPORTED, "msq_quantize_elemwise: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    return check_launch("msq_quantize_elemwise");
+}
+
+int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_t pre, int64_t axis_len,
+                    int64_t post, int scale_bits, int elem_ebits, int elem_mbits, float elem_max_norm,
+                    int flush_fp32_subnorms, int rmode, void* stream) {
+    if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx: negative size");
+    const int64_t total = pre * axis_len * post;
+    if (total == 0) return MSQ_OK;
+    if (!in || !out || !max_values) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx: null buffer");
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx: bad rounding mode");
+    hipLaunchKernelGGL(k_mx_maxvals, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, max_values, total, axis_len, post, scale_bits, elem_ebits, elem_mbits,
+                       elem_max_norm, flush_fp32_subnorms, rmode);
+    return check_launch("msq_quantize_mx");
+}
+
+int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                            int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                            float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
+    if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: negative size");
+    const int64_t total = pre * axis_len * post;
+    if (total == 0) return MSQ_OK;
+    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: null buffer");
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: bad rounding mode");
+    if (tile_size <= 0) tile_size = (int)axis_len;
+    hipStream_t st = (hipStream_t)stream;
+    const bool pow2 = (tile_size & (tile_size - 1)) == 0;
+    if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
+        const int g = grid_for(total, 256);
+#define MSQ_TI(TS) case TS: hipLaunchKernelGGL(k_mx_tile_inner<TS>, dim3(g), dim3(256), 0, st, in, out, total, \
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
+        switch (tile_size) { MSQ_TI(1) MSQ_TI(2) MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
+#undef MSQ_TI
+    } else {
+        const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
+        hipLaunchKernelGGL(k_mx_tile_generic, dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
+                           in, out, pre, axis_len, post, tile_size, ntiles, scale_bits, elem_ebits, elem_mbits,
+                           elem_max_norm, flush_fp32_subnorms, rmode);
+    }
+    return check_launch("msq_quantize_mx_by_tile");
+}
+
+int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream) {
+    if (outer < 0 || inner < 0) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_sum_inner: negative size");
+    if (outer == 0) return MSQ_OK;
+    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_sum_inner: null buffer");
+    hipLaunchKernelGGL(k_reduce_inner<false>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, outer, inner);
+    return check_launch("msq_reduce_sum_inner");
+}
+
+int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream) {
+    if (outer < 0 || inner < 0) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_max_inner: negative size");
+    if (outer == 0) return MSQ_OK;
+    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_max_inner: null buffer");
+    hipLaunchKernelGGL(k_reduce_inner<true>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, outer, inner);
+    return check_launch("msq_reduce_max_inner");
+}
+
+int64_t msq_outlier_workspace_bytes(int64_t pre, int64_t axis_len, int64_t post, int block, int variant) {
+    if (variant != MSQ_VARIANT_MXOPS) return 0;
+    if (block <= 0) block = (int)axis_len;
+    return 2 * (int64_t)sizeof(float) * pre * block * post;
+}
+
+int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in, float* e_out,
+                          int8_t* num_outliers, int* status_flag, void* workspace, int64_t workspace_bytes,
+                          int dtype, int64_t pre, int64_t axis_len, int64_t post, int block, int inlier_fmt,
+                          int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits, float std_dev,
+                          int rmode, int flush_fp32_subnorms, int variant, void* stream) {
+    if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: negative size");
+    if (pre * axis_len * post == 0) return MSQ_OK;
+    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: null buffer");
+    if (inlier_scale_bits <= 0 || outlier_scale_bits <= 0 || inlier_scale_bits > 8 || outlier_scale_bits > 8)
+        return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: scale bits must be in [1,8]");   // utils/quant.py:168
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: bad rounding mode");
+    if (variant != MSQ_VARIANT_QUANT && variant != MSQ_VARIANT_MXOPS)
+        return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: bad variant");
+    msq_host::FmtInfo fi, fo;
+    if (!msq_host::format_info(inlier_fmt, &fi) || !msq_host::format_info(outlier_fmt, &fo))
+        return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: unknown element format");
+    if (block <= 0) block = (int)axis_len;
+    OutlierArgs A;
+    A.fi = Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm};
+    A.fo = Fmt{fo.kind, fo.ebits, fo.mbits, fo.emax, fo.max_norm};
+    A.in_sb = inlier_scale_bits; A.out_sb = outlier_scale_bits;
+    A.k = std_dev; A.rmode = rmode; A.flush = flush_fp32_subnorms; A.variant = variant;
+    A.pre = pre; A.axis_len = axis_len; A.post = post; A.nblk = (axis_len + block - 1) / block;
+    A.mask = mask; A.e_in = e_in; A.e_out = e_out; A.n_out = num_outliers; A.status = status_flag;
+    A.vmean = nullptr; A.vstd = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == MSQ_VARIANT_MXOPS) {
+        if (dtype != 0) return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: variant mx_ops is f32 only");
+        const int64_t need = msq_outlier_workspace_bytes(pre, axis_len, post, block, variant);
+        if (!workspace || workspace_bytes < need)
+            return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: workspace too small (msq_outlier_workspace_bytes)");
+        float* vmean = (float*)workspace;
+        float* vstd = vmean + pre * block * post;
+        hipLaunchKernelGGL(k_mxops_stats, dim3(grid_for(pre * block * post, 256)), dim3(256), 0, st,
+                           (const float*)in, vmean, vstd, pre, axis_len, post, block, A.nblk, status_flag);
+        int rc = check_launch("msq_outlier_fakequant(stats)");
+        if (rc) return rc;
+        A.vmean = vmean; A.vstd = vstd;
+    }
+    int rc;
+    if (dtype == 0) rc = launch_outlier<float>(in, out, A, block, st);
+    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: only dtype 0 (f32) is built; the host shim upcasts f16/bf16");
+    if (rc) return rc;
+    return check_launch("msq_outlier_fakequant");
+}
+
+}  // extern "C"
