@@ -65,6 +65,16 @@ extern "C" {
 
 /* status bits written to *status_flag by the outlier kernels */
 #define MSQ_STATUS_NAN 1 /* one of the reference's NaN asserts (utils/quant.py:225-250) would fire */
+#define MSQ_STATUS_INEXACT 2 /* pack: a value is not exactly code * 2^scale (never silently wrong) */
+
+/* GEMM-ready plane kinds (what the fused kernel converts in-register with the CDNA4
+ * v_cvt_scalef32_pk_bf16_{fp4,fp8,bf8} instructions) */
+#define MSQ_PLANE_NONE 0
+#define MSQ_PLANE_FP4 1  /* e2m1 nibbles                      (inlier formats fp4, int2)           */
+#define MSQ_PLANE_FP8 2  /* OCP e4m3 bytes                    (outlier formats fp8_e4m3, fp4, fp6, int4) */
+#define MSQ_PLANE_BF8 3  /* OCP e5m2 bytes                    (outlier format fp8_e5m2)            */
+#define MSQ_PLANE_BF16 4 /* final values, bf16, no scale      (posit / int8 outliers; any format when
+                            the inlier plane is NONE: the whole fake-quant value)                 */
 
 int msq_version(void);
 const char* msq_last_error(void);
@@ -116,6 +126,50 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
                           int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits,
                           float std_dev, int rmode, int flush_fp32_subnorms, int variant,
                           void* stream);
+
+/* ---------------------------------------------------------------------------
+ * NEW -- packed ("GEMM-ready", tile-major) weight format and the fused
+ * unpack-dequant-GEMM.  The reference has no packed format (llm/opt.py:254-264
+ * "TODO: perform packing on GPU", Quant3Linear undefined); the contract is the
+ * fake-quant value: unpack(pack(W)) == quantize_mx_outlier_v1(W) bit for bit.
+ *
+ * Layout (DESIGN.md "MSQ-T1"): W is [N, K] (out_features, in_features), blocks of
+ * `block` run along K (the reference's axes=[-1]); N % 64 == 0, K % 64 == 0.
+ * The tensor is cut into 64(n) x 64(k) tiles, tile index = (n/64) * (K/64) + k/64;
+ * inside a tile the data is stored exactly as one wavefront consumes it for
+ * v_mfma_f32_16x16x32_bf16 (lane l: column c = l & 15, k-group g = l >> 4; fragment
+ * (nf, kf) = 8 elements n = 16 nf + c, k = 32 kf + 8 g + j):
+ *   inlier plane : per tile 2 slots (kf) of 64 lanes x 16 B; dword nf of a lane = 8 e2m1 nibbles (j)
+ *   outlier plane: per tile 4 slots (kf*2 + nf/2) of 64 lanes x 16 B (8-bit kinds: 2 dwords per
+ *                  fragment) or 8 slots (kf*4 + nf) for the bf16 kind
+ *   scale plane  : per tile 16 B per lane group: byte nf*4 + kf*2 + {0: inlier E8M0, 1: outlier E8M0
+ *                  (= e_out - e_in + 127)}; one group per column (16 groups) when block >= 32,
+ *                  one per lane (64 groups) when block < 32.
+ * Zero is always stored as +0 so that inlier and outlier parts combine with a bitwise OR.
+ * ------------------------------------------------------------------------- */
+int msq_packed_kinds(int inlier_fmt, int outlier_fmt, int* in_kind, int* out_kind);
+int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind, int64_t* inl_bytes,
+                     int64_t* out_bytes, int64_t* scale_bytes, int64_t* workspace_bytes);
+
+/* quantise W [N,K] f32 (utils/quant.py:147-266 semantics, axes=[-1]) and emit the planes.
+ * status_flag (device int, may be NULL) receives MSQ_STATUS_* bits. */
+int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* scale_plane,
+                     int* status_flag, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
+                     int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
+                     int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms,
+                     void* stream);
+
+/* planes -> dense dequantised W [N,K]; out_dtype 0 = f32, 2 = bf16 (both exact). */
+int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,
+                       int out_dtype, int64_t N, int64_t K, int block, int in_kind, int out_kind,
+                       void* stream);
+
+/* fused unpack-dequant-GEMM: Y[M,N] = X[M,K] (bf16) . W^T (+ bias f32 [N] or NULL), fp32 accumulate on
+ * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 2 = bf16.  Replaces the dense F.linear the reference
+ * runs on the fake-quantised weight (number_system/mx/linear.py:91, llm/llama.py:255-256). */
+int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
+                     int in_kind, int out_kind, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,472 @@
+// msq_gemm.hip -- packed ("GEMM-ready", tile-major MSQ-T1) weight format, its
+// repack / unpack kernels and the fused unpack-dequant-GEMM for gfx950.
+//
+// Design: the weight operand never touches LDS.  Every wavefront streams
+// its own 64(n) x 64(k) packed tiles straight from global memory (L2-resident across
+// the row-tiles of an XCD) in the exact fragment order of v_mfma_f32_16x16x32_bf16,
+// converts them in-register with the CDNA4 scaled converts
+// (v_cvt_scalef32_pk_bf16_fp4 / _fp8 / _bf8: two elements + E8M0 block scale per
+// instruction) and ORs inlier and outlier parts (one of them is always +0).  Only the
+// activation tile is staged through LDS (global_load_lds, XOR-swizzled on the source
+// side so the LDS image stays lane-linear and ds_read_b128 is conflict-free).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+#include "msq_host.h"
+
+using namespace msq;
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+#define TILE_N 64
+#define TILE_K 64
+
+// ---------------------------------------------------------------------------
+// fragment dequant: 8 elements (one MFMA operand fragment) -> 4 dwords of bf16x2
+// ---------------------------------------------------------------------------
+template <int OUT_KIND>
+MSQ_D u32x4_t dequant_frag(uint32_t inl, uint32_t o0, uint32_t o1, float s_in, float s_out) {
+    u32x4_t r;
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 0));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 1));
+    r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 2));
+    r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 3));
+    if (OUT_KIND == MSQ_PLANE_FP8) {
+        r[0] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o0, s_out, false));
+        r[1] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o0, s_out, true));
+        r[2] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o1, s_out, false));
+        r[3] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o1, s_out, true));
+    } else {
+        r[0] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o0, s_out, false));
+        r[1] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o0, s_out, true));
+        r[2] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o1, s_out, false));
+        r[3] |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o1, s_out, true));
+    }
+    return r;
+}
+
+MSQ_D u32x4_t dequant_frag_in_only(uint32_t inl, float s_in) {
+    u32x4_t r;
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 0));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 1));
+    r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 2));
+    r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(inl, s_in, 3));
+    return r;
+}
+
+// E8M0 byte `idx` (0..3) of a scale dword as the f32 operand of the scaled converts:
+// the hardware reads only the exponent field (sign and mantissa are ignored; verified
+// on MI355X), so one shift is enough.
+MSQ_D float scale_operand(uint32_t d, int idx) {
+    uint32_t s = (idx == 3) ? (d >> 1) : (d << (23 - 8 * idx));
+    return __builtin_bit_cast(float, s);
+}
+
+// all 8 fragments of one 64x64 tile for this lane
+struct TileRegs {
+    u32x4_t inl[2];      // [kf]  dword nf
+    u32x4_t out[8];      // 8-bit kinds use [0..3] = (kf*2 + nf/2); bf16 kind uses [kf*4 + nf]
+    u32x4_t scl;         // dword nf: bytes kf*2 + io
+};
+
+template <int IN_KIND, int OUT_KIND>
+MSQ_D u32x4_t tile_frag(const TileRegs& t, int nf, int kf) {
+    if (IN_KIND == MSQ_PLANE_NONE) return t.out[kf * 4 + nf];
+    const uint32_t sd = t.scl[nf];
+    const float s_in = scale_operand(sd, kf * 2);
+    if (OUT_KIND == MSQ_PLANE_BF16) {
+        u32x4_t r = dequant_frag_in_only(t.inl[kf][nf], s_in);
+        const u32x4_t o = t.out[kf * 4 + nf];
+        r[0] |= o[0]; r[1] |= o[1]; r[2] |= o[2]; r[3] |= o[3];
+        return r;
+    } else {
+        const float s_out = scale_operand(sd, kf * 2 + 1);
+        const u32x4_t o = t.out[kf * 2 + (nf >> 1)];
+        return dequant_frag<OUT_KIND>(t.inl[kf][nf], o[(nf & 1) * 2], o[(nf & 1) * 2 + 1], s_in, s_out);
+    }
+}
+
+template <int OUT_KIND> struct OutSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 8 : 4; };
+
+// ---------------------------------------------------------------------------
+// repack: codes[N][K] (u32: bits 0-7 inlier code, 8-23 outlier code) + per-block
+// exponents -> tile-major planes.  One wave per tile.
+// ---------------------------------------------------------------------------
+template <int IN_KIND, int OUT_KIND>
+__global__ void __launch_bounds__(256)
+k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, const float* __restrict__ e_out,
+         uint8_t* __restrict__ inl_plane, uint8_t* __restrict__ out_plane, uint8_t* __restrict__ scl_plane,
+         int64_t N, int64_t K, int block, int* status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t KT = K / TILE_K, NT = N / TILE_N;
+    if (tile >= KT * NT) return;
+    const int64_t nt = tile / KT, kt = tile % KT;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t nblk = K / block;
+    constexpr int OS = OutSlots<OUT_KIND>::n;
+    uint32_t sc[4] = {0, 0, 0, 0};
+    int st = 0;
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf) {
+        u32x4_t inl4;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int64_t n = nt * TILE_N + nf * 16 + c;
+            const int64_t k = kt * TILE_K + kf * 32 + g * 8;
+            const u32x4_t c0 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k);
+            const u32x4_t c1 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k + 4);
+            const uint32_t cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            uint32_t iw = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) iw |= (cc[j] & 0xFu) << (4 * j);
+            inl4[nf] = iw;
+            if (OUT_KIND == MSQ_PLANE_BF16) {
+                u32x4_t o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = ((cc[2 * w] >> 8) & 0xFFFFu) | (((cc[2 * w + 1] >> 8) & 0xFFFFu) << 16);
+                *reinterpret_cast<u32x4_t*>(out_plane + ((tile * OS + kf * 4 + nf) * 64 + lane) * 16) = o;
+            } else {
+                uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o0 |= ((cc[j] >> 8) & 0xFFu) << (8 * j); o1 |= ((cc[4 + j] >> 8) & 0xFFu) << (8 * j); }
+                // slot kf*2 + nf/2, dwords (nf&1)*2 .. +1 of the lane's 16 bytes
+                uint8_t* dst = out_plane + ((tile * OS + kf * 2 + (nf >> 1)) * 64 + lane) * 16 + (nf & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(o0, o1);
+            }
+            // scales of the block holding this fragment
+            const int64_t kb = k / block;
+            const float ei = e_in[n * nblk + kb], eo = e_out[n * nblk + kb];
+            uint32_t bi, bo;
+            if (ei != ei) { bi = 255; st |= MSQ_STATUS_NAN; } else { const float b = ei + 127.f; bi = (b < 0.f || b > 254.f) ? 255u : (uint32_t)b; if (b < 0.f || b > 254.f) st |= MSQ_STATUS_INEXACT; }
+            const float ef = eo - ei;
+            if (ef != ef) { bo = 255; st |= MSQ_STATUS_NAN; } else { const float b = ef + 127.f; bo = (b < 0.f) ? 0u : ((b > 254.f) ? 254u : (uint32_t)b); }
+            sc[nf] |= (bi << (16 * kf)) | (bo << (16 * kf + 8));
+        }
+        if (IN_KIND != MSQ_PLANE_NONE)
+            *reinterpret_cast<u32x4_t*>(inl_plane + ((tile * 2 + kf) * 64 + lane) * 16) = inl4;
+    }
+    if (IN_KIND != MSQ_PLANE_NONE) {
+        const bool per_lane = block < 32;
+        const int groups = per_lane ? 64 : 16;
+        if (per_lane || g == 0) {
+            u32x4_t s4; s4[0] = sc[0]; s4[1] = sc[1]; s4[2] = sc[2]; s4[3] = sc[3];
+            *reinterpret_cast<u32x4_t*>(scl_plane + (tile * groups + (per_lane ? lane : c)) * 16) = s4;
+        }
+    }
+    if (st && status) atomicOr(status, st);
+}
+
+// load all packed data of a tile for this lane (coalesced: every slot is 64 lanes x 16 B)
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_plane, const uint8_t* scl_plane,
+                     int64_t tile, int lane, int scl_groups) {
+    constexpr int OS = OutSlots<OUT_KIND>::n;
+    if (IN_KIND != MSQ_PLANE_NONE) {
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+            t.inl[kf] = *reinterpret_cast<const u32x4_t*>(inl_plane + ((tile * 2 + kf) * 64 + lane) * 16);
+        t.scl = *reinterpret_cast<const u32x4_t*>(scl_plane + (tile * scl_groups + (lane & (scl_groups - 1))) * 16);
+    }
+#pragma unroll
+    for (int s = 0; s < OS; ++s)
+        t.out[s] = *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * OS + s) * 64 + lane) * 16);
+}
+
+// ---------------------------------------------------------------------------
+// unpack: planes -> dense W[N][K] (f32 or bf16), same converts as the GEMM.
+// ---------------------------------------------------------------------------
+template <int IN_KIND, int OUT_KIND, typename OT>
+__global__ void __launch_bounds__(256)
+k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+         const uint8_t* __restrict__ scl_plane, OT* __restrict__ W, int64_t N, int64_t K, int scl_groups) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t KT = K / TILE_K, NT = N / TILE_N;
+    if (tile >= KT * NT) return;
+    const int64_t nt = tile / KT, kt = tile % KT;
+    const int c = lane & 15, g = lane >> 4;
+    TileRegs t;
+    load_tile<IN_KIND, OUT_KIND>(t, inl_plane, out_plane, scl_plane, tile, lane, scl_groups);
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const u32x4_t f = tile_frag<IN_KIND, OUT_KIND>(t, nf, kf);
+            const int64_t n = nt * TILE_N + nf * 16 + c;
+            const int64_t k = kt * TILE_K + kf * 32 + g * 8;
+            if (sizeof(OT) == 2) {
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(W) + n * K + k) = f;
+            } else {
+                float* d = reinterpret_cast<float*>(W) + n * K + k;
+                *reinterpret_cast<float4*>(d) = make_float4(u2f(f[0] << 16), u2f(f[0] & 0xFFFF0000u), u2f(f[1] << 16), u2f(f[1] & 0xFFFF0000u));
+                *reinterpret_cast<float4*>(d + 4) = make_float4(u2f(f[2] << 16), u2f(f[2] & 0xFFFF0000u), u2f(f[3] << 16), u2f(f[3] & 0xFFFF0000u));
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// fused unpack-dequant-GEMM.  Block tile 256(m) x 256(n), K-step 64, 8 waves as
+// 2(m) x 4(n): wave tile 128 x 64 = 8 x 4 MFMA tiles of 16x16, fp32 accumulators.
+// W fragment is the MFMA "A" operand (rows = n) and the X fragment the "B" operand
+// (cols = m): D[n][m], so a lane ends up with 4 consecutive n of one output row m.
+// ---------------------------------------------------------------------------
+#define BM 256
+#define BN 256
+#define BK 64
+#define A_TILE_BYTES (BM * BK * 2)
+
+template <int IN_KIND, int OUT_KIND, typename YT>
+__global__ void __launch_bounds__(512)
+k_qgemm(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+        const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+        int scl_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + BM - 1) / BM, NTB = N / BN;
+    // XCD-aware tile order: the 8 XCDs are dealt blocks round-robin; give every XCD whole
+    // column panels so that the packed W panel and the X tiles are re-used out of its own L2.
+    int bid = blockIdx.x;
+    int bm, bn;
+    if ((NTB & 7) == 0) {
+        const int xcd = bid & 7, i = bid >> 3;
+        bn = (i / MT) * 8 + xcd;
+        bm = i % MT;
+    } else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int KT = K / BK;
+    const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;      // this wave's packed tiles
+
+    // --- A (activation) staging: 32 pieces of 1 KiB (8 rows x 128 B) per K-step; wave w owns
+    // pieces 4w..4w+3.  LDS image is lane-linear; the XOR swizzle is applied to the SOURCE
+    // chunk: LDS slot s of row r holds logical 16-byte chunk s ^ ((r >> 1) & 7).
+    auto stage_A = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = wid * 4 + p;
+            const int row = piece * 8 + (lane >> 3);
+            const int slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            int gr = m0 + row; gr = gr < M ? gr : M - 1;
+            const uint16_t* src = X + (int64_t)gr * K + (int64_t)kt * BK + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + piece * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    TileRegs cur, nxt;
+    stage_A(0, 0);
+    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row, lane, scl_groups);
+    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) {
+            stage_A(kt + 1, buf ^ 1);
+            load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + kt + 1, lane, scl_groups);
+        }
+        const char* abase = smem + buf * A_TILE_BYTES;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+            bf16x8_t wf[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+                wf[nf] = __builtin_bit_cast(bf16x8_t, tile_frag<IN_KIND, OUT_KIND>(cur, nf, kf));
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+                const int row = wm * 128 + mf * 16 + c;
+                const int slot = (kf * 4 + g) ^ ((row >> 1) & 7);
+                const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(abase + row * 128 + slot * 16);
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf, acc[mf][nf], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // --- epilogue: lane holds D[n = 4g + r][m = c] of every 16x16 tile -> 4 consecutive n
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+        const int m = m0 + wm * 128 + mf * 16 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + wn * 64 + nf * 16 + g * 4;
+            f32x4_t v = acc[mf][nf];
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (sizeof(YT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
+                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+static thread_local char g_err2[256] = "";
+extern "C" const char* msq_last_error(void);
+static int fail2(int code, const char* msg);
+static int check_launch2(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char b[200]; snprintf(b, sizeof(b), "%s: %s", what, hipGetErrorString(e)); return fail2(MSQ_ERR_LAUNCH, b); }
+    return MSQ_OK;
+}
+extern "C" void msq_set_error_(const char* msg);
+static int fail2(int code, const char* msg) { msq_set_error_(msg); (void)g_err2; return code; }
+
+extern "C" {
+
+int msq_packed_kinds(int inlier_fmt, int outlier_fmt, int* in_kind, int* out_kind) {
+    msq_host::FmtInfo fi, fo;
+    if (!msq_host::format_info(inlier_fmt, &fi) || !msq_host::format_info(outlier_fmt, &fo))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_packed_kinds: unknown element format");
+    int ik = MSQ_PLANE_NONE, ok = MSQ_PLANE_BF16;
+    if (inlier_fmt == MSQ_FMT_FP4_E2M1 || inlier_fmt == MSQ_FMT_INT2) {
+        ik = MSQ_PLANE_FP4;
+        switch (outlier_fmt) {
+            case MSQ_FMT_FP8_E4M3: case MSQ_FMT_FP4_E2M1: case MSQ_FMT_FP6_E3M2: case MSQ_FMT_FP6_E2M3:
+            case MSQ_FMT_INT4: case MSQ_FMT_INT2: ok = MSQ_PLANE_FP8; break;
+            case MSQ_FMT_FP8_E5M2: ok = MSQ_PLANE_BF8; break;
+            default: ok = MSQ_PLANE_BF16; break;      // posit<n,es>, int8, fp16, bf16
+        }
+    }
+    if (in_kind) *in_kind = ik;
+    if (out_kind) *out_kind = ok;
+    return MSQ_OK;
+}
+
+int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind, int64_t* inl_bytes,
+                     int64_t* out_bytes, int64_t* scale_bytes, int64_t* workspace_bytes) {
+    if (N <= 0 || K <= 0 || (N % TILE_N) || (K % TILE_K))
+        return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: N and K must be positive multiples of 64");
+    if (!(block == 8 || block == 16 || block == 32 || block == 64 || block == 128) || (K % block))
+        return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: block must be 8/16/32/64/128 and divide K");
+    const int64_t tiles = (N / TILE_N) * (K / TILE_K);
+    const int groups = block < 32 ? 64 : 16;
+    if (inl_bytes) *inl_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * 2 * 1024;
+    if (out_bytes) *out_bytes = tiles * ((out_kind == MSQ_PLANE_BF16) ? 8 : 4) * 1024;
+    if (scale_bytes) *scale_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * groups * 16;
+    if (workspace_bytes) *workspace_bytes = N * K * 4 + 2 * N * (K / block) * 4;
+    return MSQ_OK;
+}
+
+// implemented in msq_pack_emit.hip (heavy template instantiations, own TU)
+int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, float* e_out, int* status, int64_t N, int64_t K,
+                   int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb, float std_dev, int rmode,
+                   int flush, int in_kind, int out_kind, void* stream);
+
+int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* scale_plane, int* status_flag,
+                     void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int block, int inlier_fmt,
+                     int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
+                     int flush_fp32_subnorms, void* stream) {
+    int ik, ok;
+    int rc = msq_packed_kinds(inlier_fmt, outlier_fmt, &ik, &ok);
+    if (rc) return rc;
+    int64_t ib, ob, sb, wb;
+    rc = msq_packed_sizes(N, K, block, ik, ok, &ib, &ob, &sb, &wb);
+    if (rc) return rc;
+    if (!W || !out_plane || (ik != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: null buffer");
+    if (!workspace || workspace_bytes < wb) return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: workspace too small (msq_packed_sizes)");
+    uint32_t* codes = (uint32_t*)workspace;
+    float* e_in = (float*)(codes + N * K);
+    float* e_out = e_in + N * (K / block);
+    rc = msq_pack_emit_(W, codes, e_in, e_out, status_flag, N, K, block, inlier_fmt, outlier_fmt, inlier_scale_bits,
+                        outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
+    if (rc) return rc;
+    const int64_t tiles = (N / TILE_N) * (K / TILE_K);
+    const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MSQ_RP(IK, OK) hipLaunchKernelGGL((k_repack<IK, OK>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
+                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag)
+    if (ik == MSQ_PLANE_NONE) MSQ_RP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+    else if (ok == MSQ_PLANE_FP8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+    else if (ok == MSQ_PLANE_BF8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+    else MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+#undef MSQ_RP
+    return check_launch2("msq_outlier_pack(repack)");
+}
+
+int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,
+                       int out_dtype, int64_t N, int64_t K, int block, int in_kind, int out_kind, void* stream) {
+    int rc = msq_packed_sizes(N, K, block, in_kind, out_kind, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (!out_plane || !W_out || (in_kind != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_unpack: null buffer");
+    if (out_dtype != 0 && out_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_outlier_unpack: out_dtype must be 0 (f32) or 2 (bf16)");
+    const int64_t tiles = (N / TILE_N) * (K / TILE_K);
+    const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = block < 32 ? 64 : 16;
+#define MSQ_UP(IK, OK)                                                                                               \
+    do { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)W_out, N, K, groups);              \
+         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t>), grid, blk, 0, st, (const uint8_t*)inl_plane,             \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); } while (0)
+    if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_UP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+    else return fail2(MSQ_ERR_UNSUPPORTED, "msq_outlier_unpack: unsupported plane kinds");
+#undef MSQ_UP
+    return check_launch2("msq_outlier_unpack");
+}
+
+int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
+                     int in_kind, int out_kind, void* stream) {
+    if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: negative M");
+    int rc = msq_packed_sizes(N, K, block, in_kind, out_kind, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (N % BN) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: N must be a multiple of 256");
+    if (!X || !Y || !out_plane || (in_kind != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
+    if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
+    if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
+    const int MT = (int)((M + BM - 1) / BM), NTB = (int)(N / BN);
+    const dim3 grid((unsigned)(MT * NTB)), blk(512);
+    const size_t lds = 2 * A_TILE_BYTES;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = block < 32 ? 64 : 16;
+#define MSQ_GM(IK, OK)                                                                                                 \
+    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
+             hipLaunchKernelGGL((k_qgemm<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
+         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
+             hipLaunchKernelGGL((k_qgemm<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
+    if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+    else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
+#undef MSQ_GM
+    return check_launch2("msq_qlinear_bf16");
+}
+
+}  // extern "C"

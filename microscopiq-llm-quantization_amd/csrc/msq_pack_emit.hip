@@ -1,0 +1,65 @@
+// msq_pack_emit.hip -- first half of msq_outlier_pack: the MicroScopiQ quantiser
+// (utils/quant.py:147-266, blocks along K) emitting per-element plane codes and the
+// per-block exponents.  One block per lane, own translation unit (heavy templates).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+#include "msq_host.h"
+#include "msq_outlier_core.h"
+
+extern "C" void msq_set_error_(const char* msg);
+
+template <int BS>
+__global__ void __launch_bounds__(256)
+k_pack_emit(const float* __restrict__ W, uint32_t* __restrict__ codes, OutlierArgs A, int in_kind, int out_kind) {
+    const int64_t nblocks = A.pre * A.nblk;
+    const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx >= nblocks) return;
+    float a[BS];
+    const float4* src = reinterpret_cast<const float4*>(W + gidx * BS);
+#pragma unroll
+    for (int i = 0; i < BS / 4; ++i) {
+        const float4 v = src[i];
+        a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+    }
+    uint32_t mkw[(BS + 31) / 32];
+    uint32_t cd[BS];
+    float se_in, se_out;
+    const int status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1,
+                                               cd, in_kind, out_kind);
+    uint4* dst = reinterpret_cast<uint4*>(codes + gidx * BS);
+#pragma unroll
+    for (int i = 0; i < BS / 4; ++i) dst[i] = make_uint4(cd[4 * i], cd[4 * i + 1], cd[4 * i + 2], cd[4 * i + 3]);
+    A.e_in[gidx] = se_in;
+    A.e_out[gidx] = se_out;
+    if (status && A.status) atomicOr(A.status, status);
+}
+
+extern "C" int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, float* e_out, int* status, int64_t N,
+                              int64_t K, int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb,
+                              float std_dev, int rmode, int flush, int in_kind, int out_kind, void* stream) {
+    msq_host::FmtInfo fi, fo;
+    if (!msq_host::format_info(inlier_fmt, &fi) || !msq_host::format_info(outlier_fmt, &fo)) {
+        msq_set_error_("msq_outlier_pack: unknown element format"); return MSQ_ERR_BAD_ARG; }
+    if (in_sb <= 0 || out_sb <= 0 || in_sb > 8 || out_sb > 8 || rmode < 0 || rmode > 2) {
+        msq_set_error_("msq_outlier_pack: bad scale bits / rounding mode"); return MSQ_ERR_BAD_ARG; }
+    OutlierArgs A;
+    A.fi = Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm};
+    A.fo = Fmt{fo.kind, fo.ebits, fo.mbits, fo.emax, fo.max_norm};
+    A.in_sb = in_sb; A.out_sb = out_sb; A.k = std_dev; A.rmode = rmode; A.flush = flush; A.variant = 0;
+    A.pre = N; A.axis_len = K; A.post = 1; A.nblk = K / block;
+    A.mask = nullptr; A.e_in = e_in; A.e_out = e_out; A.n_out = nullptr; A.status = status;
+    A.vmean = nullptr; A.vstd = nullptr;
+    const int64_t nblocks = N * A.nblk;
+    const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MSQ_PE(BS) case BS: hipLaunchKernelGGL(k_pack_emit<BS>, grid, blk, 0, st, W, codes, A, in_kind, out_kind); break;
+    switch (block) { MSQ_PE(8) MSQ_PE(16) MSQ_PE(32) MSQ_PE(64) MSQ_PE(128)
+        default: msq_set_error_("msq_outlier_pack: block must be 8/16/32/64/128"); return MSQ_ERR_UNSUPPORTED; }
+#undef MSQ_PE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}

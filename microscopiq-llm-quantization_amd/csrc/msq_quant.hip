@@ -182,102 +182,7 @@ k_reduce_inner(const float* __restrict__ in, float* __restrict__ out, int64_t ou
     if (lane == 0) out[row] = acc;
 }
 
-// ===========================================================================
-// MicroScopiQ outlier-aware fake-quant, one block per lane.
-// ===========================================================================
-struct OutlierArgs {
-    Fmt fi, fo;
-    int in_sb, out_sb;
-    float k;          // std_dev as fp32 (python scalar * fp32 tensor)
-    int rmode, flush, variant;
-    int64_t pre, axis_len, post, nblk;
-    uint8_t* mask;
-    float* e_in;
-    float* e_out;
-    int8_t* n_out;
-    int* status;
-    const float* vmean;   // variant 1 statistics [pre, BS, post]
-    const float* vstd;
-};
-
-// per-block maths on a register-resident block.  a[] in, result written back to a[];
-// mk[] receives the 0/1 mask.  Returns status bits.
-template <int BS>
-MSQ_D int outlier_block(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
-                        const OutlierArgs& A, int order, const float* vmean, const float* vstd,
-                        int64_t vstride) {
-    int status = 0;
-    float lo, hi;
-    if (A.variant == 0) {
-        float ab[BS];
-#pragma unroll
-        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(a[b]);
-        float s;
-        if (order == 1) s = sum_inner8<BS>(ab);
-        else if (order == 2) s = sum_ilp4<BS>(ab);
-        else s = sum_cascade<BS>(ab);
-        const float mean = s / (float)BS;                    // utils/quant.py:477
-        const float sd = std_welford<BS>(ab, 0);             // :478
-        const float ks = A.k * sd;
-        lo = mean - ks; hi = mean + ks;                      // :489-490
-    }
-#pragma unroll
-    for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
-    float mx_in = 0.f;
-    float inl[BS];
-#pragma unroll
-    for (int b = 0; b < BS; ++b) {
-        if (A.variant != 0) {
-            const float mean = vmean[b * vstride], sd = vstd[b * vstride];
-            const float ks = A.k * sd;
-            lo = mean - ks; hi = mean + ks;
-        }
-        const bool m = (a[b] < lo) || (a[b] > hi);           // :492 on the SIGNED value
-        mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
-        const float mf = m ? 1.f : 0.f;
-        inl[b] = a[b] * (1.0f - mf);                         // :192
-        a[b] = a[b] * mf;                                    // :193 (a[] now holds the outlier part)
-        const float t = __builtin_fabsf(inl[b]);
-        mx_in = (t > mx_in || t != t) ? t : mx_in;
-    }
-    float se_in = shared_exp_of_max(mx_in);                  // :196-198
-    const bool fl = A.flush && !(se_in > -127.f);            // :201-202
-    se_in = se_in - (float)A.fi.emax;                        // :207
-    se_in = clamp_scale_exp(se_in, A.in_sb, A.variant);      // :208-211
-    const float sc_in = exp2f_int(se_in);
-    const float rc_in = exp2f_int(-se_in);                   // x / 2^e == x * 2^-e exactly
-    float mx_out = 0.f;
-#pragma unroll
-    for (int b = 0; b < BS; ++b) {
-        float v = inl[b];
-        if (fl) v = v * 0.f;
-        v = v * rc_in;                                       // :214
-        a[b] = a[b] * sc_in;                                 // :216
-        v = quant_elem(v, A.fi, A.rmode);                    // :218-221
-        v = v * sc_in;                                       // :224
-        if (v != v || a[b] != a[b]) status |= MSQ_STATUS_NAN; // :225-226
-        inl[b] = v;
-        const float t = __builtin_fabsf(a[b]);
-        mx_out = (t > mx_out || t != t) ? t : mx_out;
-    }
-    float se_out = shared_exp_of_max(mx_out);                // :229-231
-    if (se_out != se_out) status |= MSQ_STATUS_NAN;
-    se_out = se_out - (float)A.fo.emax;                      // :237
-    se_out = clamp_scale_exp(se_out, A.out_sb, A.variant);   // :239-242
-    if (se_out != se_out) status |= MSQ_STATUS_NAN;          // :244
-    const float sc_out = exp2f_int(se_out);
-    const float rc_out = exp2f_int(-se_out);
-#pragma unroll
-    for (int b = 0; b < BS; ++b) {
-        float o = a[b] * rc_out;                             // :247
-        if (o != o) status |= MSQ_STATUS_NAN;                // :250
-        o = quant_elem(o, A.fo, A.rmode);                    // :252-255
-        o = (o * sc_out) * rc_in;                            // :258
-        a[b] = inl[b] + o;                                   // :262
-    }
-    se_in_o = se_in; se_out_o = se_out;
-    return status;
-}
+#include "msq_outlier_core.h"
 
 template <int BS>
 MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS + 31) / 32], float se_in,
@@ -480,6 +385,7 @@ static int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
 }
+extern "C" void msq_set_error_(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
