@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- fused unpack-dequant-GEMM throughput (BASELINE.json metric) on MI355X.
+
+A "step" is one pass of the hot path over one synthetic batch: Y[M,N] = X[M,K] . Wq^T with the
+packed MicroScopiQ W4 weight dequantised inside the MFMA kernel (msq_qlinear_bf16).
+Workload (BASELINE.json configs[1], north_star "[B.S, H] x [H, 4H]"): Llama-2-7B shape
+H = 4096, M = B.S = 2048 tokens, W = [4H, H] = [16384, 4096], MX-FP4 (e2m1) inliers + 8-bit
+outliers (posit8_es1 by default, --outlier fp8_e4m3 for the all-HW-convert variant), block 32
+along K, scale bits 8/8, std_dev 2, heavy-tailed synthetic weights (0.5 % of entries x16).
+
+N > 1: the 7B path does not shard ("7B = replicas only"): every rank runs an
+independent replica on its own GPU, no data-path collective, value = sum over ranks ("weak").
+--workload llama70b_rowparallel shards K over the ranks with one RCCL all-reduce per step.
+
+Prints ONE JSON line (rank 0).  The timed region starts with all inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_weight(N, K, dev, seed=0):
+    import torch
+    g = torch.Generator(device=dev).manual_seed(seed)
+    W = torch.randn(N, K, generator=g, device=dev) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev) < 0.005] *= 16.0
+    return W
+
+
+def cpu_baseline(M, N, K, bs, fi, fo):
+    """The oracle (a scalar C port of the reference's CPU fake-quant + the dense linear it feeds)
+    timed on the host on a bounded sample of the same workload.  Reported, never optimised."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.RandomState(0)
+    rows = N                                     # fake-quant sample: the whole [N, K] weight (~10 s)
+    Ws = (rng.randn(rows, K) * 0.02).astype(np.float32)
+    Ws[rng.rand(rows, K) < 0.005] *= 16
+    t0 = time.perf_counter()
+    r = O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs)
+    t_q = time.perf_counter() - t0
+    ms, ns = 512, 1024                           # linear sample: [512, K] x [1024, K]^T (~2-4 s)
+    Xs = rng.randn(ms, K).astype(np.float32)
+    t0 = time.perf_counter()
+    O.linear(Xs, r["out"][:ns])
+    t_l = time.perf_counter() - t0
+    # the reference itself runs torch F.linear on the host cores (number_system/mx/linear.py:91)
+    torch_tf, threads = None, None
+    try:
+        import torch
+        threads = torch.get_num_threads()
+        Xt = torch.randn(1024, K); Wt = torch.from_numpy(r["out"])
+        torch.nn.functional.linear(Xt, Wt)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.nn.functional.linear(Xt, Wt)
+        torch_tf = 3 * 2.0 * 1024 * rows * K / (time.perf_counter() - t0) / 1e12
+        del Wt
+    except Exception:
+        pass
+    return {
+        "value": 2.0 * ms * ns * K / t_l / 1e12, "unit": "TFLOP/s", "cores": 1, "kind": "port",
+        "sample": "oracle dense linear X[%d,%d].Wq[%d,%d]^T (double accumulate, 1 thread) after oracle "
+                  "fake-quant of W[%d,%d]" % (ms, K, ns, K, rows, K),
+        "fakequant_s_per_weight": t_q * (N / rows),
+        "fakequant_sample_s": t_q,
+        "torch_cpu_fp32_linear_tflops": torch_tf, "torch_cpu_threads": threads,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--H", type=int, default=4096)
+    ap.add_argument("--inlier", default="fp4_e2m1")
+    ap.add_argument("--outlier", default="posit8_es1")
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
+                    choices=["llama7b_w4_fused_gemm", "llama70b_rowparallel"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from msq import qlinear
+
+    M = args.M
+    if args.workload == "llama70b_rowparallel":
+        H, N = 8192, 8192                                  # Llama-2-70B down_proj: K = 28672 split over ranks
+        K_full = 28672
+        if K_full % (world * 64):
+            raise SystemExit("K=28672 must split into 64-multiples over the ranks")
+        K = K_full // world
+        name = "Llama-2-70B W4 row-parallel QuantLinear down_proj [8192 x 28672], K split over %d GPU(s)" % world
+    else:
+        H = args.H
+        N, K = 4 * H, H
+        name = ("Llama-2-7B MicroScopiQ W4 (MX-FP4 inliers + %s outliers), fused dequant-GEMM "
+                "X[%d,%d] x W[%d,%d]^T" % (args.outlier, M, K, N, K))
+    W = synth_weight(N, K, dev, seed=rank)
+    P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block)
+    del W
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    torch.cuda.synchronize()
+
+    def step():
+        y = qlinear.qlinear(X, P, None, torch.bfloat16)
+        if args.workload == "llama70b_rowparallel" and world > 1:
+            dist.all_reduce(y)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    flops_step = 2.0 * M * N * K                            # algorithmic: dequant flops not counted
+    total_flops = flops_step * args.steps * world
+    value = total_flops / wall / 1e12
+    achieved = flops_step / (kern_ms * 1e-3) / 1e12
+    out = {
+        "metric": "fused dequant-GEMM TFLOPS (% MFMA peak) + PPL delta, Llama-7B W4 1xMI355X",
+        "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": name, "M": M, "N": N, "K": K, "block": args.block, "inlier": args.inlier,
+                   "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element,
+                   "parallelism": ("replicas x%d" % world) if args.workload != "llama70b_rowparallel"
+                   else ("row-parallel K/%d + RCCL all-reduce" % world)},
+        "pct_of_mfma_peak": 100.0 * (value / world) / PEAK_BF16_TFLOPS,
+        "ppl_delta": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "kernel": "k_qgemm", "kernel_ms": kern_ms, "flops_per_launch": flops_step},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,11 @@ int msq_quantize_elemwise(const void* in, void* out, int64_t n, int dtype, int b
                           float max_norm, int rmode, int saturate_normals, int allow_denorm,
                           void* stream);
 
+/* NEW: elementwise round to a NAMED format id (posit<n,es> included) with the saturating,
+ * denorm-keeping codec MicroScopiQ uses (elemwise_ops.py:84-174 with saturate_normals=True,
+ * allow_denorm=True; posit: number_system/posit/Posit.py:221-385 round-to-nearest-even). */
+int msq_quantize_format(const float* in, float* out, int64_t n, int fmt, int rmode, void* stream);
+
 /* replaces quantize_mx_func_cuda (cpp/funcs.cpp:138-159, cpp/mx.cu:13-72):
  * max_values is [pre, post] = max |.| over the whole axis (the caller has already
  * reshaped to blocks, mx_ops.py:397-415). */

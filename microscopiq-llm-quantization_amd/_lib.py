@@ -21,6 +21,7 @@ _SIGS = {
     "msq_format_id": (C.c_int, [C.c_char_p]),
     "msq_format_params": (C.c_int, [_i32] + [C.POINTER(_i32)] * 3 + [C.POINTER(_f32)] * 2 + [C.POINTER(_i32)]),
     "msq_quantize_elemwise": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "msq_quantize_format": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msq_quantize_mx": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_quantize_mx_by_tile": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_reduce_sum_inner": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),

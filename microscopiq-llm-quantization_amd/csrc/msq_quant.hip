@@ -64,6 +64,15 @@ k_elemwise_16(const T* __restrict__ in, T* __restrict__ out, int64_t n, int bits
         IO<T>::st(out, i, quant_bits(IO<T>::ld(in, i), bits, ebits, max_norm, rmode, saturate, allow_denorm));
 }
 
+// elementwise quantise to a NAMED format (posit<n,es> included) with the saturating,
+// denorm-keeping codec the MicroScopiQ quantiser uses (utils/quant.py:218-221)
+__global__ void __launch_bounds__(256)
+k_elem_format(const float* __restrict__ in, float* __restrict__ out, int64_t n, Fmt f, int rmode) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = quant_elem(in[i], f, rmode);
+}
+
 // ===========================================================================
 // MX shared scale with the native semantics (cpp/shared_exp.cuh:14-53): NaN scale on
 // overflow, 2^-emax floor, subnormal/NaN scale mantissa bit.
@@ -460,6 +469,17 @@ int msq_quantize_elemwise(const void* in, void* out, int64_t n, int dtype, int b
                            rmode, saturate_normals, allow_denorm);
     } else return fail(MSQ_ERR_UNSUPPORTED, "msq_quantize_elemwise: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
     return check_launch("msq_quantize_elemwise");
+}
+
+int msq_quantize_format(const float* in, float* out, int64_t n, int fmt, int rmode, void* stream) {
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_format: null buffer");
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_format: bad rounding mode");
+    msq_host::FmtInfo fi;
+    if (!msq_host::format_info(fmt, &fi)) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_format: unknown element format");
+    if (n == 0) return MSQ_OK;
+    hipLaunchKernelGGL(k_elem_format, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, in, out, n,
+                       Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm}, rmode);
+    return check_launch("msq_quantize_format");
 }
 
 int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_t pre, int64_t axis_len,

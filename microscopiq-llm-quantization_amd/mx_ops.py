@@ -1,0 +1,89 @@
+"""MX block quantisation -- the surface of number_system/mx/mx_ops.py (_quantize_mx :332,
+quantize_mx_op :460, _quantize_mx_outlier_v1 :210, quantize_mx_outlier_op :492), on the GPU.
+
+``_quantize_mx`` follows the upstream OCP-MX / native-kernel semantics (cpp/mx.cuh), i.e.
+WITHOUT the `+1e-6` that the reference added at mx_ops.py:444 (a reference defect that
+breaks three of its own KATs)."""
+import torch
+
+from . import funcs
+from ._lib import MsqError
+from .formats import ElemFormat, RoundingMode, _get_format_params
+from .quant import VARIANT_MXOPS, outlier_fakequant
+from .specs import mx_assert_test
+
+
+def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None, block_size=0, round="nearest",
+                 flush_fp32_subnorms=False, custom_cuda=False):
+    """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile."""
+    if elem_format == None:
+        return A
+    assert (scale_bits > 0)
+    if shared_exp_method != "max":
+        raise Exception("Unrecognized shared exponent selection method %s" % (shared_exp_method))
+    if round not in RoundingMode.string_enums():
+        raise Exception("Unrecognized round method %s" % (round))
+    axes = [axes] if type(axes) == int else axes
+    axes = [x + A.ndim if x < 0 else x for x in axes]
+    if len(axes) != 1:
+        raise MsqError("the MI355X kernels quantise along exactly one axis (got %r)" % (axes,))
+    ebits, mbits, emax, max_norm, _ = _get_format_params(elem_format)
+    axis = axes[0]
+    tile = block_size if block_size > 0 else A.shape[axis]
+    x = A.contiguous()
+    y = funcs.quantize_mx_by_tile_func_cuda(x.float() if x.dtype != torch.float32 else x, scale_bits, ebits, mbits,
+                                            max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]))
+    return y if A.dtype == torch.float32 else y.to(A.dtype)
+
+
+def quantize_mx_op(A, mx_specs, elem_format=None, block_size=None, axes=None, round="nearest",
+                   expand_and_reshape=False):
+    """mx_ops.py:460-490"""
+    mx_assert_test(mx_specs)
+    if elem_format == None:
+        return A
+    elif type(elem_format) is str:
+        elem_format = ElemFormat.from_str(elem_format)
+    if block_size == None:
+        block_size = mx_specs["block_size"]
+    scale_bits = 8 if mx_specs["scale_bits"] == 0 else mx_specs["scale_bits"]
+    return _quantize_mx(A, scale_bits, elem_format, block_size=block_size, axes=axes, round=round,
+                        shared_exp_method=mx_specs["shared_exp_method"],
+                        flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], custom_cuda=mx_specs["custom_cuda"])
+
+
+def _quantize_mx_outlier_v1(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
+                            shared_exp_method="max", std_dev=5, axes=None, block_size=0, round="nearest",
+                            flush_fp32_subnorms=False, custom_cuda=False):
+    """mx_ops.py:210-330 -- the older outlier quantiser MXLinear uses: statistics of the signed
+    values over the block-COUNT axis with unbiased std (:62-66,:248), clamp to -scale_emax (:273)."""
+    if inlier_elem_format == None:
+        return A
+    if shared_exp_method != "max":
+        raise Exception("Unrecognized shared exponent selection method %s" % (shared_exp_method))
+    axes = [axes] if type(axes) == int else axes
+    axes = [x + A.ndim if x < 0 else x for x in axes]
+    if len(axes) != 1:
+        raise MsqError("the MI355X kernels quantise along exactly one axis (got %r)" % (axes,))
+    return outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
+                             std_dev, axes[0], block_size, round, flush_fp32_subnorms, variant=VARIANT_MXOPS)["out"]
+
+
+def quantize_mx_outlier_op(A, mx_specs, inlier_elem_format=None, outlier_elem_format=None, block_size=None,
+                           axes=None, round="nearest", expand_and_reshape=False):
+    """mx_ops.py:492-533"""
+    mx_assert_test(mx_specs)
+    if inlier_elem_format == None or outlier_elem_format == None:
+        return A
+    if type(inlier_elem_format) is str:
+        inlier_elem_format = ElemFormat.from_str(inlier_elem_format)
+    if type(outlier_elem_format) is str:
+        outlier_elem_format = ElemFormat.from_str(outlier_elem_format)
+    if block_size == None:
+        block_size = mx_specs["block_size"]
+    inlier_scale_bits = 4 if mx_specs["scale_bits"] == 0 else mx_specs["scale_bits"]     # mx_ops.py:519-524
+    return _quantize_mx_outlier_v1(A, inlier_scale_bits, inlier_scale_bits, inlier_elem_format, outlier_elem_format,
+                                   block_size=block_size, axes=axes, round=round,
+                                   shared_exp_method=mx_specs["shared_exp_method"],
+                                   flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"],
+                                   custom_cuda=mx_specs["custom_cuda"])

@@ -1,0 +1,244 @@
+"""QuantLinear -- the packed MicroScopiQ Linear the reference only sketches
+(`make_quant3` / `Quant3Linear` are called at llm/opt.py:255-294 but defined nowhere).
+
+Contract: for x in bf16, ``QuantLinear.forward(x)`` equals ``F.linear(x, Wq)`` where
+``Wq = quantize_mx_outlier_v1(W, ...)`` is the reference fake-quant (utils/quant.py:147-266)
+-- the dequantised values are exact in bf16, only the fp32 summation order differs.
+The weight lives in HBM as GEMM-ready tile-major planes (include/msq.h "MSQ-T1") and is
+dequantised inside the MFMA kernel (csrc/msq_gemm.hip), never materialised.
+
+Row-parallel (K-split) sharding for the 70B configuration: RowParallelQuantLinear keeps
+W[:, rank*K/G:(rank+1)*K/G] packed on every rank and all-reduces the partial outputs over
+RCCL.  Blocks run along K, so a K split on a multiple of the block size
+never cuts a block and every shard's masks / scales equal the unsharded ones.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ._lib import MsqError, check, current_stream, lib, ptr
+from .formats import RoundingMode, format_id
+
+_PLANE_NONE = 0
+
+
+class PackedWeight:
+    """Device buffers + metadata of one packed [N, K] weight."""
+
+    def __init__(self, inl, out, scl, N, K, block, in_kind, out_kind):
+        self.inl, self.out, self.scl = inl, out, scl
+        self.N, self.K, self.block, self.in_kind, self.out_kind = N, K, block, in_kind, out_kind
+
+    @property
+    def nbytes(self):
+        return sum(int(t.numel()) for t in (self.inl, self.out, self.scl) if t is not None)
+
+    @property
+    def bits_per_element(self):
+        return 8.0 * self.nbytes / (self.N * self.K)
+
+
+def packed_kinds(inlier_elem_format, outlier_elem_format):
+    ik, ok = C.c_int(), C.c_int()
+    check(lib().msq_packed_kinds(format_id(inlier_elem_format), format_id(outlier_elem_format), C.byref(ik),
+                                 C.byref(ok)), "msq_packed_kinds")
+    return ik.value, ok.value
+
+
+def packed_sizes(N, K, block, in_kind, out_kind):
+    ib, ob, sb, wb = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib().msq_packed_sizes(N, K, block, in_kind, out_kind, C.byref(ib), C.byref(ob), C.byref(sb), C.byref(wb)),
+          "msq_packed_sizes")
+    return ib.value, ob.value, sb.value, wb.value
+
+
+def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp4_e2m1",
+                outlier_elem_format="fp8_e4m3", std_dev=2, block_size=32, round="nearest",
+                flush_fp32_subnorms=False):
+    """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it."""
+    if not W.is_cuda:
+        raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
+    if W.ndim != 2:
+        raise MsqError("pack_weight expects a 2-D [out_features, in_features] weight")
+    Wf = W.detach().contiguous().float()
+    N, K = Wf.shape
+    ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format)
+    ib, ob, sb, wb = packed_sizes(N, K, block_size, ik, ok)
+    dev = Wf.device
+    inl = torch.empty(ib, dtype=torch.uint8, device=dev) if ib else None
+    out = torch.empty(ob, dtype=torch.uint8, device=dev)
+    scl = torch.empty(sb, dtype=torch.uint8, device=dev) if sb else None
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().msq_outlier_pack(ptr(Wf), ptr(inl), ptr(out), ptr(scl), ptr(status), ptr(ws), wb, N, K, block_size,
+                                 format_id(inlier_elem_format), format_id(outlier_elem_format),
+                                 int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
+                                 int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), current_stream(dev)),
+          "msq_outlier_pack")
+    st = int(status.item())
+    if st & 1:
+        raise AssertionError("shared_exp contains NaN values (scale overflow) while packing")
+    if st & 2:
+        raise MsqError("pack_weight: a value is not exactly code * 2^scale in the packed format "
+                       "(degenerate block scale); keep this layer unpacked")
+    return PackedWeight(inl, out, scl, N, K, block_size, ik, ok)
+
+
+def unpack_weight(P, dtype=torch.float32):
+    """Dense dequantised weight [N, K] (exact in f32 and bf16)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise MsqError("unpack_weight: dtype must be float32 or bfloat16")
+    W = torch.empty(P.N, P.K, dtype=dtype, device=P.out.device)
+    check(lib().msq_outlier_unpack(ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(W), 0 if dtype == torch.float32 else 2,
+                                   P.N, P.K, P.block, P.in_kind, P.out_kind, current_stream(W.device)),
+          "msq_outlier_unpack")
+    return W
+
+
+def qlinear(x, P, bias=None, out_dtype=torch.bfloat16):
+    """y = x . Wq^T (+ bias): the fused unpack-dequant-GEMM.  x: [..., K] (cast to bf16)."""
+    if not x.is_cuda:
+        raise MsqError("qlinear needs CUDA/HIP tensors (no CPU fallback)")
+    K = x.shape[-1]
+    if K != P.K:
+        raise MsqError("qlinear: in_features mismatch (%d vs %d)" % (K, P.K))
+    xb = x.reshape(-1, K)
+    if xb.dtype != torch.bfloat16:
+        xb = xb.to(torch.bfloat16)
+    xb = xb.contiguous()
+    M = xb.shape[0]
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise MsqError("qlinear: out_dtype must be float32 or bfloat16")
+    y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
+    b = None
+    if bias is not None:
+        b = bias.detach().float().contiguous()
+    check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
+                                 0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
+                                 current_stream(x.device)), "msq_qlinear_bf16")
+    return y.reshape(*x.shape[:-1], P.N)
+
+
+class QuantLinear(nn.Module):
+    """Packed Linear.  ``pack(linear, quantizer)`` consumes an nn.Linear and an MXQuantizer
+    (the GPTQ-style contract implied by llm/opt.py:255-264); state_dict round-trips the
+    packed planes (llm/opt.py:510-512, :290)."""
+
+    def __init__(self, in_features, out_features, bias=True, block_size=32, inlier_elem_format="fp4_e2m1",
+                 outlier_elem_format="fp8_e4m3", out_dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.block_size = block_size
+        self.inlier_elem_format, self.outlier_elem_format = inlier_elem_format, outlier_elem_format
+        self.out_dtype = out_dtype
+        ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format)
+        ib, ob, sb, _ = packed_sizes(out_features, in_features, block_size, ik, ok)
+        self.in_kind, self.out_kind = ik, ok
+        self.register_buffer("inl_plane", torch.zeros(ib, dtype=torch.uint8, device=device))
+        self.register_buffer("out_plane", torch.zeros(ob, dtype=torch.uint8, device=device))
+        self.register_buffer("scale_plane", torch.zeros(sb, dtype=torch.uint8, device=device))
+        if bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, device=device))
+        else:
+            self.bias = None
+
+    def _packed(self):
+        return PackedWeight(self.inl_plane if self.inl_plane.numel() else None, self.out_plane,
+                            self.scale_plane if self.scale_plane.numel() else None, self.out_features,
+                            self.in_features, self.block_size, self.in_kind, self.out_kind)
+
+    def pack(self, linear, quantizer=None):
+        q = quantizer
+        kw = dict(inlier_elem_format=self.inlier_elem_format, outlier_elem_format=self.outlier_elem_format,
+                  block_size=self.block_size)
+        if q is not None:
+            axes = q.axes if isinstance(q.axes, (list, tuple)) else [q.axes]
+            if [a % 2 for a in axes] != [1]:
+                raise MsqError("QuantLinear packs blocks along in_features (axes=[-1]); "
+                               "use quantize_mx_outlier_v1 + a bf16 plane for axes=[0]")
+            kw.update(inlier_scale_bits=q.inlier_scale_bits, outlier_scale_bits=q.outlier_scale_bits,
+                      inlier_elem_format=q.inlier_elem_format, outlier_elem_format=q.outlier_elem_format,
+                      std_dev=q.std_dev, block_size=q.block_size, round=q.round,
+                      flush_fp32_subnorms=q.flush_fp32_subnorms)
+        P = pack_weight(linear.weight.data, **kw)
+        if (P.in_kind, P.out_kind, P.block) != (self.in_kind, self.out_kind, self.block_size):
+            raise MsqError("quantizer formats do not match the formats this QuantLinear was built for")
+        if P.inl is not None:
+            self.inl_plane.copy_(P.inl)
+            self.scale_plane.copy_(P.scl)
+        self.out_plane.copy_(P.out)
+        if self.bias is not None and linear.bias is not None:
+            self.bias.copy_(linear.bias.data.float())
+        return self
+
+    @classmethod
+    def from_linear(cls, linear, quantizer=None, **kw):
+        if quantizer is not None:
+            kw.setdefault("block_size", quantizer.block_size)
+            kw.setdefault("inlier_elem_format", quantizer.inlier_elem_format)
+            kw.setdefault("outlier_elem_format", quantizer.outlier_elem_format)
+        m = cls(linear.in_features, linear.out_features, linear.bias is not None, device=linear.weight.device, **kw)
+        return m.pack(linear, quantizer)
+
+    def dequantize(self, dtype=torch.float32):
+        return unpack_weight(self._packed(), dtype)
+
+    def forward(self, x):
+        return qlinear(x, self._packed(), self.bias, self.out_dtype).to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
+
+
+def make_quant(module, quantizers, name=''):
+    """Swap every nn.Linear whose qualified name is in `quantizers` (name -> MXQuantizer) for a
+    packed QuantLinear (the make_quant3 contract of llm/opt.py:258-264)."""
+    for attr in list(dict(module.named_children()).keys()):
+        child = getattr(module, attr)
+        full = name + '.' + attr if name != '' else attr
+        if isinstance(child, nn.Linear) and full in quantizers:
+            setattr(module, attr, QuantLinear.from_linear(child, quantizers[full]))
+        else:
+            make_quant(child, quantizers, full)
+    return module
+
+
+class RowParallelQuantLinear(nn.Module):
+    """K-split QuantLinear: rank r owns in_features [r*K/G, (r+1)*K/G); forward all-reduces the
+    fp32 partial outputs (torch.distributed: backend "nccl" == RCCL over xGMI on MI355X, "gloo"
+    on CPU for tests -- there the partial product must be supplied by `partial_fn`)."""
+
+    def __init__(self, shard, world_size, rank, process_group=None, partial_fn=None):
+        super().__init__()
+        self.shard = shard                    # QuantLinear over the local K slice (bias only on rank 0)
+        self.world_size, self.rank, self.process_group = world_size, rank, process_group
+        self.partial_fn = partial_fn
+
+    @staticmethod
+    def shard_bounds(in_features, world_size, rank, block_size):
+        """[k0, k1) of a rank; the split must fall on a 64-multiple (tile) and a block multiple."""
+        if in_features % world_size:
+            raise MsqError("in_features must divide evenly over the ranks")
+        per = in_features // world_size
+        if per % 64 or per % block_size:
+            raise MsqError("per-rank in_features (%d) must be a multiple of 64 and of the block size" % per)
+        return rank * per, (rank + 1) * per
+
+    @classmethod
+    def from_linear(cls, linear, quantizer, world_size, rank, process_group=None):
+        k0, k1 = cls.shard_bounds(linear.in_features, world_size, rank, quantizer.block_size)
+        local = nn.Linear(k1 - k0, linear.out_features, bias=(linear.bias is not None and rank == 0),
+                          device=linear.weight.device, dtype=linear.weight.dtype)
+        with torch.no_grad():
+            local.weight.copy_(linear.weight[:, k0:k1])
+            if local.bias is not None:
+                local.bias.copy_(linear.bias)
+        return cls(QuantLinear.from_linear(local, quantizer, out_dtype=torch.float32), world_size, rank,
+                   process_group)
+
+    def forward(self, x_local):
+        """x_local: [..., K/G] (this rank's slice of the activations)."""
+        import torch.distributed as dist
+        y = self.partial_fn(x_local) if self.partial_fn is not None else self.shard(x_local)
+        y = y.float()
+        if self.world_size > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.process_group)
+        return y

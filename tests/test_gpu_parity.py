@@ -1,0 +1,384 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI via
+the Python shim, against (1) the golden fixtures generated from the imported reference, (2) the
+CPU oracle on seeded inputs, (3) size-independent properties at BASELINE.json's full sizes.
+Integer / bit work (masks, codes, exponents, fp32 fake-quant values) is compared bit-exact;
+floating-point GEMM output within the tolerance written next to each check."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def msq():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import msq as m
+    m._lib.lib()          # fail loudly if libmsq_hip.so is missing
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _eq(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+# ---------------------------------------------------------------- a6/a4/a5/a7 outlier fake-quant
+def test_outlier_fakequant_golden_bit_exact(msq):
+    z = np.load(os.path.join(G, "outlier_fakequant.npz"))
+    meta = json.load(open(os.path.join(G, "outlier_fakequant_meta.json")))
+    n = 0
+    for key, m in sorted(meta.items()):
+        cname, tname = key.split("|")
+        A = z[f"in|{tname}"]
+        if "assert" in m:
+            continue
+        isb, osb, ifmt, ofmt, sd, ax, bs, rnd = m["cfg"]
+        r = msq.quant.outlier_fakequant(_t(A), isb, osb, ifmt, ofmt, sd, ax[0], bs, rnd, want_mask=True)
+        out = r["out"].cpu().numpy(); mask = r["mask"].cpu().numpy()
+        assert (mask == z[f"mask|{key}"]).all(), (key, "mask bits differ", int((mask != z[f"mask|{key}"]).sum()))
+        ok = _eq(out, z[f"out|{key}"])
+        assert ok.all(), (key, int((~ok).sum()))
+        assert (np.signbit(out) == np.signbit(z[f"out|{key}"]))[out == 0].all(), key
+        # the reference-named entry point returns the same tensor
+        y = msq.quant.quantize_mx_outlier_v1(_t(A), isb, osb, ifmt, ofmt, "max", sd, ax, bs, rnd, False, True)
+        assert torch.equal(y, r["out"])
+        n += 1
+    assert n >= 80
+
+
+def test_reference_nan_assert_is_raised(msq):
+    z = np.load(os.path.join(G, "outlier_fakequant.npz"))
+    A = z["in|big"]                      # the reference raised AssertionError for this config (scale overflow)
+    with pytest.raises(AssertionError):
+        msq.quant.quantize_mx_outlier_v1(_t(A), 4, 5, "fp6_e2m3", "fp8_e4m3", "max", 2, [0], 8)
+
+
+def test_hessian_num_outliers_golden(msq):
+    z = np.load(os.path.join(G, "outlier_fakequant.npz"))
+    for tname in ("gauss", "heavy", "ragged"):
+        col = z[f"in|{tname}"][:, 5:6]
+        q, n_out = msq.quant.quantize_mx_outlier_hessian(_t(col), 8, 8, "int2", "fp4", "max", 2, [0], 16,
+                                                         "nearest", False, False, False)
+        assert _eq(q.cpu().numpy(), z[f"hess_out|{tname}"]).all()
+        assert n_out.dtype == torch.int8 and (n_out.cpu().numpy() == z[f"hess_nout|{tname}"]).all()
+
+
+@pytest.mark.parametrize("shape,axis,bs", [((64, 96), 0, 16), ((64, 96), -1, 32), ((20, 40), 0, 16), ((20, 40), -1, 32),
+                                           ((2, 40, 64), 1, 16), ((512, 1), 0, 16), ((64, 100), 0, 32), ((64, 6), 0, 8),
+                                           ((48, 128), -1, 64), ((128, 64), 0, 128), ((300, 4096), 0, 16),
+                                           ((129, 4096), -1, 32), ((16, 16), 0, 16), ((1, 32), -1, 32)])
+@pytest.mark.parametrize("fi,fo", [("fp4_e2m1", "fp8_e4m3"), ("int2", "fp4"), ("fp4_e2m1", "posit8_es1"),
+                                   ("fp6_e3m2", "fp8_e5m2"), ("int4", "int8")])
+def test_outlier_fakequant_vs_oracle(msq, O, shape, axis, bs, fi, fo):
+    g = torch.Generator().manual_seed(hash((shape, axis, bs, fi, fo)) % (2 ** 31))
+    A = torch.randn(*shape, generator=g) * 0.02
+    A[torch.rand(*shape, generator=g) < 0.01] *= 20
+    if A.numel() > 64:
+        A.view(-1)[7] = 0.0
+    r = msq.quant.outlier_fakequant(A.to(dev()), 8, 8, fi, fo, 2, axis, bs, want_mask=True, want_exps=True)
+    o = O.outlier_fakequant(A.numpy(), 8, 8, fi, fo, 2, axis, bs)
+    assert (r["mask"].cpu().numpy() == o["mask"]).all()
+    assert _eq(r["out"].cpu().numpy(), o["out"]).all()
+    assert _eq(r["e_in"].cpu().numpy(), o["e_in"]).all() and _eq(r["e_out"].cpu().numpy(), o["e_out"]).all()
+
+
+def test_outlier_edge_cases_vs_oracle(msq, O):
+    cases = {
+        "zeros": np.zeros((32, 64), np.float32),
+        "one_hot": np.eye(32, 64, dtype=np.float32) * 3.0,
+        "all_negative": -np.abs(np.random.RandomState(0).randn(32, 64)).astype(np.float32),
+        "all_equal": np.full((32, 64), 0.125, np.float32),
+        "tiny": (np.random.RandomState(1).randn(32, 64) * 1e-30).astype(np.float32),
+        "subnormal": (np.random.RandomState(2).randn(32, 64) * 1e-41).astype(np.float32),
+        "huge_ok": (np.random.RandomState(3).randn(32, 64) * 1e20).astype(np.float32),
+        "std_dev_frac": (np.random.RandomState(4).randn(32, 64)).astype(np.float32),
+    }
+    for name, A in cases.items():
+        for axis, bs in ((0, 16), (-1, 32)):
+            for fi, fo in (("fp4_e2m1", "fp8_e4m3"), ("int2", "fp4")):
+                sd = 1.7 if name == "std_dev_frac" else 2
+                o = O.outlier_fakequant(A, 8, 8, fi, fo, sd, axis, bs)
+                if o["status"] & 1:
+                    with pytest.raises(AssertionError):
+                        msq.quant.outlier_fakequant(_t(A), 8, 8, fi, fo, sd, axis, bs)
+                    continue
+                r = msq.quant.outlier_fakequant(_t(A), 8, 8, fi, fo, sd, axis, bs, want_mask=True)
+                assert (r["mask"].cpu().numpy() == o["mask"]).all(), (name, axis, fi)
+                assert _eq(r["out"].cpu().numpy(), o["out"]).all(), (name, axis, fi)
+
+
+def test_rounding_modes_and_flush_vs_oracle(msq, O):
+    A = (np.random.RandomState(5).randn(64, 128) * 0.05).astype(np.float32)
+    for rnd in ("nearest", "floor", "even"):
+        for flush in (False, True):
+            o = O.outlier_fakequant(A, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32, rnd, flush)
+            r = msq.quant.outlier_fakequant(_t(A), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32, rnd, flush)
+            assert _eq(r["out"].cpu().numpy(), o["out"]).all(), (rnd, flush)
+    with pytest.raises(Exception):
+        msq.quant.quantize_mx_outlier_v1(_t(A), 8, 8, "fp4", "fp8_e4m3", "max", 2, [-1], 32, "dither")
+
+
+def test_low_precision_inputs_documented_delta(msq):
+    """fp16 / bf16 weights (RTN path, llm/llama.py:238): computed in fp32 here, in the tensor dtype
+    by the reference.  Tolerance: at most 2% of elements may differ and by at most one inlier step."""
+    z = np.load(os.path.join(G, "outlier_fakequant.npz"))
+    for nm, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        A = torch.from_numpy(z[f"lowp_in|{nm}"]).to(dt).to(dev())
+        y = msq.quant.quantize_mx_outlier_v1(A, 8, 8, "fp4_e2m1", "fp8_e4m3", "max", 2, [-1], 32)
+        assert y.dtype == dt
+        ref = z[f"lowp_out|{nm}"]
+        diff = np.abs(y.float().cpu().numpy() - ref)
+        assert (diff > 0).mean() <= 0.02, (nm, (diff > 0).mean())
+        assert diff.max() <= 0.5 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------- a10 mx_ops variant / a11 MXLinear
+def test_mxops_variant_golden(msq):
+    z = np.load(os.path.join(G, "mxops_variant.npz"))
+    for key in z.files:
+        if not key.startswith("v1|"):
+            continue
+        _, nm, fmt, sb = key.split("|")
+        sbits = int(sb[2:])
+        y = msq.mx_ops._quantize_mx_outlier_v1(_t(z[nm]), sbits, sbits, fmt, fmt, "max", 5, [1], 32)
+        assert _eq(y.cpu().numpy(), z[key]).all(), key
+
+
+def test_mxlinear_golden(msq):
+    """MXLinear forward vs the reference's fp32 CPU result.  The GEMM runs in fp32 on the GPU with a
+    different summation order and its output is then re-rounded to bfloat16: tolerance = one bf16
+    ulp of the output magnitude (2^-7 relative) on at most 1% of the elements, exact elsewhere."""
+    z = np.load(os.path.join(G, "mxlinear.npz"))
+    specs = {
+        "fp6": {"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32, "bfloat": 16, "custom_cuda": True},
+        "w4a8": {"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": 32, "bfloat": 16, "custom_cuda": True},
+        "w4a8_nobf": {"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": 32, "custom_cuda": True},
+    }
+    for nm, sp in specs.items():
+        sp = msq.specs.finalize_mx_specs(dict(sp))
+        lin = msq.linear.MXLinear(128, 512, True, mx_specs=sp).to(dev())
+        with torch.no_grad():
+            lin.weight.copy_(_t(z["W"])); lin.bias.copy_(_t(z["b"]))
+            y = lin(_t(z["X"])).cpu().numpy()
+        ref = z[f"y|{nm}"]
+        err = np.abs(y - ref)
+        tol = np.abs(ref) * 2.0 ** -7 + 1e-6
+        assert (err <= tol).all(), (nm, float(err.max()))
+        if nm != "w4a8_nobf":
+            assert (err > 0).mean() <= 0.01, (nm, float((err > 0).mean()))
+        else:
+            assert err.max() <= 1e-4 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------- a2/a12 scalar codec, a9 MX, reduce
+def test_elemwise_sweep_golden(msq, O):
+    z = np.load(os.path.join(G, "elemwise_sweep.npz"))
+    x = z["x"]
+    normal = ((np.abs(x) >= 2.0 ** -126) | (x == 0)) & np.isfinite(x)
+    xt = _t(x)
+    for key in z.files:
+        if key == "x":
+            continue
+        name, rnd, sat, dn = key.split("|")
+        e, m, ex, mx, mn = msq.formats._get_format_params(name)
+        y = msq.elemwise_ops._quantize_elemwise_core(xt, m, e, mx, rnd, sat == "sat1", dn == "dn1", True).cpu().numpy()
+        ok = _eq(y, z[key]) | ~normal
+        assert ok.all(), (key, x[~ok][:4], y[~ok][:4], z[key][~ok][:4])
+        yo = O.quantize_elemwise_core(x, m, e, mx, rnd, sat == "sat1", dn == "dn1", bitwise=True)
+        ok2 = _eq(y, yo) | ~np.isfinite(x)                       # identical to the native-semantics oracle everywhere
+        assert ok2.all(), (key, x[~ok2][:4], y[~ok2][:4], yo[~ok2][:4])
+
+
+def test_elemwise_half_and_bf16_dtypes(msq):
+    x = (torch.randn(4096) * 3).to(dev())
+    for dt in (torch.float16, torch.bfloat16):
+        xh = x.to(dt)
+        y = msq.funcs.quantize_elemwise_func_cuda(xh, 5, 4, 448.0, 0, True, True)
+        yr = msq.funcs.quantize_elemwise_func_cuda(xh.float(), 5, 4, 448.0, 0, True, True).to(dt)
+        assert y.dtype == dt and torch.equal(y, yr)
+
+
+def test_reference_kats(msq):
+    kat = json.load(open(os.path.join(G, "kat_vectors.json")))
+    f = lambda v: float(v) if isinstance(v, str) else v
+    arr = lambda x: np.array([[f(v) for v in r] if isinstance(r, list) else f(r) for r in x], dtype=np.float32)
+    for k in kat["elemwise"]:
+        mx = msq.formats._get_format_params(k["max_norm"])[3]
+        y = msq.elemwise_ops._quantize_elemwise_core(_t(arr(k["x"])), k["bits"], k["exp_bits"], mx, k["round"],
+                                                     k["saturate"], k["allow_denorm"], True).cpu().numpy()
+        assert _eq(y, arr(k["t"])).all(), (k["src"], y)
+    for k in kat["mx"]:
+        x = arr(k["x"]); t = arr(k["t"])
+        for sgn in ((1, -1) if k.get("negate_too") else (1,)):
+            y = msq.mx_ops._quantize_mx(_t(sgn * x), k["scale_bits"], k["fmt"], "max", [k["axis"]], k["block_size"],
+                                        k["round"], False, True).cpu().numpy()
+            tt = sgn * t
+            bad = ~np.isfinite(tt)
+            assert (bad == ~np.isfinite(y)).all(), (k["src"], y)
+            assert (np.where(bad, 0, y) == np.where(bad, 0, tt)).all(), (k["src"], y, tt)
+
+
+def test_quantize_mx_golden_upstream(msq):
+    z = np.load(os.path.join(G, "quantize_mx.npz"))
+    n = 0
+    for key in z.files:
+        if not key.startswith("upstream|"):
+            continue
+        _, tname, fmt, ax, bs = key.split("|")
+        A = z[f"in|{tname}"]
+        y = msq.mx_ops._quantize_mx(_t(A), 8, fmt, "max", [int(ax[2:])], int(bs[2:]), "nearest", False, True)
+        assert _eq(y.cpu().numpy(), z[key]).all(), key
+        n += 1
+    assert n == 50
+
+
+def test_quantize_mx_with_max_values_entry(msq, O):
+    A = (np.random.RandomState(0).randn(6, 32, 40) * 2).astype(np.float32)
+    At = _t(A)
+    e, m, ex, mx, mn = msq.formats._get_format_params("fp8_e4m3")
+    maxv = At.abs().max(dim=1, keepdim=True).values.contiguous()
+    y = msq.funcs.quantize_mx_func_cuda(At, 8, e, m, mx, maxv, 1, False, 0).cpu().numpy()
+    yo = O.quantize_mx_native(A, 8, e, m, mx, 32, 1)
+    assert _eq(y, yo).all()
+
+
+def test_reduce_inner_dim(msq):
+    for inner in (32, 64, 100, 1024, 4096, 5000):                     # tests/test_reduce.py:17-46 sweeps H
+        A = torch.randn(37, 3, inner, device=dev())
+        s = msq.funcs.reduce_sum_inner_dim(A); mx = msq.funcs.reduce_max_inner_dim(A)
+        assert torch.equal(mx, A.max(dim=-1).values)
+        assert torch.allclose(s, A.sum(dim=-1), rtol=1e-5, atol=1e-4)
+
+
+def test_posit_tables(msq):
+    z = np.load(os.path.join(G, "posit.npz"))
+    for (n, es) in ((8, 1), (8, 0), (8, 2), (6, 1), (4, 1)):
+        dec = z[f"decode|{n}|{es}"]
+        grid = np.sort(dec[np.isfinite(dec)])
+        xs = z[f"enc_x|{n}|{es}"]; codes = z[f"enc_code|{n}|{es}"]
+        y = msq.posit.posit_round(_t(xs.astype(np.float32)), n, es).cpu().numpy().astype(np.float64)
+        want = dec[codes]
+        assert (y == want).all(), (n, es, xs[y != want][:5], y[y != want][:5], want[y != want][:5])
+        assert np.isin(y, grid).all()
+
+
+# ---------------------------------------------------------------- packed format + fused GEMM
+CFGS = [("fp4_e2m1", "fp8_e4m3", 32), ("fp4_e2m1", "posit8_es1", 32), ("int2", "fp4", 16), ("fp4", "fp8_e5m2", 32),
+        ("fp6_e3m2", "fp8_e4m3", 64), ("fp4", "fp8_e4m3", 8), ("fp4", "int8", 128)]
+
+
+@pytest.mark.parametrize("fi,fo,bs", CFGS)
+def test_pack_unpack_equals_fakequant(msq, O, fi, fo, bs):
+    g = torch.Generator().manual_seed(1)
+    W = torch.randn(256, 512, generator=g) * 0.02
+    W[torch.rand(256, 512, generator=g) < 0.01] *= 20
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, fi, fo, 2, bs)
+    o = O.outlier_fakequant(W.numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
+    assert (msq.qlinear.unpack_weight(P, torch.float32).cpu().numpy() == o).all()
+    assert (msq.qlinear.unpack_weight(P, torch.bfloat16).float().cpu().numpy() == o).all()   # exact in bf16
+
+
+@pytest.mark.parametrize("fi,fo,bs", CFGS[:4])
+@pytest.mark.parametrize("M", [1, 16, 300, 513])
+def test_fused_gemm_vs_oracle_linear(msq, O, fi, fo, bs, M):
+    """Tolerance: fp32 accumulation of K=512 products of bf16 x exact weights; the oracle accumulates in
+    double, so |err| <= K * 2^-24 * sum|x.w| -- bounded here by 2e-5 * max|y| + 1e-6."""
+    g = torch.Generator().manual_seed(2)
+    W = torch.randn(256, 512, generator=g) * 0.02
+    W[torch.rand(256, 512, generator=g) < 0.01] *= 20
+    X = torch.randn(M, 512, generator=g).to(torch.bfloat16)
+    bias = torch.randn(256, generator=g)
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, fi, fo, 2, bs)
+    Wq = O.outlier_fakequant(W.numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
+    y = msq.qlinear.qlinear(X.to(dev()), P, bias.to(dev()), torch.float32).cpu().numpy()
+    ref = O.linear(X.float().numpy(), Wq, bias.numpy())
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+    yb = msq.qlinear.qlinear(X.to(dev()), P, bias.to(dev()), torch.bfloat16).float().cpu().numpy()
+    assert np.abs(yb - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6          # one bf16 rounding
+
+
+def test_full_size_properties(msq):
+    """BASELINE.json full size (W [16384, 4096], M = 2048), properties that need no CPU pass:
+    unpack(pack(W)) == fake-quant(W) bit for bit; the fused GEMM equals a dense bf16 GEMM on the
+    unpacked weight (independent hipBLASLt kernel) up to one bf16 ulp; column checksum of the GEMM
+    output equals the GEMM of the row-summed input (linearity in X)."""
+    N, K, M = 16384, 4096, 2048
+    g = torch.Generator(device=dev()).manual_seed(3)
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    for fo in ("fp8_e4m3", "posit8_es1"):
+        P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32)
+        Wq = msq.quant.quantize_mx_outlier_v1(W, 8, 8, "fp4_e2m1", fo, "max", 2, [-1], 32)
+        Wu = msq.qlinear.unpack_weight(P, torch.float32)
+        assert torch.equal(Wu, Wq)
+        X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
+        Y = msq.qlinear.qlinear(X, P, None, torch.float32)
+        Yr = (X.float() @ Wu.t())
+        assert (Y - Yr).abs().max().item() <= 2e-5 * Yr.abs().max().item() + 1e-6
+        xs = X.float().sum(dim=0, keepdim=True)                         # checksum row
+        ys = msq.qlinear.qlinear(xs.to(torch.bfloat16), P, None, torch.float32)
+        ref = xs.to(torch.bfloat16).float() @ Wu.t()
+        assert (ys - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
+
+
+def test_quantlinear_module_and_state_dict(msq):
+    g = torch.Generator().manual_seed(4)
+    lin = torch.nn.Linear(512, 256, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(256, 512, generator=g) * 0.02)
+    lin = lin.to(dev())
+    q = msq.quant.MXQuantizer()
+    q.configure(8, 8, "fp4_e2m1", "fp8_e4m3", axes=[-1], block_size=32)
+    ql = msq.qlinear.QuantLinear.from_linear(lin, q)
+    Wq = q.quantize(lin.weight.data)
+    assert torch.equal(ql.dequantize(), Wq)
+    x = torch.randn(3, 7, 512, device=dev()).to(torch.bfloat16)
+    y = ql(x)
+    ref = torch.nn.functional.linear(x.float(), Wq, lin.bias.float())
+    assert y.shape == (3, 7, 256) and (y.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    ql2 = msq.qlinear.QuantLinear(512, 256, True, 32, "fp4_e2m1", "fp8_e4m3", device=dev())
+    ql2.load_state_dict(ql.state_dict())
+    assert torch.equal(ql2(x), y)
+    # make_quant swaps named Linears (llm/opt.py:258-264 contract)
+    model = torch.nn.Sequential(torch.nn.Linear(512, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(dev())
+    msq.qlinear.make_quant(model, {"0": q})
+    assert isinstance(model[0], msq.qlinear.QuantLinear) and isinstance(model[2], torch.nn.Linear)
+    q0 = msq.quant.MXQuantizer(); q0.configure(8, 8, "int2", "fp4", axes=[0], block_size=16)
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.QuantLinear.from_linear(lin, q0)                    # axes=[0] blocks are not packable along K
+
+
+def test_c_abi_error_codes(msq):
+    L = msq._lib.lib()
+    x = torch.zeros(64, device=dev())
+    assert L.msq_quantize_elemwise(msq._lib.ptr(x), msq._lib.ptr(x), 64, 0, 30, 4, 448.0, 0, 1, 1, None) == -1
+    assert b"bits" in L.msq_last_error()
+    assert L.msq_outlier_fakequant(msq._lib.ptr(x), msq._lib.ptr(x), None, None, None, None, None, None, 0, 0, 1, 64, 1,
+                                   24, 8, 5, 8, 8, 2.0, 0, 0, 0, None) == -2            # unsupported block size
+    assert L.msq_outlier_fakequant(msq._lib.ptr(x), msq._lib.ptr(x), None, None, None, None, None, None, 0, 0, 1, 64, 1,
+                                   16, 77, 5, 8, 8, 2.0, 0, 0, 0, None) == -1           # unknown format
+    assert L.msq_quantize_elemwise(None, None, 0, 0, 5, 4, 448.0, 0, 1, 1, None) == 0       # empty input is fine
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_weight(torch.zeros(100, 64, device=dev()))                         # N not a multiple of 64

@@ -1,0 +1,191 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/msq.h declares
+(no compute calls without a GPU), the host-side mirror of the reference interface, and the
+N>1 (row-parallel) path over gloo with world_size 2."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def msq():
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, "microscopiq-llm-quantization_amd", "libmsq_hip.so")
+    if not os.path.exists(so):
+        ge.build()
+    import msq as m
+    return m
+
+
+def test_library_exports_every_declared_symbol(msq):
+    hdr = open(os.path.join(ROOT, "include", "msq.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(msq_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 15, names
+    lib = ctypes.CDLL(msq._lib.so_path())
+    for n in sorted(names):
+        assert hasattr(lib, n), "libmsq_hip.so does not export %s" % n
+    # and the Python binding covers all of them
+    assert names == set(msq._lib._SIGS.keys()), names ^ set(msq._lib._SIGS.keys())
+
+
+def test_format_table_matches_reference(msq):
+    tab = json.load(open(os.path.join(G, "format_table.json")))
+    for name, vals in tab.items():
+        got = msq.formats._get_format_params(name)
+        assert tuple(float(v) for v in got) == tuple(np.float32(v).item() if i >= 3 else v for i, v in enumerate(vals)), name
+    with pytest.raises(Exception):
+        msq.formats._get_format_params("fp5_e1m3")
+    assert msq.formats.ElemFormat.from_str("FP4").value == 8
+    assert [int(m) for m in msq.formats.RoundingMode] == [0, 1, 2]
+    # posit extension
+    e, m, ex, mx, mn = msq.formats._get_format_params("posit8_es1")
+    assert (e, m, ex, mx) == (1, 8, 1, 4096.0)
+
+
+def test_reference_api_surface(msq):
+    import inspect
+    q = msq.quant
+    sig = list(inspect.signature(q.quantize_mx_outlier_v1).parameters)
+    assert sig == ["A", "inlier_scale_bits", "outlier_scale_bits", "inlier_elem_format", "outlier_elem_format",
+                   "shared_exp_method", "std_dev", "axes", "block_size", "round", "flush_fp32_subnorms",
+                   "custom_cuda"]                                  # utils/quant.py:147-160
+    sig = list(inspect.signature(q.quantize_mx_outlier_hessian).parameters)
+    assert sig[-2:] == ["prune_inliers", "custom_cuda"]              # utils/quant.py:35-36
+    mq = q.MXQuantizer()
+    mq.configure(inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format='int2', outlier_elem_format='fp4',
+                 axes=[0], block_size=16)                            # llm/llama.py:229-237
+    for a in ("inlier_scale_bits", "outlier_scale_bits", "inlier_elem_format", "outlier_elem_format",
+              "shared_exp_method", "std_dev", "axes", "block_size", "round", "flush_fp32_subnorms", "custom_cuda"):
+        assert hasattr(mq, a)                                        # read by llm/llama.py:242-252, llm/gptq.py:132-142
+    assert mq.std_dev == 2 and mq.round == "nearest" and mq.ready() is True and mq.enabled() is None
+    assert mq.find_params(torch.zeros(2, 2), weight=True) is None
+    for n in ("quantize_mx_func_cpp", "quantize_elemwise_func_cpp", "quantize_mx_func_cuda",
+              "quantize_mx_by_tile_func_cuda", "quantize_elemwise_func_cuda", "reduce_sum_inner_dim",
+              "reduce_max_inner_dim"):                               # cpp/funcs.cpp:218-226
+        assert callable(getattr(msq.funcs, n))
+    assert issubclass(msq.linear.MXLinear, torch.nn.Linear)
+
+
+def test_no_cpu_fallback(msq):
+    x = torch.randn(32, 32)
+    with pytest.raises(msq._lib.MsqError):
+        msq.quant.quantize_mx_outlier_v1(x, 8, 8, "fp4", "fp8_e4m3", "max", 2, [0], 16)
+    with pytest.raises(msq._lib.MsqError):
+        msq.funcs.quantize_elemwise_func_cuda(x, 5, 4, 448.0)
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_weight(x)
+    # shortcut for "no quantisation" (utils/quant.py:165-166)
+    assert msq.quant.quantize_mx_outlier_v1(x, 8, 8, None, None, axes=[0]) is x
+
+
+def test_missing_library_fails_loudly(msq, tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import msq; from msq import _lib; "
+            "_lib._SO = %r; _lib._lib = None\n"
+            "try:\n  _lib.lib()\nexcept _lib.MsqError as e:\n  print('LOUD', 'no CPU fallback' in str(e).lower() or 'not found' in str(e))\n"
+            % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.check_output([sys.executable, "-c", code], text=True)
+    assert "LOUD True" in out
+
+
+def test_reshape_to_blocks_semantics(msq):
+    q = msq.quant
+    A = torch.arange(20 * 3, dtype=torch.float32).reshape(20, 3)
+    B, axes, orig, padded = q._reshape_to_blocks(A, [0], 16)          # utils/quant.py:544-603
+    assert list(B.shape) == [2, 16, 3] and axes == [0] and list(orig) == [20, 1, 3] and list(padded) == [32, 1, 3]
+    assert (B[1, 4:, :] == 0).all() and (B[0, :, 1] == A[:16, 1]).all()
+    back = q._undo_reshape_to_blocks(B, padded, orig, axes)
+    assert back.shape == A.shape and (back == A).all()
+    B, axes, orig, padded = q._reshape_to_blocks(A, [-1], 2)
+    assert list(B.shape) == [20, 2, 2] and (B[:, 1, 1] == 0).all()
+    with pytest.raises(Exception):
+        q._reshape_to_blocks(A, None, 16)
+    with pytest.raises(Exception):
+        q._reshape_to_blocks(A, [0], 0)
+
+
+def test_legacy_quantizer(msq):
+    q = msq.quant.Quantizer()
+    q.configure(4, perchannel=True, sym=False, mse=False)
+    W = torch.tensor([[0.0, 1.0, 2.0, 3.0], [-1.0, 0.0, 1.0, 0.5]])
+    q.find_params(W, weight=True)
+    assert q.ready() and q.enabled()
+    Wq = q.quantize(W)
+    assert torch.allclose(Wq[0], W[0], atol=1e-6)                     # 0..3 with 15 levels of 0.2
+    assert (Wq - W).abs().max() <= (q.scale.max() / 2 + 1e-6)
+    assert torch.equal(msq.quant.quantize(W, q.scale, q.zero, q.maxq), Wq)
+    q2 = msq.quant.Quantizer()
+    q2.configure(3, perchannel=False, sym=True, mse=True, grid=20)
+    q2.find_params(W, weight=True)
+    assert q2.scale.shape == (2, 1)
+
+
+def test_specs(msq):
+    s = msq.specs
+    assert s.finalize_mx_specs({}) is None                             # early exit, specs.py:282-292
+    sp = s.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4,
+                              "block_size": 32, "bfloat": 16})
+    assert sp["w_elem_format_bp"] == "fp6_e3m2" and sp["round_mx_output"] == "nearest" and sp["bfloat_subnorms"]
+    with pytest.raises(Exception):
+        s.MxSpecs({"not_a_key": 1})
+    assert s.apply_mx_specs(None) is None
+
+
+def test_row_parallel_shard_bounds(msq):
+    R = msq.qlinear.RowParallelQuantLinear
+    assert R.shard_bounds(28672, 8, 3, 32) == (3 * 3584, 4 * 3584)    # 70B down_proj
+    assert R.shard_bounds(8192, 8, 7, 32) == (7168, 8192)
+    with pytest.raises(msq._lib.MsqError):
+        R.shard_bounds(4096, 3, 0, 32)
+    with pytest.raises(msq._lib.MsqError):
+        R.shard_bounds(4096 + 32 * 8, 8, 0, 64)                       # per-rank slice not a 64 multiple
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import msq
+from msq.qlinear import RowParallelQuantLinear
+from oracle import oracle as O
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.RandomState(0)
+N, K, M = 64, 256, 8
+W = (rng.randn(N, K) * 0.02).astype(np.float32); X = rng.randn(M, K).astype(np.float32)
+bias = rng.randn(N).astype(np.float32)
+k0, k1 = RowParallelQuantLinear.shard_bounds(K, world, rank, 32)
+# the local fake-quant of the K slice equals the slice of the full fake-quant (blocks never straddle the cut)
+full = O.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+loc = O.outlier_fakequant(np.ascontiguousarray(W[:, k0:k1]), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+assert (loc == full[:, k0:k1]).all()
+def partial(x):            # CPU stand-in for the HIP shard (tests only): oracle linear on the local slice
+    return torch.from_numpy(O.linear(x.numpy(), loc, bias if rank == 0 else None))
+rp = RowParallelQuantLinear(None, world, rank, None, partial_fn=partial)
+y = rp(torch.from_numpy(np.ascontiguousarray(X[:, k0:k1])))
+ref = O.linear(X, full, bias)
+assert np.abs(y.numpy() - ref).max() < 1e-5, np.abs(y.numpy() - ref).max()
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_row_parallel_two_ranks_gloo(msq, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = str(29500 + (os.getpid() % 500))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o
