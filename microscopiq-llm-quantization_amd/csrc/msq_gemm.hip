@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/msq.h"
 #include "msq_device.h"
@@ -325,6 +326,357 @@ k_qgemm(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// v2: software-pipelined at half-K-step (one MFMA k-fragment = 32 k) granularity.
+//   half-step h:  issue packed loads for h+2 | convert packed(h+1) -> wf[(h+1)&1] | 32 MFMAs on wf[h&1]
+// so the scaled converts of the next fragment set fill the VALU slots between the MFMAs of the
+// current one (sched_group_barrier pins the interleave), and only one half-step of packed data
+// is in flight per buffer (register budget: 128 acc + 32 wf + <=48 packed + 12 xf).
+// ---------------------------------------------------------------------------
+template <int OUT_KIND> struct HalfSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 4 : 2; };
+
+template <int IN_KIND, int OUT_KIND>
+struct HalfRegs {
+    u32x4_t inl;
+    u32x4_t out[HalfSlots<OUT_KIND>::n];
+};
+
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void load_half(HalfRegs<IN_KIND, OUT_KIND>& h, const uint8_t* inl_lane, const uint8_t* out_lane, int64_t tile, int kf) {
+    constexpr int HS = HalfSlots<OUT_KIND>::n;
+    if (IN_KIND != MSQ_PLANE_NONE)
+        h.inl = *reinterpret_cast<const u32x4_t*>(inl_lane + (tile * 2 + kf) * 1024);
+#pragma unroll
+    for (int s = 0; s < HS; ++s)
+        h.out[s] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * HS + s) * 1024);
+}
+
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void convert_half(bf16x8_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h, const u32x4_t& scl, int kf) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        u32x4_t r;
+        if (IN_KIND == MSQ_PLANE_NONE) {
+            r = h.out[nf];
+        } else {
+            const float s_in = scale_operand(scl[nf], kf * 2);
+            if (OUT_KIND == MSQ_PLANE_BF16) {
+                r = dequant_frag_in_only(h.inl[nf], s_in);
+                const u32x4_t o = h.out[nf];
+                r[0] |= o[0]; r[1] |= o[1]; r[2] |= o[2]; r[3] |= o[3];
+            } else {
+                const float s_out = scale_operand(scl[nf], kf * 2 + 1);
+                const u32x4_t o = h.out[nf >> 1];
+                r = dequant_frag<OUT_KIND>(h.inl[nf], o[(nf & 1) * 2], o[(nf & 1) * 2 + 1], s_in, s_out);
+            }
+        }
+        wf[nf] = __builtin_bit_cast(bf16x8_t, r);
+    }
+}
+
+// one quarter of a half-step's conversion work: fragment nf = q/2, dwords 2*(q%2) .. +1
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void convert_quarter(u32x4_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h, const u32x4_t& scl, int kf, int q) {
+    const int nf = q >> 1, hh = q & 1;
+    if (IN_KIND == MSQ_PLANE_NONE) {
+        wf[nf][2 * hh] = h.out[nf][2 * hh]; wf[nf][2 * hh + 1] = h.out[nf][2 * hh + 1];
+        return;
+    }
+    const float s_in = scale_operand(scl[nf], kf * 2);
+    uint32_t r0, r1;
+    if (hh == 0) {
+        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(h.inl[nf], s_in, 0));
+        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(h.inl[nf], s_in, 1));
+    } else {
+        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(h.inl[nf], s_in, 2));
+        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(h.inl[nf], s_in, 3));
+    }
+    if (OUT_KIND == MSQ_PLANE_BF16) {
+        r0 |= h.out[nf][2 * hh]; r1 |= h.out[nf][2 * hh + 1];
+    } else {
+        const float s_out = scale_operand(scl[nf], kf * 2 + 1);
+        const uint32_t o = h.out[nf >> 1][(nf & 1) * 2 + hh];
+        if (OUT_KIND == MSQ_PLANE_FP8) {
+            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, false));
+            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, true));
+        } else {
+            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, false));
+            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, true));
+        }
+    }
+    wf[nf][2 * hh] = r0; wf[nf][2 * hh + 1] = r1;
+}
+
+// force the compiler to have these registers loaded here (its s_waitcnt lands at this point)
+MSQ_D void keep_live4(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
+    if (IN_KIND != MSQ_PLANE_NONE) keep_live4(h.inl);
+#pragma unroll
+    for (int s = 0; s < HalfSlots<OUT_KIND>::n; ++s) keep_live4(h.out[s]);
+}
+
+template <int IN_KIND, int OUT_KIND, typename YT>
+__global__ void __launch_bounds__(512)
+k_qgemm2(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+         const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+         int scl_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + BM - 1) / BM, NTB = N / BN;
+    int bid = blockIdx.x, bm, bn;
+    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
+    else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int KT = K / BK;
+    const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
+
+    // per-lane bases of the packed planes (every slot is 64 lanes x 16 B)
+    const uint8_t* inl_lane = inl_plane + lane * 16;
+    const uint8_t* out_lane = out_plane + lane * 16;
+    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16;
+    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
+
+    // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
+    const uint16_t* asrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int piece = wid * 4 + p;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        asrc[p] = X + (int64_t)gr * K + chunk * 8;
+    }
+    auto stage_A = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
+                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
+                                             16, 0, 0);
+    };
+    // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
+    const int sw = (c >> 1) & 7;
+    const int rd0 = (wm * 128 + c) * 128 + (((0 + g) ^ sw) << 4);
+    const int rd1 = (wm * 128 + c) * 128 + (((4 + g) ^ sw) << 4);
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    HalfRegs<IN_KIND, OUT_KIND> pkA, pkB;      // pkA: even half-steps (kf = 0), pkB: odd (kf = 1)
+    bf16x8_t wfA[4], wfB[4];
+    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0};
+
+    // ---- prologue: A(0) -> buf 0, packed(0), packed(1), scales(0); convert half 0
+    stage_A(0, 0);
+    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0);
+    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1);
+    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + tile_row * scl_tile_bytes);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    convert_half<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0);
+
+    // one half-step: 32 MFMAs on wf with the A fragments prefetched two ahead; everything else that
+    // was issued before it in program order (packed loads, scaled converts of the next fragment
+    // set) is spread between the MFMAs by the sched_group_barrier sequence.
+    auto mfma_block = [&](const bf16x8_t (&wf)[4], const char* abase, int rd) {
+        bf16x8_t xf[3];
+        xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + rd);
+        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + rd + 2048);
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) {
+            if (mf + 2 < 8) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + rd + (mf + 2) * 2048);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf % 3], acc[mf][nf], 0, 0, 0);
+        }
+    };
+    auto pin_schedule = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) {
+            if (mf + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        }
+    };
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* abase = smem + buf * A_TILE_BYTES;
+        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;          // branch-free tail: re-load the last tile
+        // ---------------- half-step kf = 0
+        stage_A(ktn, buf ^ 1);
+        load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
+        if (IN_KIND != MSQ_PLANE_NONE)
+            sc_nxt = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
+        convert_half<IN_KIND, OUT_KIND>(wfB, pkB, sc_cur, 1);
+        mfma_block(wfA, abase, rd0);
+        pin_schedule();
+        // ---------------- half-step kf = 1
+        load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
+        convert_half<IN_KIND, OUT_KIND>(wfA, pkA, sc_nxt, 0);
+        mfma_block(wfB, abase, rd1);
+        pin_schedule();
+        sc_cur = sc_nxt;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+        const int m = m0 + wm * 128 + mf * 16 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + wn * 64 + nf * 16 + g * 4;
+            f32x4_t v = acc[mf][nf];
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (sizeof(YT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
+                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        }
+    }
+}
+
+template <int IN_KIND, int OUT_KIND, typename YT>
+__global__ void __launch_bounds__(512)
+k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+         const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+         int scl_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + BM - 1) / BM, NTB = N / BN;
+    int bid = blockIdx.x, bm, bn;
+    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
+    else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int KT = K / BK;
+    const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
+
+    // per-lane bases of the packed planes (every slot is 64 lanes x 16 B)
+    const uint8_t* inl_lane = inl_plane + lane * 16;
+    const uint8_t* out_lane = out_plane + lane * 16;
+    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16;
+    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
+
+    // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
+    const uint16_t* asrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int piece = wid * 4 + p;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        asrc[p] = X + (int64_t)gr * K + chunk * 8;
+    }
+    auto stage_A = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
+                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
+                                             16, 0, 0);
+    };
+    // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
+    const int sw = (c >> 1) & 7;
+    const int rd0 = (wm * 128 + c) * 128 + (((0 + g) ^ sw) << 4);
+    const int rd1 = (wm * 128 + c) * 128 + (((4 + g) ^ sw) << 4);
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    HalfRegs<IN_KIND, OUT_KIND> pkA, pkB;      // pkA: even half-steps (kf = 0), pkB: odd (kf = 1)
+    u32x4_t wfA[4], wfB[4];
+    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0};
+
+    stage_A(0, 0);
+    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0);
+    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1);
+    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + tile_row * scl_tile_bytes);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) convert_quarter<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0, q);
+
+    // One half-step, hand-interleaved: group mf = { LDS read of A fragment mf+2, 4 MFMAs on fragment mf,
+    // one quarter (2 dwords) of the NEXT half-step's weight fragments converted }, groups fenced with
+    // sched_barrier so the compiler keeps the interleave.
+#define MSQ_HALF_STEP(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, RD)                                         \
+    {                                                                                                        \
+        bf16x8_t xf[3];                                                                                      \
+        xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
+        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
+        _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
+            if (mf + 2 < 8) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+            _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
+            convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* abase = smem + buf * A_TILE_BYTES;
+        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;          // branch-free tail: re-load the last tile
+        // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
+        keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
+        stage_A(ktn, buf ^ 1);
+        load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
+        if (IN_KIND != MSQ_PLANE_NONE)
+            sc_nxt = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
+        __builtin_amdgcn_sched_barrier(0);
+        MSQ_HALF_STEP(wfA, wfB, pkB, sc_cur, 1, rd0)
+        // ---------------- half-step kf = 1: MFMAs on wfB, make next wfA from pkA
+        keep_live(pkA);
+        if (IN_KIND != MSQ_PLANE_NONE) keep_live4(sc_nxt);
+        load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
+        sc_cur = sc_nxt;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+#undef MSQ_HALF_STEP
+
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+        const int m = m0 + wm * 128 + mf * 16 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + wn * 64 + nf * 16 + g * 4;
+            f32x4_t v = acc[mf][nf];
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (sizeof(YT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
+                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        }
+    }
+}
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -453,6 +805,38 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const size_t lds = 2 * A_TILE_BYTES;
     hipStream_t st = (hipStream_t)stream;
     const int groups = block < 32 ? 64 : 16;
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MSQ_GEMM_VARIANT"); variant = e ? atoi(e) : 3; }
+#define MSQ_GM2(IK, OK)                                                                                                \
+    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm2<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
+             hipLaunchKernelGGL((k_qgemm2<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
+         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm2<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
+             hipLaunchKernelGGL((k_qgemm2<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
+#define MSQ_GM3(IK, OK)                                                                                                \
+    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm3<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
+             hipLaunchKernelGGL((k_qgemm3<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
+         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm3<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
+             hipLaunchKernelGGL((k_qgemm3<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
+    if (variant == 3) {
+        if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM3(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+        else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
+        return check_launch2("msq_qlinear_bf16");
+    }
+    if (variant == 2) {
+        if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM2(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+        else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
+        return check_launch2("msq_qlinear_bf16");
+    }
 #define MSQ_GM(IK, OK)                                                                                                 \
     do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
              hipLaunchKernelGGL((k_qgemm<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
