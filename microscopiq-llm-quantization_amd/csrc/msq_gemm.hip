@@ -25,6 +25,15 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MSQ_DRAIN
+#define MSQ_DRAIN 0
+#endif
+#ifndef MSQ_ABL
+#define MSQ_ABL 0
+#endif
+#ifndef MSQ_PRIO
+#define MSQ_PRIO 0
+#endif
 #define TILE_N 64
 #define TILE_K 64
 
@@ -212,122 +221,13 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
         }
 }
 
-// ---------------------------------------------------------------------------
-// fused unpack-dequant-GEMM.  Block tile 256(m) x 256(n), K-step 64, 8 waves as
-// 2(m) x 4(n): wave tile 128 x 64 = 8 x 4 MFMA tiles of 16x16, fp32 accumulators.
-// W fragment is the MFMA "A" operand (rows = n) and the X fragment the "B" operand
-// (cols = m): D[n][m], so a lane ends up with 4 consecutive n of one output row m.
-// ---------------------------------------------------------------------------
 #define BM 256
 #define BN 256
 #define BK 64
 #define A_TILE_BYTES (BM * BK * 2)
 
-template <int IN_KIND, int OUT_KIND, typename YT>
-__global__ void __launch_bounds__(512)
-k_qgemm(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
-        const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-        int scl_groups) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + BM - 1) / BM, NTB = N / BN;
-    // XCD-aware tile order: the 8 XCDs are dealt blocks round-robin; give every XCD whole
-    // column panels so that the packed W panel and the X tiles are re-used out of its own L2.
-    int bid = blockIdx.x;
-    int bm, bn;
-    if ((NTB & 7) == 0) {
-        const int xcd = bid & 7, i = bid >> 3;
-        bn = (i / MT) * 8 + xcd;
-        bm = i % MT;
-    } else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int KT = K / BK;
-    const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;      // this wave's packed tiles
-
-    // --- A (activation) staging: 32 pieces of 1 KiB (8 rows x 128 B) per K-step; wave w owns
-    // pieces 4w..4w+3.  LDS image is lane-linear; the XOR swizzle is applied to the SOURCE
-    // chunk: LDS slot s of row r holds logical 16-byte chunk s ^ ((r >> 1) & 7).
-    auto stage_A = [&](int kt, int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int piece = wid * 4 + p;
-            const int row = piece * 8 + (lane >> 3);
-            const int slot = lane & 7;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            int gr = m0 + row; gr = gr < M ? gr : M - 1;
-            const uint16_t* src = X + (int64_t)gr * K + (int64_t)kt * BK + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + piece * 1024),
-                                             16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    TileRegs cur, nxt;
-    stage_A(0, 0);
-    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row, lane, scl_groups);
-    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) lgkmcnt(0)
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) {
-            stage_A(kt + 1, buf ^ 1);
-            load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + kt + 1, lane, scl_groups);
-        }
-        const char* abase = smem + buf * A_TILE_BYTES;
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf) {
-            bf16x8_t wf[4];
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-                wf[nf] = __builtin_bit_cast(bf16x8_t, tile_frag<IN_KIND, OUT_KIND>(cur, nf, kf));
-#pragma unroll
-            for (int mf = 0; mf < 8; ++mf) {
-                const int row = wm * 128 + mf * 16 + c;
-                const int slot = (kf * 4 + g) ^ ((row >> 1) & 7);
-                const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(abase + row * 128 + slot * 16);
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf, acc[mf][nf], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        cur = nxt;
-    }
-
-    // --- epilogue: lane holds D[n = 4g + r][m = c] of every 16x16 tile -> 4 consecutive n
-#pragma unroll
-    for (int mf = 0; mf < 8; ++mf) {
-        const int m = m0 + wm * 128 + mf * 16 + c;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + wn * 64 + nf * 16 + g * 4;
-            f32x4_t v = acc[mf][nf];
-            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
-            if (sizeof(YT) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x2_t lo, hi;
-                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
-                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// v2: software-pipelined at half-K-step (one MFMA k-fragment = 32 k) granularity.
+// fused unpack-dequant-GEMM, software-pipelined at half-K-step (one MFMA k-fragment = 32 k) granularity.
 //   half-step h:  issue packed loads for h+2 | convert packed(h+1) -> wf[(h+1)&1] | 32 MFMAs on wf[h&1]
 // so the scaled converts of the next fragment set fill the VALU slots between the MFMAs of the
 // current one (sched_group_barrier pins the interleave), and only one half-step of packed data
@@ -418,141 +318,6 @@ MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
 
 template <int IN_KIND, int OUT_KIND, typename YT>
 __global__ void __launch_bounds__(512)
-k_qgemm2(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
-         const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-         int scl_groups) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + BM - 1) / BM, NTB = N / BN;
-    int bid = blockIdx.x, bm, bn;
-    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
-    else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int KT = K / BK;
-    const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
-
-    // per-lane bases of the packed planes (every slot is 64 lanes x 16 B)
-    const uint8_t* inl_lane = inl_plane + lane * 16;
-    const uint8_t* out_lane = out_plane + lane * 16;
-    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16;
-    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
-
-    // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
-    const uint16_t* asrc[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int piece = wid * 4 + p;
-        const int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gr = m0 + row; gr = gr < M ? gr : M - 1;
-        asrc[p] = X + (int64_t)gr * K + chunk * 8;
-    }
-    auto stage_A = [&](int kt, int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
-                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
-                                             16, 0, 0);
-    };
-    // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
-    const int sw = (c >> 1) & 7;
-    const int rd0 = (wm * 128 + c) * 128 + (((0 + g) ^ sw) << 4);
-    const int rd1 = (wm * 128 + c) * 128 + (((4 + g) ^ sw) << 4);
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    HalfRegs<IN_KIND, OUT_KIND> pkA, pkB;      // pkA: even half-steps (kf = 0), pkB: odd (kf = 1)
-    bf16x8_t wfA[4], wfB[4];
-    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0};
-
-    // ---- prologue: A(0) -> buf 0, packed(0), packed(1), scales(0); convert half 0
-    stage_A(0, 0);
-    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0);
-    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1);
-    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + tile_row * scl_tile_bytes);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    convert_half<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0);
-
-    // one half-step: 32 MFMAs on wf with the A fragments prefetched two ahead; everything else that
-    // was issued before it in program order (packed loads, scaled converts of the next fragment
-    // set) is spread between the MFMAs by the sched_group_barrier sequence.
-    auto mfma_block = [&](const bf16x8_t (&wf)[4], const char* abase, int rd) {
-        bf16x8_t xf[3];
-        xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + rd);
-        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + rd + 2048);
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf) {
-            if (mf + 2 < 8) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + rd + (mf + 2) * 2048);
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf % 3], acc[mf][nf], 0, 0, 0);
-        }
-    };
-    auto pin_schedule = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf) {
-            if (mf + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            }
-        }
-    };
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        const char* abase = smem + buf * A_TILE_BYTES;
-        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;          // branch-free tail: re-load the last tile
-        // ---------------- half-step kf = 0
-        stage_A(ktn, buf ^ 1);
-        load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
-        if (IN_KIND != MSQ_PLANE_NONE)
-            sc_nxt = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
-        convert_half<IN_KIND, OUT_KIND>(wfB, pkB, sc_cur, 1);
-        mfma_block(wfA, abase, rd0);
-        pin_schedule();
-        // ---------------- half-step kf = 1
-        load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
-        convert_half<IN_KIND, OUT_KIND>(wfA, pkA, sc_nxt, 0);
-        mfma_block(wfB, abase, rd1);
-        pin_schedule();
-        sc_cur = sc_nxt;
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int mf = 0; mf < 8; ++mf) {
-        const int m = m0 + wm * 128 + mf * 16 + c;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + wn * 64 + nf * 16 + g * 4;
-            f32x4_t v = acc[mf][nf];
-            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
-            if (sizeof(YT) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x2_t lo, hi;
-                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
-                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-            }
-        }
-    }
-}
-
-template <int IN_KIND, int OUT_KIND, typename YT>
-__global__ void __launch_bounds__(512)
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int scl_groups) {
@@ -624,10 +389,12 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
         xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 2 < 8) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+            if (mf + 2 < 8 && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+            if (MSQ_PRIO) __builtin_amdgcn_s_setprio(1);                                                     \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
-            convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);                        \
+            if (MSQ_PRIO) __builtin_amdgcn_s_setprio(0);                                                     \
+            if (!(MSQ_ABL & 2)) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);    \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
@@ -638,8 +405,8 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         const int ktn = (kt + 1 < KT) ? kt + 1 : kt;          // branch-free tail: re-load the last tile
         // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
         keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
-        stage_A(ktn, buf ^ 1);
-        load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
+        if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);
+        if (!(MSQ_ABL & 4)) load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
         if (IN_KIND != MSQ_PLANE_NONE)
             sc_nxt = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
         __builtin_amdgcn_sched_barrier(0);
@@ -647,12 +414,14 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         // ---------------- half-step kf = 1: MFMAs on wfB, make next wfA from pkA
         keep_live(pkA);
         if (IN_KIND != MSQ_PLANE_NONE) keep_live4(sc_nxt);
-        load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
+        if (!(MSQ_ABL & 4)) load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
         sc_cur = sc_nxt;
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
+        // A(kt+1) has landed: its LDS-DMA ops are older than the pkA loads this wave waited for at the
+        // top of the second half-step (in-order vmcnt).  The pkB loads stay in flight across the barrier.
+        if (MSQ_DRAIN) { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+        else { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
     }
 #undef MSQ_HALF_STEP
 
@@ -663,6 +432,192 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = n0 + wn * 64 + nf * 16 + g * 4;
+            f32x4_t v = acc[mf][nf];
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (sizeof(YT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
+                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// v4: 8 waves as 1(m) x 8(n): wave tile 256 x 32.  Every packed weight fragment is converted by
+// exactly ONE wave (v3's 2(m) x 4(n) converted each fragment twice), which halves the VALU and
+// VMEM issue per MFMA -- the measured limiter of v3 (ablation: converts 17 %, packed loads 13 %).
+// The price is that every wave reads all 256 rows of the activation tile from LDS (16 ds_read_b128
+// per half-step instead of 8; LDS array ~50 % busy).  Two waves share one 64-column packed tile:
+// wave wn takes fragments nf = 2 (wn & 1) .. +1, i.e. half of every 16-byte lane slot.
+// ---------------------------------------------------------------------------
+template <int IN_KIND, int OUT_KIND>
+struct PairRegs {            // one half-step (kf) of one fragment pair
+    uint2 inl;               // dword per nf
+    u32x4_t out[(OUT_KIND == MSQ_PLANE_BF16) ? 2 : 1];
+};
+
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void load_pair(PairRegs<IN_KIND, OUT_KIND>& h, const uint8_t* inl_lane, const uint8_t* out_lane, int64_t tile, int kf, int np) {
+    if (IN_KIND != MSQ_PLANE_NONE)
+        h.inl = *reinterpret_cast<const uint2*>(inl_lane + (tile * 2 + kf) * 1024 + np * 8);
+    if (OUT_KIND == MSQ_PLANE_BF16) {
+        h.out[0] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 4 + np * 2) * 1024);
+        h.out[1] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 4 + np * 2 + 1) * 1024);
+    } else {
+        h.out[0] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 2 + np) * 1024);
+    }
+}
+
+// quarter q (0..3): fragment nf = q / 2 of the pair, dwords 2 (q % 2) .. +1
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void convert_pair_quarter(u32x4_t (&wf)[2], const PairRegs<IN_KIND, OUT_KIND>& h, uint2 scl, int kf, int q) {
+    const int nf = q >> 1, hh = q & 1;
+    if (IN_KIND == MSQ_PLANE_NONE) {
+        wf[nf][2 * hh] = h.out[nf][2 * hh]; wf[nf][2 * hh + 1] = h.out[nf][2 * hh + 1];
+        return;
+    }
+    const uint32_t sd = nf ? scl.y : scl.x;
+    const uint32_t iw = nf ? h.inl.y : h.inl.x;
+    const float s_in = scale_operand(sd, kf * 2);
+    uint32_t r0, r1;
+    if (hh == 0) {
+        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 0));
+        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 1));
+    } else {
+        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 2));
+        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 3));
+    }
+    if (OUT_KIND == MSQ_PLANE_BF16) {
+        r0 |= h.out[nf][2 * hh]; r1 |= h.out[nf][2 * hh + 1];
+    } else {
+        const float s_out = scale_operand(sd, kf * 2 + 1);
+        const uint32_t o = h.out[0][nf * 2 + hh];
+        if (OUT_KIND == MSQ_PLANE_FP8) {
+            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, false));
+            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, true));
+        } else {
+            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, false));
+            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, true));
+        }
+    }
+    wf[nf][2 * hh] = r0; wf[nf][2 * hh + 1] = r1;
+}
+
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void keep_live_pair(PairRegs<IN_KIND, OUT_KIND>& h) {
+    if (IN_KIND != MSQ_PLANE_NONE) asm volatile("" : "+v"(h.inl));
+    keep_live4(h.out[0]);
+    if (OUT_KIND == MSQ_PLANE_BF16) keep_live4(h.out[1]);
+}
+
+template <int IN_KIND, int OUT_KIND, typename YT>
+__global__ void __launch_bounds__(512)
+k_qgemm4(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+         const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+         int scl_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid;                       // 8 waves along n, 32 columns each
+    const int np = wn & 1;                    // which fragment pair of the 64-column packed tile
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + BM - 1) / BM, NTB = N / BN;
+    int bid = blockIdx.x, bm, bn;
+    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
+    else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int KT = K / BK;
+    const int64_t tile_row = (int64_t)(n0 / TILE_N + (wn >> 1)) * KT;
+
+    const uint8_t* inl_lane = inl_plane + lane * 16;
+    const uint8_t* out_lane = out_plane + lane * 16;
+    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16 + np * 8;
+    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
+
+    const uint16_t* asrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int piece = wid * 4 + p;
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        asrc[p] = X + (int64_t)gr * K + chunk * 8;
+    }
+    auto stage_A = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
+                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
+                                             16, 0, 0);
+    };
+    const int sw = (c >> 1) & 7;
+    const int rd0 = c * 128 + (((0 + g) ^ sw) << 4);
+    const int rd1 = c * 128 + (((4 + g) ^ sw) << 4);
+
+    f32x4_t acc[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    PairRegs<IN_KIND, OUT_KIND> pkA, pkB;
+    u32x4_t wfA[2], wfB[2];
+    uint2 sc_cur = make_uint2(0, 0), sc_nxt = make_uint2(0, 0);
+
+    stage_A(0, 0);
+    load_pair<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0, np);
+    load_pair<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1, np);
+    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const uint2*>(scl_lane + tile_row * scl_tile_bytes);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) convert_pair_quarter<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0, q);
+
+#define MSQ_HALF_STEP4(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, RD)                                        \
+    {                                                                                                        \
+        bf16x8_t xf[3];                                                                                      \
+        xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
+        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
+        _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                  \
+            if (mf + 2 < 16) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                 \
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
+            if ((mf & 3) == 1) convert_pair_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf >> 2); \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* abase = smem + buf * A_TILE_BYTES;
+        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
+        keep_live_pair(pkB);
+        stage_A(ktn, buf ^ 1);
+        load_pair<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0, np);
+        if (IN_KIND != MSQ_PLANE_NONE) sc_nxt = *reinterpret_cast<const uint2*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
+        __builtin_amdgcn_sched_barrier(0);
+        MSQ_HALF_STEP4(wfA, wfB, pkB, sc_cur, 1, rd0)
+        keep_live_pair(pkA);
+        if (IN_KIND != MSQ_PLANE_NONE) asm volatile("" : "+v"(sc_nxt));
+        load_pair<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1, np);
+        __builtin_amdgcn_sched_barrier(0);
+        MSQ_HALF_STEP4(wfB, wfA, pkA, sc_nxt, 0, rd1)
+        sc_cur = sc_nxt;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+    }
+#undef MSQ_HALF_STEP4
+
+#pragma unroll
+    for (int mf = 0; mf < 16; ++mf) {
+        const int m = m0 + mf * 16 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            const int n = n0 + wn * 32 + nf * 16 + g * 4;
             f32x4_t v = acc[mf][nf];
             if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
             if (sizeof(YT) == 4) {
@@ -807,49 +762,24 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const int groups = block < 32 ? 64 : 16;
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("MSQ_GEMM_VARIANT"); variant = e ? atoi(e) : 3; }
-#define MSQ_GM2(IK, OK)                                                                                                \
-    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm2<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
-             hipLaunchKernelGGL((k_qgemm2<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
+#define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
+    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)KERN<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
+             hipLaunchKernelGGL((KERN<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
                     (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
-         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm2<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
-             hipLaunchKernelGGL((k_qgemm2<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)KERN<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
+             hipLaunchKernelGGL((KERN<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
                     (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
-#define MSQ_GM3(IK, OK)                                                                                                \
-    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm3<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
-             hipLaunchKernelGGL((k_qgemm3<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
-         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm3<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
-             hipLaunchKernelGGL((k_qgemm3<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
-    if (variant == 3) {
-        if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM3(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM3(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
-        else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
-        return check_launch2("msq_qlinear_bf16");
-    }
-    if (variant == 2) {
-        if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM2(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
-        else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM2(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
-        else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
-        return check_launch2("msq_qlinear_bf16");
-    }
-#define MSQ_GM(IK, OK)                                                                                                 \
-    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)k_qgemm<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
-             hipLaunchKernelGGL((k_qgemm<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
-         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)k_qgemm<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
-             hipLaunchKernelGGL((k_qgemm<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
-    if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GM(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GM(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
-    else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
-#undef MSQ_GM
+#define MSQ_DISPATCH(KERN)                                                                                             \
+    do { if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_BF16); \
+         else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_FP8); \
+         else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF8); \
+         else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF16); \
+         else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds"); } while (0)
+    if (variant == 3) MSQ_DISPATCH(k_qgemm3);
+    else if (variant == 4) MSQ_DISPATCH(k_qgemm4);
+    else return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: MSQ_GEMM_VARIANT must be 3 (2x4 waves) or 4 (1x8 waves)");
+#undef MSQ_DISPATCH
+#undef MSQ_LAUNCH
     return check_launch2("msq_qlinear_bf16");
 }
 
