@@ -172,6 +172,18 @@ def main():
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                      "kernel": "k_qgemm", "kernel_ms": kern_ms, "flops_per_launch": flops_step},
     }
+    # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    # scripts/profile_gpu.sh, scripts/summarize_profiles.py); they cannot be collected from inside this run.
+    tag = {"posit8_es1": "posit", "fp8_e4m3": "fp8"}.get(args.outlier)
+    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % tag) if tag else None
+    if prof and os.path.exists(prof) and args.workload == "llama7b_w4_fused_gemm" and (M, H) == (2048, 4096):
+        try:
+            pj = json.load(open(prof))
+            out["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/r01_%s_summary.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" % tag
+            out["roofline"]["algorithmic_bytes"] = pj.get("algorithmic_bytes_per_launch")
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier)
     if rank == 0:

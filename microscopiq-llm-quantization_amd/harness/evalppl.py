@@ -1,0 +1,60 @@
+"""Shared pieces of llama_eval / opt_eval: in-place RTN quantisation of every Linear inside the
+decoder layers (embeddings and lm_head untouched, llm/llama.py:262-272) and the reference's
+perplexity formula (llm/llama.py:264-282):
+
+    nsamples = numel // seqlen                      (tail dropped)
+    nll_i    = CrossEntropy(logits_i[:-1], tok_i[1:]) * seqlen
+    ppl      = exp( sum_i nll_i / (nsamples * seqlen) )
+
+The reference evaluates layer by layer with CPU offload (llm/llama.py:195-260); that loop calls
+decoder layers with the transformers-4.26 signature and does not run on current transformers, so
+the windows are pushed through the whole model instead -- the same numbers, no offload."""
+import torch
+import torch.nn as nn
+
+from ..quant import MXQuantizer, quantize_mx_outlier_v1
+from .modelutils import find_layers
+
+# llm/llama.py:229-237, llm/opt.py:193-201: the harness hard-codes this configuration
+DEFAULT_QUANT = dict(inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format='int2',
+                     outlier_elem_format='fp4', axes=[0], block_size=16)
+
+
+@torch.no_grad()
+def quantize_layers_nearest(layers, dev, quant_cfg=None, log=None):
+    """RTN path (`--nearest`, llm/llama.py:226-253): weight.data <- quantize_mx_outlier_v1(weight)."""
+    cfg = dict(DEFAULT_QUANT)
+    if quant_cfg:
+        cfg.update(quant_cfg)
+    for i, layer in enumerate(layers):
+        layer.to(dev)
+        subset = find_layers(layer)
+        for name in subset:
+            quantizer = MXQuantizer()
+            quantizer.configure(**cfg)
+            W = subset[name].weight.data
+            quantizer.find_params(W, weight=True)
+            subset[name].weight.data = quantize_mx_outlier_v1(
+                W, quantizer.inlier_scale_bits, quantizer.outlier_scale_bits, quantizer.inlier_elem_format,
+                quantizer.outlier_elem_format, quantizer.shared_exp_method, quantizer.std_dev, quantizer.axes,
+                quantizer.block_size, quantizer.round, quantizer.flush_fp32_subnorms, quantizer.custom_cuda
+            ).to(next(iter(layer.parameters())).dtype)
+        if log:
+            log(i)
+
+
+@torch.no_grad()
+def perplexity(model, testenc, dev, seqlen):
+    ids = testenc.input_ids if hasattr(testenc, "input_ids") else testenc
+    nsamples = ids.numel() // seqlen
+    model.to(dev)
+    nlls = []
+    loss_fct = nn.CrossEntropyLoss()
+    for i in range(nsamples):
+        batch = ids[:, (i * seqlen):((i + 1) * seqlen)].to(dev)
+        lm_logits = model(batch).logits
+        shift_logits = lm_logits[:, :-1, :].contiguous()
+        shift_labels = batch[:, 1:]
+        loss = loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.reshape(-1))
+        nlls.append(loss.float() * seqlen)
+    return torch.exp(torch.stack(nlls).sum() / (nsamples * seqlen)).item()

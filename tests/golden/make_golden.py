@@ -350,6 +350,70 @@ def main():
         d[f"enc_code|{n}|{es}"] = codes
     np.savez_compressed(os.path.join(HERE, "posit.npz"), **d)
 
+
+    # (8) a14 tiny-model perplexity (llm/llama.py:176-284 formula; weights quantised by the reference's
+    # quantize_mx_outlier_v1 with the harness configuration llm/llama.py:229-237, whole-model forward) ----
+    import torch.nn as nn
+    from transformers import LlamaConfig, LlamaForCausalLM, OPTConfig, OPTForCausalLM
+    d = {}
+    def ppl_of(model, ids, seqlen):
+        n = ids.numel() // seqlen
+        nlls = []
+        with torch.no_grad():
+            for i in range(n):
+                b = ids[:, i * seqlen:(i + 1) * seqlen]
+                lg = model(b).logits
+                loss = nn.CrossEntropyLoss()(lg[:, :-1, :].reshape(-1, lg.size(-1)), b[:, 1:].reshape(-1))
+                nlls.append(loss.float() * seqlen)
+        return torch.exp(torch.stack(nlls).sum() / (n * seqlen)).item()
+    def find_linears(mod, name=''):
+        if type(mod) is nn.Linear:
+            return {name: mod}
+        r = {}
+        for n1, c in mod.named_children():
+            r.update(find_linears(c, name + '.' + n1 if name else n1))
+        return r
+    torch.manual_seed(0)
+    models = {
+        "llama": (LlamaForCausalLM(LlamaConfig(hidden_size=64, intermediate_size=176, num_hidden_layers=2,
+                                               num_attention_heads=4, num_key_value_heads=4, vocab_size=128,
+                                               max_position_embeddings=64)), lambda m: m.model.layers),
+        "opt": (OPTForCausalLM(OPTConfig(hidden_size=64, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4,
+                                         vocab_size=128, max_position_embeddings=64, word_embed_proj_dim=64)),
+                lambda m: m.model.decoder.layers),
+    }
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, 128, (1, 32 * 8 + 5), generator=g)
+    d["tokens"] = ids.numpy()
+    for nm, (model, layers_of) in models.items():
+        model.eval()
+        with torch.no_grad():      # give the weights a realistic spread incl. a heavy tail
+            for p_ in model.parameters():
+                if p_.ndim == 2:
+                    p_.mul_(1.0 + 4.0 * (torch.rand(p_.shape, generator=g) < 0.02).float())
+        for k, v in model.state_dict().items():
+            d[f"{nm}|sd|{k}"] = v.numpy()
+        d[f"{nm}|ppl_fp32"] = np.float64(ppl_of(model, ids, 32))
+        for cfgname, (fi, fo, ax, bs) in {"int2_fp4_ax0": ("int2", "fp4", [0], 16),
+                                          "fp4_fp8_axm1": ("fp4_e2m1", "fp8_e4m3", [-1], 32)}.items():
+            import copy
+            mq = copy.deepcopy(model)
+            for layer in layers_of(mq):
+                for lname, lin in find_linears(layer).items():
+                    lin.weight.data = quant.quantize_mx_outlier_v1(lin.weight.data, 8, 8, fi, fo, "max", 2, ax, bs,
+                                                                   "nearest", False, False)
+            d[f"{nm}|{cfgname}|ppl"] = np.float64(ppl_of(mq, ids, 32))
+            l0 = find_linears(layers_of(mq)[0])
+            for lname in sorted(l0)[:2]:
+                d[f"{nm}|{cfgname}|w|{lname}"] = l0[lname].weight.data.numpy()
+            tot = 0.0
+            for layer in layers_of(mq):
+                for lname, lin in find_linears(layer).items():
+                    tot += float(lin.weight.data.double().abs().sum())
+            d[f"{nm}|{cfgname}|abs_sum"] = np.float64(tot)
+    np.savez_compressed(os.path.join(HERE, "tiny_ppl.npz"), **d)
+    print({k: float(v) for k, v in d.items() if k.endswith("ppl") or k.endswith("ppl_fp32")})
+
     # (9) torch CPU reduction-order pins (what torch.mean / torch.std compute) ---
     d = {}
     g = torch.Generator().manual_seed(5)
