@@ -168,3 +168,131 @@ MSQ_D int outlier_block(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& 
     return status;
 }
 
+
+// ===========================================================================
+// Fast form of the same maths (fake-quant kernels; float/int element formats).  Bit-identical to
+// outlier_block<> / the oracle by construction:
+//  * std: two-pass variance in double; the float result can differ from the sequential Welford
+//    result only when the double lies within 2^-40 (relative) of a float rounding boundary -- those
+//    blocks (about 1 in 65000) fall back to the Welford loop, so the float is always Welford's.
+//  * both shared exponents are known before any element is rounded (max |o * 2^e_in| =
+//    fl(max|o| * 2^e_in): the scaling is monotone), so every element takes ONE trip through the
+//    codec with per-element selected parameters instead of an inlier and an outlier trip.
+//  * 2^k scalings are applied with the same sequence of single-rounded multiplies as the reference.
+// ===========================================================================
+MSQ_D float quant_core_fast(float a, int shift, int min_exp, bool is_int, float max_norm, int rmode) {
+    // elemwise_ops.py:84-174 with saturate_normals, allow_denorm; finite or non-finite input
+    const uint32_t ua = f2u(a);
+    int pe = 0;
+    if (!is_int) {
+        pe = __builtin_amdgcn_frexp_expf(a) - 1;          // exact floor(log2|a|), subnormals included; a == 0 -> -1 (harmless)
+        pe = pe < min_exp ? min_exp : pe;
+    }
+    float x = __builtin_ldexpf(a, shift - pe);             // == a / 2^pe * 2^(bits-2) (first product exact)
+    float r;
+    const float m = __builtin_fabsf(x);
+    if (rmode == 0) r = __builtin_floorf(m + 0.5f);
+    else if (rmode == 1) r = __builtin_floorf(m);
+    else {
+        float q = __builtin_fmodf(m - 0.5f, 2.0f);
+        if (q != 0.f && q < 0.f) q += 2.0f;
+        r = __builtin_floorf(m + 0.5f) - ((q == 0.f) ? 1.f : 0.f);
+    }
+    r = __builtin_copysignf(r, x);
+    float out = __builtin_ldexpf(r, pe - shift);           // == r / 2^(bits-2) * 2^pe
+    out = __builtin_fminf(__builtin_fmaxf(out, -max_norm), max_norm);
+    // NaN in -> NaN out; +-Inf in -> +-Inf out (elemwise_ops.py:165-166)
+    return ((ua & 0x7F800000u) == 0x7F800000u) ? a : out;
+}
+
+template <int BS>
+MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) s += (double)x[i];
+    const double mean = s / (double)BS;
+    double m2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) { const double d = (double)x[i] - mean; m2 = __builtin_fma(d, d, m2); }
+    double den = (double)BS - (double)correction; den = den < 0 ? 0 : den;
+    const double sd = __builtin_sqrt(m2 / den);
+    // distance of the double from the nearest float rounding boundary, in units of the dropped 29 bits
+    const uint64_t bits = __builtin_bit_cast(uint64_t, sd);
+    const uint32_t dropped = (uint32_t)(bits & 0x1FFFFFFFull);
+    const uint32_t dist = dropped > 0x10000000u ? dropped - 0x10000000u : 0x10000000u - dropped;
+    const bool safe = (dist > 0x2000u) && (sd == sd) && (sd > 1e-300) && (sd < 1e300);
+    if (__builtin_expect(safe, 1)) return (float)sd;
+    return std_welford<BS>(x, correction);
+}
+
+template <int BS>
+MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
+                             const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride) {
+    int status = 0;
+    float lo = 0.f, hi = 0.f;
+    if (A.variant == 0) {
+        float ab[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(a[b]);
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        const float mean = s / (float)BS;
+        const float sd = std_twopass_checked<BS>(ab, 0);
+        const float ks = A.k * sd;
+        lo = mean - ks; hi = mean + ks;
+    }
+#pragma unroll
+    for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
+    float mx_in = 0.f, mx_o = 0.f;
+    bool nonfinite = false;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        if (A.variant != 0) {
+            const float mean = vmean[b * vstride], sd = vstd[b * vstride];
+            const float ks = A.k * sd;
+            lo = mean - ks; hi = mean + ks;
+        }
+        const bool m = (a[b] < lo) || (a[b] > hi);
+        mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
+        const float t = __builtin_fabsf(a[b]);
+        nonfinite |= ((f2u(a[b]) & 0x7F800000u) == 0x7F800000u);
+        mx_in = (!m && t > mx_in) ? t : mx_in;
+        mx_o = (m && t > mx_o) ? t : mx_o;
+    }
+    // a NaN / Inf element poisons inlier_val = A*(1-mask) or outlier_val = A*mask (x*0 = NaN) and one of
+    // the reference's NaN asserts fires (utils/quant.py:225-250): only the flag matters then
+    if (nonfinite) { status |= MSQ_STATUS_NAN; mx_in = u2f(0x7FC00000u); }
+    float se_in = shared_exp_of_max(mx_in);
+    const bool fl = A.flush && !(se_in > -127.f);
+    se_in = clamp_scale_exp(se_in - (float)A.fi.emax, A.in_sb, A.variant);
+    const float sc_in = exp2f_int(se_in), rc_in = exp2f_int(-se_in);
+    const float mx_out = mx_o * sc_in;                         // = max |outlier_val * 2^e_in|
+    float se_out = shared_exp_of_max(mx_out);
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    se_out = clamp_scale_exp(se_out - (float)A.fo.emax, A.out_sb, A.variant);
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    const float sc_out = exp2f_int(se_out), rc_out = exp2f_int(-se_out);
+    if (sc_in != sc_in) status |= MSQ_STATUS_NAN;
+    const int sh_i = A.fi.mbits - 2, sh_o = A.fo.mbits - 2;
+    const int me_i = 2 - (1 << (A.fi.ebits ? A.fi.ebits - 1 : 0)), me_o = 2 - (1 << (A.fo.ebits ? A.fo.ebits - 1 : 0));
+    const bool int_i = (A.fi.ebits == 0), int_o = (A.fo.ebits == 0);
+    const float pre_in = fl ? 0.f : rc_in;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        const bool m = (mkw[b >> 5] >> (b & 31)) & 1u;
+        float t = a[b];
+        t = m ? t * sc_in : t;                                  // :216 (outliers only)
+        t = t * (m ? rc_out : pre_in);                          // :247 / :214 (+ flush :202)
+        float q;
+        if (m) q = quant_core_fast(t, sh_o, me_o, int_o, A.fo.max_norm, A.rmode);
+        else q = quant_core_fast(t, sh_i, me_i, int_i, A.fi.max_norm, A.rmode);
+        float u = q * (m ? sc_out : sc_in);                     // :258 / :224
+        u = m ? u * rc_in : u;                                  // :258
+        if (u != u) status |= MSQ_STATUS_NAN;
+        a[b] = u + 0.0f;                                        // inlier + outlier part: the other part is +0
+    }
+    se_in_o = se_in; se_out_o = se_out;
+    return status;
+}

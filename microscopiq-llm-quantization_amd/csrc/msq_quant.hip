@@ -233,7 +233,9 @@ k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) 
     float se_in, se_out;
     const float* vm = A.vmean ? A.vmean + (p * BS) * A.post + q : nullptr;
     const float* vs = A.vstd ? A.vstd + (p * BS) * A.post + q : nullptr;
-    const int status = outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+    const int status = (A.fi.kind == 0 && A.fo.kind == 0)
+        ? outlier_block_fast<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post)
+        : outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         if (a0 + b < A.axis_len) {
@@ -291,7 +293,8 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     if (g < nblocks) {
         const float* vm = A.vmean ? A.vmean + p * BS : nullptr;
         const float* vs = A.vstd ? A.vstd + p * BS : nullptr;
-        status = outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+        status = (A.fi.kind == 0 && A.fo.kind == 0) ? outlier_block_fast<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1)
+                                                     : outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
     }
     if (fast) {
         __builtin_amdgcn_wave_barrier();
