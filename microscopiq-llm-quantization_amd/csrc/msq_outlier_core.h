@@ -180,26 +180,27 @@ MSQ_D int outlier_block(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& 
 //    codec with per-element selected parameters instead of an inlier and an outlier trip.
 //  * 2^k scalings are applied with the same sequence of single-rounded multiplies as the reference.
 // ===========================================================================
-MSQ_D float quant_core_fast(float a, int shift, int min_exp, bool is_int, float max_norm, int rmode) {
-    // elemwise_ops.py:84-174 with saturate_normals, allow_denorm; finite or non-finite input
+template <int RM>
+MSQ_D float quant_core_fast(float a, int shift, int pe_lo, int pe_hi, float max_norm, int rmode) {
+    // elemwise_ops.py:84-174 with saturate_normals, allow_denorm.  The private exponent is clamped to
+    // [pe_lo, pe_hi]: (min_exp, 127) for float formats, (0, 0) for the integer formats.
     const uint32_t ua = f2u(a);
-    int pe = 0;
-    if (!is_int) {
-        pe = __builtin_amdgcn_frexp_expf(a) - 1;          // exact floor(log2|a|), subnormals included; a == 0 -> -1 (harmless)
-        pe = pe < min_exp ? min_exp : pe;
-    }
-    float x = __builtin_ldexpf(a, shift - pe);             // == a / 2^pe * 2^(bits-2) (first product exact)
-    float r;
+    int pe = __builtin_amdgcn_frexp_expf(a) - 1;           // exact floor(log2|a|), subnormals included; a == 0 -> -1 (harmless)
+    pe = pe < pe_lo ? pe_lo : pe;
+    pe = pe > pe_hi ? pe_hi : pe;
+    const float x = __builtin_ldexpf(a, shift - pe);        // == a / 2^pe * 2^(bits-2) (first product exact)
     const float m = __builtin_fabsf(x);
-    if (rmode == 0) r = __builtin_floorf(m + 0.5f);
-    else if (rmode == 1) r = __builtin_floorf(m);
+    float r;
+    const int rm = (RM >= 0) ? RM : rmode;
+    if (rm == 0) r = __builtin_floorf(m + 0.5f);
+    else if (rm == 1) r = __builtin_floorf(m);
     else {
         float q = __builtin_fmodf(m - 0.5f, 2.0f);
         if (q != 0.f && q < 0.f) q += 2.0f;
         r = __builtin_floorf(m + 0.5f) - ((q == 0.f) ? 1.f : 0.f);
     }
     r = __builtin_copysignf(r, x);
-    float out = __builtin_ldexpf(r, pe - shift);           // == r / 2^(bits-2) * 2^pe
+    float out = __builtin_ldexpf(r, pe - shift);            // == r / 2^(bits-2) * 2^pe
     out = __builtin_fminf(__builtin_fmaxf(out, -max_norm), max_norm);
     // NaN in -> NaN out; +-Inf in -> +-Inf out (elemwise_ops.py:165-166)
     return ((ua & 0x7F800000u) == 0x7F800000u) ? a : out;
@@ -225,7 +226,7 @@ MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
     return std_welford<BS>(x, correction);
 }
 
-template <int BS>
+template <int BS, int RM>
 MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
                              const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride) {
     int status = 0;
@@ -276,20 +277,18 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     const float sc_out = exp2f_int(se_out), rc_out = exp2f_int(-se_out);
     if (sc_in != sc_in) status |= MSQ_STATUS_NAN;
     const int sh_i = A.fi.mbits - 2, sh_o = A.fo.mbits - 2;
-    const int me_i = 2 - (1 << (A.fi.ebits ? A.fi.ebits - 1 : 0)), me_o = 2 - (1 << (A.fo.ebits ? A.fo.ebits - 1 : 0));
-    const bool int_i = (A.fi.ebits == 0), int_o = (A.fo.ebits == 0);
+    const int lo_i = A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0, hi_i = A.fi.ebits ? 127 : 0;
+    const int lo_o = A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0, hi_o = A.fo.ebits ? 127 : 0;
     const float pre_in = fl ? 0.f : rc_in;
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         const bool m = (mkw[b >> 5] >> (b & 31)) & 1u;
-        float t = a[b];
-        t = m ? t * sc_in : t;                                  // :216 (outliers only)
+        float t = a[b] * (m ? sc_in : 1.0f);                    // :216 (outliers only; x1 is exact)
         t = t * (m ? rc_out : pre_in);                          // :247 / :214 (+ flush :202)
-        float q;
-        if (m) q = quant_core_fast(t, sh_o, me_o, int_o, A.fo.max_norm, A.rmode);
-        else q = quant_core_fast(t, sh_i, me_i, int_i, A.fi.max_norm, A.rmode);
+        const float q = quant_core_fast<RM>(t, m ? sh_o : sh_i, m ? lo_o : lo_i, m ? hi_o : hi_i,
+                                            m ? A.fo.max_norm : A.fi.max_norm, A.rmode);
         float u = q * (m ? sc_out : sc_in);                     // :258 / :224
-        u = m ? u * rc_in : u;                                  // :258
+        u = u * (m ? rc_in : 1.0f);                             // :258
         if (u != u) status |= MSQ_STATUS_NAN;
         a[b] = u + 0.0f;                                        // inlier + outlier part: the other part is +0
     }

@@ -209,7 +209,7 @@ MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS 
 
 // --- layout A: post > 1.  lane <-> (p, nb, q), q fastest: each of the BS row reads
 // of a wave is one contiguous 256-byte segment.
-template <int BS, typename T>
+template <int BS, typename T, int FAST>
 __global__ void __launch_bounds__(256)
 k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     const int64_t total = A.pre * A.nblk * A.post;
@@ -233,9 +233,10 @@ k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) 
     float se_in, se_out;
     const float* vm = A.vmean ? A.vmean + (p * BS) * A.post + q : nullptr;
     const float* vs = A.vstd ? A.vstd + (p * BS) * A.post + q : nullptr;
-    const int status = (A.fi.kind == 0 && A.fo.kind == 0)
-        ? outlier_block_fast<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post)
-        : outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+    int status;
+    if (FAST == 1) status = outlier_block_fast<BS, 0>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+    else if (FAST == 2) status = outlier_block_fast<BS, -1>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+    else status = outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         if (a0 + b < A.axis_len) {
@@ -251,7 +252,7 @@ k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) 
 // streams it with 16-byte coalesced accesses and transposes through LDS (row stride
 // BS+4 floats: conflict-free ds_read_b128 for 16-lane groups) so that each lane ends
 // up with its own block in registers; results go back the same way.
-template <int BS, typename T>
+template <int BS, typename T, int FAST>
 __global__ void __launch_bounds__(256)
 k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     constexpr int LDS_STRIDE = BS + 4;
@@ -293,8 +294,9 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     if (g < nblocks) {
         const float* vm = A.vmean ? A.vmean + p * BS : nullptr;
         const float* vs = A.vstd ? A.vstd + p * BS : nullptr;
-        status = (A.fi.kind == 0 && A.fo.kind == 0) ? outlier_block_fast<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1)
-                                                     : outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+        if (FAST == 1) status = outlier_block_fast<BS, 0>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+        else if (FAST == 2) status = outlier_block_fast<BS, -1>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+        else status = outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
     }
     if (fast) {
         __builtin_amdgcn_wave_barrier();
@@ -413,21 +415,29 @@ static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
     return (int)g;
 }
 
-template <typename T>
-static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
+template <typename T, int FAST>
+static int launch_outlier_impl(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
     const int64_t nthreads = A.pre * A.nblk * A.post;
-#define MSQ_OL(BS)                                                                                      \
-    case BS:                                                                                            \
-        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T>), dim3(grid_for(nthreads, 256)),   \
-                                            dim3(256), 0, st, (const T*)in, (T*)out, A);                \
-        else hipLaunchKernelGGL((k_outlier_strided<BS, T>), dim3(grid_for(nthreads, 256)), dim3(256),   \
-                                0, st, (const T*)in, (T*)out, A);                                       \
+#define MSQ_OL(BS)                                                                                        \
+    case BS:                                                                                              \
+        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T, FAST>), dim3(grid_for(nthreads, 256)), \
+                                            dim3(256), 0, st, (const T*)in, (T*)out, A);                  \
+        else hipLaunchKernelGGL((k_outlier_strided<BS, T, FAST>), dim3(grid_for(nthreads, 256)), dim3(256), \
+                                0, st, (const T*)in, (T*)out, A);                                         \
         break;
     switch (block) { MSQ_OL(8) MSQ_OL(16) MSQ_OL(32) MSQ_OL(64) MSQ_OL(128)
         default: return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
     }
 #undef MSQ_OL
     return MSQ_OK;
+}
+template <typename T>
+static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
+    // float / int element formats take the fast block maths, posit formats the generic one
+    // 1: nearest rounding specialised, 2: any rounding mode, 0: generic maths (posit)
+    if (A.fi.kind == 0 && A.fo.kind == 0)
+        return (A.rmode == 0) ? launch_outlier_impl<T, 1>(in, out, A, block, st) : launch_outlier_impl<T, 2>(in, out, A, block, st);
+    return launch_outlier_impl<T, 0>(in, out, A, block, st);
 }
 
 extern "C" {
