@@ -31,6 +31,9 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MSQ_ABL
 #define MSQ_ABL 0
 #endif
+#ifndef MSQ_NT
+#define MSQ_NT 0
+#endif
 #ifndef MSQ_PRIO
 #define MSQ_PRIO 0
 #endif
@@ -316,6 +319,65 @@ MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
     for (int s = 0; s < HalfSlots<OUT_KIND>::n; ++s) keep_live4(h.out[s]);
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue of a 128(m) x 64(n) wave tile through LDS: the MFMA result layout gives every lane 4
+// consecutive n of one row (8-byte pieces, 32-byte runs per row) -- stored directly they reach L2 as
+// partial lines and the store tail is issue-bound (measured 7 % of the kernel).  Each wave instead
+// transposes its tile through its own 8 KiB LDS slice (XOR-swizzled 16-byte chunks, no block barrier
+// needed) and writes whole 128-byte (bf16) / 256-byte (f32) row segments with 16-byte stores.
+// ---------------------------------------------------------------------------
+template <typename YT>
+MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[8][4], char* wsm, YT* __restrict__ Y, int m_base, int n_base,
+                               int M, int N, const float* __restrict__ bias, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int ROW_B = 64 * (int)sizeof(YT);             // bytes per tile row: 128 (bf16) / 256 (f32)
+    constexpr int RP = 8192 / ROW_B;                         // rows per pass: 64 / 32
+    constexpr int MF_PER_PASS = RP / 16;                     // 4 / 2
+    constexpr int CHUNKS = ROW_B / 16;                       // 16-byte chunks per row: 8 / 16
+    float bv[4][4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[nf][j] = bias ? bias[n_base + nf * 16 + g * 4 + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8 / MF_PER_PASS; ++p) {
+#pragma unroll
+        for (int i = 0; i < MF_PER_PASS; ++i) {
+            const int mf = p * MF_PER_PASS + i;
+            const int row = i * 16 + c;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                f32x4_t v = acc[mf][nf];
+                v[0] += bv[nf][0]; v[1] += bv[nf][1]; v[2] += bv[nf][2]; v[3] += bv[nf][3];
+                if (sizeof(YT) == 4) {
+                    const int chunk = (nf * 4 + g) ^ (row & (CHUNKS - 1));
+                    *reinterpret_cast<float4*>(wsm + row * ROW_B + chunk * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16x2_t lo, hi;
+                    lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                    const int chunk = (nf * 2 + (g >> 1)) ^ (row & (CHUNKS - 1));
+                    *reinterpret_cast<uint2*>(wsm + row * ROW_B + chunk * 16 + (g & 1) * 8) =
+                        make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        constexpr int ROWS_PER_INSTR = 64 / CHUNKS;          // 8 / 4
+#pragma unroll
+        for (int t = 0; t < RP / ROWS_PER_INSTR; ++t) {
+            const int row = t * ROWS_PER_INSTR + lane / CHUNKS;
+            const int chunk = lane % CHUNKS;
+            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(wsm + row * ROW_B + ((chunk ^ (row & (CHUNKS - 1))) * 16));
+            const int m = m_base + p * RP + row;
+            if (m < M)
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Y) + ((int64_t)m * N + n_base) * (int64_t)sizeof(YT) + chunk * 16) = d;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next pass overwrites
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int IN_KIND, int OUT_KIND, typename YT>
 __global__ void __launch_bounds__(512)
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
@@ -425,25 +487,9 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     }
 #undef MSQ_HALF_STEP
 
-#pragma unroll
-    for (int mf = 0; mf < 8; ++mf) {
-        const int m = m0 + wm * 128 + mf * 16 + c;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + wn * 64 + nf * 16 + g * 4;
-            f32x4_t v = acc[mf][nf];
-            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
-            if (sizeof(YT) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x2_t lo, hi;
-                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
-                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-            }
-        }
-    }
+    if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
+    store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
 }
 
 // ---------------------------------------------------------------------------
