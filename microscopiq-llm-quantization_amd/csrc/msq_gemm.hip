@@ -25,17 +25,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-#ifndef MSQ_DRAIN
-#define MSQ_DRAIN 0
-#endif
 #ifndef MSQ_ABL
 #define MSQ_ABL 0
-#endif
-#ifndef MSQ_NT
-#define MSQ_NT 0
-#endif
-#ifndef MSQ_PRIO
-#define MSQ_PRIO 0
 #endif
 #define TILE_N 64
 #define TILE_K 64
@@ -105,13 +96,22 @@ MSQ_D u32x4_t tile_frag(const TileRegs& t, int nf, int kf) {
     }
 }
 
+// Lane / fragment -> (n, k) maps of the two tile layouts.  Both have, per half tile (32 k), four
+// fragments f = 0..3 of 8 consecutive k per lane, so slots, loads and converts are shared:
+//   layout 1 (v_mfma_f32_16x16x32_bf16): f = nf,            n = 16 f + (l & 15),        k = 32 kf + 8 (l >> 4) + j
+//   layout 2 (v_mfma_f32_32x32x16_bf16): f = 2 nt + kk,     n = 32 (f >> 1) + (l & 31), k = 32 kf + 16 (f & 1) + 8 (l >> 5) + j
+template <int LAYOUT> MSQ_D int frag_n(int lane, int f) { return LAYOUT == 1 ? f * 16 + (lane & 15) : (f >> 1) * 32 + (lane & 31); }
+template <int LAYOUT> MSQ_D int frag_k(int lane, int f, int kf) { return LAYOUT == 1 ? kf * 32 + (lane >> 4) * 8 : kf * 32 + (f & 1) * 16 + (lane >> 5) * 8; }
+template <int LAYOUT> MSQ_D int scale_group(int lane) { return LAYOUT == 1 ? (lane & 15) : (lane & 31); }
+template <int LAYOUT> MSQ_D bool scale_writer(int lane) { return LAYOUT == 1 ? (lane >> 4) == 0 : (lane >> 5) == 0; }
+
 template <int OUT_KIND> struct OutSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 8 : 4; };
 
 // ---------------------------------------------------------------------------
 // repack: codes[N][K] (u32: bits 0-7 inlier code, 8-23 outlier code) + per-block
 // exponents -> tile-major planes.  One wave per tile.
 // ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND>
+template <int IN_KIND, int OUT_KIND, int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, const float* __restrict__ e_out,
          uint8_t* __restrict__ inl_plane, uint8_t* __restrict__ out_plane, uint8_t* __restrict__ scl_plane,
@@ -121,7 +121,6 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
     const int64_t KT = K / TILE_K, NT = N / TILE_N;
     if (tile >= KT * NT) return;
     const int64_t nt = tile / KT, kt = tile % KT;
-    const int c = lane & 15, g = lane >> 4;
     const int64_t nblk = K / block;
     constexpr int OS = OutSlots<OUT_KIND>::n;
     uint32_t sc[4] = {0, 0, 0, 0};
@@ -131,8 +130,8 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
         u32x4_t inl4;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const int64_t n = nt * TILE_N + nf * 16 + c;
-            const int64_t k = kt * TILE_K + kf * 32 + g * 8;
+            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
             const u32x4_t c0 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k);
             const u32x4_t c1 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k + 4);
             const uint32_t cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -167,10 +166,10 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
     }
     if (IN_KIND != MSQ_PLANE_NONE) {
         const bool per_lane = block < 32;
-        const int groups = per_lane ? 64 : 16;
-        if (per_lane || g == 0) {
+        const int groups = per_lane ? 64 : (LAYOUT == 1 ? 16 : 32);
+        if (per_lane || scale_writer<LAYOUT>(lane)) {
             u32x4_t s4; s4[0] = sc[0]; s4[1] = sc[1]; s4[2] = sc[2]; s4[3] = sc[3];
-            *reinterpret_cast<u32x4_t*>(scl_plane + (tile * groups + (per_lane ? lane : c)) * 16) = s4;
+            *reinterpret_cast<u32x4_t*>(scl_plane + (tile * groups + (per_lane ? lane : scale_group<LAYOUT>(lane))) * 16) = s4;
         }
     }
     if (st && status) atomicOr(status, st);
@@ -195,7 +194,7 @@ MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_p
 // ---------------------------------------------------------------------------
 // unpack: planes -> dense W[N][K] (f32 or bf16), same converts as the GEMM.
 // ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND, typename OT>
+template <int IN_KIND, int OUT_KIND, typename OT, int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, OT* __restrict__ W, int64_t N, int64_t K, int scl_groups) {
@@ -204,7 +203,6 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
     const int64_t KT = K / TILE_K, NT = N / TILE_N;
     if (tile >= KT * NT) return;
     const int64_t nt = tile / KT, kt = tile % KT;
-    const int c = lane & 15, g = lane >> 4;
     TileRegs t;
     load_tile<IN_KIND, OUT_KIND>(t, inl_plane, out_plane, scl_plane, tile, lane, scl_groups);
 #pragma unroll
@@ -212,8 +210,8 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const u32x4_t f = tile_frag<IN_KIND, OUT_KIND>(t, nf, kf);
-            const int64_t n = nt * TILE_N + nf * 16 + c;
-            const int64_t k = kt * TILE_K + kf * 32 + g * 8;
+            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
             if (sizeof(OT) == 2) {
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(W) + n * K + k) = f;
             } else {
@@ -452,10 +450,8 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
             if (mf + 2 < 8 && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
-            if (MSQ_PRIO) __builtin_amdgcn_s_setprio(1);                                                     \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
-            if (MSQ_PRIO) __builtin_amdgcn_s_setprio(0);                                                     \
             if (!(MSQ_ABL & 2)) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);    \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
@@ -482,200 +478,14 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         sc_cur = sc_nxt;
         // A(kt+1) has landed: its LDS-DMA ops are older than the pkA loads this wave waited for at the
         // top of the second half-step (in-order vmcnt).  The pkB loads stay in flight across the barrier.
-        if (MSQ_DRAIN) { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
-        else { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
     }
 #undef MSQ_HALF_STEP
 
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
     store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
-}
-
-// ---------------------------------------------------------------------------
-// v4: 8 waves as 1(m) x 8(n): wave tile 256 x 32.  Every packed weight fragment is converted by
-// exactly ONE wave (v3's 2(m) x 4(n) converted each fragment twice), which halves the VALU and
-// VMEM issue per MFMA -- the measured limiter of v3 (ablation: converts 17 %, packed loads 13 %).
-// The price is that every wave reads all 256 rows of the activation tile from LDS (16 ds_read_b128
-// per half-step instead of 8; LDS array ~50 % busy).  Two waves share one 64-column packed tile:
-// wave wn takes fragments nf = 2 (wn & 1) .. +1, i.e. half of every 16-byte lane slot.
-// ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND>
-struct PairRegs {            // one half-step (kf) of one fragment pair
-    uint2 inl;               // dword per nf
-    u32x4_t out[(OUT_KIND == MSQ_PLANE_BF16) ? 2 : 1];
-};
-
-template <int IN_KIND, int OUT_KIND>
-MSQ_D void load_pair(PairRegs<IN_KIND, OUT_KIND>& h, const uint8_t* inl_lane, const uint8_t* out_lane, int64_t tile, int kf, int np) {
-    if (IN_KIND != MSQ_PLANE_NONE)
-        h.inl = *reinterpret_cast<const uint2*>(inl_lane + (tile * 2 + kf) * 1024 + np * 8);
-    if (OUT_KIND == MSQ_PLANE_BF16) {
-        h.out[0] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 4 + np * 2) * 1024);
-        h.out[1] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 4 + np * 2 + 1) * 1024);
-    } else {
-        h.out[0] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * 2 + np) * 1024);
-    }
-}
-
-// quarter q (0..3): fragment nf = q / 2 of the pair, dwords 2 (q % 2) .. +1
-template <int IN_KIND, int OUT_KIND>
-MSQ_D void convert_pair_quarter(u32x4_t (&wf)[2], const PairRegs<IN_KIND, OUT_KIND>& h, uint2 scl, int kf, int q) {
-    const int nf = q >> 1, hh = q & 1;
-    if (IN_KIND == MSQ_PLANE_NONE) {
-        wf[nf][2 * hh] = h.out[nf][2 * hh]; wf[nf][2 * hh + 1] = h.out[nf][2 * hh + 1];
-        return;
-    }
-    const uint32_t sd = nf ? scl.y : scl.x;
-    const uint32_t iw = nf ? h.inl.y : h.inl.x;
-    const float s_in = scale_operand(sd, kf * 2);
-    uint32_t r0, r1;
-    if (hh == 0) {
-        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 0));
-        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 1));
-    } else {
-        r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 2));
-        r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(iw, s_in, 3));
-    }
-    if (OUT_KIND == MSQ_PLANE_BF16) {
-        r0 |= h.out[nf][2 * hh]; r1 |= h.out[nf][2 * hh + 1];
-    } else {
-        const float s_out = scale_operand(sd, kf * 2 + 1);
-        const uint32_t o = h.out[0][nf * 2 + hh];
-        if (OUT_KIND == MSQ_PLANE_FP8) {
-            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, false));
-            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s_out, true));
-        } else {
-            r0 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, false));
-            r1 |= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(o, s_out, true));
-        }
-    }
-    wf[nf][2 * hh] = r0; wf[nf][2 * hh + 1] = r1;
-}
-
-template <int IN_KIND, int OUT_KIND>
-MSQ_D void keep_live_pair(PairRegs<IN_KIND, OUT_KIND>& h) {
-    if (IN_KIND != MSQ_PLANE_NONE) asm volatile("" : "+v"(h.inl));
-    keep_live4(h.out[0]);
-    if (OUT_KIND == MSQ_PLANE_BF16) keep_live4(h.out[1]);
-}
-
-template <int IN_KIND, int OUT_KIND, typename YT>
-__global__ void __launch_bounds__(512)
-k_qgemm4(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
-         const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-         int scl_groups) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wn = wid;                       // 8 waves along n, 32 columns each
-    const int np = wn & 1;                    // which fragment pair of the 64-column packed tile
-    const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + BM - 1) / BM, NTB = N / BN;
-    int bid = blockIdx.x, bm, bn;
-    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
-    else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int KT = K / BK;
-    const int64_t tile_row = (int64_t)(n0 / TILE_N + (wn >> 1)) * KT;
-
-    const uint8_t* inl_lane = inl_plane + lane * 16;
-    const uint8_t* out_lane = out_plane + lane * 16;
-    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16 + np * 8;
-    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
-
-    const uint16_t* asrc[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int piece = wid * 4 + p;
-        const int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gr = m0 + row; gr = gr < M ? gr : M - 1;
-        asrc[p] = X + (int64_t)gr * K + chunk * 8;
-    }
-    auto stage_A = [&](int kt, int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
-                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
-                                             16, 0, 0);
-    };
-    const int sw = (c >> 1) & 7;
-    const int rd0 = c * 128 + (((0 + g) ^ sw) << 4);
-    const int rd1 = c * 128 + (((4 + g) ^ sw) << 4);
-
-    f32x4_t acc[16][2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    PairRegs<IN_KIND, OUT_KIND> pkA, pkB;
-    u32x4_t wfA[2], wfB[2];
-    uint2 sc_cur = make_uint2(0, 0), sc_nxt = make_uint2(0, 0);
-
-    stage_A(0, 0);
-    load_pair<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0, np);
-    load_pair<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1, np);
-    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const uint2*>(scl_lane + tile_row * scl_tile_bytes);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) convert_pair_quarter<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0, q);
-
-#define MSQ_HALF_STEP4(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, RD)                                        \
-    {                                                                                                        \
-        bf16x8_t xf[3];                                                                                      \
-        xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
-        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
-        _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                  \
-            if (mf + 2 < 16) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
-            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                 \
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
-            if ((mf & 3) == 1) convert_pair_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf >> 2); \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-        }                                                                                                    \
-    }
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        const char* abase = smem + buf * A_TILE_BYTES;
-        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;
-        keep_live_pair(pkB);
-        stage_A(ktn, buf ^ 1);
-        load_pair<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0, np);
-        if (IN_KIND != MSQ_PLANE_NONE) sc_nxt = *reinterpret_cast<const uint2*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
-        __builtin_amdgcn_sched_barrier(0);
-        MSQ_HALF_STEP4(wfA, wfB, pkB, sc_cur, 1, rd0)
-        keep_live_pair(pkA);
-        if (IN_KIND != MSQ_PLANE_NONE) asm volatile("" : "+v"(sc_nxt));
-        load_pair<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1, np);
-        __builtin_amdgcn_sched_barrier(0);
-        MSQ_HALF_STEP4(wfB, wfA, pkA, sc_nxt, 0, rd1)
-        sc_cur = sc_nxt;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-    }
-#undef MSQ_HALF_STEP4
-
-#pragma unroll
-    for (int mf = 0; mf < 16; ++mf) {
-        const int m = m0 + mf * 16 + c;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            const int n = n0 + wn * 32 + nf * 16 + g * 4;
-            f32x4_t v = acc[mf][nf];
-            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
-            if (sizeof(YT) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x2_t lo, hi;
-                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) =
-                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-            }
-        }
-    }
 }
 
 // ===========================================================================
@@ -690,6 +500,10 @@ static int check_launch2(const char* what) {
     return MSQ_OK;
 }
 extern "C" void msq_set_error_(const char* msg);
+// tile layout of the packed planes: 1 = 16x16x32 fragments.  (Layout 2 = 32x32x16 fragments was built
+// and measured 8-10 % slower end to end -- the chip holds a lower clock on that MFMA shape -- and removed;
+// the frag_n / frag_k maps keep the seam.)
+static int msq_layout() { return 1; }
 static int fail2(int code, const char* msg) { msq_set_error_(msg); (void)g_err2; return code; }
 
 extern "C" {
@@ -720,7 +534,7 @@ int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind,
     if (!(block == 8 || block == 16 || block == 32 || block == 64 || block == 128) || (K % block))
         return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: block must be 8/16/32/64/128 and divide K");
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
-    const int groups = block < 32 ? 64 : 16;
+    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
     if (inl_bytes) *inl_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * 2 * 1024;
     if (out_bytes) *out_bytes = tiles * ((out_kind == MSQ_PLANE_BF16) ? 8 : 4) * 1024;
     if (scale_bytes) *scale_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * groups * 16;
@@ -755,8 +569,10 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define MSQ_RP(IK, OK) hipLaunchKernelGGL((k_repack<IK, OK>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
-                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag)
+#define MSQ_RP(IK, OK) do { if (msq_layout() == 1) hipLaunchKernelGGL((k_repack<IK, OK, 1>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
+                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag);            \
+                            else hipLaunchKernelGGL((k_repack<IK, OK, 2>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
+                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag); } while (0)
     if (ik == MSQ_PLANE_NONE) MSQ_RP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
     else if (ok == MSQ_PLANE_FP8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (ok == MSQ_PLANE_BF8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
@@ -775,12 +591,16 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    const int groups = block < 32 ? 64 : 16;
+    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
 #define MSQ_UP(IK, OK)                                                                                               \
-    do { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
+    do { if (msq_layout() == 1) { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float, 1>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
                     (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)W_out, N, K, groups);              \
-         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t>), grid, blk, 0, st, (const uint8_t*)inl_plane,             \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); } while (0)
+         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t, 1>), grid, blk, 0, st, (const uint8_t*)inl_plane,          \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); }          \
+         else { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float, 2>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)W_out, N, K, groups);              \
+         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t, 2>), grid, blk, 0, st, (const uint8_t*)inl_plane,          \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); } } while (0)
     if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_UP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
@@ -805,9 +625,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const dim3 grid((unsigned)(MT * NTB)), blk(512);
     const size_t lds = 2 * A_TILE_BYTES;
     hipStream_t st = (hipStream_t)stream;
-    const int groups = block < 32 ? 64 : 16;
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MSQ_GEMM_VARIANT"); variant = e ? atoi(e) : 3; }
+    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
 #define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
     do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)KERN<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
              hipLaunchKernelGGL((KERN<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
@@ -821,9 +639,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF8); \
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF16); \
          else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds"); } while (0)
-    if (variant == 3) MSQ_DISPATCH(k_qgemm3);
-    else if (variant == 4) MSQ_DISPATCH(k_qgemm4);
-    else return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: MSQ_GEMM_VARIANT must be 3 (2x4 waves) or 4 (1x8 waves)");
+    MSQ_DISPATCH(k_qgemm3);
 #undef MSQ_DISPATCH
 #undef MSQ_LAUNCH
     return check_launch2("msq_qlinear_bf16");
