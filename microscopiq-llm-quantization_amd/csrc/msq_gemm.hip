@@ -380,17 +380,33 @@ template <int IN_KIND, int OUT_KIND, typename YT>
 __global__ void __launch_bounds__(512)
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-         int scl_groups) {
+         int scl_groups, int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
     const int c = lane & 15, g = lane >> 4;
     const int MT = (M + BM - 1) / BM, NTB = N / BN;
-    int bid = blockIdx.x, bm, bn;
-    if ((NTB & 7) == 0) { const int xcd = bid & 7, i = bid >> 3; bn = (i / MT) * 8 + xcd; bm = i % MT; }
-    else { bm = bid % MT; bn = bid / MT; }
+    const int ks = (int)(blockIdx.x % (unsigned)ksplit);
+    const int bid = (int)(blockIdx.x / (unsigned)ksplit);
+    int bm, bn;
+    if ((NTB & 7) == 0 && ksplit == 1) {
+        // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): XCD x owns the column panels
+        // bn = 8 cp + x and walks them in super-tiles of (up to) 8 row tiles x 4 panels, so the 32 blocks
+        // resident on an XCD share 4 packed W panels and 8 activation tiles out of its own L2.
+        const int xcd = bid & 7, i = bid >> 3;
+        const int npx = NTB >> 3, per_group = 8 * npx, full = MT >> 3;
+        int rg, j, R;
+        if (i < full * per_group) { rg = i / per_group; j = i % per_group; R = 8; }
+        else { rg = full; j = i - full * per_group; R = MT - full * 8; }
+        bm = rg * 8 + j % R;
+        bn = (j / R) * 8 + xcd;
+    } else { bm = bid % MT; bn = bid / MT; }
     const int m0 = bm * BM, n0 = bn * BN;
     const int KT = K / BK;
+    // split-K: this block covers K-steps [kt_lo, kt_hi) and writes an fp32 partial tile
+    const int kchunk = (KT + ksplit - 1) / ksplit;
+    const int kt_lo = ks * kchunk;
+    const int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
     const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
 
     // per-lane bases of the packed planes (every slot is 64 lanes x 16 B)
@@ -431,10 +447,11 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     u32x4_t wfA[4], wfB[4];
     u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0};
 
-    stage_A(0, 0);
-    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row, 0);
-    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row, 1);
-    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + tile_row * scl_tile_bytes);
+    const int kt0 = (kt_lo < KT) ? kt_lo : KT - 1;             // an empty split still runs a harmless prologue
+    stage_A(kt0, 0);
+    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + kt0, 0);
+    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + kt0, 1);
+    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + kt0) * scl_tile_bytes);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #pragma unroll
@@ -457,10 +474,10 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         }                                                                                                    \
     }
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int buf = (kt - kt_lo) & 1;
         const char* abase = smem + buf * A_TILE_BYTES;
-        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;          // branch-free tail: re-load the last tile
+        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;       // branch-free tail: re-load the last tile
         // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
         keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
         if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);
@@ -485,7 +502,32 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
-    store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
+    if (ksplit > 1)
+        store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * 128, n0 + wn * 64, M, N,
+                                   nullptr, lane);
+    else
+        store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
+}
+
+// sum of the split-K partial tiles (+ bias) -> Y
+template <typename YT>
+__global__ void __launch_bounds__(256)
+k_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bias, YT* __restrict__ Y, int64_t MN, int N,
+                int ksplit) {
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= MN) return;
+    float4 s = *reinterpret_cast<const float4*>(partial + i4);
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(partial + (int64_t)k * MN + i4);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    if (bias) { const int n = (int)(i4 % N); s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
+    if (sizeof(YT) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + i4) = s;
+    else {
+        bf16x2_t lo, hi;
+        lo[0] = (__bf16)s.x; lo[1] = (__bf16)s.y; hi[0] = (__bf16)s.z; hi[1] = (__bf16)s.w;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + i4) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+    }
 }
 
 // ===========================================================================
@@ -610,9 +652,26 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     return check_launch2("msq_outlier_unpack");
 }
 
+// split-K factor: enough blocks to fill the 256 CUs when M is small (decode / short prefill)
+static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
+    const int64_t blocks = ((M + BM - 1) / BM) * (N / BN);
+    const int64_t KT = K / BK;
+    if (blocks >= 256 || KT < 8) return 1;
+    int64_t ks = (512 + blocks - 1) / blocks;
+    if (ks > KT / 4) ks = KT / 4;
+    if (ks > 32) ks = 32;
+    return ks < 1 ? 1 : (int)ks;
+}
+
+int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
+    const int ks = pick_ksplit(M, N, K);
+    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+}
+
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
-                     int in_kind, int out_kind, void* stream) {
+                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: negative M");
     int rc = msq_packed_sizes(N, K, block, in_kind, out_kind, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -622,17 +681,20 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     const int MT = (int)((M + BM - 1) / BM), NTB = (int)(N / BN);
-    const dim3 grid((unsigned)(MT * NTB)), blk(512);
+    int ksplit = pick_ksplit(M, N, K);
+    if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;   // no scratch: one pass
+    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(512);
     const size_t lds = 2 * A_TILE_BYTES;
     hipStream_t st = (hipStream_t)stream;
     const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    float* partial = (float*)workspace;
 #define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
     do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)KERN<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
              hipLaunchKernelGGL((KERN<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups); } \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } \
          else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)KERN<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
              hipLaunchKernelGGL((KERN<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups); } } while (0)
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } } while (0)
 #define MSQ_DISPATCH(KERN)                                                                                             \
     do { if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_BF16); \
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_FP8); \
@@ -642,7 +704,13 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     MSQ_DISPATCH(k_qgemm3);
 #undef MSQ_DISPATCH
 #undef MSQ_LAUNCH
-    return check_launch2("msq_qlinear_bf16");
+    rc = check_launch2("msq_qlinear_bf16");
+    if (rc || ksplit == 1) return rc;
+    const int64_t MN = M * N;
+    const dim3 rgrid((unsigned)((MN / 4 + 255) / 256));
+    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
+    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
+    return check_launch2("msq_qlinear_bf16(split-K reduce)");
 }
 
 }  // extern "C"

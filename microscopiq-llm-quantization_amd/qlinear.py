@@ -114,9 +114,11 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16):
     b = None
     if bias is not None:
         b = bias.detach().float().contiguous()
+    wsb = lib().msq_qlinear_workspace_bytes(M, P.N, K)        # > 0 only for small M (split-K partial tiles)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
                                  0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
-                                 current_stream(x.device)), "msq_qlinear_bf16")
+                                 ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
     return y.reshape(*x.shape[:-1], P.N)
 
 

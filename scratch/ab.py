@@ -22,7 +22,7 @@ for fo in outs:
     Wu = qlinear.unpack_weight(P, torch.bfloat16); Yr = X @ Wu.t()
     Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     def call(fn):
-        rc = fn(_lib.ptr(X), _lib.ptr(P.inl), _lib.ptr(P.out), _lib.ptr(P.scl), None, _lib.ptr(Y), 2, M, N, K, P.block, P.in_kind, P.out_kind, _lib.current_stream())
+        rc = fn(_lib.ptr(X), _lib.ptr(P.inl), _lib.ptr(P.out), _lib.ptr(P.scl), None, _lib.ptr(Y), 2, M, N, K, P.block, P.in_kind, P.out_kind, None, 0, _lib.current_stream())
         assert rc == 0, rc
     res = {n: [] for n, _ in handles}; errs = {}
     for n, fn in handles:
