@@ -206,6 +206,22 @@ MSQ_D float quant_core_fast(float a, int shift, int pe_lo, int pe_hi, float max_
     return ((ua & 0x7F800000u) == 0x7F800000u) ? a : out;
 }
 
+// posit<n,es> rounding of an fp32 value, fast path: when at least one FRACTION bit survives
+// (fb >= 1) the posit's round-to-nearest-even on the bit pattern is an ordinary RNE of the
+// significand to fb fraction bits; everything else (exponent bits cut, saturation, specials)
+// goes through the generic posit_round().  Identical results (tests/test_gpu_parity.py::test_posit_tables).
+MSQ_D float posit_round_fast(float t, int n, int es) {
+    const uint32_t ut = f2u(t) & 0x7FFFFFFFu;
+    if (ut - 1u >= 0x7F7FFFFFu) return posit_round(t, n, es);          // 0, Inf, NaN
+    const int s = __builtin_amdgcn_frexp_expf(t) - 1;
+    const int k = s >> es;                                               // floor(s / 2^es)
+    const int rl = (k >= 0) ? k + 2 : 1 - k;
+    const int fb = n - 1 - rl - es;
+    if (fb < 1) return posit_round(t, n, es);
+    const float r = __builtin_rintf(__builtin_ldexpf(t, fb - s));       // RNE (default rounding mode)
+    return __builtin_ldexpf(r, s - fb);
+}
+
 template <int BS>
 MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
     double s = 0.0;
@@ -226,9 +242,10 @@ MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
     return std_welford<BS>(x, correction);
 }
 
-template <int BS, int RM>
+template <int BS, int RM, bool EMIT = false>
 MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
-                             const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride) {
+                             const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride,
+                             uint32_t* codes = nullptr, int in_kind = 0, int out_kind = 0) {
     int status = 0;
     float lo = 0.f, hi = 0.f;
     if (A.variant == 0) {
@@ -285,12 +302,40 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
         const bool m = (mkw[b >> 5] >> (b & 31)) & 1u;
         float t = a[b] * (m ? sc_in : 1.0f);                    // :216 (outliers only; x1 is exact)
         t = t * (m ? rc_out : pre_in);                          // :247 / :214 (+ flush :202)
-        const float q = quant_core_fast<RM>(t, m ? sh_o : sh_i, m ? lo_o : lo_i, m ? hi_o : hi_i,
-                                            m ? A.fo.max_norm : A.fi.max_norm, A.rmode);
+        float q;
+        if (A.fo.kind == 1) {                                   // posit outliers: per-element choice of codec
+            q = m ? posit_round_fast(t, A.fo.mbits, A.fo.ebits)
+                  : quant_core_fast<RM>(t, sh_i, lo_i, hi_i, A.fi.max_norm, A.rmode);
+        } else {
+            q = quant_core_fast<RM>(t, m ? sh_o : sh_i, m ? lo_o : lo_i, m ? hi_o : hi_i,
+                                    m ? A.fo.max_norm : A.fi.max_norm, A.rmode);
+        }
         float u = q * (m ? sc_out : sc_in);                     // :258 / :224
         u = u * (m ? rc_in : 1.0f);                             // :258
         if (u != u) status |= MSQ_STATUS_NAN;
         a[b] = u + 0.0f;                                        // inlier + outlier part: the other part is +0
+        if (EMIT) {
+            // plane codes + proof that value == code * 2^scale exactly (see outlier_block<>)
+            uint32_t cd;
+            bool exact = true;
+            const float v = a[b];
+            if (in_kind == MSQ_PLANE_NONE) {
+                cd = (f2u(v) >> 16) << 8;
+                exact = (u2f((f2u(v) >> 16) << 16) == v) || (v != v);
+            } else if (!m) {
+                cd = encode_e2m1(q);
+                if (se_in == se_in) exact = (scale_pow2(decode_e2m1(cd), (int)se_in) == v);
+            } else if (out_kind == MSQ_PLANE_BF16) {
+                cd = (f2u(v) >> 16) << 8;
+                exact = (u2f((f2u(v) >> 16) << 16) == v) || (v != v);
+            } else {
+                cd = ((out_kind == MSQ_PLANE_BF8) ? encode_e5m2(q) : encode_e4m3(q)) << 8;
+                const float eff = se_out - se_in;
+                if (q != 0.f) exact = (eff >= -127.f) && (eff <= 127.f) && (scale_pow2(q, (int)(eff == eff ? eff : 0.f)) == v);
+            }
+            codes[b] = cd;
+            if (!exact) status |= MSQ_STATUS_INEXACT;
+        }
     }
     se_in_o = se_in; se_out_o = se_out;
     return status;

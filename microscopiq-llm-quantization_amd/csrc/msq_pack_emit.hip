@@ -27,8 +27,11 @@ k_pack_emit(const float* __restrict__ W, uint32_t* __restrict__ codes, OutlierAr
     uint32_t mkw[(BS + 31) / 32];
     uint32_t cd[BS];
     float se_in, se_out;
-    const int status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1,
-                                               cd, in_kind, out_kind);
+    int status;
+    if (A.fi.kind == 0 && A.rmode == 0)
+        status = outlier_block_fast<BS, 0, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
+    else
+        status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
     uint4* dst = reinterpret_cast<uint4*>(codes + gidx * BS);
 #pragma unroll
     for (int i = 0; i < BS / 4; ++i) dst[i] = make_uint4(cd[4 * i], cd[4 * i + 1], cd[4 * i + 2], cd[4 * i + 3]);

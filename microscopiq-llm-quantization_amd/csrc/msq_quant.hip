@@ -435,7 +435,7 @@ template <typename T>
 static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
     // float / int element formats take the fast block maths, posit formats the generic one
     // 1: nearest rounding specialised, 2: any rounding mode, 0: generic maths (posit)
-    if (A.fi.kind == 0 && A.fo.kind == 0)
+    if (A.fi.kind == 0)        // float/int inliers; outliers float/int or posit
         return (A.rmode == 0) ? launch_outlier_impl<T, 1>(in, out, A, block, st) : launch_outlier_impl<T, 2>(in, out, A, block, st);
     return launch_outlier_impl<T, 0>(in, out, A, block, st);
 }
