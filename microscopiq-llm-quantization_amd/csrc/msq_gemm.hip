@@ -275,6 +275,31 @@ MSQ_D void convert_half(bf16x8_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h,
     }
 }
 
+// --- packed-plane loads through buffer descriptors: the per-lane offset (lane * 16) never changes and the
+// slot offset is wave-uniform, so it rides in the SGPR soffset operand: zero VALU address arithmetic.
+struct PlaneRsrc {
+    __amdgpu_buffer_rsrc_t inl, out, scl;
+};
+MSQ_D __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64_t bytes) {
+    // make every descriptor input provably wave-uniform (otherwise hipcc wraps each buffer op in a
+    // waterfall loop: guide T20)
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    uint32_t n = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes;
+    n = __builtin_amdgcn_readfirstlane(n);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+MSQ_D uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int IN_KIND, int OUT_KIND>
+MSQ_D void load_half_buf(HalfRegs<IN_KIND, OUT_KIND>& h, const PlaneRsrc& r, int lane16, uint32_t tile2kf) {
+    constexpr int HS = HalfSlots<OUT_KIND>::n;
+    if (IN_KIND != MSQ_PLANE_NONE)
+        h.inl = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r.inl, lane16, uni(tile2kf * 1024u), 0));
+#pragma unroll
+    for (int s = 0; s < HS; ++s)
+        h.out[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r.out, lane16, uni((tile2kf * HS + s) * 1024u), 0));
+}
+
 // one quarter of a half-step's conversion work: fragment nf = q/2, dwords 2*(q%2) .. +1
 template <int IN_KIND, int OUT_KIND>
 MSQ_D void convert_quarter(u32x4_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h, const u32x4_t& scl, int kf, int q) {
@@ -382,7 +407,8 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int scl_groups, int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR offsets below)
     const int wm = wid >> 2, wn = wid & 3;
     const int c = lane & 15, g = lane >> 4;
     const int MT = (M + BM - 1) / BM, NTB = N / BN;
@@ -409,28 +435,33 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     const int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
     const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
 
-    // per-lane bases of the packed planes (every slot is 64 lanes x 16 B)
-    const uint8_t* inl_lane = inl_plane + lane * 16;
-    const uint8_t* out_lane = out_plane + lane * 16;
-    const uint8_t* scl_lane = scl_plane + (lane & (scl_groups - 1)) * 16;
-    const int64_t scl_tile_bytes = (int64_t)scl_groups * 16;
+    // packed planes and activations through buffer descriptors (SGPR slot / K-step offsets)
+    const int64_t ntiles = (int64_t)(N / TILE_N) * KT;
+    PlaneRsrc pr;
+    pr.inl = make_rsrc(inl_plane, ntiles * 2 * 1024);
+    pr.out = make_rsrc(out_plane, ntiles * 2 * HalfSlots<OUT_KIND>::n * 1024);
+    pr.scl = make_rsrc(scl_plane, ntiles * scl_groups * 16);
+    const int lane16 = lane * 16;
+    const int scl_lane_off = (lane & (scl_groups - 1)) * 16;
+    const uint32_t scl_tile_bytes = (uint32_t)scl_groups * 16u;
+    const uint32_t tile_row32 = (uint32_t)tile_row;
 
     // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
-    const uint16_t* asrc[4];
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, (int64_t)M * K * 2);
+    int aoff[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int piece = wid * 4 + p;
         const int row = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
-        asrc[p] = X + (int64_t)gr * K + chunk * 8;
+        aoff[p] = (int)(((int64_t)gr * K + chunk * 8) * 2);
     }
     auto stage_A = [&](int kt, int buf) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[p] + (int64_t)kt * BK),
-                                             (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
-                                             16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
+                                                     16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
     };
     // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
     const int sw = (c >> 1) & 7;
@@ -449,9 +480,9 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 
     const int kt0 = (kt_lo < KT) ? kt_lo : KT - 1;             // an empty split still runs a harmless prologue
     stage_A(kt0, 0);
-    load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + kt0, 0);
-    load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + kt0, 1);
-    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + kt0) * scl_tile_bytes);
+    load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
+    load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
+    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni((tile_row32 + kt0) * scl_tile_bytes), 0));
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #pragma unroll
@@ -481,15 +512,15 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
         keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
         if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);
-        if (!(MSQ_ABL & 4)) load_half<IN_KIND, OUT_KIND>(pkA, inl_lane, out_lane, tile_row + ktn, 0);
+        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + ktn) * 2u + 0u);
         if (IN_KIND != MSQ_PLANE_NONE)
-            sc_nxt = *reinterpret_cast<const u32x4_t*>(scl_lane + (tile_row + ktn) * scl_tile_bytes);
+            sc_nxt = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni((tile_row32 + ktn) * scl_tile_bytes), 0));
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfA, wfB, pkB, sc_cur, 1, rd0)
         // ---------------- half-step kf = 1: MFMAs on wfB, make next wfA from pkA
         keep_live(pkA);
         if (IN_KIND != MSQ_PLANE_NONE) keep_live4(sc_nxt);
-        if (!(MSQ_ABL & 4)) load_half<IN_KIND, OUT_KIND>(pkB, inl_lane, out_lane, tile_row + ktn, 1);
+        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + ktn) * 2u + 1u);
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
         sc_cur = sc_nxt;
