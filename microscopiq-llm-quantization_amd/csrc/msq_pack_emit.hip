@@ -11,32 +11,71 @@
 
 extern "C" void msq_set_error_(const char* msg);
 
+// A wave owns 64 consecutive blocks = one contiguous run of 64*BS floats (K % BS == 0): it streams the
+// run with 16-byte coalesced loads, transposes through LDS (row stride BS+4 words: conflict-free
+// ds_read_b128) so that every lane holds its own block, and sends the 32-bit codes back the same way.
 template <int BS>
 __global__ void __launch_bounds__(256)
 k_pack_emit(const float* __restrict__ W, uint32_t* __restrict__ codes, OutlierArgs A, int in_kind, int out_kind) {
+    constexpr int LDS_STRIDE = BS + 4;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t nblocks = A.pre * A.nblk;
-    const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gidx >= nblocks) return;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (g0 >= nblocks) return;
+    const bool full = (g0 + 64 <= nblocks);
+    const int64_t gidx = g0 + lane;
+    float* tl = tile[wv];
     float a[BS];
-    const float4* src = reinterpret_cast<const float4*>(W + gidx * BS);
+    if (full) {
+        const float4* src = reinterpret_cast<const float4*>(W + g0 * BS);
 #pragma unroll
-    for (int i = 0; i < BS / 4; ++i) {
-        const float4 v = src[i];
-        a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+        for (int t = 0; t < BS / 4; ++t) {
+            const int f = lane + 64 * t;
+            const int row = f / (BS / 4), c4 = f % (BS / 4);
+            *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int c = 0; c < BS / 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
+            a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) a[b] = (gidx < nblocks) ? W[gidx * BS + b] : 0.f;
     }
     uint32_t mkw[(BS + 31) / 32];
     uint32_t cd[BS];
-    float se_in, se_out;
-    int status;
-    if (A.fi.kind == 0 && A.rmode == 0)
-        status = outlier_block_fast<BS, 0, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
-    else
-        status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
-    uint4* dst = reinterpret_cast<uint4*>(codes + gidx * BS);
+    float se_in = 0.f, se_out = 0.f;
+    int status = 0;
+    if (gidx < nblocks) {
+        if (A.fi.kind == 0 && A.rmode == 0)
+            status = outlier_block_fast<BS, 0, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
+        else
+            status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
+        A.e_in[gidx] = se_in;
+        A.e_out[gidx] = se_out;
+    }
+    if (full) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < BS / 4; ++i) dst[i] = make_uint4(cd[4 * i], cd[4 * i + 1], cd[4 * i + 2], cd[4 * i + 3]);
-    A.e_in[gidx] = se_in;
-    A.e_out[gidx] = se_out;
+        for (int c = 0; c < BS / 4; ++c)
+            *reinterpret_cast<uint4*>(tl + lane * LDS_STRIDE + c * 4) = make_uint4(cd[c * 4], cd[c * 4 + 1], cd[c * 4 + 2], cd[c * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        uint4* dst = reinterpret_cast<uint4*>(codes + g0 * BS);
+#pragma unroll
+        for (int t = 0; t < BS / 4; ++t) {
+            const int f = lane + 64 * t;
+            const int row = f / (BS / 4), c4 = f % (BS / 4);
+            dst[f] = *reinterpret_cast<const uint4*>(tl + row * LDS_STRIDE + c4 * 4);
+        }
+    } else if (gidx < nblocks) {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) codes[gidx * BS + b] = cd[b];
+    }
     if (status && A.status) atomicOr(A.status, status);
 }
 
@@ -56,7 +95,7 @@ extern "C" int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, floa
     A.mask = nullptr; A.e_in = e_in; A.e_out = e_out; A.n_out = nullptr; A.status = status;
     A.vmean = nullptr; A.vstd = nullptr;
     const int64_t nblocks = N * A.nblk;
-    const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);
+    const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);   // 4 waves x 64 blocks per workgroup
     hipStream_t st = (hipStream_t)stream;
 #define MSQ_PE(BS) case BS: hipLaunchKernelGGL(k_pack_emit<BS>, grid, blk, 0, st, W, codes, A, in_kind, out_kind); break;
     switch (block) { MSQ_PE(8) MSQ_PE(16) MSQ_PE(32) MSQ_PE(64) MSQ_PE(128)
