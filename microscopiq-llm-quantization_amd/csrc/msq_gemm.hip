@@ -540,6 +540,78 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Small-M (decode) kernel: M <= 64.  HBM-bound: the job is to stream the packed weight once at full
+// rate.  One wave = one task = KC consecutive 64x64 packed tiles of one 64-column strip; per tile it
+// converts the 8 fragments and issues 8*MG MFMAs against the activation fragments, which it reads
+// straight from global memory (the whole X is <= 512 KiB and stays in L2).  Next tile's packed data
+// is in flight while the current one is consumed; 12 waves per CU keep ~80 KiB of loads in flight.
+// Every task writes an fp32 partial tile, k_splitk_reduce sums them.
+// ---------------------------------------------------------------------------
+template <int IN_KIND, int OUT_KIND, int MG>
+__global__ void __launch_bounds__(256)
+k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
+        const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int KT = K / TILE_K;
+    const int nks = (KT + kc - 1) / kc;                        // k-chunks per strip = number of partial planes
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t ntasks = (int64_t)(N / TILE_N) * nks;
+    if (task >= ntasks) return;
+    // consecutive tasks walk k-chunks of the same strip: neighbouring waves share the X rows in L1/L2
+    const int strip = (int)(task / nks), ks = (int)(task % nks);
+    const int kt_lo = ks * kc;
+    const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
+    const int64_t tile_row = (int64_t)strip * KT;
+
+    f32x4_t acc[4][MG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // activation fragment rows of this lane (rows >= M are clamped; their results are never stored)
+    const uint16_t* xrow[MG];
+#pragma unroll
+    for (int j = 0; j < MG; ++j) { int m = j * 16 + c; m = m < M ? m : M - 1; xrow[j] = X + (int64_t)m * K + g * 8; }
+
+    TileRegs cur, nxt;
+    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + kt_lo, lane, scl_groups);
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
+        load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups);
+        bf16x8_t xf[2][MG];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int j = 0; j < MG; ++j)
+                xf[kf][j] = *reinterpret_cast<const bf16x8_t*>(xrow[j] + (int64_t)kt * TILE_K + kf * 32);
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, tile_frag<IN_KIND, OUT_KIND>(cur, nf, kf));
+#pragma unroll
+                for (int j = 0; j < MG; ++j)
+                    acc[nf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[kf][j], acc[nf][j], 0, 0, 0);
+            }
+        cur = nxt;
+    }
+    // D[n = 4 g + r][m = c]: 4 consecutive n of row m
+    float* pbase = partial + (int64_t)ks * M * N;
+#pragma unroll
+    for (int j = 0; j < MG; ++j) {
+        const int m = j * 16 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = strip * TILE_N + nf * 16 + g * 4;
+            *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(acc[nf][j][0], acc[nf][j][1], acc[nf][j][2], acc[nf][j][3]);
+        }
+    }
+}
+
 // sum of the split-K partial tiles (+ bias) -> Y
 template <typename YT>
 __global__ void __launch_bounds__(256)
@@ -694,8 +766,19 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
     return ks < 1 ? 1 : (int)ks;
 }
 
+// small-M path: tiles per task so that there are ~3000 tasks (12 waves x 256 CUs) but at most 32 partial planes
+#define MSQ_GEMV_MAX_M 64
+static int pick_kc(int64_t N, int64_t K) {
+    const int64_t KT = K / BK, strips = N / TILE_N;
+    int64_t kc = (strips * KT + 3071) / 3072;
+    if (kc < 1) kc = 1;
+    while ((KT + kc - 1) / kc > 32) ++kc;
+    return (int)kc;
+}
+
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
+    if (M <= MSQ_GEMV_MAX_M) { const int kc = pick_kc(N, K); return ((K / BK + kc - 1) / kc) * M * N * 4; }
     const int ks = pick_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -711,6 +794,36 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
+    hipStream_t st0 = (hipStream_t)stream;
+    const int groups0 = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    if (M <= MSQ_GEMV_MAX_M && workspace) {
+        const int kc = pick_kc(N, K);
+        const int nks = (int)((K / BK + kc - 1) / kc);
+        if (workspace_bytes >= (int64_t)nks * M * N * 4) {
+            const int64_t ntasks = (N / TILE_N) * nks;
+            const dim3 vgrid((unsigned)((ntasks + 3) / 4)), vblk(256);
+            const int mg = (int)((M + 15) / 16);
+#define MSQ_GV(IK, OK)                                                                                                  \
+            do { switch (mg) {                                                                                          \
+                case 1: hipLaunchKernelGGL((k_qgemv<IK, OK, 1>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
+                case 2: hipLaunchKernelGGL((k_qgemv<IK, OK, 2>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
+                case 3: hipLaunchKernelGGL((k_qgemv<IK, OK, 3>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
+                default: hipLaunchKernelGGL((k_qgemv<IK, OK, 4>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; } } while (0)
+            if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
+            else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
+            else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
+            else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+            else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
+#undef MSQ_GV
+            rc = check_launch2("msq_qlinear_bf16(gemv)");
+            if (rc) return rc;
+            const int64_t MN0 = M * N;
+            const dim3 rg((unsigned)((MN0 / 4 + 255) / 256));
+            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks);
+            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks);
+            return check_launch2("msq_qlinear_bf16(gemv reduce)");
+        }
+    }
     const int MT = (int)((M + BM - 1) / BM), NTB = (int)(N / BN);
     int ksplit = pick_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;   // no scratch: one pass
