@@ -414,6 +414,38 @@ def main():
     np.savez_compressed(os.path.join(HERE, "tiny_ppl.npz"), **d)
     print({k: float(v) for k, v in d.items() if k.endswith("ppl") or k.endswith("ppl_fp32")})
 
+
+    # (10) f1 GPTQ + MicroScopiQ pruning (llm/gptq.py:60-184) on a small Linear, reference solver on the CPU
+    import types
+    gsrc = open(os.path.join(REF, "llm", "gptq.py")).read()
+    gmod = types.ModuleType("ref_gptq")
+    exec(compile(gsrc.replace("torch.cuda.synchronize()", "pass"), "<reference llm/gptq.py, cuda sync removed>", "exec"), gmod.__dict__)
+    d = {}
+    g = torch.Generator().manual_seed(21)
+    lin = torch.nn.Linear(48, 64, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(64, 48, generator=g) * 0.05)
+    X = torch.randn(4, 32, 48, generator=g)
+    d["W"] = lin.weight.detach().numpy().copy(); d["X"] = X.numpy()
+    gp = gmod.GPTQ(lin)
+    gp.quantizer = quant.MXQuantizer()
+    gp.quantizer.configure(8, 8, "int2", "fp4", axes=[0], block_size=16)
+    for b in range(4):
+        gp.add_batch(X[b], None)
+    d["H"] = gp.H.numpy().copy()
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gp.fasterquant(blocksize=16, percdamp=.01)
+    d["Q"] = lin.weight.detach().numpy().copy()
+    d["error"] = np.float64(float(buf.getvalue().split("error")[1]))
+    Wq_rtn = quant.quantize_mx_outlier_v1(torch.from_numpy(d["W"]), 8, 8, "int2", "fp4", "max", 2, [0], 16)
+    Y = X.reshape(-1, 48) @ torch.from_numpy(d["W"]).t()
+    d["out_err_gptq"] = np.float64(((X.reshape(-1, 48) @ torch.from_numpy(d["Q"]).t() - Y) ** 2).sum().item())
+    d["out_err_rtn"] = np.float64(((X.reshape(-1, 48) @ Wq_rtn.t() - Y) ** 2).sum().item())
+    np.savez_compressed(os.path.join(HERE, "gptq.npz"), **d)
+    print("gptq fixture: error", float(d["error"]), "out err gptq/rtn", float(d["out_err_gptq"]), float(d["out_err_rtn"]))
+
     # (9) torch CPU reduction-order pins (what torch.mean / torch.std compute) ---
     d = {}
     g = torch.Generator().manual_seed(5)
