@@ -688,6 +688,9 @@ int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind,
 }
 
 // implemented in msq_pack_emit.hip (heavy template instantiations, own TU)
+int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane, void* scale_plane, int* status, int64_t N,
+                    int64_t K, int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb, float std_dev, int rmode,
+                    int flush, int in_kind, int out_kind, void* stream);
 int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, float* e_out, int* status, int64_t N, int64_t K,
                    int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb, float std_dev, int rmode,
                    int flush, int in_kind, int out_kind, void* stream);
@@ -704,6 +707,13 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     if (rc) return rc;
     if (!W || !out_plane || (ik != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: null buffer");
+    // single-pass kernel for the common configurations (float/int inliers, nearest rounding, block <= 64) ...
+    if (getenv("MSQ_PACK_TWO_PASS") == nullptr) {
+        rc = msq_pack_fused_(W, inl_plane, out_plane, scale_plane, status_flag, N, K, block, inlier_fmt, outlier_fmt,
+                             inlier_scale_bits, outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
+        if (rc != MSQ_ERR_UNSUPPORTED) return rc;
+    }
+    // ... everything else: emit u32 codes + exponents into the workspace, then repack
     if (!workspace || workspace_bytes < wb) return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: workspace too small (msq_packed_sizes)");
     uint32_t* codes = (uint32_t*)workspace;
     float* e_in = (float*)(codes + N * K);
