@@ -222,10 +222,8 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
         }
 }
 
-#define BM 256
 #define BN 256
 #define BK 64
-#define A_TILE_BYTES (BM * BK * 2)
 
 // ---------------------------------------------------------------------------
 // fused unpack-dequant-GEMM, software-pipelined at half-K-step (one MFMA k-fragment = 32 k) granularity.
@@ -401,17 +399,19 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[8][4], char* wsm, YT* __rest
     }
 }
 
-template <int IN_KIND, int OUT_KIND, typename YT>
-__global__ void __launch_bounds__(512)
+template <int IN_KIND, int OUT_KIND, typename YT, int WM>
+__global__ void __launch_bounds__(256 * WM, 2)
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int scl_groups, int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR offsets below)
-    const int wm = wid >> 2, wn = wid & 3;
+    constexpr int BMT = 128 * WM;                               // block rows: WM wave rows of 128
+    constexpr int A_TILE = BMT * BK * 2;
+    const int wm = (WM == 2) ? wid >> 2 : 0, wn = wid & 3;
     const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + BM - 1) / BM, NTB = N / BN;
+    const int MT = (M + BMT - 1) / BMT, NTB = N / BN;
     const int ks = (int)(blockIdx.x % (unsigned)ksplit);
     const int bid = (int)(blockIdx.x / (unsigned)ksplit);
     int bm, bn;
@@ -427,7 +427,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         bm = rg * 8 + j % R;
         bn = (j / R) * 8 + xcd;
     } else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * BMT, n0 = bn * BN;
     const int KT = K / BK;
     // split-K: this block covers K-steps [kt_lo, kt_hi) and writes an fp32 partial tile
     const int kchunk = (KT + ksplit - 1) / ksplit;
@@ -460,7 +460,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     auto stage_A = [&](int kt, int buf) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE_BYTES + (wid * 4 + p) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 4 + p) * 1024),
                                                      16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
     };
     // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
@@ -507,7 +507,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int buf = (kt - kt_lo) & 1;
-        const char* abase = smem + buf * A_TILE_BYTES;
+        const char* abase = smem + buf * A_TILE;
         const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;       // branch-free tail: re-load the last tile
         // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
         keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
@@ -524,9 +524,12 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
         sc_cur = sc_nxt;
-        // A(kt+1) has landed: its LDS-DMA ops are older than the pkA loads this wave waited for at the
-        // top of the second half-step (in-order vmcnt).  The pkB loads stay in flight across the barrier.
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+        // A(kt+1) must have landed before the barrier.  The compiler is free to order this wave's LDS-DMA
+        // ops after the pkA loads inside the first group, so the waits it places for pkA do not cover
+        // them: wait explicitly for everything older than the pkB loads (vmcnt is in-order), which stay
+        // in flight across the barrier.  (Without this, two co-resident blocks showed stale A rows.)
+        constexpr int N_PKB = (IN_KIND != MSQ_PLANE_NONE ? 1 : 0) + HalfSlots<OUT_KIND>::n;
+        __builtin_amdgcn_s_waitcnt(0x0070 | (N_PKB & 15) | ((N_PKB >> 4) << 14));   // vmcnt(N_PKB) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     }
 #undef MSQ_HALF_STEP
@@ -765,12 +768,28 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     return check_launch2("msq_outlier_unpack");
 }
 
+// Block shape: 128 x 256 (4 waves, two blocks per CU) or 256 x 256 (8 waves, one block per CU).  Both keep
+// the same per-wave tile, so the instruction mix is identical.  Measured over the Llama shapes
+// (scratch/wm_sweep.py) the small block wins or ties nearly everywhere (finer tail, half the wasted
+// activation rows, two independent barriers per CU), so it is the default; MSQ_GEMM_WM=2 forces the
+// large one for experiments.
+static int pick_wm(int64_t M, int64_t N) {
+    static const int forced = [] { const char* e = getenv("MSQ_GEMM_WM"); return e ? atoi(e) : 0; }();
+    (void)M; (void)N;
+    return forced == 2 ? 2 : 1;
+}
+
 // split-K factor: enough blocks to fill the 256 CUs when M is small (decode / short prefill)
 static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
-    const int64_t blocks = ((M + BM - 1) / BM) * (N / BN);
+    static const int forced = [] { const char* e = getenv("MSQ_GEMM_KS"); return e ? atoi(e) : 0; }();
+    const int wm = pick_wm(M, N);
+    const int64_t blocks = ((M + 128 * wm - 1) / (128 * wm)) * (N / BN);
     const int64_t KT = K / BK;
-    if (blocks >= 256 || KT < 8) return 1;
-    int64_t ks = (512 + blocks - 1) / blocks;
+    if (forced > 0) return forced < KT ? forced : (int)KT;
+    if (blocks >= 192 || KT < 8) return 1;
+    // measured (scratch/ks_sweep.py): best is about one block per CU, power-of-two splits (even K chunks)
+    int64_t ks = 1;
+    while (ks * blocks < 256) ks *= 2;
     if (ks > KT / 4) ks = KT / 4;
     if (ks > 32) ks = 32;
     return ks < 1 ? 1 : (int)ks;
@@ -834,21 +853,23 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             return check_launch2("msq_qlinear_bf16(gemv reduce)");
         }
     }
-    const int MT = (int)((M + BM - 1) / BM), NTB = (int)(N / BN);
+    const int wm_sel = pick_wm(M, N);
+    const int MT = (int)((M + 128 * wm_sel - 1) / (128 * wm_sel)), NTB = (int)(N / BN);
     int ksplit = pick_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;   // no scratch: one pass
-    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(512);
-    const size_t lds = 2 * A_TILE_BYTES;
+    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256 * wm_sel);
+    const size_t lds = (size_t)2 * 128 * wm_sel * BK * 2;
     hipStream_t st = (hipStream_t)stream;
     const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
     float* partial = (float*)workspace;
+#define MSQ_LAUNCH1(KERN, IK, OK, YT, WMV)                                                                             \
+    do { static bool attr_set = false;                                                                                 \
+         if (!attr_set) { hipFuncSetAttribute((const void*)KERN<IK, OK, YT, WMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+         hipLaunchKernelGGL((KERN<IK, OK, YT, WMV>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,  \
+                (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
 #define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
-    do { if (y_dtype == 0) { static bool a0 = false; if (!a0) { hipFuncSetAttribute((const void*)KERN<IK, OK, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a0 = true; } \
-             hipLaunchKernelGGL((KERN<IK, OK, float>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,   \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (float*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } \
-         else { static bool a1 = false; if (!a1) { hipFuncSetAttribute((const void*)KERN<IK, OK, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; } \
-             hipLaunchKernelGGL((KERN<IK, OK, uint16_t>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } } while (0)
+    do { if (y_dtype == 0) { if (wm_sel == 2) MSQ_LAUNCH1(KERN, IK, OK, float, 2); else MSQ_LAUNCH1(KERN, IK, OK, float, 1); } \
+         else { if (wm_sel == 2) MSQ_LAUNCH1(KERN, IK, OK, uint16_t, 2); else MSQ_LAUNCH1(KERN, IK, OK, uint16_t, 1); } } while (0)
 #define MSQ_DISPATCH(KERN)                                                                                             \
     do { if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_BF16); \
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_FP8); \
@@ -858,6 +879,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     MSQ_DISPATCH(k_qgemm3);
 #undef MSQ_DISPATCH
 #undef MSQ_LAUNCH
+#undef MSQ_LAUNCH1
     rc = check_launch2("msq_qlinear_bf16");
     if (rc || ksplit == 1) return rc;
     const int64_t MN = M * N;

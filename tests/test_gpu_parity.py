@@ -343,6 +343,26 @@ def test_full_size_properties(msq):
         assert (ys - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_fused_gemm_llama_shapes_repeatable(msq, N, K):
+    """Llama-7B layer shapes (llm/llama.py:find_layers): every M takes a different block count / split-K
+    factor; the result must equal the dense GEMM on the unpacked weight and be bit-identical run after run
+    (the K loop hands activation tiles between waves through LDS-DMA: a missing wait shows up as stale
+    8-row pieces in a few runs out of 30)."""
+    g = torch.Generator(device=dev()).manual_seed(5)
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32)
+    Wu = msq.qlinear.unpack_weight(P, torch.float32)
+    for M in (65, 128, 1000, 2048):
+        X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
+        Yr = X.float() @ Wu.t()
+        Y0 = msq.qlinear.qlinear(X, P, None, torch.float32)
+        assert (Y0 - Yr).abs().max().item() <= 4e-5 * Yr.abs().max().item() + 1e-6
+        for _ in range(30):
+            assert torch.equal(msq.qlinear.qlinear(X, P, None, torch.float32), Y0)
+
+
 def test_quantlinear_module_and_state_dict(msq):
     g = torch.Generator().manual_seed(4)
     lin = torch.nn.Linear(512, 256, bias=True)
