@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--outlier", default="posit8_es1")
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama70b_rowparallel"])
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama70b_rowparallel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,12 +121,25 @@ def main():
         name = ("Llama-2-7B MicroScopiQ W4 (MX-FP4 inliers + %s outliers), fused dequant-GEMM "
                 "X[%d,%d] x W[%d,%d]^T" % (args.outlier, M, K, N, K))
     W = synth_weight(N, K, dev, seed=rank)
-    P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block)
+    w4a8 = args.workload == "llama7b_w4a8"
+    if w4a8:
+        # BASELINE config 3 = MXLinear(w=fp4_e2m1, a=fp8_e4m3, block 32) semantics (mx_ops variant, std_dev 5):
+        # a step = activation quantisation of X (fp32 in, one pass) + the fused dequant-GEMM
+        name = ("Llama-2-7B W4A8 (MX-FP4 weights + FP8-e4m3 activations, MXLinear semantics), act-quant + fused "
+                "dequant-GEMM X[%d,%d] x W[%d,%d]^T" % (M, K, N, K))
+        args.outlier = "fp4_e2m1"
+        P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 5, args.block, variant=1)
+        X = torch.randn(M, K, device=dev)
+    else:
+        P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block)
+        X = torch.randn(M, K, device=dev).to(torch.bfloat16)
     del W
-    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
     torch.cuda.synchronize()
 
     def step():
+        if w4a8:
+            return qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5,
+                                        a_block_size=args.block, a_variant=1)
         y = qlinear.qlinear(X, P, None, torch.bfloat16)
         if args.workload == "llama70b_rowparallel" and world > 1:
             dist.all_reduce(y)

@@ -162,7 +162,7 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
                      int* status_flag, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
                      int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
                      int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms,
-                     void* stream);
+                     int variant, void* stream);
 
 /* planes -> dense dequantised W [N,K]; out_dtype 0 = f32, 2 = bf16 (both exact). */
 int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,
@@ -178,6 +178,28 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * W4A8 Linear -- NEW; replaces the activation quantisation + F.linear of
+ * number_system/mx/linear.py:66-73,91 (MXLinear with an 8-bit a_elem_format; BASELINE config 3).
+ *   msq_act_quant_bf16: X [M,K] f32 -> MicroScopiQ outlier-aware MX fake-quant along K
+ *       (variant 0 = utils/quant.py:147-266, 1 = mx_ops.py:210-330 as MXLinear uses it), written as
+ *       bf16.  Exact for element formats of <= 8 bits (MSQ_STATUS_INEXACT is raised otherwise).
+ *   msq_qlinear_w4a8: the same followed by the fused dequant-GEMM on packed weights;
+ *       Y [M,N] = Q_a(X) . W^T + bias.  Workspace from msq_qlinear_w4a8_workspace_bytes.
+ * ------------------------------------------------------------------------- */
+int64_t msq_act_quant_workspace_bytes(int64_t M, int64_t K, int block, int variant);
+int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
+                       int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt,
+                       int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
+                       int flush_fp32_subnorms, int variant, void* stream);
+int64_t msq_qlinear_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_block, int a_variant);
+int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block,
+                     int in_kind, int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt,
+                     int a_inlier_scale_bits, int a_outlier_scale_bits, float a_std_dev, int a_rmode,
+                     int a_flush_fp32_subnorms, int a_variant, int* status_flag, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -686,7 +686,8 @@ int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind,
     if (inl_bytes) *inl_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * 2 * 1024;
     if (out_bytes) *out_bytes = tiles * ((out_kind == MSQ_PLANE_BF16) ? 8 : 4) * 1024;
     if (scale_bytes) *scale_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * groups * 16;
-    if (workspace_bytes) *workspace_bytes = N * K * 4 + 2 * N * (K / block) * 4;
+    // two-pass path: u32 codes + block exponents (+ the [N, block] mean/std tables of variant 1)
+    if (workspace_bytes) *workspace_bytes = N * K * 4 + 2 * N * (K / block) * 4 + 2 * N * block * 4;
     return MSQ_OK;
 }
 
@@ -696,12 +697,16 @@ int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane, void* scal
                     int flush, int in_kind, int out_kind, void* stream);
 int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, float* e_out, int* status, int64_t N, int64_t K,
                    int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb, float std_dev, int rmode,
-                   int flush, int in_kind, int out_kind, void* stream);
+                   int flush, int in_kind, int out_kind, int variant, const float* vmean, const float* vstd, void* stream);
+// implemented in msq_quant.hip: mean / unbiased std over the block-count axis (mx_ops.py:62-66,248)
+int msq_mxops_stats_(const float* in, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post, int block,
+                     int* status, void* stream);
 
 int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* scale_plane, int* status_flag,
                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int block, int inlier_fmt,
                      int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
-                     int flush_fp32_subnorms, void* stream) {
+                     int flush_fp32_subnorms, int variant, void* stream) {
+    if (variant != MSQ_VARIANT_QUANT && variant != MSQ_VARIANT_MXOPS) return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: bad variant");
     int ik, ok;
     int rc = msq_packed_kinds(inlier_fmt, outlier_fmt, &ik, &ok);
     if (rc) return rc;
@@ -711,7 +716,7 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     if (!W || !out_plane || (ik != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: null buffer");
     // single-pass kernel for the common configurations (float/int inliers, nearest rounding, block <= 64) ...
-    if (getenv("MSQ_PACK_TWO_PASS") == nullptr) {
+    if (variant == MSQ_VARIANT_QUANT && getenv("MSQ_PACK_TWO_PASS") == nullptr) {
         rc = msq_pack_fused_(W, inl_plane, out_plane, scale_plane, status_flag, N, K, block, inlier_fmt, outlier_fmt,
                              inlier_scale_bits, outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
         if (rc != MSQ_ERR_UNSUPPORTED) return rc;
@@ -721,8 +726,14 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     uint32_t* codes = (uint32_t*)workspace;
     float* e_in = (float*)(codes + N * K);
     float* e_out = e_in + N * (K / block);
+    float *vmean = nullptr, *vstd = nullptr;
+    if (variant == MSQ_VARIANT_MXOPS) {
+        vmean = e_out + N * (K / block); vstd = vmean + N * block;
+        rc = msq_mxops_stats_(W, vmean, vstd, N, K, 1, block, status_flag, stream);
+        if (rc) return rc;
+    }
     rc = msq_pack_emit_(W, codes, e_in, e_out, status_flag, N, K, block, inlier_fmt, outlier_fmt, inlier_scale_bits,
-                        outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
+                        outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, variant, vmean, vstd, stream);
     if (rc) return rc;
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
@@ -887,6 +898,47 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
     else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
     return check_launch2("msq_qlinear_bf16(split-K reduce)");
+}
+
+// ---------------------------------------------------------------------------
+// W4A8 Linear (BASELINE config 3; number_system/mx/linear.py:66-91 with a_elem_format = an 8-bit
+// format): quantise the activations along K (one HBM-bound pass, bf16 out, exact) and run the fused
+// dequant-GEMM on them.  The reference multiplies the two fake-quantised fp32 tensors with F.linear;
+// both operands are exact in bf16, so the MFMA bf16 path computes the same products (fp32 accumulate).
+// A scaled-fp8 MFMA formulation needs one product per (inlier, outlier) x (inlier, outlier) scale pair
+// = 4 v_mfma_scale_f32_16x16x128_f8f6f4 at 32 cycles each per 128 k, twice the matrix time of bf16.
+// ---------------------------------------------------------------------------
+int64_t msq_act_quant_workspace_bytes(int64_t M, int64_t K, int block, int variant);
+int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes, int64_t M,
+                       int64_t K, int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits,
+                       float std_dev, int rmode, int flush_fp32_subnorms, int variant, void* stream);
+
+static int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+
+int64_t msq_qlinear_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_block, int a_variant) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return align256(M * K * 2) + align256(msq_act_quant_workspace_bytes(M, K, a_block, a_variant)) +
+           msq_qlinear_workspace_bytes(M, N, K);
+}
+
+int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block, int in_kind,
+                     int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt, int a_inlier_scale_bits,
+                     int a_outlier_scale_bits, float a_std_dev, int a_rmode, int a_flush_fp32_subnorms, int a_variant,
+                     int* status_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_w4a8: negative M");
+    if (!workspace || workspace_bytes < msq_qlinear_w4a8_workspace_bytes(M, N, K, a_block, a_variant))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_w4a8: workspace too small (msq_qlinear_w4a8_workspace_bytes)");
+    char* xq = (char*)workspace;
+    char* aws = xq + align256(M * K * 2);
+    const int64_t aws_bytes = align256(msq_act_quant_workspace_bytes(M, K, a_block, a_variant));
+    char* gws = aws + aws_bytes;
+    int rc = msq_act_quant_bf16(X, xq, status_flag, aws, aws_bytes, M, K, a_block, a_inlier_fmt, a_outlier_fmt,
+                                a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode, a_flush_fp32_subnorms,
+                                a_variant, stream);
+    if (rc) return rc;
+    return msq_qlinear_bf16(xq, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, w_block, in_kind, out_kind,
+                            gws, workspace_bytes - (gws - (char*)workspace), stream);
 }
 
 }  // extern "C"

@@ -51,10 +51,13 @@ k_pack_emit(const float* __restrict__ W, uint32_t* __restrict__ codes, OutlierAr
     float se_in = 0.f, se_out = 0.f;
     int status = 0;
     if (gidx < nblocks) {
+        // variant 1 (mx_ops.py:210-330) statistics are per (row, position-in-block): [N, BS]
+        const float* vm = A.vmean ? A.vmean + (gidx / A.nblk) * BS : nullptr;
+        const float* vs = A.vstd ? A.vstd + (gidx / A.nblk) * BS : nullptr;
         if (A.fi.kind == 0 && A.rmode == 0)
-            status = outlier_block_fast<BS, 0, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
+            status = outlier_block_fast<BS, 0, true>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1, cd, in_kind, out_kind);
         else
-            status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, 1, nullptr, nullptr, 1, cd, in_kind, out_kind);
+            status = outlier_block<BS, true>(a, mkw, se_in, se_out, A, 1, vm, vs, 1, cd, in_kind, out_kind);
         A.e_in[gidx] = se_in;
         A.e_out[gidx] = se_out;
     }
@@ -81,7 +84,8 @@ k_pack_emit(const float* __restrict__ W, uint32_t* __restrict__ codes, OutlierAr
 
 extern "C" int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, float* e_out, int* status, int64_t N,
                               int64_t K, int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb,
-                              float std_dev, int rmode, int flush, int in_kind, int out_kind, void* stream) {
+                              float std_dev, int rmode, int flush, int in_kind, int out_kind, int variant,
+                              const float* vmean, const float* vstd, void* stream) {
     msq_host::FmtInfo fi, fo;
     if (!msq_host::format_info(inlier_fmt, &fi) || !msq_host::format_info(outlier_fmt, &fo)) {
         msq_set_error_("msq_outlier_pack: unknown element format"); return MSQ_ERR_BAD_ARG; }
@@ -90,10 +94,10 @@ extern "C" int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, floa
     OutlierArgs A;
     A.fi = Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm};
     A.fo = Fmt{fo.kind, fo.ebits, fo.mbits, fo.emax, fo.max_norm};
-    A.in_sb = in_sb; A.out_sb = out_sb; A.k = std_dev; A.rmode = rmode; A.flush = flush; A.variant = 0;
+    A.in_sb = in_sb; A.out_sb = out_sb; A.k = std_dev; A.rmode = rmode; A.flush = flush; A.variant = variant;
     A.pre = N; A.axis_len = K; A.post = 1; A.nblk = K / block;
     A.mask = nullptr; A.e_in = e_in; A.e_out = e_out; A.n_out = nullptr; A.status = status;
-    A.vmean = nullptr; A.vstd = nullptr;
+    A.vmean = vmean; A.vstd = vstd;
     const int64_t nblocks = N * A.nblk;
     const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);   // 4 waves x 64 blocks per workgroup
     hipStream_t st = (hipStream_t)stream;

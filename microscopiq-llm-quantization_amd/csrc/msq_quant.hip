@@ -391,6 +391,89 @@ k_mxops_stats(const float* __restrict__ in, float* __restrict__ vmean, float* __
     if (sd != sd && status) atomicOr(status, MSQ_STATUS_NAN);   // mx_ops.py:66 assert
 }
 
+// Row-parallel form of the same statistics for contiguous blocks (post == 1, BS a multiple of 32, K % BS == 0):
+// one workgroup per row; thread (r, b) sums the 16-block runs r, r+R, ... of column b exactly as torch's
+// cascade does (each run starts from 0), thread (0, b) then folds the run sums in cascade order.  The
+// double-precision std is accumulated as shifted sums per thread and combined; it is rounded to float
+// only when it is provably on the same side of the rounding boundary as torch's Welford result, else the
+// column is redone sequentially.  Reads each row once, coalesced.
+template <int BS>
+__global__ void __launch_bounds__(256)
+k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, float* __restrict__ vstd,
+                   int64_t axis_len, int64_t nblk, int* status) {
+    constexpr int R = 256 / BS;                 // threads per column
+    constexpr int MAXRUNS = 64;                 // nblk <= 1024
+    __shared__ float run_sum[MAXRUNS + 1][BS];
+    __shared__ double part_s[R][BS], part_q[R][BS];
+    const int b = threadIdx.x % BS, r = threadIdx.x / BS;
+    const int64_t p = blockIdx.x;
+    const float* row = in + p * axis_len;
+    const int nruns = (int)(nblk / 16), tail = (int)(nblk % 16);
+    const double shift = (double)row[b];        // element of block 0: keeps the shifted sums small
+    double ds = 0.0, dq = 0.0;
+    for (int j = r; j < nruns; j += R) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = row[(int64_t)(j * 16 + i) * BS + b];
+            acc += v;
+            const double d = (double)v - shift;
+            ds += d; dq = __builtin_fma(d, d, dq);
+        }
+        run_sum[j][b] = acc;
+    }
+    if (r == (nruns % R)) {                      // the tail run (may be empty)
+        float acc = 0.f;
+        for (int i = 0; i < tail; ++i) {
+            const float v = row[(int64_t)(nruns * 16 + i) * BS + b];
+            acc += v;
+            const double d = (double)v - shift;
+            ds += d; dq = __builtin_fma(d, d, dq);
+        }
+        run_sum[MAXRUNS][b] = acc;
+    }
+    part_s[r][b] = ds; part_q[r][b] = dq;
+    __syncthreads();
+    if (r != 0) return;
+    // cascade fold (ATen: level-1 accumulator folded every 256 elements, level-2 every 4096)
+    float acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int j = 0; j < nruns; ++j) {
+        acc1 += run_sum[j][b];
+        const int i = (j + 1) * 16;
+        if ((i & (15 << 4)) == 0) { acc2 += acc1; acc1 = 0.f;
+            if ((i & (15 << 8)) == 0) { acc3 += acc2; acc2 = 0.f; } }
+    }
+    float acc0 = run_sum[MAXRUNS][b];
+    acc0 += acc1; acc0 += acc2; acc0 += acc3;
+    double S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { S += part_s[k][b]; Q += part_q[k][b]; }
+    const double n = (double)nblk;
+    double den = n - 1.0; den = den < 0 ? 0 : den;
+    double m2 = Q - S * S / n; m2 = m2 < 0 ? 0 : m2;
+    double sdd = __builtin_sqrt(m2 / den);
+    const uint64_t bits = __builtin_bit_cast(uint64_t, sdd);
+    const uint32_t dropped = (uint32_t)(bits & 0x1FFFFFFFull);
+    const uint32_t dist = dropped > 0x10000000u ? dropped - 0x10000000u : 0x10000000u - dropped;
+    // the shifted-sum form loses up to ~33 n ulps when the shift was good (|S|^2/n <= 16 m2): accept it
+    // only then, and only when the result is farther than 512 n double ulps from a float boundary
+    const bool safe = (dist > 512u * (uint32_t)nblk) && (sdd == sdd) && (sdd > 1e-150) && (sdd < 1e150) && (S * S / n <= 16.0 * m2);
+    if (!safe) {
+        double mean = 0.0; m2 = 0.0;
+        for (int64_t i = 0; i < nblk; ++i) {
+            const double d = (double)row[i * BS + b];
+            const double delta = d - mean;
+            mean = mean + delta / (double)(i + 1);
+            m2 = m2 + delta * (d - mean);
+        }
+        sdd = __builtin_sqrt(m2 / den);
+    }
+    const float sd = (float)sdd;
+    vmean[p * BS + b] = acc0 / (float)nblk;
+    vstd[p * BS + b] = sd;
+    if (sd != sd && status) atomicOr(status, MSQ_STATUS_NAN);
+}
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -553,6 +636,24 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
     return check_launch("msq_reduce_max_inner");
 }
 
+// internal (msq_outlier_pack / msq_act_quant_bf16 with variant 1)
+int msq_mxops_stats_(const float* in, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post, int block,
+                     int* status, void* stream) {
+    const int64_t nblk = (axis_len + block - 1) / block;
+    hipStream_t st = (hipStream_t)stream;
+    if (post == 1 && axis_len % block == 0 && nblk <= 1024 && nblk >= 2 && pre < (1ll << 31) &&
+        (block == 32 || block == 64 || block == 128)) {
+        const dim3 grid((unsigned)pre), blk(256);
+        if (block == 32) hipLaunchKernelGGL(k_mxops_stats_rows<32>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
+        else if (block == 64) hipLaunchKernelGGL(k_mxops_stats_rows<64>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
+        else hipLaunchKernelGGL(k_mxops_stats_rows<128>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
+    } else {
+        hipLaunchKernelGGL(k_mxops_stats, dim3(grid_for(pre * block * post, 256)), dim3(256), 0, st,
+                           in, vmean, vstd, pre, axis_len, post, block, nblk, status);
+    }
+    return check_launch("mx_ops statistics");
+}
+
 int64_t msq_outlier_workspace_bytes(int64_t pre, int64_t axis_len, int64_t post, int block, int variant) {
     if (variant != MSQ_VARIANT_MXOPS) return 0;
     if (block <= 0) block = (int)axis_len;
@@ -592,9 +693,7 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
             return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: workspace too small (msq_outlier_workspace_bytes)");
         float* vmean = (float*)workspace;
         float* vstd = vmean + pre * block * post;
-        hipLaunchKernelGGL(k_mxops_stats, dim3(grid_for(pre * block * post, 256)), dim3(256), 0, st,
-                           (const float*)in, vmean, vstd, pre, axis_len, post, block, A.nblk, status_flag);
-        int rc = check_launch("msq_outlier_fakequant(stats)");
+        int rc = msq_mxops_stats_((const float*)in, vmean, vstd, pre, axis_len, post, block, status_flag, stream);
         if (rc) return rc;
         A.vmean = vmean; A.vstd = vstd;
     }

@@ -5,7 +5,11 @@ inlier format == outlier format), dense GEMM, cast, + bias, cast.
 
 Every quantisation step is one HIP launch; the GEMM runs in fp32 on the GPU exactly like the
 reference's F.linear (linear.py:91).  Forward only: the reference's backward is broken as
-shipped (linear.py:129-136 passes unknown kwargs)."""
+shipped (linear.py:129-136 passes unknown kwargs).
+
+``MXLinear.pack()`` (new) freezes the weight into the packed tile-major planes once and turns the
+forward into the W4A8 hot path: activation quantisation (one pass, bf16 out) + fused
+dequant-GEMM (msq_qlinear_w4a8) instead of re-quantising the weight on every call."""
 import torch
 import torch.nn.functional as F
 
@@ -31,6 +35,37 @@ def _forward(input, weight, bias, mx_specs):
     if bias is not None:
         output = quantize_elemwise_op(output + bf_bias, mx_specs=mx_specs, round=mx_specs["round_output"])  # :99-102
     return output
+
+
+def _mx_scale_bits(mx_specs):
+    return 4 if mx_specs["scale_bits"] == 0 else mx_specs["scale_bits"]          # mx_ops.py:519-524
+
+
+def pack_mx_weight(weight, mx_specs):
+    """weight -> (bf16 elementwise cast, linear.py:39) -> mx_ops outlier quantiser along in_features
+    (linear.py:78-85) -> packed planes."""
+    from .qlinear import pack_weight
+    mx_specs = apply_mx_specs(mx_specs)
+    bf_weight = quantize_elemwise_op(weight.detach(), mx_specs=mx_specs, round=mx_specs["round_weight"])
+    sb = _mx_scale_bits(mx_specs)
+    return pack_weight(bf_weight, sb, sb, mx_specs["w_elem_format"], mx_specs["w_elem_format"], std_dev=5,
+                       block_size=mx_specs["block_size"], round=mx_specs["round_mx_output"],
+                       flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], variant=1)
+
+
+def _forward_packed(input, P, bias, mx_specs):
+    """Same dataflow as _forward with the weight side precomputed and the two middle steps fused."""
+    from .qlinear import qlinear_w4a8
+    bf_in = quantize_elemwise_op(input, mx_specs=mx_specs, round=mx_specs["round_output"])
+    sb = _mx_scale_bits(mx_specs)
+    output = qlinear_w4a8(bf_in, P, None, torch.float32, a_elem_format=mx_specs["a_elem_format"], a_scale_bits=sb,
+                          a_std_dev=5, a_block_size=mx_specs["block_size"], a_round=mx_specs["round_mx_output"],
+                          a_flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], a_variant=1)
+    output = quantize_elemwise_op(output, mx_specs=mx_specs, round=mx_specs["round_output"])
+    if bias is not None:
+        bf_bias = quantize_elemwise_op(bias, mx_specs=mx_specs, round=mx_specs["round_weight"])
+        output = quantize_elemwise_op(output + bf_bias, mx_specs=mx_specs, round=mx_specs["round_output"])
+    return output.to(input.dtype) if output.dtype != input.dtype else output
 
 
 def linear(input, weight, bias=None, mx_specs=None, name=None):
@@ -61,7 +96,17 @@ class MXLinear(torch.nn.Linear):
     def append_name(self, postfix):
         self.name += postfix
 
+    def pack(self):
+        """Freeze the current weight into packed planes; forward then runs the fused W4A8 kernels."""
+        if self.mx_none:
+            raise ValueError("MXLinear.pack needs mx_specs")
+        self._packed = pack_mx_weight(self.weight.data, self.mx_specs)
+        return self
+
     def forward(self, inputs):
         if self.mx_none:
             return super().forward(inputs)
+        if getattr(self, "_packed", None) is not None:
+            with torch.no_grad():
+                return _forward_packed(inputs, self._packed, self.bias, self.mx_specs)
         return linear(input=inputs, weight=self.weight, bias=self.bias, mx_specs=self.mx_specs, name=self.name)

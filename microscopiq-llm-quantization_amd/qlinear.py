@@ -55,7 +55,7 @@ def packed_sizes(N, K, block, in_kind, out_kind):
 
 def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp4_e2m1",
                 outlier_elem_format="fp8_e4m3", std_dev=2, block_size=32, round="nearest",
-                flush_fp32_subnorms=False):
+                flush_fp32_subnorms=False, variant=0):
     """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it."""
     if not W.is_cuda:
         raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
@@ -74,7 +74,8 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
     check(lib().msq_outlier_pack(ptr(Wf), ptr(inl), ptr(out), ptr(scl), ptr(status), ptr(ws), wb, N, K, block_size,
                                  format_id(inlier_elem_format), format_id(outlier_elem_format),
                                  int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
-                                 int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), current_stream(dev)),
+                                 int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), int(variant),
+                                 current_stream(dev)),
           "msq_outlier_pack")
     st = int(status.item())
     if st & 1:
@@ -119,6 +120,64 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16):
     check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
                                  0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
                                  ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
+    return y.reshape(*x.shape[:-1], P.N)
+
+
+def act_quant(x, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp8_e4m3",
+              outlier_elem_format="fp8_e4m3", std_dev=2, block_size=32, round="nearest",
+              flush_fp32_subnorms=False, variant=0):
+    """MicroScopiQ outlier-aware MX fake-quant of activations along the last axis, returned as bf16
+    (exact for element formats of at most 8 bits).  variant 0 = utils/quant.py:147-266,
+    1 = number_system/mx/mx_ops.py:210-330 (what MXLinear applies, linear.py:66-73)."""
+    if not x.is_cuda:
+        raise MsqError("act_quant needs a CUDA/HIP tensor (no CPU fallback)")
+    K = x.shape[-1]
+    xf = x.reshape(-1, K).float().contiguous()
+    M = xf.shape[0]
+    xq = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    wsb = lib().msq_act_quant_workspace_bytes(M, K, block_size, int(variant))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(lib().msq_act_quant_bf16(ptr(xf), ptr(xq), ptr(status), ptr(ws), wsb, M, K, block_size,
+                                   format_id(inlier_elem_format), format_id(outlier_elem_format),
+                                   int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
+                                   int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), int(variant),
+                                   current_stream(x.device)), "msq_act_quant_bf16")
+    return xq.reshape(x.shape), status
+
+
+def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4m3", a_scale_bits=8, a_std_dev=2,
+                 a_block_size=32, a_round="nearest", a_flush_fp32_subnorms=False, a_variant=0,
+                 a_outlier_elem_format=None, check_status=False):
+    """y = Q_a(x) . Wq^T (+ bias): activation quantisation (one pass, bf16, exact) + fused dequant-GEMM
+    (BASELINE config 3, W4A8).  x: [..., K] float."""
+    if not x.is_cuda:
+        raise MsqError("qlinear_w4a8 needs CUDA/HIP tensors (no CPU fallback)")
+    K = x.shape[-1]
+    if K != P.K:
+        raise MsqError("qlinear_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
+    xf = x.reshape(-1, K).float().contiguous()
+    M = xf.shape[0]
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise MsqError("qlinear_w4a8: out_dtype must be float32 or bfloat16")
+    y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    wsb = lib().msq_qlinear_w4a8_workspace_bytes(M, P.N, K, a_block_size, int(a_variant))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    fo = a_outlier_elem_format or a_elem_format
+    check(lib().msq_qlinear_w4a8(ptr(xf), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
+                                 0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
+                                 a_block_size, format_id(a_elem_format), format_id(fo), int(a_scale_bits),
+                                 int(a_scale_bits), float(a_std_dev), int(RoundingMode[a_round]),
+                                 int(bool(a_flush_fp32_subnorms)), int(a_variant), ptr(status), ptr(ws), wsb,
+                                 current_stream(x.device)), "msq_qlinear_w4a8")
+    if check_status:
+        st = int(status.item())
+        if st & 1:
+            raise AssertionError("shared_exp contains NaN values (activation scale overflow)")
+        if st & 2:
+            raise MsqError("qlinear_w4a8: a quantised activation is not exact in bf16")
     return y.reshape(*x.shape[:-1], P.N)
 
 

@@ -190,6 +190,50 @@ def test_mxlinear_golden(msq):
             assert (err > 0).mean() <= 0.01, (nm, float((err > 0).mean()))
         else:
             assert err.max() <= 1e-4 * np.abs(ref).max()
+        if nm.startswith("w4a8"):
+            # packed weight + fused activation-quant / dequant-GEMM (msq_qlinear_w4a8): same contract
+            with torch.no_grad():
+                yp = lin.pack()(_t(z["X"])).cpu().numpy()
+            errp = np.abs(yp - ref)
+            assert (errp <= tol).all(), (nm, "packed", float(errp.max()))
+            if nm != "w4a8_nobf":
+                assert (errp > 0).mean() <= 0.01
+            else:
+                assert errp.max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("variant,std_dev", [(0, 2), (1, 5)])
+@pytest.mark.parametrize("afmt", ["fp8_e4m3", "fp8_e5m2", "int8", "fp6_e3m2"])
+def test_act_quant_and_w4a8_vs_oracle(msq, O, variant, std_dev, afmt):
+    """msq_act_quant_bf16 == the oracle fake-quant of X (bit for bit, bf16 holds it exactly) for both
+    quantiser variants; msq_qlinear_w4a8 == oracle linear on the two oracle-quantised operands
+    (fp32 accumulation vs double: 2e-5 relative to max|y|)."""
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 70, 256, 256
+    X = torch.randn(M, K, generator=g)
+    X[torch.rand(M, K, generator=g) < 0.02] *= 12
+    W = torch.randn(N, K, generator=g) * 0.02
+    W[torch.rand(N, K, generator=g) < 0.01] *= 20
+    bias = torch.randn(N, generator=g)
+    xq, st = msq.qlinear.act_quant(X.to(dev()), 8, 8, afmt, afmt, std_dev, 32, "nearest", False, variant)
+    assert int(st.item()) == 0
+    Xo = O.outlier_fakequant(X.numpy(), 8, 8, afmt, afmt, std_dev, -1, 32, variant=("quant", "mx_ops")[variant])["out"]
+    assert _eq(xq.float().cpu().numpy(), Xo).all()
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, "fp4_e2m1", "fp4_e2m1", std_dev, 32, variant=variant)
+    Wo = O.outlier_fakequant(W.numpy(), 8, 8, "fp4_e2m1", "fp4_e2m1", std_dev, -1, 32, variant=("quant", "mx_ops")[variant])["out"]
+    assert _eq(msq.qlinear.unpack_weight(P).cpu().numpy(), Wo).all()
+    y = msq.qlinear.qlinear_w4a8(X.to(dev()), P, bias.to(dev()), torch.float32, a_elem_format=afmt, a_std_dev=std_dev,
+                                 a_variant=variant, check_status=True).cpu().numpy()
+    ref = O.linear(Xo, Wo, bias.numpy())
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+def test_act_quant_rejects_wide_formats(msq):
+    x = torch.randn(4, 64, device=dev())
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.act_quant(x, 8, 8, "fp16", "fp16")
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.act_quant(x, 8, 8, "posit8_es1", "posit8_es1")
 
 
 # ---------------------------------------------------------------- a2/a12 scalar codec, a9 MX, reduce
