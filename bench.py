@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
                     choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama70b_rowparallel"])
+    ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
+                    help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,7 +133,7 @@ def main():
         P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 5, args.block, variant=1)
         X = torch.randn(M, K, device=dev)
     else:
-        P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block)
+        P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block, layout=args.layout)
         X = torch.randn(M, K, device=dev).to(torch.bfloat16)
     del W
     torch.cuda.synchronize()
@@ -177,6 +179,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": name, "M": M, "N": N, "K": K, "block": args.block, "inlier": args.inlier,
                    "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element,
+                   "layout": {(1, 2): "planes", (1, 3): "planes", (1, 4): "planes", (0, 4): "bf16", (0, 5): "unified",
+                              (0, 6): "unified+ext"}.get((P.in_kind, P.out_kind)),
                    "parallelism": ("replicas x%d" % world) if args.workload != "llama70b_rowparallel"
                    else ("row-parallel K/%d + RCCL all-reduce" % world)},
         "pct_of_mfma_peak": 100.0 * (value / world) / PEAK_BF16_TFLOPS,

@@ -75,6 +75,14 @@ extern "C" {
 #define MSQ_PLANE_BF8 3  /* OCP e5m2 bytes                    (outlier format fp8_e5m2)            */
 #define MSQ_PLANE_BF16 4 /* final values, bf16, no scale      (posit / int8 outliers; any format when
                             the inlier plane is NONE: the whole fake-quant value)                 */
+#define MSQ_PLANE_U8 5   /* unified: ONE e4m3 byte per weight + one E8M0 scale per 32 k; inlier plane
+                            NONE (inlier codes are widened to e4m3 at pack time)                   */
+#define MSQ_PLANE_U8X 6  /* unified e4m3 byte + 1 extension bit per weight (a 4th fraction bit: holds
+                            posit<8,1> outliers exactly); the extension plane travels as inl_plane   */
+
+/* packed layouts */
+#define MSQ_LAYOUT_PLANES 0  /* "MSQ-T1": inlier plane + outlier plane + two scales per block          */
+#define MSQ_LAYOUT_UNIFIED 1 /* "MSQ-U1": one 8-bit code plane (+ extension bits) + one scale per 32 k */
 
 int msq_version(void);
 const char* msq_last_error(void);
@@ -151,8 +159,22 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
  *                  (= e_out - e_in + 127)}; one group per column (16 groups) when block >= 32,
  *                  one per lane (64 groups) when block < 32.
  * Zero is always stored as +0 so that inlier and outlier parts combine with a bitwise OR.
+ *
+ * Unified layout ("MSQ-U1", MSQ_PLANE_U8 / _U8X with in_kind NONE): every fake-quant value of a 32-k
+ * group of one column is code * 2^scale with ONE shared E8M0 scale and an e4m3 code (inlier e2m1 codes
+ * widen exactly; outlier e4m3 codes are kept as they are whenever the outlier holds the group maximum):
+ *   code plane   : as the 8-bit outlier plane above (4 slots per tile)
+ *   scale plane  : per tile 16 groups (columns c) x 8 B: byte kf*4 + nf
+ *   extension    : (U8X only, passed as inl_plane) per tile 2 slots (kf) of 64 lanes x 4 B: the bit of
+ *                  element j of fragment nf sits at bit (3 + 16 (j & 1) + 4 nf + (j >> 1)) mod 32, so that
+ *                  rotating by 4 nf + (j >> 1) and masking with 0x00080008 drops it onto bf16 mantissa bit 3
+ * 8.25 (U8) / 9.25 (U8X) bits per weight.  The pack kernel decodes every code exactly as the GEMM will
+ * and raises MSQ_STATUS_INEXACT if a group cannot be represented (range of more than ~2^15 inside one
+ * group); callers then keep the two-plane layout for that tensor.
  * ------------------------------------------------------------------------- */
 int msq_packed_kinds(int inlier_fmt, int outlier_fmt, int* in_kind, int* out_kind);
+/* layout-aware form; MSQ_ERR_UNSUPPORTED when the formats cannot use the unified layout */
+int msq_packed_kinds_layout(int inlier_fmt, int outlier_fmt, int layout, int* in_kind, int* out_kind);
 int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind, int64_t* inl_bytes,
                      int64_t* out_bytes, int64_t* scale_bytes, int64_t* workspace_bytes);
 
@@ -162,7 +184,7 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
                      int* status_flag, void* workspace, int64_t workspace_bytes, int64_t N, int64_t K,
                      int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
                      int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms,
-                     int variant, void* stream);
+                     int variant, int layout, void* stream);
 
 /* planes -> dense dequantised W [N,K]; out_dtype 0 = f32, 2 = bf16 (both exact). */
 int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,

@@ -72,15 +72,45 @@ MSQ_D float scale_operand(uint32_t d, int idx) {
     return __builtin_bit_cast(float, s);
 }
 
+// unified layout (MSQ-U1): one e4m3 code per weight, one scale per 32 k, optional extension bit
+template <int OUT_KIND> struct IsUnified { static constexpr bool v = (OUT_KIND == MSQ_PLANE_U8 || OUT_KIND == MSQ_PLANE_U8X); };
+// does this (in, out) kind pair carry a scale plane?
+template <int IN_KIND, int OUT_KIND> struct HasScale { static constexpr bool v = (IN_KIND != MSQ_PLANE_NONE) || IsUnified<OUT_KIND>::v; };
+
+// extension bit of the two elements of dword d of fragment nf -> bf16 mantissa bit 3 of both halves
+MSQ_D uint32_t ext_or(uint32_t r, uint32_t ext, int nf, int d) {
+    const int sh = nf * 4 + d;
+    const uint32_t rot = sh ? __builtin_amdgcn_alignbit(ext, ext, sh) : ext;
+    return (rot & 0x00080008u) | r;
+}
+template <int OUT_KIND>
+MSQ_D u32x4_t dequant_frag_unified(uint32_t o0, uint32_t o1, float s, uint32_t ext, int nf) {
+    u32x4_t r;
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o0, s, false));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o0, s, true));
+    r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o1, s, false));
+    r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o1, s, true));
+    if (OUT_KIND == MSQ_PLANE_U8X) {
+        r[0] = ext_or(r[0], ext, nf, 0); r[1] = ext_or(r[1], ext, nf, 1);
+        r[2] = ext_or(r[2], ext, nf, 2); r[3] = ext_or(r[3], ext, nf, 3);
+    }
+    return r;
+}
+
 // all 8 fragments of one 64x64 tile for this lane
 struct TileRegs {
     u32x4_t inl[2];      // [kf]  dword nf
     u32x4_t out[8];      // 8-bit kinds use [0..3] = (kf*2 + nf/2); bf16 kind uses [kf*4 + nf]
-    u32x4_t scl;         // dword nf: bytes kf*2 + io
+    u32x4_t scl;         // dword nf: bytes kf*2 + io   (unified: dword kf: byte nf)
+    uint32_t ext[2];     // unified U8X: extension bits of half kf
 };
 
 template <int IN_KIND, int OUT_KIND>
 MSQ_D u32x4_t tile_frag(const TileRegs& t, int nf, int kf) {
+    if (IsUnified<OUT_KIND>::v) {
+        const u32x4_t o = t.out[kf * 2 + (nf >> 1)];
+        return dequant_frag_unified<OUT_KIND>(o[(nf & 1) * 2], o[(nf & 1) * 2 + 1], scale_operand(t.scl[kf], nf), t.ext[kf], nf);
+    }
     if (IN_KIND == MSQ_PLANE_NONE) return t.out[kf * 4 + nf];
     const uint32_t sd = t.scl[nf];
     const float s_in = scale_operand(sd, kf * 2);
@@ -106,6 +136,8 @@ template <int LAYOUT> MSQ_D int scale_group(int lane) { return LAYOUT == 1 ? (la
 template <int LAYOUT> MSQ_D bool scale_writer(int lane) { return LAYOUT == 1 ? (lane >> 4) == 0 : (lane >> 5) == 0; }
 
 template <int OUT_KIND> struct OutSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 8 : 4; };
+// bytes of the scale plane per tile and lane group
+template <int OUT_KIND> struct SclBytes { static constexpr int n = IsUnified<OUT_KIND>::v ? 8 : 16; };
 
 // ---------------------------------------------------------------------------
 // repack: codes[N][K] (u32: bits 0-7 inlier code, 8-23 outlier code) + per-block
@@ -180,7 +212,14 @@ template <int IN_KIND, int OUT_KIND>
 MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_plane, const uint8_t* scl_plane,
                      int64_t tile, int lane, int scl_groups) {
     constexpr int OS = OutSlots<OUT_KIND>::n;
-    if (IN_KIND != MSQ_PLANE_NONE) {
+    if (IsUnified<OUT_KIND>::v) {
+        const uint2 sc = *reinterpret_cast<const uint2*>(scl_plane + (tile * 16 + (lane & 15)) * 8);
+        t.scl[0] = sc.x; t.scl[1] = sc.y;
+        if (OUT_KIND == MSQ_PLANE_U8X) {
+            t.ext[0] = *reinterpret_cast<const uint32_t*>(inl_plane + ((tile * 2 + 0) * 64 + lane) * 4);
+            t.ext[1] = *reinterpret_cast<const uint32_t*>(inl_plane + ((tile * 2 + 1) * 64 + lane) * 4);
+        } else { t.ext[0] = 0; t.ext[1] = 0; }
+    } else if (IN_KIND != MSQ_PLANE_NONE) {
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
             t.inl[kf] = *reinterpret_cast<const u32x4_t*>(inl_plane + ((tile * 2 + kf) * 64 + lane) * 16);
@@ -233,11 +272,16 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
 // is in flight per buffer (register budget: 128 acc + 32 wf + <=48 packed + 12 xf).
 // ---------------------------------------------------------------------------
 template <int OUT_KIND> struct HalfSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 4 : 2; };
+// vector-memory loads one half-step issues for the packed operand (vmcnt bookkeeping)
+template <int IN_KIND, int OUT_KIND> struct HalfLoads {
+    static constexpr int n = (IN_KIND != MSQ_PLANE_NONE ? 1 : 0) + HalfSlots<OUT_KIND>::n + (OUT_KIND == MSQ_PLANE_U8X ? 1 : 0);
+};
 
 template <int IN_KIND, int OUT_KIND>
 struct HalfRegs {
     u32x4_t inl;
     u32x4_t out[HalfSlots<OUT_KIND>::n];
+    uint32_t ext;        // U8X: extension bits of this half
 };
 
 template <int IN_KIND, int OUT_KIND>
@@ -296,12 +340,23 @@ MSQ_D void load_half_buf(HalfRegs<IN_KIND, OUT_KIND>& h, const PlaneRsrc& r, int
 #pragma unroll
     for (int s = 0; s < HS; ++s)
         h.out[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r.out, lane16, uni((tile2kf * HS + s) * 1024u), 0));
+    if (OUT_KIND == MSQ_PLANE_U8X)     // extension plane rides in the inlier descriptor: 64 lanes x 4 B per half
+        h.ext = __builtin_amdgcn_raw_buffer_load_b32(r.inl, lane16 >> 2, uni(tile2kf * 256u), 0);
 }
 
 // one quarter of a half-step's conversion work: fragment nf = q/2, dwords 2*(q%2) .. +1
 template <int IN_KIND, int OUT_KIND>
 MSQ_D void convert_quarter(u32x4_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h, const u32x4_t& scl, int kf, int q) {
     const int nf = q >> 1, hh = q & 1;
+    if (IsUnified<OUT_KIND>::v) {      // scl[kf] byte nf; one convert per dword (+ rotate / and-or for the extension bit)
+        const float s = scale_operand(scl[kf], nf);
+        const uint32_t o = h.out[nf >> 1][(nf & 1) * 2 + hh];
+        uint32_t r0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, false));
+        uint32_t r1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, true));
+        if (OUT_KIND == MSQ_PLANE_U8X) { r0 = ext_or(r0, h.ext, nf, 2 * hh); r1 = ext_or(r1, h.ext, nf, 2 * hh + 1); }
+        wf[nf][2 * hh] = r0; wf[nf][2 * hh + 1] = r1;
+        return;
+    }
     if (IN_KIND == MSQ_PLANE_NONE) {
         wf[nf][2 * hh] = h.out[nf][2 * hh]; wf[nf][2 * hh + 1] = h.out[nf][2 * hh + 1];
         return;
@@ -333,9 +388,11 @@ MSQ_D void convert_quarter(u32x4_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& 
 
 // force the compiler to have these registers loaded here (its s_waitcnt lands at this point)
 MSQ_D void keep_live4(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+MSQ_D void keep_live1(uint32_t& v) { asm volatile("" : "+v"(v)); }
 template <int IN_KIND, int OUT_KIND>
 MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
     if (IN_KIND != MSQ_PLANE_NONE) keep_live4(h.inl);
+    if (OUT_KIND == MSQ_PLANE_U8X) keep_live1(h.ext);
 #pragma unroll
     for (int s = 0; s < HalfSlots<OUT_KIND>::n; ++s) keep_live4(h.out[s]);
 }
@@ -438,12 +495,20 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     // packed planes and activations through buffer descriptors (SGPR slot / K-step offsets)
     const int64_t ntiles = (int64_t)(N / TILE_N) * KT;
     PlaneRsrc pr;
-    pr.inl = make_rsrc(inl_plane, ntiles * 2 * 1024);
+    pr.inl = make_rsrc(inl_plane, ntiles * 2 * (OUT_KIND == MSQ_PLANE_U8X ? 256 : 1024));
     pr.out = make_rsrc(out_plane, ntiles * 2 * HalfSlots<OUT_KIND>::n * 1024);
-    pr.scl = make_rsrc(scl_plane, ntiles * scl_groups * 16);
+    constexpr bool HAS_SCALE = HasScale<IN_KIND, OUT_KIND>::v;
+    constexpr int SCLB = SclBytes<OUT_KIND>::n;               // scale bytes per lane group and tile
+    pr.scl = make_rsrc(scl_plane, ntiles * scl_groups * SCLB);
     const int lane16 = lane * 16;
-    const int scl_lane_off = (lane & (scl_groups - 1)) * 16;
-    const uint32_t scl_tile_bytes = (uint32_t)scl_groups * 16u;
+    const int scl_lane_off = (lane & (scl_groups - 1)) * SCLB;
+    const uint32_t scl_tile_bytes = (uint32_t)scl_groups * (uint32_t)SCLB;
+    auto load_scales = [&](uint32_t tile) -> u32x4_t {
+        if (SCLB == 16) return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni(tile * scl_tile_bytes), 0));
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(pr.scl, scl_lane_off, uni(tile * scl_tile_bytes), 0));
+        return u32x4_t{v[0], v[1], 0u, 0u};
+    };
     const uint32_t tile_row32 = (uint32_t)tile_row;
 
     // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
@@ -482,7 +547,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     stage_A(kt0, 0);
     load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
     load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
-    if (IN_KIND != MSQ_PLANE_NONE) sc_cur = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni((tile_row32 + kt0) * scl_tile_bytes), 0));
+    if (HAS_SCALE) sc_cur = load_scales(tile_row32 + kt0);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #pragma unroll
@@ -513,13 +578,12 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
         if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + ktn) * 2u + 0u);
-        if (IN_KIND != MSQ_PLANE_NONE)
-            sc_nxt = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni((tile_row32 + ktn) * scl_tile_bytes), 0));
+        if (HAS_SCALE) sc_nxt = load_scales(tile_row32 + ktn);
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfA, wfB, pkB, sc_cur, 1, rd0)
         // ---------------- half-step kf = 1: MFMAs on wfB, make next wfA from pkA
         keep_live(pkA);
-        if (IN_KIND != MSQ_PLANE_NONE) keep_live4(sc_nxt);
+        if (HAS_SCALE) keep_live4(sc_nxt);
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + ktn) * 2u + 1u);
         __builtin_amdgcn_sched_barrier(0);
         MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
@@ -528,7 +592,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         // ops after the pkA loads inside the first group, so the waits it places for pkA do not cover
         // them: wait explicitly for everything older than the pkB loads (vmcnt is in-order), which stay
         // in flight across the barrier.  (Without this, two co-resident blocks showed stale A rows.)
-        constexpr int N_PKB = (IN_KIND != MSQ_PLANE_NONE ? 1 : 0) + HalfSlots<OUT_KIND>::n;
+        constexpr int N_PKB = HalfLoads<IN_KIND, OUT_KIND>::n;
         __builtin_amdgcn_s_waitcnt(0x0070 | (N_PKB & 15) | ((N_PKB >> 4) << 14));   // vmcnt(N_PKB) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     }
@@ -675,6 +739,31 @@ int msq_packed_kinds(int inlier_fmt, int outlier_fmt, int* in_kind, int* out_kin
     return MSQ_OK;
 }
 
+// significant bits (implicit 1 + fraction) a format's values can carry
+static int sig_bits(const msq_host::FmtInfo& f, int fmt_id) {
+    if (f.kind == 1) {                                         // posit<n,es>: n - 1 (sign) - 2 (shortest regime) - es fraction bits
+        const int n = (fmt_id >> 2) & 0x3F, es = fmt_id & 3;
+        const int fr = n - 3 - es;
+        return 1 + (fr > 0 ? fr : 0);
+    }
+    return f.mbits - 1;                                        // mbits counts sign + implicit one (formats.py:65-129)
+}
+
+int msq_packed_kinds_layout(int inlier_fmt, int outlier_fmt, int layout, int* in_kind, int* out_kind) {
+    if (layout == MSQ_LAYOUT_PLANES) return msq_packed_kinds(inlier_fmt, outlier_fmt, in_kind, out_kind);
+    if (layout != MSQ_LAYOUT_UNIFIED) return fail2(MSQ_ERR_BAD_ARG, "msq_packed_kinds_layout: bad layout");
+    msq_host::FmtInfo fi, fo;
+    if (!msq_host::format_info(inlier_fmt, &fi) || !msq_host::format_info(outlier_fmt, &fo))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_packed_kinds_layout: unknown element format");
+    const int si = sig_bits(fi, inlier_fmt), so = sig_bits(fo, outlier_fmt);
+    const int sg = si > so ? si : so;
+    if (fi.kind != 0 || sg > 5)
+        return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_kinds_layout: the unified layout holds float/int inliers and values of at most 5 significant bits");
+    if (in_kind) *in_kind = MSQ_PLANE_NONE;
+    if (out_kind) *out_kind = (sg <= 4) ? MSQ_PLANE_U8 : MSQ_PLANE_U8X;
+    return MSQ_OK;
+}
+
 int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind, int64_t* inl_bytes,
                      int64_t* out_bytes, int64_t* scale_bytes, int64_t* workspace_bytes) {
     if (N <= 0 || K <= 0 || (N % TILE_N) || (K % TILE_K))
@@ -683,6 +772,15 @@ int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind,
         return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: block must be 8/16/32/64/128 and divide K");
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    if (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X) {
+        if (in_kind != MSQ_PLANE_NONE) return fail2(MSQ_ERR_BAD_ARG, "msq_packed_sizes: unified planes have no inlier plane");
+        if (msq_layout() != 1) return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: unified layout needs the 16x16x32 tile order");
+        if (inl_bytes) *inl_bytes = (out_kind == MSQ_PLANE_U8X) ? tiles * 2 * 256 : 0;      // extension bits
+        if (out_bytes) *out_bytes = tiles * 4 * 1024;
+        if (scale_bytes) *scale_bytes = tiles * 16 * 8;
+        if (workspace_bytes) *workspace_bytes = 0;
+        return MSQ_OK;
+    }
     if (inl_bytes) *inl_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * 2 * 1024;
     if (out_bytes) *out_bytes = tiles * ((out_kind == MSQ_PLANE_BF16) ? 8 : 4) * 1024;
     if (scale_bytes) *scale_bytes = (in_kind == MSQ_PLANE_NONE) ? 0 : tiles * groups * 16;
@@ -705,16 +803,24 @@ int msq_mxops_stats_(const float* in, float* vmean, float* vstd, int64_t pre, in
 int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* scale_plane, int* status_flag,
                      void* workspace, int64_t workspace_bytes, int64_t N, int64_t K, int block, int inlier_fmt,
                      int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
-                     int flush_fp32_subnorms, int variant, void* stream) {
+                     int flush_fp32_subnorms, int variant, int layout, void* stream) {
     if (variant != MSQ_VARIANT_QUANT && variant != MSQ_VARIANT_MXOPS) return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: bad variant");
     int ik, ok;
-    int rc = msq_packed_kinds(inlier_fmt, outlier_fmt, &ik, &ok);
+    int rc = msq_packed_kinds_layout(inlier_fmt, outlier_fmt, layout, &ik, &ok);
     if (rc) return rc;
     int64_t ib, ob, sb, wb;
     rc = msq_packed_sizes(N, K, block, ik, ok, &ib, &ob, &sb, &wb);
     if (rc) return rc;
     if (!W || !out_plane || (ik != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: null buffer");
+    if (layout == MSQ_LAYOUT_UNIFIED) {
+        if (!scale_plane || (ok == MSQ_PLANE_U8X && !inl_plane)) return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_pack: null buffer");
+        if (variant != MSQ_VARIANT_QUANT) return fail2(MSQ_ERR_UNSUPPORTED, "msq_outlier_pack: the unified layout packs the canonical quantiser only");
+        rc = msq_pack_fused_(W, inl_plane, out_plane, scale_plane, status_flag, N, K, block, inlier_fmt, outlier_fmt,
+                             inlier_scale_bits, outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
+        if (rc == MSQ_ERR_UNSUPPORTED) return fail2(rc, "msq_outlier_pack: the unified layout needs nearest rounding and block <= 64");
+        return rc;
+    }
     // single-pass kernel for the common configurations (float/int inliers, nearest rounding, block <= 64) ...
     if (variant == MSQ_VARIANT_QUANT && getenv("MSQ_PACK_TWO_PASS") == nullptr) {
         rc = msq_pack_fused_(W, inl_plane, out_plane, scale_plane, status_flag, N, K, block, inlier_fmt, outlier_fmt,
@@ -756,6 +862,8 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     if (rc) return rc;
     if (!out_plane || !W_out || (in_kind != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_unpack: null buffer");
+    if ((out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X) && (!scale_plane || (out_kind == MSQ_PLANE_U8X && !inl_plane)))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_outlier_unpack: null buffer");
     if (out_dtype != 0 && out_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_outlier_unpack: out_dtype must be 0 (f32) or 2 (bf16)");
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
@@ -774,6 +882,8 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+    else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8) MSQ_UP(MSQ_PLANE_NONE, MSQ_PLANE_U8);
+    else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8X) MSQ_UP(MSQ_PLANE_NONE, MSQ_PLANE_U8X);
     else return fail2(MSQ_ERR_UNSUPPORTED, "msq_outlier_unpack: unsupported plane kinds");
 #undef MSQ_UP
     return check_launch2("msq_outlier_unpack");
@@ -832,10 +942,13 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (N % BN) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: N must be a multiple of 256");
     if (!X || !Y || !out_plane || (in_kind != MSQ_PLANE_NONE && (!inl_plane || !scale_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
+    const bool unified = (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X);
+    if (unified && (!scale_plane || (out_kind == MSQ_PLANE_U8X && !inl_plane)))
+        return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     hipStream_t st0 = (hipStream_t)stream;
-    const int groups0 = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    const int groups0 = unified ? 16 : (block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32));
     if (M <= MSQ_GEMV_MAX_M && workspace) {
         const int kc = pick_kc(N, K);
         const int nks = (int)((K / BK + kc - 1) / kc);
@@ -853,6 +966,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+            else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_U8);
+            else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8X) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_U8X);
             else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
 #undef MSQ_GV
             rc = check_launch2("msq_qlinear_bf16(gemv)");
@@ -871,7 +986,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256 * wm_sel);
     const size_t lds = (size_t)2 * 128 * wm_sel * BK * 2;
     hipStream_t st = (hipStream_t)stream;
-    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    const int groups = groups0;
     float* partial = (float*)workspace;
 #define MSQ_LAUNCH1(KERN, IK, OK, YT, WMV)                                                                             \
     do { static bool attr_set = false;                                                                                 \
@@ -886,6 +1001,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_FP8); \
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF8); \
          else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_LAUNCH(KERN, MSQ_PLANE_FP4, MSQ_PLANE_BF16); \
+         else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_U8); \
+         else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8X) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_U8X); \
          else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds"); } while (0)
     MSQ_DISPATCH(k_qgemm3);
 #undef MSQ_DISPATCH

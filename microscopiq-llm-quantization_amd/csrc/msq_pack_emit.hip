@@ -281,6 +281,139 @@ k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_
     if (status && A.status) atomicOr(A.status, status);
 }
 
+// ===========================================================================
+// Fused pack, unified layout (MSQ-U1): as k_pack_tile, but every 32-k half row gets ONE scale and every
+// weight one e4m3 code (+ one extension bit when EXT: the 4th fraction bit of posit<8,1> outliers).
+//   scale s = floor(log2(max|v|)) - 8 (+1 when max|v| 2^-s > 448): when an e4m3 outlier holds the maximum
+//   this is the outlier's own scale, so its codes are unchanged; inlier e2m1 values widen exactly.
+// Every code is decoded back with the GEMM's own instruction and compared with the fake-quant value.
+// ===========================================================================
+template <int BS, bool EXT>
+__global__ void __launch_bounds__(256)
+k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
+              uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
+    constexpr int WAVE_LDS = 64 * 68 * 4;
+    constexpr int CODE_STRIDE = 18;                              // dwords per row (16 used)
+    constexpr int CODE_OFF = 0, SCL_OFF = 64 * CODE_STRIDE * 4, EXT_OFF = SCL_OFF + 64 * 4;
+    static_assert(EXT_OFF + 64 * 8 <= WAVE_LDS, "LDS overlay does not fit");
+    __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t KT = K / 64, NT = N / 64;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    if (tile >= KT * NT) return;
+    const int64_t nt = tile / KT, kt = tile % KT;
+    char* wl = lds + wv * WAVE_LDS;
+    float* ft = reinterpret_cast<float*>(wl);
+    {
+        const float* src = W + (nt * 64) * K + kt * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = i * 4 + (lane >> 4), c4 = lane & 15;
+            *reinterpret_cast<float4*>(ft + row * 68 + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)row * K + c4 * 4);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    float all[64];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(ft + lane * 68 + c * 4);
+        all[c * 4 + 0] = v.x; all[c * 4 + 1] = v.y; all[c * 4 + 2] = v.z; all[c * 4 + 3] = v.w;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* codeT = reinterpret_cast<uint32_t*>(wl + CODE_OFF);
+    uint8_t* sclT = reinterpret_cast<uint8_t*>(wl + SCL_OFF);    // [row][4]: bytes 0..1 = halves
+    uint8_t* extT = reinterpret_cast<uint8_t*>(wl + EXT_OFF);    // [row][8]: one byte per 8-k group
+    int status = 0;
+    // fake-quant of the whole row (final values replace all[])
+#pragma unroll
+    for (int j = 0; j < 64 / BS; ++j) {
+        float a[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) a[b] = all[j * BS + b];
+        uint32_t mkw[(BS + 31) / 32];
+        float se_in, se_out;
+        status |= outlier_block_fast<BS, 0, false>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
+#pragma unroll
+        for (int b = 0; b < BS; ++b) all[j * BS + b] = a[b];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float mx = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) { const float t = __builtin_fabsf(all[h * 32 + b]); mx = t > mx ? t : mx; bad |= !(t == t) || t > 3.0e38f; }
+        int su = 0;
+        if (mx > 0.f) {
+            su = ilog2f(mx) - 8;
+            if (scale_pow2(mx, -su) > 448.f) su += 1;
+        }
+        su = su < -126 ? -126 : su;
+        if (su > 127) { su = 127; status |= MSQ_STATUS_INEXACT; }
+        if (bad) status |= MSQ_STATUS_NAN;
+        const uint32_t sb = (uint32_t)(su + 127);
+        const float s_op = u2f(sb << 23);
+        sclT[lane * 4 + h] = (uint8_t)sb;
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+            const int k8 = h * 4 + t8;
+            uint32_t ow[2] = {0, 0}, eb = 0;
+            bool ok = true;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                typedef short v2s_t __attribute__((ext_vector_type(2)));
+                const float v0 = all[k8 * 8 + 2 * p] + 0.0f, v1 = all[k8 * 8 + 2 * p + 1] + 0.0f;   // -0 -> +0
+                uint32_t u0 = f2u(v0), u1 = f2u(v1);
+                if (EXT) {                                       // split off the bf16 mantissa bit 3 (f32 bit 19)
+                    eb |= ((u0 >> 19) & 1u) << (2 * p);
+                    eb |= ((u1 >> 19) & 1u) << (2 * p + 1);
+                    u0 &= ~(1u << 19); u1 &= ~(1u << 19);
+                }
+                const float q0 = scale_pow2(u2f(u0), -su), q1 = scale_pow2(u2f(u1), -su);
+                v2s_t cur = __builtin_bit_cast(v2s_t, ow[p >> 1]);
+                if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, q0, q1, 1.0f, false);
+                else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, q0, q1, 1.0f, true);
+                ow[p >> 1] = __builtin_bit_cast(uint32_t, cur);
+                uint32_t d = ((p & 1) == 0) ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ow[p >> 1], s_op, false))
+                                            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ow[p >> 1], s_op, true));
+                if (EXT) d |= (((eb >> (2 * p)) & 1u) << 3) | (((eb >> (2 * p + 1)) & 1u) << 19);
+                const uint32_t expect = (f2u(v0) >> 16) | (f2u(v1) & 0xFFFF0000u);
+                ok = ok && (d == expect) && (((f2u(v0) | f2u(v1)) & 0xFFFFu) == 0u);
+            }
+            if (!ok && !bad) status |= MSQ_STATUS_INEXACT;
+            codeT[lane * CODE_STRIDE + k8 * 2] = ow[0];
+            codeT[lane * CODE_STRIDE + k8 * 2 + 1] = ow[1];
+            if (EXT) extT[lane * 8 + k8] = (uint8_t)eb;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // fragment gather + slot stores
+    const int c = lane & 15, g = lane >> 4;
+    uint32_t sc[2] = {0, 0};
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf) {
+        uint32_t ew = 0;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = nf * 16 + c, k8 = kf * 4 + g;
+            sc[kf] |= (uint32_t)sclT[n * 4 + kf] << (8 * nf);
+            const uint2 o = *reinterpret_cast<const uint2*>(codeT + n * CODE_STRIDE + k8 * 2);
+            *reinterpret_cast<uint2*>(code_plane + ((tile * 4 + kf * 2 + (nf >> 1)) * 64 + lane) * 16 + (nf & 1) * 8) = o;
+            if (EXT) {
+                const uint32_t eb = extT[n * 8 + k8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    ew |= ((eb >> j) & 1u) << ((3 + 16 * (j & 1) + 4 * nf + (j >> 1)) & 31);
+            }
+        }
+        if (EXT) *reinterpret_cast<uint32_t*>(ext_plane + ((tile * 2 + kf) * 64 + lane) * 4) = ew;
+    }
+    if (g == 0) *reinterpret_cast<uint2*>(scl_plane + (tile * 16 + c) * 8) = make_uint2(sc[0], sc[1]);
+    if (status && A.status) atomicOr(A.status, status);
+}
+
 // returns MSQ_ERR_UNSUPPORTED when the configuration needs the generic two-kernel path
 extern "C" int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane, void* scale_plane, int* status,
                                int64_t N, int64_t K, int block, int inlier_fmt, int outlier_fmt, int in_sb, int out_sb,
@@ -307,6 +440,14 @@ extern "C" int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane,
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+    else if (in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
+#define MSQ_PU(BS) do { if (out_kind == MSQ_PLANE_U8) hipLaunchKernelGGL((k_pack_tile_u<BS, false>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
+                                (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K); \
+                        else hipLaunchKernelGGL((k_pack_tile_u<BS, true>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
+                                (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K); } while (0)
+        switch (block) { case 8: MSQ_PU(8); break; case 16: MSQ_PU(16); break; case 32: MSQ_PU(32); break; default: MSQ_PU(64); break; }
+#undef MSQ_PU
+    }
     else return MSQ_ERR_UNSUPPORTED;
 #undef MSQ_PTB
 #undef MSQ_PT

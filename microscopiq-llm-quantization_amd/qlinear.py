@@ -39,10 +39,17 @@ class PackedWeight:
         return 8.0 * self.nbytes / (self.N * self.K)
 
 
-def packed_kinds(inlier_elem_format, outlier_elem_format):
+LAYOUT_PLANES, LAYOUT_UNIFIED = 0, 1
+_LAYOUTS = {"planes": LAYOUT_PLANES, "unified": LAYOUT_UNIFIED, LAYOUT_PLANES: LAYOUT_PLANES,
+            LAYOUT_UNIFIED: LAYOUT_UNIFIED}
+
+
+def packed_kinds(inlier_elem_format, outlier_elem_format, layout="planes"):
+    """Plane kinds of a packed layout: "planes" = MSQ-T1 (inlier plane + outlier plane, two scales per
+    block), "unified" = MSQ-U1 (one e4m3 code per weight [+ extension bit], one scale per 32 k)."""
     ik, ok = C.c_int(), C.c_int()
-    check(lib().msq_packed_kinds(format_id(inlier_elem_format), format_id(outlier_elem_format), C.byref(ik),
-                                 C.byref(ok)), "msq_packed_kinds")
+    check(lib().msq_packed_kinds_layout(format_id(inlier_elem_format), format_id(outlier_elem_format),
+                                        _LAYOUTS[layout], C.byref(ik), C.byref(ok)), "msq_packed_kinds_layout")
     return ik.value, ok.value
 
 
@@ -55,34 +62,52 @@ def packed_sizes(N, K, block, in_kind, out_kind):
 
 def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp4_e2m1",
                 outlier_elem_format="fp8_e4m3", std_dev=2, block_size=32, round="nearest",
-                flush_fp32_subnorms=False, variant=0):
-    """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it."""
+                flush_fp32_subnorms=False, variant=0, layout="planes"):
+    """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it.
+
+    layout: "planes" (MSQ-T1), "unified" (MSQ-U1, smaller and faster; raises MsqError if a 32-k group
+    cannot be represented exactly) or "auto" (unified when the formats allow it and every group is
+    exact, otherwise planes)."""
     if not W.is_cuda:
         raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
     if W.ndim != 2:
         raise MsqError("pack_weight expects a 2-D [out_features, in_features] weight")
     Wf = W.detach().contiguous().float()
+    if layout == "auto":
+        if variant == 0 and round == "nearest" and block_size <= 64:
+            try:
+                return _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev,
+                             block_size, round, flush_fp32_subnorms, variant, "unified")
+            except MsqError:
+                pass
+        layout = "planes"
+    return _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev,
+                 block_size, round, flush_fp32_subnorms, variant, layout)
+
+
+def _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev, block_size,
+          round, flush_fp32_subnorms, variant, layout):
     N, K = Wf.shape
-    ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format)
+    ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format, layout)
     ib, ob, sb, wb = packed_sizes(N, K, block_size, ik, ok)
     dev = Wf.device
     inl = torch.empty(ib, dtype=torch.uint8, device=dev) if ib else None
     out = torch.empty(ob, dtype=torch.uint8, device=dev)
     scl = torch.empty(sb, dtype=torch.uint8, device=dev) if sb else None
-    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev) if wb else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib().msq_outlier_pack(ptr(Wf), ptr(inl), ptr(out), ptr(scl), ptr(status), ptr(ws), wb, N, K, block_size,
                                  format_id(inlier_elem_format), format_id(outlier_elem_format),
                                  int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
                                  int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), int(variant),
-                                 current_stream(dev)),
+                                 _LAYOUTS[layout], current_stream(dev)),
           "msq_outlier_pack")
     st = int(status.item())
     if st & 1:
         raise AssertionError("shared_exp contains NaN values (scale overflow) while packing")
     if st & 2:
-        raise MsqError("pack_weight: a value is not exactly code * 2^scale in the packed format "
-                       "(degenerate block scale); keep this layer unpacked")
+        raise MsqError("pack_weight: a value is not exactly code * 2^scale in the %s layout "
+                       "(degenerate block scale / too wide a range inside one group)" % layout)
     return PackedWeight(inl, out, scl, N, K, block_size, ik, ok)
 
 
@@ -187,13 +212,14 @@ class QuantLinear(nn.Module):
     packed planes (llm/opt.py:510-512, :290)."""
 
     def __init__(self, in_features, out_features, bias=True, block_size=32, inlier_elem_format="fp4_e2m1",
-                 outlier_elem_format="fp8_e4m3", out_dtype=torch.bfloat16, device=None):
+                 outlier_elem_format="fp8_e4m3", out_dtype=torch.bfloat16, device=None, layout="planes"):
         super().__init__()
+        self.layout = layout
         self.in_features, self.out_features = in_features, out_features
         self.block_size = block_size
         self.inlier_elem_format, self.outlier_elem_format = inlier_elem_format, outlier_elem_format
         self.out_dtype = out_dtype
-        ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format)
+        ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format, layout)
         ib, ob, sb, _ = packed_sizes(out_features, in_features, block_size, ik, ok)
         self.in_kind, self.out_kind = ik, ok
         self.register_buffer("inl_plane", torch.zeros(ib, dtype=torch.uint8, device=device))
@@ -222,11 +248,12 @@ class QuantLinear(nn.Module):
                       inlier_elem_format=q.inlier_elem_format, outlier_elem_format=q.outlier_elem_format,
                       std_dev=q.std_dev, block_size=q.block_size, round=q.round,
                       flush_fp32_subnorms=q.flush_fp32_subnorms)
-        P = pack_weight(linear.weight.data, **kw)
+        P = pack_weight(linear.weight.data, layout=self.layout, **kw)
         if (P.in_kind, P.out_kind, P.block) != (self.in_kind, self.out_kind, self.block_size):
             raise MsqError("quantizer formats do not match the formats this QuantLinear was built for")
         if P.inl is not None:
             self.inl_plane.copy_(P.inl)
+        if P.scl is not None:
             self.scale_plane.copy_(P.scl)
         self.out_plane.copy_(P.out)
         if self.bias is not None and linear.bias is not None:
@@ -239,6 +266,15 @@ class QuantLinear(nn.Module):
             kw.setdefault("block_size", quantizer.block_size)
             kw.setdefault("inlier_elem_format", quantizer.inlier_elem_format)
             kw.setdefault("outlier_elem_format", quantizer.outlier_elem_format)
+        kw.setdefault("layout", "auto")
+        if kw["layout"] == "auto":              # unified when the formats allow it and every group is exact
+            q = quantizer
+            if q is None or (q.round == "nearest" and q.block_size <= 64):
+                try:
+                    return cls.from_linear(linear, quantizer, **dict(kw, layout="unified"))
+                except MsqError:
+                    pass
+            kw = dict(kw, layout="planes")
         m = cls(linear.in_features, linear.out_features, linear.bias is not None, device=linear.weight.device, **kw)
         return m.pack(linear, quantizer)
 
@@ -249,16 +285,16 @@ class QuantLinear(nn.Module):
         return qlinear(x, self._packed(), self.bias, self.out_dtype).to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
 
 
-def make_quant(module, quantizers, name=''):
+def make_quant(module, quantizers, name='', layout="auto"):
     """Swap every nn.Linear whose qualified name is in `quantizers` (name -> MXQuantizer) for a
     packed QuantLinear (the make_quant3 contract of llm/opt.py:258-264)."""
     for attr in list(dict(module.named_children()).keys()):
         child = getattr(module, attr)
         full = name + '.' + attr if name != '' else attr
         if isinstance(child, nn.Linear) and full in quantizers:
-            setattr(module, attr, QuantLinear.from_linear(child, quantizers[full]))
+            setattr(module, attr, QuantLinear.from_linear(child, quantizers[full], layout=layout))
         else:
-            make_quant(child, quantizers, full)
+            make_quant(child, quantizers, full, layout)
     return module
 
 

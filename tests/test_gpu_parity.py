@@ -344,6 +344,61 @@ def test_pack_unpack_equals_fakequant(msq, O, fi, fo, bs):
     assert (msq.qlinear.unpack_weight(P, torch.bfloat16).float().cpu().numpy() == o).all()   # exact in bf16
 
 
+# unified layout (MSQ-U1): one e4m3 code (+ extension bit) per weight, one scale per 32 k
+UCFGS = [("fp4_e2m1", "fp8_e4m3", 32, 5), ("fp4_e2m1", "posit8_es1", 32, 6), ("int2", "fp4", 16, 5), ("fp4", "fp8_e4m3", 16, 5),
+         ("fp6_e3m2", "fp8_e4m3", 64, 5), ("fp4", "fp6_e2m3", 32, 5), ("int4", "posit8_es1", 16, 6)]
+
+
+@pytest.mark.parametrize("fi,fo,bs,kind", UCFGS)
+def test_unified_pack_unpack_equals_fakequant(msq, O, fi, fo, bs, kind):
+    g = torch.Generator().manual_seed(1)
+    W = torch.randn(256, 512, generator=g) * 0.02
+    W[torch.rand(256, 512, generator=g) < 0.01] *= 20
+    W[5, 64:96] = 0                                                     # an all-zero group
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, fi, fo, 2, bs, layout="unified")
+    assert (P.in_kind, P.out_kind) == (0, kind)
+    assert abs(P.bits_per_element - (8.25 if kind == 5 else 9.25)) < 1e-9
+    o = O.outlier_fakequant(W.numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
+    assert _eq(msq.qlinear.unpack_weight(P, torch.float32).cpu().numpy(), o).all()
+    assert _eq(msq.qlinear.unpack_weight(P, torch.bfloat16).float().cpu().numpy(), o).all()
+
+
+@pytest.mark.parametrize("fi,fo,bs,kind", UCFGS[:3])
+@pytest.mark.parametrize("M", [1, 16, 65, 300, 513])
+def test_unified_fused_gemm_vs_oracle_linear(msq, O, fi, fo, bs, kind, M):
+    g = torch.Generator().manual_seed(2)
+    W = torch.randn(256, 512, generator=g) * 0.02
+    W[torch.rand(256, 512, generator=g) < 0.01] *= 20
+    X = torch.randn(M, 512, generator=g).to(torch.bfloat16)
+    bias = torch.randn(256, generator=g)
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, fi, fo, 2, bs, layout="unified")
+    Wq = O.outlier_fakequant(W.numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
+    y = msq.qlinear.qlinear(X.to(dev()), P, bias.to(dev()), torch.float32).cpu().numpy()
+    ref = O.linear(X.float().numpy(), Wq, bias.numpy())
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+def test_unified_layout_limits(msq):
+    """Formats with more than 5 significant bits cannot use the unified layout; a group whose values span
+    more than the e4m3 range is reported (never silently rounded) and layout="auto" falls back to planes."""
+    W = torch.randn(64, 64, device=dev()) * 0.02
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "int8", 2, 32, layout="unified")
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es0", 2, 32, layout="unified")
+    Wr = W.clone()
+    Wr[0, :32] = 2.0 ** -20                     # inliers near 2^-20 ...
+    Wr[0, 3] = 1.0e4                            # ... next to one huge outlier: > 2^30 apart in one group
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_weight(Wr, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="unified")
+    P = msq.qlinear.pack_weight(Wr, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="auto")
+    assert (P.in_kind, P.out_kind) == (1, 2)
+    Wq = msq.quant.quantize_mx_outlier_v1(Wr, 8, 8, "fp4_e2m1", "fp8_e4m3", "max", 2, [-1], 32)
+    assert torch.equal(msq.qlinear.unpack_weight(P), Wq)
+    P2 = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="auto")
+    assert (P2.in_kind, P2.out_kind) == (0, 5)
+
+
 @pytest.mark.parametrize("fi,fo,bs", CFGS[:4])
 @pytest.mark.parametrize("M", [1, 16, 300, 513])
 def test_fused_gemm_vs_oracle_linear(msq, O, fi, fo, bs, M):
@@ -372,8 +427,8 @@ def test_full_size_properties(msq):
     g = torch.Generator(device=dev()).manual_seed(3)
     W = torch.randn(N, K, generator=g, device=dev()) * 0.02
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
-    for fo in ("fp8_e4m3", "posit8_es1"):
-        P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32)
+    for fo, layout in (("fp8_e4m3", "planes"), ("posit8_es1", "planes"), ("fp8_e4m3", "unified"), ("posit8_es1", "unified")):
+        P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
         Wq = msq.quant.quantize_mx_outlier_v1(W, 8, 8, "fp4_e2m1", fo, "max", 2, [-1], 32)
         Wu = msq.qlinear.unpack_weight(P, torch.float32)
         assert torch.equal(Wu, Wq)
@@ -387,8 +442,9 @@ def test_full_size_properties(msq):
         assert (ys - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("layout", ["planes", "unified"])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
-def test_fused_gemm_llama_shapes_repeatable(msq, N, K):
+def test_fused_gemm_llama_shapes_repeatable(msq, N, K, layout):
     """Llama-7B layer shapes (llm/llama.py:find_layers): every M takes a different block count / split-K
     factor; the result must equal the dense GEMM on the unpacked weight and be bit-identical run after run
     (the K loop hands activation tiles between waves through LDS-DMA: a missing wait shows up as stale
@@ -396,7 +452,7 @@ def test_fused_gemm_llama_shapes_repeatable(msq, N, K):
     g = torch.Generator(device=dev()).manual_seed(5)
     W = torch.randn(N, K, generator=g, device=dev()) * 0.02
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
-    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32)
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3" if N != 11008 else "posit8_es1", 2, 32, layout=layout)
     Wu = msq.qlinear.unpack_weight(P, torch.float32)
     for M in (65, 128, 1000, 2048):
         X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
@@ -422,7 +478,8 @@ def test_quantlinear_module_and_state_dict(msq):
     y = ql(x)
     ref = torch.nn.functional.linear(x.float(), Wq, lin.bias.float())
     assert y.shape == (3, 7, 256) and (y.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
-    ql2 = msq.qlinear.QuantLinear(512, 256, True, 32, "fp4_e2m1", "fp8_e4m3", device=dev())
+    assert ql.layout == "unified"                                       # from_linear defaults to layout="auto"
+    ql2 = msq.qlinear.QuantLinear(512, 256, True, 32, "fp4_e2m1", "fp8_e4m3", device=dev(), layout=ql.layout)
     ql2.load_state_dict(ql.state_dict())
     assert torch.equal(ql2(x), y)
     # make_quant swaps named Linears (llm/opt.py:258-264 contract)
