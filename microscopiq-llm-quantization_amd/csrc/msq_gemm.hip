@@ -608,7 +608,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 }
 
 // ---------------------------------------------------------------------------
-// Small-M (decode) kernel: M <= 64.  HBM-bound: the job is to stream the packed weight once at full
+// Small-M (decode) kernel: M <= 16 (MG = 1; the template still takes MG 16-row groups).  HBM-bound: the job is to stream the packed weight once at full
 // rate.  One wave = one task = KC consecutive 64x64 packed tiles of one 64-column strip; per tile it
 // converts the 8 fragments and issues 8*MG MFMAs against the activation fragments, which it reads
 // straight from global memory (the whole X is <= 512 KiB and stays in L2).  Next tile's packed data
@@ -917,7 +917,9 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
 }
 
 // small-M path: tiles per task so that there are ~3000 tasks (12 waves x 256 CUs) but at most 32 partial planes
-#define MSQ_GEMV_MAX_M 64
+// measured (scratch/gemv_thr.py): the decode kernel wins up to M = 16, the split-K GEMM from M = 32 on
+#define MSQ_GEMV_MAX_M 16
+static int gemv_max_m() { return MSQ_GEMV_MAX_M; }
 static int pick_kc(int64_t N, int64_t K) {
     const int64_t KT = K / BK, strips = N / TILE_N;
     int64_t kc = (strips * KT + 3071) / 3072;
@@ -928,7 +930,7 @@ static int pick_kc(int64_t N, int64_t K) {
 
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
-    if (M <= MSQ_GEMV_MAX_M) { const int kc = pick_kc(N, K); return ((K / BK + kc - 1) / kc) * M * N * 4; }
+    if (M <= gemv_max_m()) { const int kc = pick_kc(N, K); return ((K / BK + kc - 1) / kc) * M * N * 4; }
     const int ks = pick_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -949,19 +951,14 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     hipStream_t st0 = (hipStream_t)stream;
     const int groups0 = unified ? 16 : (block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32));
-    if (M <= MSQ_GEMV_MAX_M && workspace) {
+    if (M <= gemv_max_m() && workspace) {
         const int kc = pick_kc(N, K);
         const int nks = (int)((K / BK + kc - 1) / kc);
         if (workspace_bytes >= (int64_t)nks * M * N * 4) {
             const int64_t ntasks = (N / TILE_N) * nks;
             const dim3 vgrid((unsigned)((ntasks + 3) / 4)), vblk(256);
-            const int mg = (int)((M + 15) / 16);
 #define MSQ_GV(IK, OK)                                                                                                  \
-            do { switch (mg) {                                                                                          \
-                case 1: hipLaunchKernelGGL((k_qgemv<IK, OK, 1>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
-                case 2: hipLaunchKernelGGL((k_qgemv<IK, OK, 2>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
-                case 3: hipLaunchKernelGGL((k_qgemv<IK, OK, 3>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; \
-                default: hipLaunchKernelGGL((k_qgemv<IK, OK, 4>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc); break; } } while (0)
+            hipLaunchKernelGGL((k_qgemv<IK, OK, 1>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc)
             if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF8);

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Timings of every kernel on the hot path at the BASELINE sizes (run on the GPU box; HIP events on the
+launch stream, inputs resident in HBM).  Writes a text table to stdout; the committed copy lives in
+profiles/r01_kernel_timings.txt.  Usage: python scripts/measure_kernels.py [section ...]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import msq
+from msq import _lib as pkg
+from msq import qlinear
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+
+
+def t(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def synth(N, K):
+    W = torch.randn(N, K, device=dev) * 0.02
+    W[torch.rand(N, K, device=dev) < 0.005] *= 16
+    return W
+
+
+def sec_fakequant():
+    L = pkg.lib()
+    print("# msq_outlier_fakequant, W[16384,4096] f32 (algorithmic bytes = 2 * numel * 4)")
+    for (axis, bs, fi, fo) in [(-1, 32, "fp4_e2m1", "fp8_e4m3"), (0, 16, "int2", "fp4"), (-1, 32, "fp4_e2m1", "posit8_es1"),
+                               (0, 32, "fp4_e2m1", "fp8_e4m3"), (-1, 16, "int2", "fp4")]:
+        A = synth(16384, 4096); out = torch.empty_like(A)
+        ax = axis % 2; pre = 16384 if ax == 1 else 1; post = 1 if ax == 1 else 4096; al = A.shape[ax]
+        def call():
+            pkg.check(L.msq_outlier_fakequant(pkg.ptr(A), pkg.ptr(out), None, None, None, None, None, None, 0, 0, pre, al, post, bs,
+                                              pkg.format_id(fi), pkg.format_id(fo), 8, 8, 2.0, 0, 0, 0, pkg.current_stream()))
+        ms = t(call)
+        print(f"fakequant axis {axis:2d} bs {bs:2d} {fi:9s} {fo:11s}: {ms*1e3:7.1f} us  {2*A.numel()*4/ms/1e6:6.0f} GB/s")
+
+
+def sec_pack():
+    print("# msq_outlier_pack / msq_outlier_unpack, W[16384,4096] (pack: numel*4 + packed bytes; unpack: packed + dense bytes;")
+    print("#   pack time includes torch allocations and the status read-back)")
+    N, K = 16384, 4096
+    W = synth(N, K)
+    for fo in ("fp8_e4m3", "posit8_es1"):
+        for layout in ("planes", "unified"):
+            P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
+            ms = t(lambda: qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout), 10)
+            mu = t(lambda: qlinear.unpack_weight(P, torch.bfloat16))
+            mf = t(lambda: qlinear.unpack_weight(P, torch.float32))
+            print(f"{fo:11s} {layout:8s} {P.bits_per_element:5.2f} b/w: pack {ms*1e3:6.0f} us ({(N*K*4+P.nbytes)/ms/1e6:5.0f} GB/s) | "
+                  f"unpack->bf16 {mu*1e3:5.0f} us ({(P.nbytes+N*K*2)/mu/1e6:5.0f} GB/s) | unpack->f32 {mf*1e3:5.0f} us ({(P.nbytes+N*K*4)/mf/1e6:5.0f} GB/s)")
+
+
+def sec_gemm():
+    print("# msq_qlinear_bf16 (fused dequant-GEMM), bf16 out; hipBLASLt = torch bf16 matmul on the unpacked weight, same data")
+    for (N, K) in [(16384, 4096), (4096, 4096), (11008, 4096), (4096, 11008)]:
+        W = synth(N, K)
+        for fo in ("fp8_e4m3", "posit8_es1"):
+            for layout in ("planes", "unified"):
+                P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
+                Wu = qlinear.unpack_weight(P, torch.bfloat16)
+                for M in (1, 16, 64, 128, 512, 2048, 8192):
+                    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+                    ms = t(lambda: qlinear.qlinear(X, P))
+                    line = f"N{N:5d} K{K:5d} {fo:11s} {layout:8s} M{M:5d}: {ms*1e3:7.1f} us {2*M*N*K/ms/1e9:7.1f} TF  packed stream {P.nbytes/ms/1e6:5.0f} GB/s"
+                    if layout == "planes" and fo == "fp8_e4m3":
+                        ms2 = t(lambda: X @ Wu.t())
+                        line += f" | hipBLASLt bf16 {ms2*1e3:7.1f} us {2*M*N*K/ms2/1e9:7.1f} TF"
+                    print(line, flush=True)
+                del P, Wu
+
+
+def sec_w4a8():
+    print("# msq_act_quant_bf16 / msq_qlinear_w4a8, X[2048,4096] f32 (act-quant algorithmic bytes = numel * 6)")
+    M, K, N = 2048, 4096, 16384
+    X = torch.randn(M, K, device=dev)
+    for variant, sd in ((0, 2), (1, 5)):
+        ms = t(lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant), 50)
+        print(f"act_quant variant {variant}: {ms*1e3:6.1f} us  {M*K*6/ms/1e6:5.0f} GB/s (host-side launch overhead included)")
+    W = synth(N, K)
+    P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp4_e2m1", 5, 32, variant=1)
+    ms = t(lambda: qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_std_dev=5, a_variant=1))
+    print(f"qlinear_w4a8 (MXLinear semantics) M{M} N{N} K{K}: {ms*1e3:6.1f} us  {2*M*N*K/ms/1e9:6.1f} TF")
+
+
+SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "w4a8": sec_w4a8}
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(SECTIONS)
+    print("device:", torch.cuda.get_device_name(0))
+    for nm in names:
+        SECTIONS[nm]()
