@@ -539,19 +539,32 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    HalfRegs<IN_KIND, OUT_KIND> pkA, pkB;      // pkA: even half-steps (kf = 0), pkB: odd (kf = 1)
+    // Packed-operand register ring: 4 half-step sets.  During half-step i the wave multiplies with the
+    // fragments of i, converts set (i + 1) and issues the loads of half-step i + 4 into the set it converted
+    // one half-step ago, so a packed load has three half-steps (~1 us) to return: long enough for an L2 miss
+    // served by the Infinity Cache (vmcnt is in-order: every wait also waits for all older loads, so the
+    // distance has to cover the slowest of them).  The ring returns to its start every 2 K-steps.
+    // (fp4 + bf16-plane operands are 20 VGPRs per set: they keep the two-set ring, distance one half-step.)
+    constexpr bool DEEP = !(IN_KIND == MSQ_PLANE_FP4 && OUT_KIND == MSQ_PLANE_BF16);
+    HalfRegs<IN_KIND, OUT_KIND> pk0, pk1, pk2, pk3;
     u32x4_t wfA[4], wfB[4];
-    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0};
+    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0}, sc_nn = {0, 0, 0, 0};
 
+    const int kt_last = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);
     const int kt0 = (kt_lo < KT) ? kt_lo : KT - 1;             // an empty split still runs a harmless prologue
+    const int kt1 = (kt0 + 1 <= kt_last) ? kt0 + 1 : kt_last;
     stage_A(kt0, 0);
-    load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
-    load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
-    if (HAS_SCALE) sc_cur = load_scales(tile_row32 + kt0);
+    load_half_buf<IN_KIND, OUT_KIND>(pk0, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
+    load_half_buf<IN_KIND, OUT_KIND>(pk1, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
+    if (DEEP) {
+        load_half_buf<IN_KIND, OUT_KIND>(pk2, pr, lane16, (tile_row32 + kt1) * 2u + 0u);
+        load_half_buf<IN_KIND, OUT_KIND>(pk3, pr, lane16, (tile_row32 + kt1) * 2u + 1u);
+    }
+    if (HAS_SCALE) { sc_cur = load_scales(tile_row32 + kt0); if (DEEP) sc_nxt = load_scales(tile_row32 + kt1); }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) convert_quarter<IN_KIND, OUT_KIND>(wfA, pkA, sc_cur, 0, q);
+    for (int q = 0; q < 8; ++q) convert_quarter<IN_KIND, OUT_KIND>(wfA, pk0, sc_cur, 0, q);
 
     // One half-step, hand-interleaved: group mf = { LDS read of A fragment mf+2, 4 MFMAs on fragment mf,
     // one quarter (2 dwords) of the NEXT half-step's weight fragments converted }, groups fenced with
@@ -569,33 +582,51 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
-
-    for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        const int buf = (kt - kt_lo) & 1;
-        const char* abase = smem + buf * A_TILE;
-        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;       // branch-free tail: re-load the last tile
-        // ---------------- half-step kf = 0: MFMAs on wfA, make wfB from pkB (loaded one half-step ago)
-        keep_live(pkB);                                        // take the (cheap) vmcnt wait BEFORE new loads are issued
-        if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);
-        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkA, pr, lane16, (tile_row32 + ktn) * 2u + 0u);
-        if (HAS_SCALE) sc_nxt = load_scales(tile_row32 + ktn);
-        __builtin_amdgcn_sched_barrier(0);
-        MSQ_HALF_STEP(wfA, wfB, pkB, sc_cur, 1, rd0)
-        // ---------------- half-step kf = 1: MFMAs on wfB, make next wfA from pkA
-        keep_live(pkA);
-        if (HAS_SCALE) keep_live4(sc_nxt);
-        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(pkB, pr, lane16, (tile_row32 + ktn) * 2u + 1u);
-        __builtin_amdgcn_sched_barrier(0);
-        MSQ_HALF_STEP(wfB, wfA, pkA, sc_nxt, 0, rd1)
-        sc_cur = sc_nxt;
-        // A(kt+1) must have landed before the barrier.  The compiler is free to order this wave's LDS-DMA
-        // ops after the pkA loads inside the first group, so the waits it places for pkA do not cover
-        // them: wait explicitly for everything older than the pkB loads (vmcnt is in-order), which stay
-        // in flight across the barrier.  (Without this, two co-resident blocks showed stale A rows.)
-        constexpr int N_PKB = HalfLoads<IN_KIND, OUT_KIND>::n;
-        __builtin_amdgcn_s_waitcnt(0x0070 | (N_PKB & 15) | ((N_PKB >> 4) << 14));   // vmcnt(N_PKB) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
+    // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted
+    // one half-step earlier (LOAD1, LOAD2) receive (kt + 2, kf 0) and (kt + 2, kf 1).
+    constexpr int N_INFLIGHT = HalfLoads<IN_KIND, OUT_KIND>::n * (DEEP ? 2 : 1);
+#define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                       \
+    {                                                                                                        \
+        const int kt_ = (KT_CUR);                                                                            \
+        const int buf = (kt_ - kt_lo) & 1;                                                                   \
+        const char* abase = smem + buf * A_TILE;                                                             \
+        const int ktn = (kt_ + 1 <= kt_last) ? kt_ + 1 : kt_last;   /* branch-free tail: re-load the last tile */ \
+        const int ktnn = DEEP ? ((kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last) : ktn;                            \
+        /* ---- half-step kf = 0: MFMAs on wfA, make wfB from CONV1 (loaded three half-steps ago) */        \
+        keep_live(CONV1);                    /* take the vmcnt wait BEFORE new loads are issued */            \
+        if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);                                                           \
+        if (HAS_SCALE) { if (DEEP) sc_nn = load_scales(tile_row32 + ktnn); else sc_nxt = load_scales(tile_row32 + ktn); } \
+        __builtin_amdgcn_sched_barrier(0);   /* the LDS-DMA and the scales are OLDER than the loads below */ \
+        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD1, pr, lane16, (tile_row32 + ktnn) * 2u + 0u); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        MSQ_HALF_STEP(wfA, wfB, CONV1, sc_cur, 1, rd0)                                                       \
+        /* ---- half-step kf = 1: MFMAs on wfB, make next wfA from CONV2 */                                  \
+        keep_live(CONV2);                                                                                    \
+        if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD2, pr, lane16, (tile_row32 + ktnn) * 2u + 1u); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        MSQ_HALF_STEP(wfB, wfA, CONV2, sc_nxt, 0, rd1)                                                       \
+        /* A(kt+1) and the scales must have landed before the barrier: wait explicitly for everything older \
+           than the two packed load groups of this K-step (vmcnt is in-order), which stay in flight.  hipcc \
+           derives its own waits from register uses only and does not cover the LDS-DMA (stale 8-row         \
+           activation pieces were seen without this once two blocks shared a CU). */                         \
+        __builtin_amdgcn_s_waitcnt(0x0070 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14));                  \
+        sc_cur = sc_nxt; if (DEEP) sc_nxt = sc_nn;                                                           \
+        __builtin_amdgcn_s_barrier();                                                                        \
     }
+
+    {
+        int kt = kt_lo;
+        if (DEEP) {
+            for (; kt + 1 < kt_hi; kt += 2) {
+                MSQ_K_STEP(kt, pk1, pk0, pk2, pk1)
+                MSQ_K_STEP(kt + 1, pk3, pk2, pk0, pk3)
+            }
+            if (kt < kt_hi) MSQ_K_STEP(kt, pk1, pk0, pk2, pk1)
+        } else {
+            for (; kt < kt_hi; ++kt) MSQ_K_STEP(kt, pk1, pk0, pk0, pk1)
+        }
+    }
+#undef MSQ_K_STEP
 #undef MSQ_HALF_STEP
 
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }

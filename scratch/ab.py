@@ -18,7 +18,7 @@ W = torch.randn(N, K, device=dev) * 0.02; W[torch.rand(N, K, device=dev) < 0.005
 X = torch.randn(M, K, device=dev).to(torch.bfloat16)
 for fo in outs:
     fi = "fp4_e2m1" if fo != "int8" else "int8"
-    P = qlinear.pack_weight(W, 8, 8, fi, fo, 2, 32)
+    P = qlinear.pack_weight(W, 8, 8, fi, fo, 2, 32, layout=os.environ.get("LAYOUT", "unified"))
     Wu = qlinear.unpack_weight(P, torch.bfloat16); Yr = X @ Wu.t()
     Y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     def call(fn):
