@@ -24,7 +24,7 @@ MSQ_D uint32_t bf16_bits_exact(float v, int& status) {
 
 // A wave owns 64 consecutive blocks = one contiguous run of 64*BS floats: coalesced 16-byte loads,
 // transpose through LDS (row stride BS+4 words), one block per lane, and back the same way as bf16.
-template <int BS, int RM>
+template <int BS, int RM, int HW>
 __global__ void __launch_bounds__(256)
 k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs A) {
     constexpr int LDS_STRIDE = BS + 4;
@@ -62,7 +62,7 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
     if (gidx < nblocks) {
         const float* vm = A.vmean ? A.vmean + (gidx / A.nblk) * BS : nullptr;
         const float* vs = A.vstd ? A.vstd + (gidx / A.nblk) * BS : nullptr;
-        status = outlier_block_fast<BS, RM>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+        status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
     }
     uint32_t h[BS / 2];
 #pragma unroll
@@ -134,9 +134,12 @@ extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, vo
     const int64_t nblocks = M * A.nblk;
     const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    // RM = 0: round-to-nearest (half away) specialised; -1: any rounding mode
-#define MSQ_AQ(BS) do { if (rmode == 0) hipLaunchKernelGGL((k_act_quant<BS, 0>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
-                        else hipLaunchKernelGGL((k_act_quant<BS, -1>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } while (0)
+    // RM = 0: round-to-nearest (half away) specialised, through the hardware converts when both formats have
+    // one (e4m3 / e5m2 / e2m1); -1: any rounding mode, arithmetic codec
+    const bool hw = (rmode == 0) && hw_codec_kind(A.fi) && hw_codec_kind(A.fo);
+#define MSQ_AQ(BS) do { if (hw) hipLaunchKernelGGL((k_act_quant<BS, 0, 1>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                        else if (rmode == 0) hipLaunchKernelGGL((k_act_quant<BS, 0, 0>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                        else hipLaunchKernelGGL((k_act_quant<BS, -1, 0>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } while (0)
     switch (block) {
         case 16: MSQ_AQ(16); break;
         case 32: MSQ_AQ(32); break;

@@ -594,7 +594,10 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         const int ktnn = DEEP ? ((kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last) : ktn;                            \
         /* ---- half-step kf = 0: MFMAs on wfA, make wfB from CONV1 (loaded three half-steps ago) */        \
         keep_live(CONV1);                    /* take the vmcnt wait BEFORE new loads are issued */            \
-        if (!(MSQ_ABL & 8)) stage_A(ktn, buf ^ 1);                                                           \
+        /* no staging in the last K-step: the copy would be unused, and in the odd-tail instance of this     \
+           macro the compiler drops the (dead) packed loads, so the vmcnt below would no longer cover an     \
+           LDS-DMA that then lands in the epilogue's LDS staging (seen once in ~1500 launches) */           \
+        if (!(MSQ_ABL & 8) && kt_ < kt_last) stage_A(ktn, buf ^ 1);                                          \
         if (HAS_SCALE) { if (DEEP) sc_nn = load_scales(tile_row32 + ktnn); else sc_nxt = load_scales(tile_row32 + ktn); } \
         __builtin_amdgcn_sched_barrier(0);   /* the LDS-DMA and the scales are OLDER than the loads below */ \
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD1, pr, lane16, (tile_row32 + ktnn) * 2u + 0u); \
@@ -629,6 +632,9 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 #undef MSQ_K_STEP
 #undef MSQ_HALF_STEP
 
+    // nothing of this block may still be writing LDS (belt and braces: no LDS-DMA is in flight here by construction)
+    __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
     if (ksplit > 1)

@@ -242,7 +242,40 @@ MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
     return std_welford<BS>(x, correction);
 }
 
-template <int BS, int RM, bool EMIT = false>
+// formats the gfx950 scaled converts implement: 1 = OCP e4m3, 2 = OCP e5m2, 3 = e2m1; 0 = none
+MSQ_HD int hw_codec_kind(const Fmt& f) {
+    if (f.kind != 0) return 0;
+    if (f.ebits == 4 && f.mbits == 5) return 1;
+    if (f.ebits == 5 && f.mbits == 4) return 2;
+    if (f.ebits == 2 && f.mbits == 3) return 3;
+    return 0;
+}
+// quantise-dequantise two values (mantissa LSB already set by the caller) on the grid `kind` with scale `s`
+MSQ_D void hw_codec_pair(int kind, float x0, float x1, float s, float bound, float& v0, float& v1) {
+    typedef short v2s_t __attribute__((ext_vector_type(2)));
+    typedef float v2f_t __attribute__((ext_vector_type(2)));
+    v2f_t v;
+    if (kind == 3) {                                             // saturates by itself
+        const uint32_t c = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, x0, x1, s, 0);
+        v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, s, 0);
+    } else {
+        const float y0 = __builtin_amdgcn_fmed3f(x0, -bound, bound), y1 = __builtin_amdgcn_fmed3f(x1, -bound, bound);
+        const v2s_t z = {0, 0};
+        if (kind == 1) {
+            const v2s_t c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, y0, y1, s, false);
+            v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(__builtin_bit_cast(uint32_t, c), s, false);
+        } else {
+            const v2s_t c = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(z, y0, y1, s, false);
+            v = __builtin_amdgcn_cvt_scalef32_pk_f32_bf8(__builtin_bit_cast(uint32_t, c), s, false);
+        }
+    }
+    v0 = v[0]; v1 = v[1];
+}
+
+// HW: 0 = arithmetic codec only; 1 = inliers and outliers through the hardware converts (the launcher
+// guarantees both formats are e2m1 / e4m3 / e5m2); 2 = inliers through the hardware converts, posit outliers
+// through posit_round_fast.  Blocks that are not "safe" (see below) take the arithmetic codec in every mode.
+template <int BS, int RM, bool EMIT = false, int HW = 0>
 MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
                              const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride,
                              uint32_t* codes = nullptr, int in_kind = 0, int out_kind = 0) {
@@ -297,6 +330,41 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     const int lo_i = A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0, hi_i = A.fi.ebits ? 127 : 0;
     const int lo_o = A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0, hi_o = A.fo.ebits ? 127 : 0;
     const float pre_in = fl ? 0.f : rc_in;
+    // ---- hardware codec path (gfx950 v_cvt_scalef32_pk_{fp4,fp8,bf8}_f32 and back): e2m1 inliers with e4m3 /
+    // e5m2 / e2m1 outliers, round-to-nearest.  The converts round to nearest EVEN; the reference rounds half
+    // AWAY from zero (elemwise_ops.py:64-65).  Setting the mantissa LSB of the fp32 input first turns every
+    // exact tie into "just above the tie" and never moves any other value across a tie or a grid point (ties
+    // and grid points of these <= 4-bit grids have >= 19 trailing zero mantissa bits), so RNE(x | 1ulp) is the
+    // half-away result.  e4m3 / e5m2 converts do not saturate (> 464 -> NaN / > 61440 -> Inf): clamp to
+    // +-max_norm * 2^scale first (max_norm is a grid point, so clamp-then-round == round-then-clamp).  All
+    // 2^k products of the reference are exact when both block exponents are moderate; elements too small to
+    // be scaled exactly round to zero on both routes.  Anything else takes the arithmetic codec below.
+    if (RM == 0 && !EMIT && HW != 0) {
+        const int in_hw = hw_codec_kind(A.fi), out_hw = hw_codec_kind(A.fo);
+        const bool safe = !nonfinite && !fl && status == 0 && se_in >= -60.f && se_in <= 60.f && se_out >= -60.f && se_out <= 60.f;
+        if (safe) {
+            const int ei = (int)se_in, eo = (int)se_out - (int)se_in;
+            const float s_in = u2f((uint32_t)(ei + 127) << 23), s_eff = u2f((uint32_t)(eo + 127) << 23);
+            const float b_in = A.fi.max_norm * s_in, b_out = A.fo.max_norm * s_eff;   // exact (|exponent| <= 120)
+#pragma unroll
+            for (int b = 0; b < BS; b += 2) {
+                const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);
+                float vi0, vi1, vo0, vo1;
+                hw_codec_pair(in_hw, x0, x1, s_in, b_in, vi0, vi1);
+                if (HW == 1) {
+                    hw_codec_pair(out_hw, x0, x1, s_eff, b_out, vo0, vo1);
+                } else {                                         // posit outliers, reference op order (:216,:247,:258)
+                    vo0 = (posit_round_fast((a[b] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in;
+                    vo1 = (posit_round_fast((a[b + 1] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in;
+                }
+                const bool m0 = (mkw[b >> 5] >> (b & 31)) & 1u, m1 = (mkw[(b + 1) >> 5] >> ((b + 1) & 31)) & 1u;
+                a[b] = (m0 ? vo0 : vi0) + 0.0f;
+                a[b + 1] = (m1 ? vo1 : vi1) + 0.0f;
+            }
+            se_in_o = se_in; se_out_o = se_out;
+            return status;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         const bool m = (mkw[b >> 5] >> (b & 31)) & 1u;

@@ -19,11 +19,7 @@ using namespace msq;
 // ===========================================================================
 // dtype helpers
 // ===========================================================================
-template <typename T> struct IO;
-template <> struct IO<float> {
-    static MSQ_D float ld(const float* p, int64_t i) { return p[i]; }
-    static MSQ_D void st(float* p, int64_t i, float v) { p[i] = v; }
-};
+#include "msq_outlier_kernels.h"
 template <> struct IO<__half> {
     static MSQ_D float ld(const __half* p, int64_t i) { return __half2float(p[i]); }
     static MSQ_D void st(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
@@ -189,143 +185,6 @@ k_reduce_inner(const float* __restrict__ in, float* __restrict__ out, int64_t ou
         acc = IS_MAX ? fmaxf(acc, o) : acc + o;
     }
     if (lane == 0) out[row] = acc;
-}
-
-#include "msq_outlier_core.h"
-
-template <int BS>
-MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS + 31) / 32], float se_in,
-                                float se_out, int status, int64_t p, int64_t nb, int64_t q) {
-    if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
-    if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
-    if (A.n_out && A.pre == 1 && (nb % BS) == 0) {           // utils/quant.py:66
-        int c = 0;
-#pragma unroll
-        for (int w = 0; w < (BS + 31) / 32; ++w) c += __builtin_popcount(mkw[w]);
-        A.n_out[(nb / BS) * A.post + q] = (int8_t)c;
-    }
-    if (status && A.status) atomicOr(A.status, status);
-}
-
-// --- layout A: post > 1.  lane <-> (p, nb, q), q fastest: each of the BS row reads
-// of a wave is one contiguous 256-byte segment.
-template <int BS, typename T, int FAST>
-__global__ void __launch_bounds__(256)
-k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
-    const int64_t total = A.pre * A.nblk * A.post;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int64_t q = t % A.post;
-    const int64_t nb = (t / A.post) % A.nblk;
-    const int64_t p = t / (A.post * A.nblk);
-    const int64_t a0 = nb * BS;
-    const int64_t base = (p * A.axis_len + a0) * A.post + q;
-    float a[BS];
-#pragma unroll
-    for (int b = 0; b < BS; ++b)
-        a[b] = (a0 + b < A.axis_len) ? IO<T>::ld(in, base + (int64_t)b * A.post) : 0.f;   // zero padding, :563-583
-    int order;
-    {   // torch's summation order for this column (oracle/msq_oracle.c sum_order_for)
-        const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
-        order = (q < lim) ? 0 : 2;
-    }
-    uint32_t mkw[(BS + 31) / 32];
-    float se_in, se_out;
-    const float* vm = A.vmean ? A.vmean + (p * BS) * A.post + q : nullptr;
-    const float* vs = A.vstd ? A.vstd + (p * BS) * A.post + q : nullptr;
-    int status;
-    if (FAST == 1) status = outlier_block_fast<BS, 0>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
-    else if (FAST == 2) status = outlier_block_fast<BS, -1>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
-    else status = outlier_block<BS>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
-#pragma unroll
-    for (int b = 0; b < BS; ++b) {
-        if (a0 + b < A.axis_len) {
-            IO<T>::st(out, base + (int64_t)b * A.post, a[b]);
-            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
-        }
-    }
-    outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, q);
-}
-
-// --- layout B: post == 1 (block contiguous).  A wave owns 64 consecutive blocks.
-// When axis_len % BS == 0 they are one contiguous run of 64*BS floats: the wave
-// streams it with 16-byte coalesced accesses and transposes through LDS (row stride
-// BS+4 floats: conflict-free ds_read_b128 for 16-lane groups) so that each lane ends
-// up with its own block in registers; results go back the same way.
-template <int BS, typename T, int FAST>
-__global__ void __launch_bounds__(256)
-k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
-    constexpr int LDS_STRIDE = BS + 4;
-    __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t nblocks = A.pre * A.nblk;
-    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;      // first block of this wave
-    if (g0 >= nblocks) return;
-    const bool fast = (A.axis_len % BS == 0) && (g0 + 64 <= nblocks) && (sizeof(T) == 4);
-    float a[BS];
-    const int64_t g = g0 + lane;
-    const int64_t p = g / A.nblk, nb = g % A.nblk;
-    const int64_t a0 = nb * BS;
-    const int64_t base = p * A.axis_len + a0;
-    float* tl = tile[wv];
-    if (fast) {
-        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + g0 * BS);
-#pragma unroll
-        for (int t = 0; t < BS / 4; ++t) {
-            const int f = lane + 64 * t;                         // float4 index inside the 64xBS tile
-            const int row = f / (BS / 4), c4 = f % (BS / 4);
-            *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
-#pragma unroll
-        for (int c = 0; c < BS / 4; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
-            a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < BS; ++b)
-            a[b] = (g < nblocks && a0 + b < A.axis_len) ? IO<T>::ld(in, base + b) : 0.f;
-    }
-    uint32_t mkw[(BS + 31) / 32];
-    float se_in, se_out;
-    int status = 0;
-    if (g < nblocks) {
-        const float* vm = A.vmean ? A.vmean + p * BS : nullptr;
-        const float* vs = A.vstd ? A.vstd + p * BS : nullptr;
-        if (FAST == 1) status = outlier_block_fast<BS, 0>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
-        else if (FAST == 2) status = outlier_block_fast<BS, -1>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
-        else status = outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
-    }
-    if (fast) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < BS / 4; ++c)
-            *reinterpret_cast<float4*>(tl + lane * LDS_STRIDE + c * 4) =
-                make_float4(a[c * 4 + 0], a[c * 4 + 1], a[c * 4 + 2], a[c * 4 + 3]);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + g0 * BS);
-#pragma unroll
-        for (int t = 0; t < BS / 4; ++t) {
-            const int f = lane + 64 * t;
-            const int row = f / (BS / 4), c4 = f % (BS / 4);
-            dst[f] = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c4 * 4);
-        }
-    } else if (g < nblocks) {
-#pragma unroll
-        for (int b = 0; b < BS; ++b)
-            if (a0 + b < A.axis_len) IO<T>::st(out, base + b, a[b]);
-    }
-    if (g < nblocks) {
-        if (A.mask) {
-#pragma unroll
-            for (int b = 0; b < BS; ++b)
-                if (a0 + b < A.axis_len) A.mask[base + b] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
-        }
-        outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, 0);
-    }
 }
 
 // variant 1 statistics (mx_ops.py:62-66,248): mean / unbiased std of the SIGNED values
@@ -498,29 +357,21 @@ static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
     return (int)g;
 }
 
-template <typename T, int FAST>
-static int launch_outlier_impl(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
-    const int64_t nthreads = A.pre * A.nblk * A.post;
-#define MSQ_OL(BS)                                                                                        \
-    case BS:                                                                                              \
-        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T, FAST>), dim3(grid_for(nthreads, 256)), \
-                                            dim3(256), 0, st, (const T*)in, (T*)out, A);                  \
-        else hipLaunchKernelGGL((k_outlier_strided<BS, T, FAST>), dim3(grid_for(nthreads, 256)), dim3(256), \
-                                0, st, (const T*)in, (T*)out, A);                                         \
-        break;
-    switch (block) { MSQ_OL(8) MSQ_OL(16) MSQ_OL(32) MSQ_OL(64) MSQ_OL(128)
-        default: return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
-    }
-#undef MSQ_OL
-    return MSQ_OK;
-}
-template <typename T>
+// implemented in msq_quant_hw.hip (hardware-convert variants, own translation unit)
+extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, void* stream);
+
 static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
-    // float / int element formats take the fast block maths, posit formats the generic one
-    // 1: nearest rounding specialised, 2: any rounding mode, 0: generic maths (posit)
-    if (A.fi.kind == 0)        // float/int inliers; outliers float/int or posit
-        return (A.rmode == 0) ? launch_outlier_impl<T, 1>(in, out, A, block, st) : launch_outlier_impl<T, 2>(in, out, A, block, st);
-    return launch_outlier_impl<T, 0>(in, out, A, block, st);
+    bool ok;
+    if (A.fi.kind == 0) {                                      // float/int inliers; outliers float/int or posit
+        if (A.rmode == 0) {
+            const int ih = hw_codec_kind(A.fi), oh = hw_codec_kind(A.fo);
+            if (ih && oh) return msq_launch_outlier_hw_(in, out, &A, block, 1, (void*)st);            // both through the converts
+            if (ih && A.fo.kind == 1) return msq_launch_outlier_hw_(in, out, &A, block, 2, (void*)st); // inliers only, posit outliers
+            ok = launch_outlier_variant<1>(in, out, A, block, st);
+        } else ok = launch_outlier_variant<2>(in, out, A, block, st);
+    } else ok = launch_outlier_variant<0>(in, out, A, block, st);   // posit inliers: generic maths
+    if (!ok) return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
+    return MSQ_OK;
 }
 
 extern "C" {
@@ -698,7 +549,7 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
         A.vmean = vmean; A.vstd = vstd;
     }
     int rc;
-    if (dtype == 0) rc = launch_outlier<float>(in, out, A, block, st);
+    if (dtype == 0) rc = launch_outlier(in, out, A, block, st);
     else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: only dtype 0 (f32) is built; the host shim upcasts f16/bf16");
     if (rc) return rc;
     return check_launch("msq_outlier_fakequant");

@@ -1,0 +1,28 @@
+import sys, os, ctypes as C
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch, msq
+from msq import _lib as pkg
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+libs = sys.argv[1].split(",")
+hs = []
+for p in libs:
+    L = C.CDLL(p); fn = L.msq_outlier_fakequant; fn.restype = C.c_int; fn.argtypes = pkg._SIGS["msq_outlier_fakequant"][1]
+    hs.append((os.path.basename(p), fn))
+A = torch.randn(16384, 4096, device=dev) * 0.02; A[torch.rand(16384, 4096, device=dev) < 0.005] *= 16
+for (axis, bs, fi, fo) in [(-1, 32, "fp4_e2m1", "fp8_e4m3"), (0, 16, "int2", "fp4"), (-1, 32, "fp4_e2m1", "posit8_es1"), (0, 32, "fp4_e2m1", "fp8_e4m3"), (-1,32,"fp8_e4m3","fp8_e4m3")]:
+    ax = axis % 2; pre = 16384 if ax == 1 else 1; post = 1 if ax == 1 else 4096; al = A.shape[ax]
+    outs = {}
+    res = {n: [] for n, _ in hs}
+    for r in range(4):
+        for n, fn in hs:
+            out = torch.empty_like(A)
+            def call():
+                rc = fn(pkg.ptr(A), pkg.ptr(out), None, None, None, None, None, None, 0, 0, pre, al, post, bs, pkg.format_id(fi), pkg.format_id(fo), 8, 8, 2.0, 0, 0, 0, pkg.current_stream()); assert rc == 0
+            call(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): call()
+            e1.record(); torch.cuda.synchronize(); res[n].append(e0.elapsed_time(e1) / 10)
+            outs[n] = out
+    same = all(torch.equal(outs[hs[0][0]], o) for o in outs.values())
+    print(f"axis {axis} bs {bs} {fi} {fo}: " + " | ".join(f"{n} {min(res[n])*1e3:.1f} us {2*A.numel()*4/min(res[n])/1e6:.0f} GB/s" for n, _ in hs) + f" | identical outputs: {same}")
