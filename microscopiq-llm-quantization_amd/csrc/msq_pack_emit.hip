@@ -122,7 +122,7 @@ extern "C" int msq_pack_emit_(const float* W, uint32_t* codes, float* e_in, floa
 //   3. every lane gathers its MFMA fragments (layout 1: n = 16 nf + (l & 15), k = 32 kf + 8 (l >> 4) + j)
 //      and stores the slots: 64 lanes x 16 B = one coalesced 1 KiB store per slot.
 // ===========================================================================
-template <int BS, int IN_KIND, int OUT_KIND>
+template <int BS, int IN_KIND, int OUT_KIND, int HW>
 __global__ void __launch_bounds__(256)
 k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_t* __restrict__ out_plane,
             uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
@@ -172,7 +172,7 @@ k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_
         for (int b = 0; b < BS; ++b) a[b] = all[j * BS + b];
         uint32_t mkw[(BS + 31) / 32];
         float se_in, se_out;
-        status |= outlier_block_fast<BS, 0, false>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
+        status |= outlier_block_fast<BS, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
         uint32_t bi, bo;
         if (se_in != se_in) { bi = 255; status |= MSQ_STATUS_NAN; }
         else { const float t = se_in + 127.f; bi = (t < 1.f || t > 254.f) ? 255u : (uint32_t)t; if (t < 1.f || t > 254.f) status |= MSQ_STATUS_INEXACT; }
@@ -288,7 +288,7 @@ k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_
 //   this is the outlier's own scale, so its codes are unchanged; inlier e2m1 values widen exactly.
 // Every code is decoded back with the GEMM's own instruction and compared with the fake-quant value.
 // ===========================================================================
-template <int BS, bool EXT>
+template <int BS, bool EXT, int HW>
 __global__ void __launch_bounds__(256)
 k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
               uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
@@ -334,7 +334,7 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
         for (int b = 0; b < BS; ++b) a[b] = all[j * BS + b];
         uint32_t mkw[(BS + 31) / 32];
         float se_in, se_out;
-        status |= outlier_block_fast<BS, 0, false>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
+        status |= outlier_block_fast<BS, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
 #pragma unroll
         for (int b = 0; b < BS; ++b) all[j * BS + b] = a[b];
     }
@@ -432,20 +432,25 @@ extern "C" int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane,
     const int64_t tiles = (N / 64) * (K / 64);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define MSQ_PT(BS, IK, OK) hipLaunchKernelGGL((k_pack_tile<BS, IK, OK>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
-                                              (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K)
-#define MSQ_PTB(IK, OK) do { switch (block) { case 8: MSQ_PT(8, IK, OK); break; case 16: MSQ_PT(16, IK, OK); break; \
-                                              case 32: MSQ_PT(32, IK, OK); break; default: MSQ_PT(64, IK, OK); break; } } while (0)
-    if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_PTB(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
-    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
+    // quantiser codec: 1 = hardware converts for inliers and outliers, 2 = for the inliers (posit outliers), 0 = arithmetic
+    const int ih = hw_codec_kind(A.fi), oh = hw_codec_kind(A.fo);
+    const int hw = (ih && oh) ? 1 : ((ih && fo.kind == 1) ? 2 : 0);
+#define MSQ_PT(BS, IK, OK, HWV) hipLaunchKernelGGL((k_pack_tile<BS, IK, OK, HWV>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
+                                                   (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K)
+#define MSQ_PTB(IK, OK, HWV) do { switch (block) { case 8: MSQ_PT(8, IK, OK, HWV); break; case 16: MSQ_PT(16, IK, OK, HWV); break; \
+                                                   case 32: MSQ_PT(32, IK, OK, HWV); break; default: MSQ_PT(64, IK, OK, HWV); break; } } while (0)
+    if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_PTB(MSQ_PLANE_NONE, MSQ_PLANE_BF16, 0);
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) { if (hw == 1) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_FP8, 1); else MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_FP8, 0); }
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) { if (hw == 1) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF8, 1); else MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF8, 0); }
+    else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF16) { if (hw == 2) MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF16, 2); else MSQ_PTB(MSQ_PLANE_FP4, MSQ_PLANE_BF16, 0); }
     else if (in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
-#define MSQ_PU(BS) do { if (out_kind == MSQ_PLANE_U8) hipLaunchKernelGGL((k_pack_tile_u<BS, false>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
-                                (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K); \
-                        else hipLaunchKernelGGL((k_pack_tile_u<BS, true>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
-                                (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K); } while (0)
-        switch (block) { case 8: MSQ_PU(8); break; case 16: MSQ_PU(16); break; case 32: MSQ_PU(32); break; default: MSQ_PU(64); break; }
+#define MSQ_PU(BS, EXTV, HWV) hipLaunchKernelGGL((k_pack_tile_u<BS, EXTV, HWV>), grid, blk, 0, st, W, (uint8_t*)inl_plane, \
+                                                 (uint8_t*)out_plane, (uint8_t*)scale_plane, A, N, K)
+#define MSQ_PUB(EXTV, HWV) do { switch (block) { case 8: MSQ_PU(8, EXTV, HWV); break; case 16: MSQ_PU(16, EXTV, HWV); break; \
+                                                 case 32: MSQ_PU(32, EXTV, HWV); break; default: MSQ_PU(64, EXTV, HWV); break; } } while (0)
+        if (out_kind == MSQ_PLANE_U8) { if (hw == 1) MSQ_PUB(false, 1); else MSQ_PUB(false, 0); }
+        else { if (hw == 2) MSQ_PUB(true, 2); else MSQ_PUB(true, 0); }
+#undef MSQ_PUB
 #undef MSQ_PU
     }
     else return MSQ_ERR_UNSUPPORTED;
