@@ -1,0 +1,89 @@
+"""On-disk format for packed models -- what the reference's vestigial ``--save`` / ``--load`` would have
+written (llm/opt.py:510-512 ``torch.save(model.state_dict(), args.save)`` after ``opt_pack3``; :287-294
+``load_quant3``: build the model, ``make_quant3`` every Linear, ``load_state_dict``).
+
+One ``.safetensors`` file: the packed planes of every QuantLinear (uint8) plus every other parameter /
+buffer of the model, and a JSON header in the metadata describing each packed layer, so that a model can be
+rebuilt without re-quantising (and, for the 70B row-parallel configuration, shard by shard: every rank saves
+and loads its own file, `shard` / `world_size` are recorded).
+
+    header = {"format": "msq-packed", "version": 1, "shard": r, "world_size": G,
+              "layers": {"<module name>": {"in_features", "out_features", "block_size", "layout",
+                                            "in_kind", "out_kind", "inlier_elem_format",
+                                            "outlier_elem_format", "bias", "out_dtype"}}}
+"""
+import json
+
+import torch
+import torch.nn as nn
+
+from ._lib import MsqError
+from .qlinear import QuantLinear
+
+FORMAT, VERSION = "msq-packed", 1
+
+
+def _packed_layers(model):
+    return {name: m for name, m in model.named_modules() if isinstance(m, QuantLinear)}
+
+
+def save_packed(model, path, shard=0, world_size=1):
+    """Write every tensor of `model` (packed planes included) and the layer table to `path`."""
+    from safetensors.torch import save_file
+    layers = {}
+    for name, m in _packed_layers(model).items():
+        layers[name] = dict(in_features=m.in_features, out_features=m.out_features, block_size=m.block_size,
+                            layout=m.layout, in_kind=m.in_kind, out_kind=m.out_kind,
+                            inlier_elem_format=m.inlier_elem_format, outlier_elem_format=m.outlier_elem_format,
+                            bias=m.bias is not None, out_dtype=str(m.out_dtype).replace("torch.", ""))
+    header = dict(format=FORMAT, version=VERSION, shard=int(shard), world_size=int(world_size), layers=layers)
+    tensors = {k: v.detach().contiguous().cpu() for k, v in model.state_dict().items()}
+    save_file(tensors, path, metadata={"msq": json.dumps(header)})
+    return header
+
+
+def read_header(path):
+    from safetensors import safe_open
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata() or {}
+    if "msq" not in meta:
+        raise MsqError("%s is not an msq-packed checkpoint (no header)" % path)
+    header = json.loads(meta["msq"])
+    if header.get("format") != FORMAT or int(header.get("version", -1)) > VERSION:
+        raise MsqError("unsupported checkpoint format %r version %r" % (header.get("format"), header.get("version")))
+    return header
+
+
+def _swap(model, name, new):
+    parent = model
+    parts = name.split(".")
+    for p in parts[:-1]:
+        parent = getattr(parent, p)
+    setattr(parent, parts[-1], new)
+
+
+def load_packed(model, path, device=None, strict=True):
+    """`model` is the freshly constructed (unquantised) architecture: every layer listed in the header is
+    replaced by an empty QuantLinear of the recorded configuration (llm/opt.py:287 ``make_quant3``), then
+    all tensors are loaded.  Returns the header."""
+    from safetensors.torch import load_file
+    header = read_header(path)
+    modules = dict(model.named_modules())
+    for name, d in header["layers"].items():
+        old = modules.get(name)
+        if old is None:
+            raise MsqError("checkpoint layer %r does not exist in the model" % name)
+        if isinstance(old, (nn.Linear, QuantLinear)):
+            if (old.in_features, old.out_features) != (d["in_features"], d["out_features"]):
+                raise MsqError("checkpoint layer %r has shape %dx%d, the model %dx%d" % (
+                    name, d["out_features"], d["in_features"], old.out_features, old.in_features))
+        dev = device if device is not None else next(old.parameters(), next(old.buffers(), torch.zeros(0))).device
+        q = QuantLinear(d["in_features"], d["out_features"], d["bias"], d["block_size"], d["inlier_elem_format"],
+                        d["outlier_elem_format"], getattr(torch, d["out_dtype"]), device=dev, layout=d["layout"])
+        if (q.in_kind, q.out_kind) != (d["in_kind"], d["out_kind"]):
+            raise MsqError("checkpoint layer %r was packed with plane kinds %r, this build derives %r" % (
+                name, (d["in_kind"], d["out_kind"]), (q.in_kind, q.out_kind)))
+        _swap(model, name, q)
+    state = load_file(path)
+    model.load_state_dict(state, strict=strict)
+    return header

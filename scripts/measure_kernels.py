@@ -18,7 +18,9 @@ torch.manual_seed(0)
 
 
 def t(fn, n=20):
-    fn(); torch.cuda.synchronize()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):

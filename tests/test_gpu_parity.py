@@ -491,6 +491,27 @@ def test_quantlinear_module_and_state_dict(msq):
         msq.qlinear.QuantLinear.from_linear(lin, q0)                    # axes=[0] blocks are not packable along K
 
 
+def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
+    """f2: a model packed with make_quant is written to disk and a freshly built architecture loaded from the
+    file computes bit-identical outputs without re-quantising (llm/opt.py:287-294, :510-512)."""
+    from msq import checkpoint
+    torch.manual_seed(0)
+    def build():
+        return torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.GELU(), torch.nn.Linear(512, 256, bias=False)).to(dev())
+    src = build()
+    q = msq.quant.MXQuantizer(); q.configure(8, 8, "fp4_e2m1", "posit8_es1", axes=[-1], block_size=32)
+    msq.qlinear.make_quant(src, {"0": q, "2": q})
+    x = torch.randn(9, 256, device=dev()).to(torch.bfloat16)
+    y = src(x)
+    path = str(tmp_path / "packed.safetensors")
+    hdr = checkpoint.save_packed(src, path)
+    assert set(hdr["layers"]) == {"0", "2"} and hdr["layers"]["0"]["layout"] == "unified"
+    dst = build()
+    checkpoint.load_packed(dst, path)
+    assert torch.equal(dst(x), y)
+    assert torch.equal(dst[0].dequantize(), src[0].dequantize())
+
+
 def test_c_abi_error_codes(msq):
     L = msq._lib.lib()
     x = torch.zeros(64, device=dev())

@@ -189,3 +189,46 @@ def test_row_parallel_two_ranks_gloo(msq, tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o
+
+
+def test_packed_checkpoint_roundtrip_cpu(msq, tmp_path):
+    """The on-disk format (f2; llm/opt.py:287-294, :510-512): header + planes survive a save / load cycle and
+    mismatching architectures are refused.  Runs without a GPU: the planes are just bytes here."""
+    import torch
+    from msq import checkpoint
+    from msq.qlinear import QuantLinear
+
+    class Net(torch.nn.Module):
+        def __init__(self, packed):
+            super().__init__()
+            mk = (lambda i, o, lay, fo: QuantLinear(i, o, True, 32, "fp4_e2m1", fo, layout=lay)) if packed else (lambda i, o, lay, fo: torch.nn.Linear(i, o))
+            self.a = mk(128, 256, "unified", "fp8_e4m3")
+            self.b = mk(256, 512, "planes", "posit8_es1")
+            self.norm = torch.nn.LayerNorm(512)
+
+    g = torch.Generator().manual_seed(0)
+    src = Net(True)
+    for m in (src.a, src.b):
+        for buf in (m.inl_plane, m.out_plane, m.scale_plane):
+            if buf.numel():
+                buf.copy_(torch.randint(0, 256, buf.shape, generator=g, dtype=torch.uint8))
+        m.bias.copy_(torch.randn(m.bias.shape, generator=g))
+    path = str(tmp_path / "m.safetensors")
+    hdr = checkpoint.save_packed(src, path, shard=1, world_size=2)
+    assert hdr["layers"]["a"]["layout"] == "unified" and hdr["layers"]["b"]["out_kind"] == 4
+    assert checkpoint.read_header(path)["world_size"] == 2
+    dst = Net(False)
+    checkpoint.load_packed(dst, path)
+    assert isinstance(dst.a, QuantLinear) and isinstance(dst.b, QuantLinear) and isinstance(dst.norm, torch.nn.LayerNorm)
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+
+    class Other(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(64, 256)
+            self.b = torch.nn.Linear(256, 512)
+            self.norm = torch.nn.LayerNorm(512)
+    with pytest.raises(msq._lib.MsqError):
+        checkpoint.load_packed(Other(), path)
+
