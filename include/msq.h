@@ -186,6 +186,13 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
                      int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms,
                      int variant, int layout, void* stream);
 
+/* pack a dense tensor that already holds fake-quant VALUES (any quantiser: blocks along out_features as
+ * in the reference harness default llm/llama.py:229-237, the GPTQ solver's output llm/gptq.py:166, ...) into a
+ * single-plane kind with in_kind MSQ_PLANE_NONE: MSQ_PLANE_U8, MSQ_PLANE_U8X or MSQ_PLANE_BF16.  Nothing is
+ * rounded: MSQ_STATUS_INEXACT is raised if a value does not fit the kind (callers try U8, U8X, BF16 in turn). */
+int msq_pack_values(const float* Wq, void* inl_plane, void* out_plane, void* scale_plane, int* status_flag,
+                    int64_t N, int64_t K, int in_kind, int out_kind, void* stream);
+
 /* planes -> dense dequantised W [N,K]; out_dtype 0 = f32, 2 = bf16 (both exact). */
 int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,
                        int out_dtype, int64_t N, int64_t K, int block, int in_kind, int out_kind,

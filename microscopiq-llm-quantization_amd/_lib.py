@@ -34,6 +34,7 @@ _SIGS = {
     "msq_packed_kinds_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "msq_outlier_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                                    _f32, _i32, _i32, _i32, _i32, _vp]),
+    "msq_pack_values": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "msq_outlier_unpack": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp]),
     "msq_qlinear_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "msq_qlinear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),

@@ -78,8 +78,12 @@ def load_packed(model, path, device=None, strict=True):
                 raise MsqError("checkpoint layer %r has shape %dx%d, the model %dx%d" % (
                     name, d["out_features"], d["in_features"], old.out_features, old.in_features))
         dev = device if device is not None else next(old.parameters(), next(old.buffers(), torch.zeros(0))).device
-        q = QuantLinear(d["in_features"], d["out_features"], d["bias"], d["block_size"], d["inlier_elem_format"],
-                        d["outlier_elem_format"], getattr(torch, d["out_dtype"]), device=dev, layout=d["layout"])
+        if d["inlier_elem_format"] == "values":          # packed from dense values (QuantLinear.from_dense)
+            q = QuantLinear.empty_single_plane(d["in_features"], d["out_features"], d["bias"], d["out_kind"],
+                                               getattr(torch, d["out_dtype"]), dev)
+        else:
+            q = QuantLinear(d["in_features"], d["out_features"], d["bias"], d["block_size"], d["inlier_elem_format"],
+                            d["outlier_elem_format"], getattr(torch, d["out_dtype"]), device=dev, layout=d["layout"])
         if (q.in_kind, q.out_kind) != (d["in_kind"], d["out_kind"]):
             raise MsqError("checkpoint layer %r was packed with plane kinds %r, this build derives %r" % (
                 name, (d["in_kind"], d["out_kind"]), (q.in_kind, q.out_kind)))

@@ -755,6 +755,35 @@ extern "C" void msq_set_error_(const char* msg);
 static int msq_layout() { return 1; }
 static int fail2(int code, const char* msg) { msq_set_error_(msg); (void)g_err2; return code; }
 
+// bf16-plane packing of given values (in_kind NONE, out_kind BF16): exact iff every value is a bf16
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_pack_values_bf16(const float* __restrict__ W, uint8_t* __restrict__ out_plane, int64_t N, int64_t K, int* status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t KT = K / TILE_K, NT = N / TILE_N;
+    if (tile >= KT * NT) return;
+    const int64_t nt = tile / KT, kt = tile % KT;
+    int st = 0;
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
+            const float4 v0 = *reinterpret_cast<const float4*>(W + n * K + k), v1 = *reinterpret_cast<const float4*>(W + n * K + k + 4);
+            const float v[8] = {v0.x + 0.f, v0.y + 0.f, v0.z + 0.f, v0.w + 0.f, v1.x + 0.f, v1.y + 0.f, v1.z + 0.f, v1.w + 0.f};
+            u32x4_t o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                o[w] = (f2u(v[2 * w]) >> 16) | (f2u(v[2 * w + 1]) & 0xFFFF0000u);
+                if (((f2u(v[2 * w]) | f2u(v[2 * w + 1])) & 0xFFFFu) != 0u) st |= (v[2 * w] != v[2 * w] || v[2 * w + 1] != v[2 * w + 1]) ? MSQ_STATUS_NAN : MSQ_STATUS_INEXACT;
+            }
+            *reinterpret_cast<u32x4_t*>(out_plane + ((tile * 8 + kf * 4 + nf) * 64 + lane) * 16) = o;
+        }
+    if (st && status) atomicOr(status, st);
+}
+
 extern "C" {
 
 int msq_packed_kinds(int inlier_fmt, int outlier_fmt, int* in_kind, int* out_kind) {
@@ -891,6 +920,28 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     else MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_BF16);
 #undef MSQ_RP
     return check_launch2("msq_outlier_pack(repack)");
+}
+
+// implemented in msq_pack_emit.hip
+int msq_pack_values_u_(const float* W, void* ext_plane, void* code_plane, void* scale_plane, int* status, int64_t N,
+                       int64_t K, int out_kind, void* stream);
+
+int msq_pack_values(const float* Wq, void* inl_plane, void* out_plane, void* scale_plane, int* status_flag, int64_t N,
+                    int64_t K, int in_kind, int out_kind, void* stream) {
+    int rc = msq_packed_sizes(N, K, 32, in_kind, out_kind, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (in_kind != MSQ_PLANE_NONE) return fail2(MSQ_ERR_UNSUPPORTED, "msq_pack_values: only single-plane kinds (U8, U8X, BF16 with in_kind NONE)");
+    if (!Wq || !out_plane) return fail2(MSQ_ERR_BAD_ARG, "msq_pack_values: null buffer");
+    if (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X) {
+        if (!scale_plane || (out_kind == MSQ_PLANE_U8X && !inl_plane)) return fail2(MSQ_ERR_BAD_ARG, "msq_pack_values: null buffer");
+        return msq_pack_values_u_(Wq, inl_plane, out_plane, scale_plane, status_flag, N, K, out_kind, stream);
+    }
+    if (out_kind != MSQ_PLANE_BF16) return fail2(MSQ_ERR_UNSUPPORTED, "msq_pack_values: unsupported plane kind");
+    const int64_t tiles = (N / TILE_N) * (K / TILE_K);
+    const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
+    if (msq_layout() == 1) hipLaunchKernelGGL(k_pack_values_bf16<1>, grid, blk, 0, (hipStream_t)stream, Wq, (uint8_t*)out_plane, N, K, status_flag);
+    else hipLaunchKernelGGL(k_pack_values_bf16<2>, grid, blk, 0, (hipStream_t)stream, Wq, (uint8_t*)out_plane, N, K, status_flag);
+    return check_launch2("msq_pack_values");
 }
 
 int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void* scale_plane, void* W_out,

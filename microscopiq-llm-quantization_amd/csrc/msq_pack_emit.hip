@@ -288,6 +288,8 @@ k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_
 //   this is the outlier's own scale, so its codes are unchanged; inlier e2m1 values widen exactly.
 // Every code is decoded back with the GEMM's own instruction and compared with the fake-quant value.
 // ===========================================================================
+// BS == 0: the input already holds fake-quant VALUES (any block direction, GPTQ output, ...): no quantiser runs,
+// the values are only encoded and checked (msq_pack_values).
 template <int BS, bool EXT, int HW>
 __global__ void __launch_bounds__(256)
 k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
@@ -327,16 +329,19 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
     uint8_t* extT = reinterpret_cast<uint8_t*>(wl + EXT_OFF);    // [row][8]: one byte per 8-k group
     int status = 0;
     // fake-quant of the whole row (final values replace all[])
+    if constexpr (BS > 0) {
 #pragma unroll
-    for (int j = 0; j < 64 / BS; ++j) {
-        float a[BS];
+        for (int j = 0; j < 64 / (BS > 0 ? BS : 64); ++j) {
+            constexpr int B = BS > 0 ? BS : 64;
+            float a[B];
 #pragma unroll
-        for (int b = 0; b < BS; ++b) a[b] = all[j * BS + b];
-        uint32_t mkw[(BS + 31) / 32];
-        float se_in, se_out;
-        status |= outlier_block_fast<BS, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
+            for (int b = 0; b < B; ++b) a[b] = all[j * B + b];
+            uint32_t mkw[(B + 31) / 32];
+            float se_in, se_out;
+            status |= outlier_block_fast<B, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
 #pragma unroll
-        for (int b = 0; b < BS; ++b) all[j * BS + b] = a[b];
+            for (int b = 0; b < B; ++b) all[j * B + b] = a[b];
+        }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -460,3 +465,19 @@ extern "C" int msq_pack_fused_(const float* W, void* inl_plane, void* out_plane,
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;
 }
+
+// values -> unified planes (no quantiser): out_kind MSQ_PLANE_U8 or MSQ_PLANE_U8X
+extern "C" int msq_pack_values_u_(const float* W, void* ext_plane, void* code_plane, void* scale_plane, int* status,
+                                  int64_t N, int64_t K, int out_kind, void* stream) {
+    OutlierArgs A = {};
+    A.status = status;
+    const int64_t tiles = (N / 64) * (K / 64);
+    const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_kind == MSQ_PLANE_U8) hipLaunchKernelGGL((k_pack_tile_u<0, false, 0>), grid, blk, 0, st, W, (uint8_t*)ext_plane, (uint8_t*)code_plane, (uint8_t*)scale_plane, A, N, K);
+    else hipLaunchKernelGGL((k_pack_tile_u<0, true, 0>), grid, blk, 0, st, W, (uint8_t*)ext_plane, (uint8_t*)code_plane, (uint8_t*)scale_plane, A, N, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+

@@ -44,6 +44,27 @@ def quantize_layers_nearest(layers, dev, quant_cfg=None, log=None):
 
 
 @torch.no_grad()
+def pack_layers(layers):
+    """After quantize_layers_nearest / the GPTQ pass: swap every (already fake-quantised) Linear inside the decoder
+    layers for a packed QuantLinear (what ``opt_pack3`` / ``make_quant3`` were meant to do, llm/opt.py:255-264).
+    The weights are stored in the smallest exact single-plane kind (8.25 bits/weight for the harness default
+    int2 / fp4 configuration) and the forward runs the fused dequant-GEMM.  Layers whose shape the kernel
+    does not take (out_features % 256, in_features % 64) stay dense.  Returns (packed, kept_dense)."""
+    from ..qlinear import make_quant
+    packed = dense = 0
+    for layer in layers:
+        names = {}
+        for name, lin in find_layers(layer, layers=[nn.Linear]).items():
+            if lin.out_features % 256 == 0 and lin.in_features % 64 == 0 and lin.weight.is_cuda:
+                names[name] = None
+                packed += 1
+            else:
+                dense += 1
+        make_quant(layer, names)
+    return packed, dense
+
+
+@torch.no_grad()
 def perplexity(model, testenc, dev, seqlen):
     ids = testenc.input_ids if hasattr(testenc, "input_ids") else testenc
     nsamples = ids.numel() // seqlen

@@ -111,6 +111,38 @@ def _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier
     return PackedWeight(inl, out, scl, N, K, block_size, ik, ok)
 
 
+PLANE_NONE, PLANE_BF16, PLANE_U8, PLANE_U8X = 0, 4, 5, 6
+
+
+def pack_values(Wq, kinds=(PLANE_U8, PLANE_U8X, PLANE_BF16)):
+    """Pack a dense [N, K] tensor that already holds fake-quant values -- blocks along out_features
+    (the reference harness default, llm/llama.py:229-237), the GPTQ solver's output (llm/gptq.py:166),
+    anything -- into the first single-plane kind of `kinds` that represents every value exactly:
+    unified e4m3 (8.25 bits/weight), unified + extension bit (9.25) or plain bf16 (16).  Nothing is rounded."""
+    if not Wq.is_cuda:
+        raise MsqError("pack_values needs a CUDA/HIP tensor (no CPU fallback)")
+    if Wq.ndim != 2:
+        raise MsqError("pack_values expects a 2-D [out_features, in_features] tensor")
+    Wf = Wq.detach().contiguous().float()
+    N, K = Wf.shape
+    dev = Wf.device
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    for ok in kinds:
+        ib, ob, sb, _ = packed_sizes(N, K, 32, PLANE_NONE, ok)
+        inl = torch.empty(ib, dtype=torch.uint8, device=dev) if ib else None
+        out = torch.empty(ob, dtype=torch.uint8, device=dev)
+        scl = torch.empty(sb, dtype=torch.uint8, device=dev) if sb else None
+        status.zero_()
+        check(lib().msq_pack_values(ptr(Wf), ptr(inl), ptr(out), ptr(scl), ptr(status), N, K, PLANE_NONE, ok,
+                                    current_stream(dev)), "msq_pack_values")
+        st = int(status.item())
+        if st & 1:
+            raise AssertionError("pack_values: the tensor contains NaN / Inf")
+        if st == 0:
+            return PackedWeight(inl, out, scl, N, K, 32, PLANE_NONE, ok)
+    raise MsqError("pack_values: the values fit none of the requested plane kinds %r exactly" % (tuple(kinds),))
+
+
 def unpack_weight(P, dtype=torch.float32):
     """Dense dequantised weight [N, K] (exact in f32 and bf16)."""
     if dtype not in (torch.float32, torch.bfloat16):
@@ -278,6 +310,48 @@ class QuantLinear(nn.Module):
         m = cls(linear.in_features, linear.out_features, linear.bias is not None, device=linear.weight.device, **kw)
         return m.pack(linear, quantizer)
 
+    @classmethod
+    def empty_single_plane(cls, in_features, out_features, bias, out_kind, out_dtype=torch.bfloat16, device=None):
+        """Unfilled module for a layer packed from dense values (checkpoint loading)."""
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.in_features, m.out_features, m.block_size = in_features, out_features, 32
+        m.inlier_elem_format = m.outlier_elem_format = "values"
+        m.out_dtype = out_dtype
+        m.layout = {PLANE_U8: "unified", PLANE_U8X: "unified", PLANE_BF16: "planes"}[out_kind]
+        m.in_kind, m.out_kind = PLANE_NONE, out_kind
+        ib, ob, sb, _ = packed_sizes(out_features, in_features, 32, PLANE_NONE, out_kind)
+        m.register_buffer("inl_plane", torch.zeros(ib, dtype=torch.uint8, device=device))
+        m.register_buffer("out_plane", torch.zeros(ob, dtype=torch.uint8, device=device))
+        m.register_buffer("scale_plane", torch.zeros(sb, dtype=torch.uint8, device=device))
+        if bias:
+            m.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, device=device))
+        else:
+            m.bias = None
+        return m
+
+    @classmethod
+    def from_dense(cls, linear, out_dtype=torch.bfloat16):
+        """Pack a Linear whose weight ALREADY holds fake-quant values (RTN with any `axes`, or the GPTQ
+        solver's output): the layer is stored in the smallest single-plane kind that is exact."""
+        P = pack_values(linear.weight.data)
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.in_features, m.out_features, m.block_size = linear.in_features, linear.out_features, 32
+        m.inlier_elem_format = m.outlier_elem_format = "values"
+        m.out_dtype = out_dtype
+        m.layout = {PLANE_U8: "unified", PLANE_U8X: "unified", PLANE_BF16: "planes"}[P.out_kind]
+        m.in_kind, m.out_kind = P.in_kind, P.out_kind
+        dev = linear.weight.device
+        m.register_buffer("inl_plane", P.inl if P.inl is not None else torch.zeros(0, dtype=torch.uint8, device=dev))
+        m.register_buffer("out_plane", P.out)
+        m.register_buffer("scale_plane", P.scl if P.scl is not None else torch.zeros(0, dtype=torch.uint8, device=dev))
+        if linear.bias is not None:
+            m.register_buffer("bias", linear.bias.data.float().clone())
+        else:
+            m.bias = None
+        return m
+
     def dequantize(self, dtype=torch.float32):
         return unpack_weight(self._packed(), dtype)
 
@@ -287,12 +361,16 @@ class QuantLinear(nn.Module):
 
 def make_quant(module, quantizers, name='', layout="auto"):
     """Swap every nn.Linear whose qualified name is in `quantizers` (name -> MXQuantizer) for a
-    packed QuantLinear (the make_quant3 contract of llm/opt.py:258-264)."""
+    packed QuantLinear (the make_quant3 contract of llm/opt.py:258-264).  A value of None means "the weight
+    already holds fake-quant values" (RTN along any axis / GPTQ): it is packed as it is (from_dense)."""
     for attr in list(dict(module.named_children()).keys()):
         child = getattr(module, attr)
         full = name + '.' + attr if name != '' else attr
         if isinstance(child, nn.Linear) and full in quantizers:
-            setattr(module, attr, QuantLinear.from_linear(child, quantizers[full], layout=layout))
+            if quantizers[full] is None:
+                setattr(module, attr, QuantLinear.from_dense(child))
+            else:
+                setattr(module, attr, QuantLinear.from_linear(child, quantizers[full], layout=layout))
         else:
             make_quant(child, quantizers, full, layout)
     return module

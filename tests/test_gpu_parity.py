@@ -491,6 +491,56 @@ def test_quantlinear_module_and_state_dict(msq):
         msq.qlinear.QuantLinear.from_linear(lin, q0)                    # axes=[0] blocks are not packable along K
 
 
+def test_pack_values_any_quantiser(msq):
+    """msq_pack_values: dense fake-quant VALUES -> single-plane kinds, nothing rounded.  Covers the reference
+    harness default (int2 / fp4, blocks of 16 along out_features, llm/llama.py:229-237), which has no packed
+    form of its own, posit outliers (extension bit), int8 outliers (bf16 plane) and a non-quantised tensor."""
+    g = torch.Generator(device=dev()).manual_seed(7)
+    W = torch.randn(512, 1024, generator=g, device=dev()) * 0.02
+    W[torch.rand(512, 1024, generator=g, device=dev()) < 0.005] *= 16
+    X = torch.randn(130, 1024, generator=g, device=dev()).to(torch.bfloat16)
+    for (fi, fo, axes, bs, kind) in (("int2", "fp4", [0], 16, 5), ("fp4_e2m1", "fp8_e4m3", [0], 32, 5),
+                                     ("fp4_e2m1", "posit8_es1", [-1], 32, 6), ("fp4_e2m1", "int8", [-1], 32, 4)):
+        Wq = msq.quant.quantize_mx_outlier_v1(W, 8, 8, fi, fo, "max", 2, axes, bs)
+        P = msq.qlinear.pack_values(Wq)
+        assert (P.in_kind, P.out_kind) == (0, kind), (fi, fo, P.out_kind)
+        assert torch.equal(msq.qlinear.unpack_weight(P), Wq)
+        y = msq.qlinear.qlinear(X, P, None, torch.float32)
+        ref = X.float() @ Wq.t()
+        assert (y - ref).abs().max().item() <= 4e-5 * ref.abs().max().item() + 1e-6
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.pack_values(W)                                      # raw fp32 weights fit no kind exactly
+    lin = torch.nn.Linear(1024, 512).to(dev())
+    with torch.no_grad():
+        lin.weight.copy_(msq.quant.quantize_mx_outlier_v1(W, 8, 8, "int2", "fp4", "max", 2, [0], 16))
+    ql = msq.qlinear.QuantLinear.from_dense(lin)
+    assert ql.out_kind == 5 and torch.equal(ql.dequantize(), lin.weight.data)
+    ref = torch.nn.functional.linear(X.float(), lin.weight.data, lin.bias.data)
+    assert (ql(X).float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
+def test_gptq_output_packs(msq):
+    """f1 -> packed path: the GPTQ solver's calibrated, pruned weights (llm/gptq.py:60-184) go through
+    pack_values and the fused GEMM unchanged."""
+    from msq.harness.gptq import GPTQ
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(256, 256, bias=False).to(dev())
+    with torch.no_grad():
+        lin.weight.mul_(0.3)
+    gp = GPTQ(lin)
+    q = msq.quant.MXQuantizer(); q.configure(8, 8, "int2", "fp4", axes=[0], block_size=16)
+    gp.quantizer = q
+    for _ in range(4):
+        inp = torch.randn(1, 64, 256, device=dev())
+        gp.add_batch(inp, None)
+    gp.fasterquant(blocksize=128, percdamp=.01, verbose=False)
+    ql = msq.qlinear.QuantLinear.from_dense(lin)
+    assert torch.equal(ql.dequantize(), lin.weight.data.float())
+    x = torch.randn(33, 256, device=dev()).to(torch.bfloat16)
+    ref = x.float() @ lin.weight.data.float().t()
+    assert (ql(x).float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() + 1e-6
+
+
 def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     """f2: a model packed with make_quant is written to disk and a freshly built architecture loaded from the
     file computes bit-identical outputs without re-quantising (llm/opt.py:287-294, :510-512)."""
@@ -500,7 +550,9 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
         return torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.GELU(), torch.nn.Linear(512, 256, bias=False)).to(dev())
     src = build()
     q = msq.quant.MXQuantizer(); q.configure(8, 8, "fp4_e2m1", "posit8_es1", axes=[-1], block_size=32)
-    msq.qlinear.make_quant(src, {"0": q, "2": q})
+    with torch.no_grad():                                           # layer 2: weights quantised along out_features, packed as values
+        src[2].weight.copy_(msq.quant.quantize_mx_outlier_v1(src[2].weight.data, 8, 8, "int2", "fp4", "max", 2, [0], 16))
+    msq.qlinear.make_quant(src, {"0": q, "2": None})
     x = torch.randn(9, 256, device=dev()).to(torch.bfloat16)
     y = src(x)
     path = str(tmp_path / "packed.safetensors")
@@ -601,6 +653,21 @@ def test_harness_quantlinear_swap_keeps_ppl(msq):
     from msq.harness.evalppl import perplexity
     ppl_packed = perplexity(m, tokens, dev(), 64)
     assert abs(ppl_packed - ppl_fake) / ppl_fake < 0.05 / 5.5, (ppl_packed, ppl_fake)
+    # the harness DEFAULT configuration (int2 inliers / fp4 outliers, blocks of 16 along out_features,
+    # llm/llama.py:229-237): fake-quantise in place as the reference does, then pack the values as they are
+    from msq.harness.evalppl import pack_layers
+    torch.manual_seed(0)
+    m2 = LlamaForCausalLM(LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)).eval()
+    m2.seqlen = 64
+    ppl_fake2 = llama.llama_eval(m2, tokens, dev(), args=types.SimpleNamespace(nearest=True, use_mx=True))
+    Wq = m2.model.layers[0].mlp.up_proj.weight.data.float().clone()
+    packed, dense = pack_layers(m2.model.layers)
+    assert (packed, dense) == (14, 0)
+    up = m2.model.layers[0].mlp.up_proj
+    assert isinstance(up, msq.qlinear.QuantLinear) and up.out_kind == 5 and torch.equal(up.dequantize(), Wq)
+    ppl_packed2 = perplexity(m2, tokens, dev(), 64)
+    assert abs(ppl_packed2 - ppl_fake2) / ppl_fake2 < 0.05 / 5.5, (ppl_packed2, ppl_fake2)
 
 
 # ---------------------------------------------------------------- f1 GPTQ + MicroScopiQ pruning (llm/gptq.py)
