@@ -126,14 +126,11 @@ MSQ_D u32x4_t tile_frag(const TileRegs& t, int nf, int kf) {
     }
 }
 
-// Lane / fragment -> (n, k) maps of the two tile layouts.  Both have, per half tile (32 k), four
-// fragments f = 0..3 of 8 consecutive k per lane, so slots, loads and converts are shared:
-//   layout 1 (v_mfma_f32_16x16x32_bf16): f = nf,            n = 16 f + (l & 15),        k = 32 kf + 8 (l >> 4) + j
-//   layout 2 (v_mfma_f32_32x32x16_bf16): f = 2 nt + kk,     n = 32 (f >> 1) + (l & 31), k = 32 kf + 16 (f & 1) + 8 (l >> 5) + j
-template <int LAYOUT> MSQ_D int frag_n(int lane, int f) { return LAYOUT == 1 ? f * 16 + (lane & 15) : (f >> 1) * 32 + (lane & 31); }
-template <int LAYOUT> MSQ_D int frag_k(int lane, int f, int kf) { return LAYOUT == 1 ? kf * 32 + (lane >> 4) * 8 : kf * 32 + (f & 1) * 16 + (lane >> 5) * 8; }
-template <int LAYOUT> MSQ_D int scale_group(int lane) { return LAYOUT == 1 ? (lane & 15) : (lane & 31); }
-template <int LAYOUT> MSQ_D bool scale_writer(int lane) { return LAYOUT == 1 ? (lane >> 4) == 0 : (lane >> 5) == 0; }
+// Lane / fragment -> (n, k) map of the tile layout (v_mfma_f32_16x16x32_bf16 operand order): per half tile
+// (32 k) four fragments f = nf of 8 consecutive k per lane: n = 16 f + (l & 15), k = 32 kf + 8 (l >> 4) + j.
+// (A 32x32x16 layout was built and measured 8-10 % slower end to end; it is gone.)
+MSQ_D int frag_n(int lane, int f) { return f * 16 + (lane & 15); }
+MSQ_D int frag_k(int lane, int kf) { return kf * 32 + (lane >> 4) * 8; }
 
 template <int OUT_KIND> struct OutSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 8 : 4; };
 // bytes of the scale plane per tile and lane group
@@ -143,7 +140,7 @@ template <int OUT_KIND> struct SclBytes { static constexpr int n = IsUnified<OUT
 // repack: codes[N][K] (u32: bits 0-7 inlier code, 8-23 outlier code) + per-block
 // exponents -> tile-major planes.  One wave per tile.
 // ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND, int LAYOUT>
+template <int IN_KIND, int OUT_KIND>
 __global__ void __launch_bounds__(256)
 k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, const float* __restrict__ e_out,
          uint8_t* __restrict__ inl_plane, uint8_t* __restrict__ out_plane, uint8_t* __restrict__ scl_plane,
@@ -162,8 +159,8 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
         u32x4_t inl4;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
-            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
+            const int64_t n = nt * TILE_N + frag_n(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k(lane, kf);
             const u32x4_t c0 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k);
             const u32x4_t c1 = *reinterpret_cast<const u32x4_t*>(codes + n * K + k + 4);
             const uint32_t cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -198,10 +195,10 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
     }
     if (IN_KIND != MSQ_PLANE_NONE) {
         const bool per_lane = block < 32;
-        const int groups = per_lane ? 64 : (LAYOUT == 1 ? 16 : 32);
-        if (per_lane || scale_writer<LAYOUT>(lane)) {
+        const int groups = per_lane ? 64 : 16;
+        if (per_lane || (lane >> 4) == 0) {
             u32x4_t s4; s4[0] = sc[0]; s4[1] = sc[1]; s4[2] = sc[2]; s4[3] = sc[3];
-            *reinterpret_cast<u32x4_t*>(scl_plane + (tile * groups + (per_lane ? lane : scale_group<LAYOUT>(lane))) * 16) = s4;
+            *reinterpret_cast<u32x4_t*>(scl_plane + (tile * groups + (per_lane ? lane : (lane & 15))) * 16) = s4;
         }
     }
     if (st && status) atomicOr(status, st);
@@ -233,7 +230,7 @@ MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_p
 // ---------------------------------------------------------------------------
 // unpack: planes -> dense W[N][K] (f32 or bf16), same converts as the GEMM.
 // ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND, typename OT, int LAYOUT>
+template <int IN_KIND, int OUT_KIND, typename OT>
 __global__ void __launch_bounds__(256)
 k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, OT* __restrict__ W, int64_t N, int64_t K, int scl_groups) {
@@ -249,8 +246,8 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const u32x4_t f = tile_frag<IN_KIND, OUT_KIND>(t, nf, kf);
-            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
-            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
+            const int64_t n = nt * TILE_N + frag_n(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k(lane, kf);
             if (sizeof(OT) == 2) {
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(W) + n * K + k) = f;
             } else {
@@ -283,39 +280,6 @@ struct HalfRegs {
     u32x4_t out[HalfSlots<OUT_KIND>::n];
     uint32_t ext;        // U8X: extension bits of this half
 };
-
-template <int IN_KIND, int OUT_KIND>
-MSQ_D void load_half(HalfRegs<IN_KIND, OUT_KIND>& h, const uint8_t* inl_lane, const uint8_t* out_lane, int64_t tile, int kf) {
-    constexpr int HS = HalfSlots<OUT_KIND>::n;
-    if (IN_KIND != MSQ_PLANE_NONE)
-        h.inl = *reinterpret_cast<const u32x4_t*>(inl_lane + (tile * 2 + kf) * 1024);
-#pragma unroll
-    for (int s = 0; s < HS; ++s)
-        h.out[s] = *reinterpret_cast<const u32x4_t*>(out_lane + ((tile * 2 + kf) * HS + s) * 1024);
-}
-
-template <int IN_KIND, int OUT_KIND>
-MSQ_D void convert_half(bf16x8_t (&wf)[4], const HalfRegs<IN_KIND, OUT_KIND>& h, const u32x4_t& scl, int kf) {
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        u32x4_t r;
-        if (IN_KIND == MSQ_PLANE_NONE) {
-            r = h.out[nf];
-        } else {
-            const float s_in = scale_operand(scl[nf], kf * 2);
-            if (OUT_KIND == MSQ_PLANE_BF16) {
-                r = dequant_frag_in_only(h.inl[nf], s_in);
-                const u32x4_t o = h.out[nf];
-                r[0] |= o[0]; r[1] |= o[1]; r[2] |= o[2]; r[3] |= o[3];
-            } else {
-                const float s_out = scale_operand(scl[nf], kf * 2 + 1);
-                const u32x4_t o = h.out[nf >> 1];
-                r = dequant_frag<OUT_KIND>(h.inl[nf], o[(nf & 1) * 2], o[(nf & 1) * 2 + 1], s_in, s_out);
-            }
-        }
-        wf[nf] = __builtin_bit_cast(bf16x8_t, r);
-    }
-}
 
 // --- packed-plane loads through buffer descriptors: the per-lane offset (lane * 16) never changes and the
 // slot offset is wave-uniform, so it rides in the SGPR soffset operand: zero VALU address arithmetic.
@@ -752,11 +716,9 @@ extern "C" void msq_set_error_(const char* msg);
 // tile layout of the packed planes: 1 = 16x16x32 fragments.  (Layout 2 = 32x32x16 fragments was built
 // and measured 8-10 % slower end to end -- the chip holds a lower clock on that MFMA shape -- and removed;
 // the frag_n / frag_k maps keep the seam.)
-static int msq_layout() { return 1; }
 static int fail2(int code, const char* msg) { msq_set_error_(msg); (void)g_err2; return code; }
 
 // bf16-plane packing of given values (in_kind NONE, out_kind BF16): exact iff every value is a bf16
-template <int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_pack_values_bf16(const float* __restrict__ W, uint8_t* __restrict__ out_plane, int64_t N, int64_t K, int* status) {
     const int lane = threadIdx.x & 63;
@@ -769,8 +731,8 @@ k_pack_values_bf16(const float* __restrict__ W, uint8_t* __restrict__ out_plane,
     for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const int64_t n = nt * TILE_N + frag_n<LAYOUT>(lane, nf);
-            const int64_t k = kt * TILE_K + frag_k<LAYOUT>(lane, nf, kf);
+            const int64_t n = nt * TILE_N + frag_n(lane, nf);
+            const int64_t k = kt * TILE_K + frag_k(lane, kf);
             const float4 v0 = *reinterpret_cast<const float4*>(W + n * K + k), v1 = *reinterpret_cast<const float4*>(W + n * K + k + 4);
             const float v[8] = {v0.x + 0.f, v0.y + 0.f, v0.z + 0.f, v0.w + 0.f, v1.x + 0.f, v1.y + 0.f, v1.z + 0.f, v1.w + 0.f};
             u32x4_t o;
@@ -837,10 +799,9 @@ int msq_packed_sizes(int64_t N, int64_t K, int block, int in_kind, int out_kind,
     if (!(block == 8 || block == 16 || block == 32 || block == 64 || block == 128) || (K % block))
         return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: block must be 8/16/32/64/128 and divide K");
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
-    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    const int groups = block < 32 ? 64 : 16;
     if (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X) {
         if (in_kind != MSQ_PLANE_NONE) return fail2(MSQ_ERR_BAD_ARG, "msq_packed_sizes: unified planes have no inlier plane");
-        if (msq_layout() != 1) return fail2(MSQ_ERR_UNSUPPORTED, "msq_packed_sizes: unified layout needs the 16x16x32 tile order");
         if (inl_bytes) *inl_bytes = (out_kind == MSQ_PLANE_U8X) ? tiles * 2 * 256 : 0;      // extension bits
         if (out_bytes) *out_bytes = tiles * 4 * 1024;
         if (scale_bytes) *scale_bytes = tiles * 16 * 8;
@@ -910,10 +871,8 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define MSQ_RP(IK, OK) do { if (msq_layout() == 1) hipLaunchKernelGGL((k_repack<IK, OK, 1>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
-                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag);            \
-                            else hipLaunchKernelGGL((k_repack<IK, OK, 2>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
-                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag); } while (0)
+#define MSQ_RP(IK, OK) hipLaunchKernelGGL((k_repack<IK, OK>), grid, blk, 0, st, codes, e_in, e_out, (uint8_t*)inl_plane, \
+                                          (uint8_t*)out_plane, (uint8_t*)scale_plane, N, K, block, status_flag)
     if (ik == MSQ_PLANE_NONE) MSQ_RP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
     else if (ok == MSQ_PLANE_FP8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (ok == MSQ_PLANE_BF8) MSQ_RP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
@@ -939,8 +898,7 @@ int msq_pack_values(const float* Wq, void* inl_plane, void* out_plane, void* sca
     if (out_kind != MSQ_PLANE_BF16) return fail2(MSQ_ERR_UNSUPPORTED, "msq_pack_values: unsupported plane kind");
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
-    if (msq_layout() == 1) hipLaunchKernelGGL(k_pack_values_bf16<1>, grid, blk, 0, (hipStream_t)stream, Wq, (uint8_t*)out_plane, N, K, status_flag);
-    else hipLaunchKernelGGL(k_pack_values_bf16<2>, grid, blk, 0, (hipStream_t)stream, Wq, (uint8_t*)out_plane, N, K, status_flag);
+    hipLaunchKernelGGL(k_pack_values_bf16, grid, blk, 0, (hipStream_t)stream, Wq, (uint8_t*)out_plane, N, K, status_flag);
     return check_launch2("msq_pack_values");
 }
 
@@ -956,16 +914,12 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
     const int64_t tiles = (N / TILE_N) * (K / TILE_K);
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    const int groups = block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32);
+    const int groups = block < 32 ? 64 : 16;
 #define MSQ_UP(IK, OK)                                                                                               \
-    do { if (msq_layout() == 1) { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float, 1>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
+    do { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float>), grid, blk, 0, st, (const uint8_t*)inl_plane,  \
                     (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)W_out, N, K, groups);              \
-         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t, 1>), grid, blk, 0, st, (const uint8_t*)inl_plane,          \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); }          \
-         else { if (out_dtype == 0) hipLaunchKernelGGL((k_unpack<IK, OK, float, 2>), grid, blk, 0, st, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)W_out, N, K, groups);              \
-         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t, 2>), grid, blk, 0, st, (const uint8_t*)inl_plane,          \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); } } while (0)
+         else hipLaunchKernelGGL((k_unpack<IK, OK, uint16_t>), grid, blk, 0, st, (const uint8_t*)inl_plane,             \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (uint16_t*)W_out, N, K, groups); } while (0)
     if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_UP(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
     else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_UP(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
@@ -979,7 +933,7 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
 
 // Block shape: 128 x 256 (4 waves, two blocks per CU) or 256 x 256 (8 waves, one block per CU).  Both keep
 // the same per-wave tile, so the instruction mix is identical.  Measured over the Llama shapes
-// (scratch/wm_sweep.py) the small block wins or ties nearly everywhere (finer tail, half the wasted
+// (scripts/experiments/wm_sweep.py) the small block wins or ties nearly everywhere (finer tail, half the wasted
 // activation rows, two independent barriers per CU), so it is the default; MSQ_GEMM_WM=2 forces the
 // large one for experiments.
 static int pick_wm(int64_t M, int64_t N) {
@@ -996,7 +950,7 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
     const int64_t KT = K / BK;
     if (forced > 0) return forced < KT ? forced : (int)KT;
     if (blocks >= 192 || KT < 8) return 1;
-    // measured (scratch/ks_sweep.py): best is about one block per CU, power-of-two splits (even K chunks)
+    // measured (scripts/experiments/ks_sweep.py): best is about one block per CU, power-of-two splits (even K chunks)
     int64_t ks = 1;
     while (ks * blocks < 256) ks *= 2;
     if (ks > KT / 4) ks = KT / 4;
@@ -1005,7 +959,7 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
 }
 
 // small-M path: tiles per task so that there are ~3000 tasks (12 waves x 256 CUs) but at most 32 partial planes
-// measured (scratch/gemv_thr.py): the decode kernel wins up to M = 16, the split-K GEMM from M = 32 on
+// measured (scripts/experiments/gemv_thr.py): the decode kernel wins up to M = 16, the split-K GEMM from M = 32 on
 #define MSQ_GEMV_MAX_M 16
 static int gemv_max_m() { return MSQ_GEMV_MAX_M; }
 static int pick_kc(int64_t N, int64_t K) {
@@ -1038,7 +992,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     hipStream_t st0 = (hipStream_t)stream;
-    const int groups0 = unified ? 16 : (block < 32 ? 64 : (msq_layout() == 1 ? 16 : 32));
+    const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     if (M <= gemv_max_m() && workspace) {
         const int kc = pick_kc(N, K);
         const int nks = (int)((K / BK + kc - 1) / kc);
