@@ -291,111 +291,117 @@ k_pack_tile(const float* __restrict__ W, uint8_t* __restrict__ inl_plane, uint8_
 // BS == 0: the input already holds fake-quant VALUES (any block direction, GPTQ output, ...): no quantiser runs,
 // the values are only encoded and checked (msq_pack_values).
 template <int BS, bool EXT, int HW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
               uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
-    constexpr int WAVE_LDS = 64 * 68 * 4;
-    constexpr int CODE_STRIDE = 18;                              // dwords per row (16 used)
-    constexpr int CODE_OFF = 0, SCL_OFF = 64 * CODE_STRIDE * 4, EXT_OFF = SCL_OFF + 64 * 4;
-    static_assert(EXT_OFF + 64 * 8 <= WAVE_LDS, "LDS overlay does not fit");
+    // Lane r owns row r of the tile in LDS (68 words = 272 B per row) and works on it IN PLACE, one block /
+    // one 32-k half at a time, so that no 64-element register array is needed: the fake-quant values
+    // overwrite the inputs; the codes of half h then go to bytes 32 h .. 32 h + 31 of the row (already
+    // consumed), the two scale bytes to 64..65 and the extension bytes to 68..75 once both halves are encoded.
+    constexpr int ROW_W = 68;                                    // words per row
+    constexpr int WAVE_LDS = 64 * ROW_W * 4;
     __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t KT = K / 64, NT = N / 64;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
     if (tile >= KT * NT) return;
     const int64_t nt = tile / KT, kt = tile % KT;
-    char* wl = lds + wv * WAVE_LDS;
-    float* ft = reinterpret_cast<float*>(wl);
+    float* ft = reinterpret_cast<float*>(lds + wv * WAVE_LDS);
     {
         const float* src = W + (nt * 64) * K + kt * 64;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = i * 4 + (lane >> 4), c4 = lane & 15;
-            *reinterpret_cast<float4*>(ft + row * 68 + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)row * K + c4 * 4);
+            *reinterpret_cast<float4*>(ft + row * ROW_W + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)row * K + c4 * 4);
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    float all[64];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(ft + lane * 68 + c * 4);
-        all[c * 4 + 0] = v.x; all[c * 4 + 1] = v.y; all[c * 4 + 2] = v.z; all[c * 4 + 3] = v.w;
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t* codeT = reinterpret_cast<uint32_t*>(wl + CODE_OFF);
-    uint8_t* sclT = reinterpret_cast<uint8_t*>(wl + SCL_OFF);    // [row][4]: bytes 0..1 = halves
-    uint8_t* extT = reinterpret_cast<uint8_t*>(wl + EXT_OFF);    // [row][8]: one byte per 8-k group
+    float* myrow = ft + lane * ROW_W;
     int status = 0;
-    // fake-quant of the whole row (final values replace all[])
+    // 1. fake-quant of the row, block by block, in place
     if constexpr (BS > 0) {
-#pragma unroll
-        for (int j = 0; j < 64 / (BS > 0 ? BS : 64); ++j) {
-            constexpr int B = BS > 0 ? BS : 64;
+        constexpr int B = BS > 0 ? BS : 64;
+#pragma nounroll
+        for (int j = 0; j < 64 / B; ++j) {
             float a[B];
 #pragma unroll
-            for (int b = 0; b < B; ++b) a[b] = all[j * B + b];
+            for (int c = 0; c < B / 4; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(myrow + j * B + c * 4);
+                a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
+            }
             uint32_t mkw[(B + 31) / 32];
             float se_in, se_out;
             status |= outlier_block_fast<B, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
 #pragma unroll
-            for (int b = 0; b < B; ++b) all[j * B + b] = a[b];
+            for (int c = 0; c < B / 4; ++c)
+                *reinterpret_cast<float4*>(myrow + j * B + c * 4) = make_float4(a[c * 4 + 0], a[c * 4 + 1], a[c * 4 + 2], a[c * 4 + 3]);
         }
     }
-#pragma unroll
+    // 2. one scale + 32 codes (+ 32 extension bits) per half
+    uint32_t sbytes = 0, eb_lo = 0, eb_hi = 0;
+#pragma nounroll
     for (int h = 0; h < 2; ++h) {
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 x = *reinterpret_cast<const float4*>(myrow + h * 32 + c * 4);
+            v[c * 4 + 0] = x.x + 0.0f; v[c * 4 + 1] = x.y + 0.0f; v[c * 4 + 2] = x.z + 0.0f; v[c * 4 + 3] = x.w + 0.0f;   // -0 -> +0
+        }
         float mx = 0.f;
         bool bad = false;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) { const float t = __builtin_fabsf(all[h * 32 + b]); mx = t > mx ? t : mx; bad |= !(t == t) || t > 3.0e38f; }
+        for (int b = 0; b < 32; ++b) { const float t = __builtin_fabsf(v[b]); mx = t > mx ? t : mx; bad |= !(t == t) || t > 3.0e38f; }
         int su = 0;
         if (mx > 0.f) {
             su = ilog2f(mx) - 8;
-            if (scale_pow2(mx, -su) > 448.f) su += 1;
+            if (__builtin_ldexpf(mx, -su) > 448.f) su += 1;      // mx * 2^-su lies in [256, 512): exact
         }
         su = su < -126 ? -126 : su;
         if (su > 127) { su = 127; status |= MSQ_STATUS_INEXACT; }
         if (bad) status |= MSQ_STATUS_NAN;
         const uint32_t sb = (uint32_t)(su + 127);
         const float s_op = u2f(sb << 23);
-        sclT[lane * 4 + h] = (uint8_t)sb;
+        sbytes |= sb << (8 * h);
+        uint32_t cw[8];
+        uint32_t eb = 0;                                         // bit j of byte t8: element 8 t8 + j
+        bool ok = true;
 #pragma unroll
-        for (int t8 = 0; t8 < 4; ++t8) {
-            const int k8 = h * 4 + t8;
-            uint32_t ow[2] = {0, 0}, eb = 0;
-            bool ok = true;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                typedef short v2s_t __attribute__((ext_vector_type(2)));
-                const float v0 = all[k8 * 8 + 2 * p] + 0.0f, v1 = all[k8 * 8 + 2 * p + 1] + 0.0f;   // -0 -> +0
-                uint32_t u0 = f2u(v0), u1 = f2u(v1);
-                if (EXT) {                                       // split off the bf16 mantissa bit 3 (f32 bit 19)
-                    eb |= ((u0 >> 19) & 1u) << (2 * p);
-                    eb |= ((u1 >> 19) & 1u) << (2 * p + 1);
-                    u0 &= ~(1u << 19); u1 &= ~(1u << 19);
-                }
-                const float q0 = scale_pow2(u2f(u0), -su), q1 = scale_pow2(u2f(u1), -su);
-                v2s_t cur = __builtin_bit_cast(v2s_t, ow[p >> 1]);
-                if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, q0, q1, 1.0f, false);
-                else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, q0, q1, 1.0f, true);
-                ow[p >> 1] = __builtin_bit_cast(uint32_t, cur);
-                uint32_t d = ((p & 1) == 0) ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ow[p >> 1], s_op, false))
-                                            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ow[p >> 1], s_op, true));
-                if (EXT) d |= (((eb >> (2 * p)) & 1u) << 3) | (((eb >> (2 * p + 1)) & 1u) << 19);
-                const uint32_t expect = (f2u(v0) >> 16) | (f2u(v1) & 0xFFFF0000u);
-                ok = ok && (d == expect) && (((f2u(v0) | f2u(v1)) & 0xFFFFu) == 0u);
+        for (int p = 0; p < 16; ++p) {                           // pairs of elements
+            typedef short v2s_t __attribute__((ext_vector_type(2)));
+            uint32_t u0 = f2u(v[2 * p]), u1 = f2u(v[2 * p + 1]);
+            const uint32_t expect = (u0 >> 16) | (u1 & 0xFFFF0000u);
+            ok = ok && (((u0 | u1) & 0xFFFFu) == 0u);
+            if (EXT) {                                           // split off bf16 mantissa bit 3 (f32 bit 19)
+                eb |= ((u0 >> 19) & 1u) << (2 * p);
+                eb |= ((u1 >> 19) & 1u) << (2 * p + 1);
+                u0 &= ~(1u << 19); u1 &= ~(1u << 19);
             }
-            if (!ok && !bad) status |= MSQ_STATUS_INEXACT;
-            codeT[lane * CODE_STRIDE + k8 * 2] = ow[0];
-            codeT[lane * CODE_STRIDE + k8 * 2 + 1] = ow[1];
-            if (EXT) extT[lane * 8 + k8] = (uint8_t)eb;
+            // the convert divides by 2^su itself (only the exponent field of the scale operand is read)
+            v2s_t cur = __builtin_bit_cast(v2s_t, (p & 1) ? cw[p >> 1] : 0u);
+            if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, u2f(u0), u2f(u1), s_op, false);
+            else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, u2f(u0), u2f(u1), s_op, true);
+            cw[p >> 1] = __builtin_bit_cast(uint32_t, cur);
+            // decode exactly as the GEMM will and compare with the fake-quant value
+            uint32_t d = ((p & 1) == 0) ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(cw[p >> 1], s_op, false))
+                                        : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(cw[p >> 1], s_op, true));
+            if (EXT) d |= (((eb >> (2 * p)) & 1u) << 3) | (((eb >> (2 * p + 1)) & 1u) << 19);
+            ok = ok && (d == expect);
         }
+        if (!ok && !bad) status |= MSQ_STATUS_INEXACT;
+        uint32_t* crow = reinterpret_cast<uint32_t*>(myrow) + h * 8;     // bytes 32 h ..
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            *reinterpret_cast<uint4*>(crow + c * 4) = make_uint4(cw[c * 4], cw[c * 4 + 1], cw[c * 4 + 2], cw[c * 4 + 3]);
+        if (h == 0) eb_lo = eb; else eb_hi = eb;
     }
+    reinterpret_cast<uint32_t*>(myrow)[16] = sbytes;             // bytes 64..65: the two scales
+    if (EXT) { reinterpret_cast<uint32_t*>(myrow)[17] = eb_lo; reinterpret_cast<uint32_t*>(myrow)[18] = eb_hi; }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    // fragment gather + slot stores
+    // 3. fragment gather + slot stores
     const int c = lane & 15, g = lane >> 4;
+    const uint32_t* rows = reinterpret_cast<const uint32_t*>(ft);
     uint32_t sc[2] = {0, 0};
 #pragma unroll
     for (int kf = 0; kf < 2; ++kf) {
@@ -403,11 +409,12 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = nf * 16 + c, k8 = kf * 4 + g;
-            sc[kf] |= (uint32_t)sclT[n * 4 + kf] << (8 * nf);
-            const uint2 o = *reinterpret_cast<const uint2*>(codeT + n * CODE_STRIDE + k8 * 2);
+            const uint32_t* r = rows + n * ROW_W;
+            sc[kf] |= ((r[16] >> (8 * kf)) & 0xFFu) << (8 * nf);
+            const uint2 o = *reinterpret_cast<const uint2*>(r + k8 * 2);
             *reinterpret_cast<uint2*>(code_plane + ((tile * 4 + kf * 2 + (nf >> 1)) * 64 + lane) * 16 + (nf & 1) * 8) = o;
             if (EXT) {
-                const uint32_t eb = extT[n * 8 + k8];
+                const uint32_t eb = (r[17 + kf] >> (8 * g)) & 0xFFu;      // elements 8 g .. 8 g + 7 of half kf
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     ew |= ((eb >> j) & 1u) << ((3 + 16 * (j & 1) + 4 * nf + (j >> 1)) & 31);
