@@ -12,8 +12,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" > $OUT/p$i.json 2> $OUT/p$i.err
 done
-python3 - <<'PY'
-import csv, glob, collections, os, sys
-out = os.environ.get("OUTDIR", "")
-PY
-find $OUT -name "*counter_collection.csv" | head
+python3 scripts/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt

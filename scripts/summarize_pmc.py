@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Average the per-dispatch PMC values of the fused GEMM kernel over the counter passes in a directory written by
+scripts/pmc_gpu.sh and print derived ratios."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+vals = collections.defaultdict(list)
+for f in glob.glob(os.path.join(d, "p*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "k_qgemm" in r["Kernel_Name"]:
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in vals.items()}
+for k in sorted(avg):
+    print("%-28s %.4g" % (k, avg[k]))
+g = avg.get
+if g("SQ_BUSY_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+    print("MFMA busy / SQ busy cycles      %.3f" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES")))
+if g("SQ_WAVE_CYCLES"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS"):
+        if g(k):
+            print("%-28s / wave cycles %.3f" % (k, g(k) / g("SQ_WAVE_CYCLES")))
+if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None:
+    print("LDS bank conflict / active      %.3f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
+if g("TCC_HIT_sum") and g("TCC_MISS_sum") is not None:
+    print("L2 hit rate                     %.3f" % (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
+if g("SQ_INSTS_VALU") and g("SQ_INSTS_MFMA"):
+    print("VALU / MFMA instructions        %.2f" % (g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA")))
