@@ -680,17 +680,31 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
     }
 }
 
-// sum of the split-K partial tiles (+ bias) -> Y
+// sum of the split-K partial tiles (+ bias) -> Y.  The grids are tiny at decode sizes (M N / 1024 workgroups), so
+// the kernel is one load round trip long only if all planes are requested before the first add: the loads are
+// issued 8 at a time, the sum keeps the k order.
 template <typename YT>
 __global__ void __launch_bounds__(256)
 k_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bias, YT* __restrict__ Y, int64_t MN, int N,
                 int ksplit) {
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= MN) return;
-    float4 s = *reinterpret_cast<const float4*>(partial + i4);
-    for (int k = 1; k < ksplit; ++k) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= ksplit; k += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(k + u) * MN + i4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k + u == 0) s = p[0];
+            else { s.x += p[u].x; s.y += p[u].y; s.z += p[u].z; s.w += p[u].w; }
+        }
+    }
+    for (; k < ksplit; ++k) {
         const float4 p = *reinterpret_cast<const float4*>(partial + (int64_t)k * MN + i4);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        if (k == 0) s = p;
+        else { s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
     }
     if (bias) { const int n = (int)(i4 % N); s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
     if (sizeof(YT) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + i4) = s;

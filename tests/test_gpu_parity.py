@@ -454,7 +454,7 @@ def test_fused_gemm_llama_shapes_repeatable(msq, N, K, layout):
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
     P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3" if N != 11008 else "posit8_es1", 2, 32, layout=layout)
     Wu = msq.qlinear.unpack_weight(P, torch.float32)
-    for M in (65, 128, 1000, 2048):
+    for M in (1, 7, 16, 65, 128, 1000, 2048):                       # decode kernel (flag-synchronised reduction), split-K, full tiles
         X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
         Yr = X.float() @ Wu.t()
         Y0 = msq.qlinear.qlinear(X, P, None, torch.float32)
