@@ -130,7 +130,8 @@ def main():
         name = ("Llama-2-7B W4A8 (MX-FP4 weights + FP8-e4m3 activations, MXLinear semantics), act-quant + fused "
                 "dequant-GEMM X[%d,%d] x W[%d,%d]^T" % (M, K, N, K))
         args.outlier = "fp4_e2m1"
-        P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 5, args.block, variant=1)
+        from msq.mx_ops import _quantize_mx_outlier_v1
+        P = qlinear.pack_values(_quantize_mx_outlier_v1(W, 8, 8, args.inlier, args.outlier, "max", 5, [1], args.block))
         X = torch.randn(M, K, device=dev)
     else:
         P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block, layout=args.layout)

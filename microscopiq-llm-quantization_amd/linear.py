@@ -44,13 +44,14 @@ def _mx_scale_bits(mx_specs):
 def pack_mx_weight(weight, mx_specs):
     """weight -> (bf16 elementwise cast, linear.py:39) -> mx_ops outlier quantiser along in_features
     (linear.py:78-85) -> packed planes."""
-    from .qlinear import pack_weight
+    from .qlinear import pack_values
     mx_specs = apply_mx_specs(mx_specs)
     bf_weight = quantize_elemwise_op(weight.detach(), mx_specs=mx_specs, round=mx_specs["round_weight"])
-    sb = _mx_scale_bits(mx_specs)
-    return pack_weight(bf_weight, sb, sb, mx_specs["w_elem_format"], mx_specs["w_elem_format"], std_dev=5,
-                       block_size=mx_specs["block_size"], round=mx_specs["round_mx_output"],
-                       flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], variant=1)
+    qis_weight = quantize_mx_outlier_op(bf_weight.float(), mx_specs, inlier_elem_format=mx_specs['w_elem_format'],
+                                        outlier_elem_format=mx_specs['w_elem_format'], axes=[1],
+                                        round=mx_specs["round_mx_output"])               # linear.py:78-85
+    # the fake-quant values go into the smallest exact single-plane kind (8.25 bits/weight for fp4 weights)
+    return pack_values(qis_weight)
 
 
 def _forward_packed(input, P, bias, mx_specs):
