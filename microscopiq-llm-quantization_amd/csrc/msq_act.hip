@@ -60,9 +60,24 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
     float se_in = 0.f, se_out = 0.f;
     int status = 0;
     if (gidx < nblocks) {
-        const float* vm = A.vmean ? A.vmean + (gidx / A.nblk) * BS : nullptr;
-        const float* vs = A.vstd ? A.vstd + (gidx / A.nblk) * BS : nullptr;
-        status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+        if (A.vmean && full && (A.nblk % 64 == 0)) {
+            // the 64 blocks of this wave lie in one row: the statistics tables are wave-uniform, read them
+            // through scalar loads (the mean / std of position b are the same for every lane)
+            const int64_t prow = g0 / A.nblk;
+            const uint64_t pm = (uint64_t)(A.vmean + prow * BS), ps = (uint64_t)(A.vstd + prow * BS);
+            auto uni64 = [](uint64_t v) -> uint64_t {            // readfirstlane returns a signed int: widen through uint32_t
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+                return ((uint64_t)hi << 32) | (uint64_t)lo;
+            };
+            const float* vm = (const float*)uni64(pm);
+            const float* vs = (const float*)uni64(ps);
+            status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+        } else {
+            const float* vm = A.vmean ? A.vmean + (gidx / A.nblk) * BS : nullptr;
+            const float* vs = A.vstd ? A.vstd + (gidx / A.nblk) * BS : nullptr;
+            status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+        }
     }
     uint32_t h[BS / 2];
 #pragma unroll

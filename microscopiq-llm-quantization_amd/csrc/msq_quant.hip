@@ -252,10 +252,11 @@ k_mxops_stats(const float* __restrict__ in, float* __restrict__ vmean, float* __
 
 // Row-parallel form of the same statistics for contiguous blocks (post == 1, BS a multiple of 32, K % BS == 0):
 // one workgroup per row; thread (r, b) sums the 16-block runs r, r+R, ... of column b exactly as torch's
-// cascade does (each run starts from 0), thread (0, b) then folds the run sums in cascade order.  The
-// double-precision std is accumulated as shifted sums per thread and combined; it is rounded to float
-// only when it is provably on the same side of the rounding boundary as torch's Welford result, else the
-// column is redone sequentially.  Reads each row once, coalesced.
+// cascade does (each run starts from 0), thread (0, b) then folds the run sums in cascade order.  The std is a
+// two-pass variance in double (column mean first, then squared deviations, every thread over its own runs); it is
+// rounded to float only when it is provably on the same side of the rounding boundary as torch's sequential
+// Welford result (both are within a few hundred double ulps of the exact value), else the column is redone
+// sequentially (about one column in 500 000).  Reads each row twice (second time from L2), coalesced.
 template <int BS>
 __global__ void __launch_bounds__(256)
 k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, float* __restrict__ vstd,
@@ -263,35 +264,45 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
     constexpr int R = 256 / BS;                 // threads per column
     constexpr int MAXRUNS = 64;                 // nblk <= 1024
     __shared__ float run_sum[MAXRUNS + 1][BS];
-    __shared__ double part_s[R][BS], part_q[R][BS];
+    __shared__ double part_s[R][BS], part_q[R][BS], part_d[R][BS];
     const int b = threadIdx.x % BS, r = threadIdx.x / BS;
     const int64_t p = blockIdx.x;
     const float* row = in + p * axis_len;
     const int nruns = (int)(nblk / 16), tail = (int)(nblk % 16);
-    const double shift = (double)row[b];        // element of block 0: keeps the shifted sums small
-    double ds = 0.0, dq = 0.0;
+    const bool has_tail = (r == (nruns % R));
+    double ds = 0.0;
     for (int j = r; j < nruns; j += R) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = row[(int64_t)(j * 16 + i) * BS + b];
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = row[(int64_t)(j * 16 + i) * BS + b];
-            acc += v;
-            const double d = (double)v - shift;
-            ds += d; dq = __builtin_fma(d, d, dq);
-        }
+        for (int i = 0; i < 16; ++i) { acc += v[i]; ds += (double)v[i]; }
         run_sum[j][b] = acc;
     }
-    if (r == (nruns % R)) {                      // the tail run (may be empty)
+    if (has_tail) {                              // the tail run (may be empty)
         float acc = 0.f;
-        for (int i = 0; i < tail; ++i) {
-            const float v = row[(int64_t)(nruns * 16 + i) * BS + b];
-            acc += v;
-            const double d = (double)v - shift;
-            ds += d; dq = __builtin_fma(d, d, dq);
-        }
+        for (int i = 0; i < tail; ++i) { const float v = row[(int64_t)(nruns * 16 + i) * BS + b]; acc += v; ds += (double)v; }
         run_sum[MAXRUNS][b] = acc;
     }
-    part_s[r][b] = ds; part_q[r][b] = dq;
+    part_s[r][b] = ds;
+    __syncthreads();
+    double S = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) S += part_s[k][b];
+    const double n = (double)nblk;
+    const double dmean = S / n;
+    double dq = 0.0, dd = 0.0;                   // sum of squared / plain deviations from dmean
+    for (int j = r; j < nruns; j += R) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = row[(int64_t)(j * 16 + i) * BS + b];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const double d = (double)v[i] - dmean; dq = __builtin_fma(d, d, dq); dd += d; }
+    }
+    if (has_tail)
+        for (int i = 0; i < tail; ++i) { const double d = (double)row[(int64_t)(nruns * 16 + i) * BS + b] - dmean; dq = __builtin_fma(d, d, dq); dd += d; }
+    part_q[r][b] = dq; part_d[r][b] = dd;
     __syncthreads();
     if (r != 0) return;
     // cascade fold (ATen: level-1 accumulator folded every 256 elements, level-2 every 4096)
@@ -304,22 +315,33 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
     }
     float acc0 = run_sum[MAXRUNS][b];
     acc0 += acc1; acc0 += acc2; acc0 += acc3;
-    double S = 0.0, Q = 0.0;
+    double Q = 0.0, D = 0.0;
 #pragma unroll
-    for (int k = 0; k < R; ++k) { S += part_s[k][b]; Q += part_q[k][b]; }
-    const double n = (double)nblk;
+    for (int k = 0; k < R; ++k) { Q += part_q[k][b]; D += part_d[k][b]; }
     double den = n - 1.0; den = den < 0 ? 0 : den;
-    double m2 = Q - S * S / n; m2 = m2 < 0 ? 0 : m2;
+    double m2 = Q - D * D / n; m2 = m2 < 0 ? 0 : m2;      // corrected two-pass: no cancellation
     double sdd = __builtin_sqrt(m2 / den);
     const uint64_t bits = __builtin_bit_cast(uint64_t, sdd);
     const uint32_t dropped = (uint32_t)(bits & 0x1FFFFFFFull);
     const uint32_t dist = dropped > 0x10000000u ? dropped - 0x10000000u : 0x10000000u - dropped;
-    // the shifted-sum form loses up to ~33 n ulps when the shift was good (|S|^2/n <= 16 m2): accept it
-    // only then, and only when the result is farther than 512 n double ulps from a float boundary
-    const bool safe = (dist > 512u * (uint32_t)nblk) && (sdd == sdd) && (sdd > 1e-150) && (sdd < 1e150) && (S * S / n <= 16.0 * m2);
+    // two-pass error <= ~(n / 2 + 3) ulps, sequential Welford <= ~2 n ulps: a band of 4 n + 64 ulps is safe
+    const bool safe = (dist > 4u * (uint32_t)nblk + 64u) && (sdd == sdd) && (sdd > 1e-150) && (sdd < 1e150);
     if (!safe) {
         double mean = 0.0; m2 = 0.0;
-        for (int64_t i = 0; i < nblk; ++i) {
+        int64_t i = 0;
+        for (; i + 16 <= nblk; i += 16) {                    // loads in batches, the recurrence stays sequential
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = row[(i + u) * BS + b];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double d = (double)v[u];
+                const double delta = d - mean;
+                mean = mean + delta / (double)(i + u + 1);
+                m2 = m2 + delta * (d - mean);
+            }
+        }
+        for (; i < nblk; ++i) {
             const double d = (double)row[i * BS + b];
             const double delta = d - mean;
             mean = mean + delta / (double)(i + 1);

@@ -228,6 +228,19 @@ def test_act_quant_and_w4a8_vs_oracle(msq, O, variant, std_dev, afmt):
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
+def test_act_quant_wide_rows_vs_oracle(msq, O):
+    """K = 2048 / 4096 with block 32: 64 / 128 blocks per row, so a wave's 64 blocks share one row and the
+    mx_ops statistics are read through scalar loads (wave-uniform tables); bit-equal to the oracle."""
+    g = torch.Generator().manual_seed(12)
+    for M, K in ((5, 2048), (3, 4096)):
+        X = torch.randn(M, K, generator=g)
+        X[torch.rand(M, K, generator=g) < 0.02] *= 12
+        for variant, sd in ((1, 5), (0, 2)):
+            xq, st = msq.qlinear.act_quant(X.to(dev()), 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant)
+            Xo = O.outlier_fakequant(X.numpy(), 8, 8, "fp8_e4m3", "fp8_e4m3", sd, -1, 32, variant=("quant", "mx_ops")[variant])["out"]
+            assert int(st.item()) == 0 and _eq(xq.float().cpu().numpy(), Xo).all(), (M, K, variant)
+
+
 def test_act_quant_rejects_wide_formats(msq):
     x = torch.randn(4, 64, device=dev())
     with pytest.raises(msq._lib.MsqError):
