@@ -83,6 +83,21 @@ def sec_gemm():
                 del P, Wu
 
 
+def sec_cfgb():
+    print("# reference harness default (cfg B: int2 inliers / fp4 outliers, blocks of 16 along out_features, llm/llama.py:229-237):")
+    print("#   fake-quant with the fused kernel, values packed as they are (msq_pack_values), fused GEMM")
+    N, K = 16384, 4096
+    W = synth(N, K)
+    Wq = msq.quant.quantize_mx_outlier_v1(W, 8, 8, "int2", "fp4", "max", 2, [0], 16)
+    P = qlinear.pack_values(Wq)
+    ms = t(lambda: qlinear.pack_values(Wq), 10)
+    print(f"pack_values -> kind {P.out_kind} {P.bits_per_element:.2f} b/w: {ms*1e3:6.0f} us ({(N*K*4+P.nbytes)/ms/1e6:5.0f} GB/s, incl. allocations and status read-back)")
+    for M in (1, 16, 2048, 8192):
+        X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        ms = t(lambda: qlinear.qlinear(X, P))
+        print(f"cfg B N{N} K{K} M{M:5d}: {ms*1e3:7.1f} us {2*M*N*K/ms/1e9:7.1f} TF")
+
+
 def sec_w4a8():
     print("# msq_act_quant_bf16 / msq_qlinear_w4a8, X[2048,4096] f32 (act-quant algorithmic bytes = numel * 6)")
     M, K, N = 2048, 4096, 16384
@@ -91,12 +106,13 @@ def sec_w4a8():
         ms = t(lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant), 50)
         print(f"act_quant variant {variant}: {ms*1e3:6.1f} us  {M*K*6/ms/1e6:5.0f} GB/s (host-side launch overhead included)")
     W = synth(N, K)
-    P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp4_e2m1", 5, 32, variant=1)
+    from msq.mx_ops import _quantize_mx_outlier_v1
+    P = qlinear.pack_values(_quantize_mx_outlier_v1(W, 8, 8, "fp4_e2m1", "fp4_e2m1", "max", 5, [1], 32))
     ms = t(lambda: qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_std_dev=5, a_variant=1))
     print(f"qlinear_w4a8 (MXLinear semantics) M{M} N{N} K{K}: {ms*1e3:6.1f} us  {2*M*N*K/ms/1e9:6.1f} TF")
 
 
-SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "w4a8": sec_w4a8}
+SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8}
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)
     print("device:", torch.cuda.get_device_name(0))
