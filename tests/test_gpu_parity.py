@@ -228,6 +228,31 @@ def test_act_quant_and_w4a8_vs_oracle(msq, O, variant, std_dev, afmt):
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
+def test_w4a8_decode_and_zero_weight_edge_cases(msq, O):
+    """W4A8 through the decode kernel (M <= 16), an all-zero weight (every scale byte is the neutral 127, codes 0)
+    and a bias-only result."""
+    g = torch.Generator().manual_seed(13)
+    K, N = 512, 256
+    X = torch.randn(3, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.02
+    bias = torch.randn(N, generator=g)
+    P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="unified")
+    Wo = O.outlier_fakequant(W.numpy(), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    Xo = O.outlier_fakequant(X.numpy(), 8, 8, "fp8_e4m3", "fp8_e4m3", 2, -1, 32)["out"]
+    y = msq.qlinear.qlinear_w4a8(X.to(dev()), P, bias.to(dev()), torch.float32, check_status=True).cpu().numpy()
+    ref = O.linear(Xo, Wo, bias.numpy())
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+    Z = torch.zeros(N, K, device=dev())
+    for layout in ("unified", "planes"):
+        Pz = msq.qlinear.pack_weight(Z, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout=layout)
+        assert torch.equal(msq.qlinear.unpack_weight(Pz), Z)
+        for M in (2, 40):
+            yz = msq.qlinear.qlinear(torch.randn(M, K, device=dev()).to(torch.bfloat16), Pz, bias.to(dev()), torch.float32)
+            assert torch.equal(yz, bias.to(dev()).expand(M, N))
+    Pv = msq.qlinear.pack_values(Z)
+    assert Pv.out_kind == 5 and torch.equal(msq.qlinear.unpack_weight(Pv), Z)
+
+
 def test_act_quant_wide_rows_vs_oracle(msq, O):
     """K = 2048 / 4096 with block 32: 64 / 128 blocks per row, so a wave's 64 blocks share one row and the
     mx_ops statistics are read through scalar loads (wave-uniform tables); bit-equal to the oracle."""
