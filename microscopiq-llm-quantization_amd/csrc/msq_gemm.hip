@@ -517,7 +517,10 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     const int kt_last = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);
     const int kt0 = (kt_lo < KT) ? kt_lo : KT - 1;             // an empty split still runs a harmless prologue
     const int kt1 = (kt0 + 1 <= kt_last) ? kt0 + 1 : kt_last;
+    // activation tiles: three LDS buffers, staged TWO K-steps ahead (an L2 miss of the activation stream is as
+    // long as a K-step; with one step of distance the wait before the barrier exposed it)
     stage_A(kt0, 0);
+    if (kt0 + 1 <= kt_last) stage_A(kt0 + 1, 1);
     load_half_buf<IN_KIND, OUT_KIND>(pk0, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
     load_half_buf<IN_KIND, OUT_KIND>(pk1, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
     if (DEEP) {
@@ -549,21 +552,26 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted
     // one half-step earlier (LOAD1, LOAD2) receive (kt + 2, kf 0) and (kt + 2, kf 1).
     constexpr int N_INFLIGHT = HalfLoads<IN_KIND, OUT_KIND>::n * (DEEP ? 2 : 1);
+    constexpr int N_WAIT_ST = N_INFLIGHT + 4;                  // + the 4 LDS-DMA ops of the tile staged in this K-step
+    int abuf = 0;
 #define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                       \
     {                                                                                                        \
         const int kt_ = (KT_CUR);                                                                            \
-        const int buf = (kt_ - kt_lo) & 1;                                                                   \
+        const int buf = abuf;                                                                                \
+        const int buf2 = (abuf == 0) ? 2 : abuf - 1;             /* (abuf + 2) % 3 */                          \
+        abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int ktn = (kt_ + 1 <= kt_last) ? kt_ + 1 : kt_last;   /* branch-free tail: re-load the last tile */ \
-        const int ktnn = DEEP ? ((kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last) : ktn;                            \
+        const int ktnn2 = (kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last;                                          \
+        const int ktnn = DEEP ? ktnn2 : ktn;                                                                 \
         /* ---- half-step kf = 0: MFMAs on wfA, make wfB from CONV1 (loaded three half-steps ago) */        \
         keep_live(CONV1);                    /* take the vmcnt wait BEFORE new loads are issued */            \
-        /* no staging in the last K-step: the copy would be unused, and in the odd-tail instance of this     \
-           macro the compiler drops the (dead) packed loads, so the vmcnt below would no longer cover an     \
-           LDS-DMA that then lands in the epilogue's LDS staging (seen once in ~1500 launches) */           \
-        if (!(MSQ_ABL & 8) && kt_ < kt_last) stage_A(ktn, buf ^ 1);                                          \
+        /* branch-free tail: the last two K-steps re-stage the last tile into a buffer nobody reads; every   \
+           LDS-DMA is drained (vmcnt(0) + barrier) before the epilogue reuses the LDS */                     \
         if (HAS_SCALE) { if (DEEP) sc_nn = load_scales(tile_row32 + ktnn); else sc_nxt = load_scales(tile_row32 + ktn); } \
-        __builtin_amdgcn_sched_barrier(0);   /* the LDS-DMA and the scales are OLDER than the loads below */ \
+        __builtin_amdgcn_sched_barrier(0);   /* issue order (vmcnt is in-order): scales, LDS-DMA, packed loads */ \
+        if (!(MSQ_ABL & 8)) stage_A(ktnn2, buf2);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD1, pr, lane16, (tile_row32 + ktnn) * 2u + 0u); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         MSQ_HALF_STEP(wfA, wfB, CONV1, sc_cur, 1, rd0)                                                       \
@@ -576,7 +584,10 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
            than the two packed load groups of this K-step (vmcnt is in-order), which stay in flight.  hipcc \
            derives its own waits from register uses only and does not cover the LDS-DMA (stale 8-row         \
            activation pieces were seen without this once two blocks shared a CU). */                         \
-        __builtin_amdgcn_s_waitcnt(0x0070 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14));                  \
+        /* the tile staged in THIS K-step (4 LDS-DMA ops, older than the packed loads and younger than the    \
+           scale load thanks to the sched_barriers above) may stay in flight too: it is needed two barriers   \
+           from now */                                                                                       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT_ST & 15) | ((N_WAIT_ST >> 4) << 14));                    \
         sc_cur = sc_nxt; if (DEEP) sc_nxt = sc_nn;                                                           \
         __builtin_amdgcn_s_barrier();                                                                        \
     }
@@ -596,7 +607,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 #undef MSQ_K_STEP
 #undef MSQ_HALF_STEP
 
-    // nothing of this block may still be writing LDS (belt and braces: no LDS-DMA is in flight here by construction)
+    // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
@@ -1037,7 +1048,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     int ksplit = pick_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;   // no scratch: one pass
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256 * wm_sel);
-    const size_t lds = (size_t)2 * 128 * wm_sel * BK * 2;
+    const size_t lds = (size_t)3 * 128 * wm_sel * BK * 2;     // three activation buffers
     hipStream_t st = (hipStream_t)stream;
     const int groups = groups0;
     float* partial = (float*)workspace;
