@@ -346,21 +346,31 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
             const int ei = (int)se_in, eo = (int)se_out - (int)se_in;
             const float s_in = u2f((uint32_t)(ei + 127) << 23), s_eff = u2f((uint32_t)(eo + 127) << 23);
             const float b_in = A.fi.max_norm * s_in, b_out = A.fo.max_norm * s_eff;   // exact (|exponent| <= 120)
-#pragma unroll
-            for (int b = 0; b < BS; b += 2) {
-                const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);
-                float vi0, vi1, vo0, vo1;
-                hw_codec_pair(in_hw, x0, x1, s_in, b_in, vi0, vi1);
-                if (HW == 1) {
-                    hw_codec_pair(out_hw, x0, x1, s_eff, b_out, vo0, vo1);
-                } else {                                         // posit outliers, reference op order (:216,:247,:258)
-                    vo0 = (posit_round_fast((a[b] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in;
-                    vo1 = (posit_round_fast((a[b + 1] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in;
-                }
-                const bool m0 = (mkw[b >> 5] >> (b & 31)) & 1u, m1 = (mkw[(b + 1) >> 5] >> ((b + 1) & 31)) & 1u;
-                a[b] = (m0 ? vo0 : vi0) + 0.0f;
-                a[b + 1] = (m1 ? vo1 : vi1) + 0.0f;
+            // the format kinds are wave-uniform run-time values: select a loop specialised on them once, outside
+            // the element loop (a per-pair switch costs four scalar branches per pair and serialises the pairs)
+            const int combo = in_hw * 4 + ((HW == 1) ? out_hw : 0);
+#define MSQ_HW_LOOP(KI, KO)                                                                                   \
+            _Pragma("unroll") for (int b = 0; b < BS; b += 2) {                                               \
+                const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);                           \
+                float vi0, vi1, vo0, vo1;                                                                     \
+                hw_codec_pair(KI, x0, x1, s_in, b_in, vi0, vi1);                                              \
+                if (HW == 1) {                                                                                \
+                    hw_codec_pair(KO, x0, x1, s_eff, b_out, vo0, vo1);                                        \
+                } else {                                 /* posit outliers, reference op order (:216,:247,:258) */ \
+                    vo0 = (posit_round_fast((a[b] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in; \
+                    vo1 = (posit_round_fast((a[b + 1] * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in; \
+                }                                                                                             \
+                const bool m0 = (mkw[b >> 5] >> (b & 31)) & 1u, m1 = (mkw[(b + 1) >> 5] >> ((b + 1) & 31)) & 1u; \
+                a[b] = (m0 ? vo0 : vi0) + 0.0f;                                                               \
+                a[b + 1] = (m1 ? vo1 : vi1) + 0.0f;                                                           \
             }
+            if (combo == 3 * 4 + 1) { MSQ_HW_LOOP(3, 1) }        // e2m1 inliers, e4m3 outliers
+            else if (combo == 3 * 4 + 0) { MSQ_HW_LOOP(3, 0) }   // e2m1 inliers, posit outliers (HW == 2)
+            else if (combo == 1 * 4 + 1) { MSQ_HW_LOOP(1, 1) }   // e4m3 / e4m3 (activations)
+            else if (combo == 3 * 4 + 2) { MSQ_HW_LOOP(3, 2) }   // e2m1 / e5m2
+            else if (combo == 3 * 4 + 3) { MSQ_HW_LOOP(3, 3) }   // e2m1 / e2m1 (MXLinear weights)
+            else { MSQ_HW_LOOP(in_hw, out_hw) }                  // any other pair: kinds stay run-time values
+#undef MSQ_HW_LOOP
             se_in_o = se_in; se_out_o = se_out;
             return status;
         }
