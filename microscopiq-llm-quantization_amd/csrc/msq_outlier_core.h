@@ -242,9 +242,11 @@ MSQ_D float std_twopass_checked(const float (&x)[BS], int correction) {
     return std_welford<BS>(x, correction);
 }
 
-// formats the gfx950 scaled converts implement: 1 = OCP e4m3, 2 = OCP e5m2, 3 = e2m1; 0 = none
+// formats with a short exact codec: the gfx950 scaled converts (1 = OCP e4m3, 2 = OCP e5m2, 3 = e2m1) and
+// 4 = int2 (values {-1, 0, 1} x scale: one compare and one select, formats.py:87-95); 0 = none
 MSQ_HD int hw_codec_kind(const Fmt& f) {
     if (f.kind != 0) return 0;
+    if (f.ebits == 0 && f.mbits == 2) return 4;
     if (f.ebits == 4 && f.mbits == 5) return 1;
     if (f.ebits == 5 && f.mbits == 4) return 2;
     if (f.ebits == 2 && f.mbits == 3) return 3;
@@ -255,7 +257,11 @@ MSQ_D void hw_codec_pair(int kind, float x0, float x1, float s, float bound, flo
     typedef short v2s_t __attribute__((ext_vector_type(2)));
     typedef float v2f_t __attribute__((ext_vector_type(2)));
     v2f_t v;
-    if (kind == 3) {                                             // saturates by itself
+    if (kind == 4) {                                             // int2: round half away of |x| / s, clamped to 1
+        const float h = 0.5f * s;                                // exact (s is a power of two)
+        v[0] = (__builtin_fabsf(x0) >= h) ? __builtin_copysignf(s, x0) : 0.f;
+        v[1] = (__builtin_fabsf(x1) >= h) ? __builtin_copysignf(s, x1) : 0.f;
+    } else if (kind == 3) {                                      // saturates by itself
         const uint32_t c = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, x0, x1, s, 0);
         v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(c, s, 0);
     } else {
@@ -369,6 +375,7 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
             else if (combo == 1 * 4 + 1) { MSQ_HW_LOOP(1, 1) }   // e4m3 / e4m3 (activations)
             else if (combo == 3 * 4 + 2) { MSQ_HW_LOOP(3, 2) }   // e2m1 / e5m2
             else if (combo == 3 * 4 + 3) { MSQ_HW_LOOP(3, 3) }   // e2m1 / e2m1 (MXLinear weights)
+            else if (combo == 4 * 4 + 3) { MSQ_HW_LOOP(4, 3) }   // int2 / fp4: the reference harness default
             else { MSQ_HW_LOOP(in_hw, out_hw) }                  // any other pair: kinds stay run-time values
 #undef MSQ_HW_LOOP
             se_in_o = se_in; se_out_o = se_out;
