@@ -17,8 +17,9 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
 
-def t(fn, n=20):
-    for _ in range(5):
+def t(fn, n=20, warm=30):
+    # the first few dozen launches after an idle phase run at lower clocks: warm up first
+    for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
