@@ -201,6 +201,7 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
 /* fused unpack-dequant-GEMM: Y[M,N] = X[M,K] (bf16) . W^T (+ bias f32 [N] or NULL), fp32 accumulate on
  * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 2 = bf16.  Replaces the dense F.linear the reference
  * runs on the fake-quantised weight (number_system/mx/linear.py:91, llm/llama.py:255-256).
+ * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0 (M <= 16 takes the decode kernel).
  * When M is small the kernel splits K over several workgroups (so that all 256 CUs stream the weight) and
  * reduces fp32 partial tiles from `workspace` (msq_qlinear_workspace_bytes(); NULL = single pass). */
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
