@@ -231,6 +231,26 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
                      int a_flush_fp32_subnorms, int a_variant, int* status_flag, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * MX-native W4A8 Linear -- NEW (BASELINE config 3, "CDNA4 fp8 MFMA path"): plain OCP-MX operands (block 32 along K,
+ * number_system/mx/mx_ops.py:332-457 _quantize_mx; native semantics cpp/mx.cuh, cpp/shared_exp.cuh, scale_bits 8,
+ * round to nearest): e4m3 activation codes x e2m1 weight codes with E8M0 block scales, multiplied by
+ * v_mfma_scale_f32_16x16x128_f8f6f4 without any dequantisation.
+ *   msq_mx_pack_a8: X [M,K] f32 -> codes [M*K] bytes (row-major) + scales [M*K/32] bytes.        K % 128 == 0
+ *   msq_mx_pack_w4: W [N,K] f32 -> codes [N*K/2] bytes in MFMA operand order (tile 64 n x 128 k, slot nf = 16 n,
+ *                   lane (n % 16, (k % 128) / 32) holds 32 k = 16 B) + scales [N*K/32] bytes ([tile][lane][nf]).
+ *                   N % 64 == 0 (N % 256 == 0 for the GEMM), K % 128 == 0.  4.25 bits per weight.
+ *   msq_qlinear_mx_w4a8: Y [M,N] = dq(X) . dq(W)^T + bias, y_dtype 0 = f32 / 2 = bf16.  The MFMA sums the 128
+ *                   products of one instruction with ~15 bits relative to the largest term: tolerance 1e-4 max|y|.
+ * status_flag receives MSQ_STATUS_NAN when a block holds Inf / NaN or its scale overflows.
+ * ------------------------------------------------------------------------- */
+int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                   int flush_fp32_subnorms, void* stream);
+int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
+                   int flush_fp32_subnorms, void* stream);
+int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
+                        const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -620,6 +620,153 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 }
 
 // ---------------------------------------------------------------------------
+// MX-native W4A8 GEMM (BASELINE config 3, "CDNA4 fp8 MFMA path"): plain OCP-MX operands (mx_ops.py:332-457, block 32
+// along K): e2m1 weight codes x e4m3 activation codes, both with E8M0 block scales, multiplied by
+// v_mfma_scale_f32_16x16x128_f8f6f4 -- no dequantisation at all: the codes and the scale bytes ARE the operands.
+// Same skeleton as k_qgemm3: block 128(m) x 256(n), 4 waves 1 x 4, wave tile 128 x 64, K-step 128 (one MFMA k),
+// two blocks per CU; activation codes global -> LDS by LDS-DMA (128 rows x 128 B per K-step: the same geometry and
+// swizzle as the bf16 tile), three buffers staged two K-steps ahead; weight codes (16 B per lane and 16 n) and scale
+// bytes stream from global memory in operand order, three K-steps deep.
+// Operand layout measured on MI355X (scripts/experiments/mx_mfma_probe.hip, mx_mfma_layout.hip): lane (r = l & 15,
+// kg = l >> 4); fp4: 32 consecutive k = 32 kg .. of row r in VGPR 0-3; fp8: k = 16 kg .. +15 in VGPR 0-3 and
+// k = 64 + 16 kg .. +15 in VGPR 4-7; the scale VGPR of lane (r, kg) carries the E8M0 byte of block kg of row r;
+// result D[lane, e] = C[a-row 4 (l >> 4) + e][b-col l & 15].
+// The MFMA accumulates the 128 products of one instruction with ~15 bits relative to the largest term (measured
+// against exact arithmetic), looser than the fp32 accumulation of the bf16 path: tolerance 1e-4 * max|y|.
+// ---------------------------------------------------------------------------
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+template <typename YT>
+__global__ void __launch_bounds__(256, 2)
+k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
+         const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BMX = 128, KS = 128, A_TILE = BMX * KS;         // 16 KiB per activation buffer
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid;
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + BMX - 1) / BMX, NTB = N / BN;
+    const int KT = K / KS;
+    const int bid = (int)blockIdx.x;
+    int bm, bn;
+    if ((NTB & 7) == 0) {                                          // XCD-aware order, as k_qgemm3
+        const int xcd = bid & 7, i = bid >> 3;
+        const int npx = NTB >> 3, per_group = 8 * npx, full = MT >> 3;
+        int rg, j, R;
+        if (i < full * per_group) { rg = i / per_group; j = i % per_group; R = 8; }
+        else { rg = full; j = i - full * per_group; R = MT - full * 8; }
+        bm = rg * 8 + j % R;
+        bn = (j / R) * 8 + xcd;
+    } else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * BMX, n0 = bn * BN;
+    const int64_t wtiles = (int64_t)(N / 64) * KT;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * 4096);
+    const __amdgpu_buffer_rsrc_t wsr = make_rsrc(Ws, wtiles * 256);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xc, (int64_t)M * K);
+    const __amdgpu_buffer_rsrc_t xsr = make_rsrc(Xs, (int64_t)M * (K / 32));
+    const uint32_t tile_row32 = (uint32_t)((n0 / 64 + wn) * KT);
+    const int lane16 = lane * 16;
+    // activation staging: piece = 4 wid + p covers rows 8 piece .. +7, 16-byte chunk (lane & 7) ^ ((row >> 1) & 7)
+    int aoff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (wid * 4 + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        aoff[p] = (int)((int64_t)gr * K + chunk * 16);
+    }
+    // the 4 scale bytes of (row, K-step) travel with the tile: every wave copies one dword per row for its 32 rows
+    // (lanes 32-63 repeat lanes 0-31 into the upper half of the wave's 256 bytes: no wave-dependent branch, the
+    // same number of vector-memory ops in every wave)
+    constexpr int XS_BASE = 3 * A_TILE;
+    int xs_goff = m0 + wid * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
+    auto stage_A = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 4 + p) * 1024),
+                                                     16, aoff[p], uni((uint32_t)kt * KS), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem + XS_BASE + buf * 1024 + wid * 256),
+                                                 4, xs_goff, uni((uint32_t)kt * 4u), 0, 0);
+    };
+    // LDS reads of one B fragment (row mf * 16 + c): chunks g and 4 + g (k = 16 g .. and 64 + 16 g ..)
+    const int sw = (c >> 1) & 7;
+    const int rdl = c * 128 + ((g ^ sw) << 4), rdh = c * 128 + (((4 + g) ^ sw) << 4);
+    // scale byte of (row mf * 16 + c, block g): row r lives at wave r / 32, slot r % 32: + (mf / 2) * 256 + (mf % 2) * 64
+    const int xs_rd = XS_BASE + c * 4 + g;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    struct WSet { u32x4_t w[4]; uint32_t s; };
+    WSet w0, w1;
+    auto load_w = [&](WSet& ws, int kt) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+            ws.w[nf] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni(((tile_row32 + (uint32_t)kt) * 4u + nf) * 1024u), 0));
+        ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
+    };
+    const int kl = KT - 1;
+    stage_A(0, 0);
+    if (KT > 1) stage_A(1, 1);
+    load_w(w0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+#define MSQ_MX_STEP(KT_CUR, WCUR, WLOAD)                                                                      \
+    {                                                                                                        \
+        const int kt_ = (KT_CUR);                                                                            \
+        const int buf = abuf, buf2 = (abuf == 0) ? 2 : abuf - 1;                                             \
+        abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
+        const char* abase = smem + buf * A_TILE;                                                             \
+        const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
+        load_w(WLOAD, k1);                   /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        stage_A(k2, buf2);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        u32x4_t xl[2], xh[2];                                                                                \
+        xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh);             \
+        uint32_t xsc[2];                                                                                     \
+        xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024);                                \
+        _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
+            if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
+                              xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + (mf + 1) * 2048);                  \
+                              xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }   \
+            const u32x4_t lo = xl[mf & 1], hi = xh[mf & 1];                                                  \
+            const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
+            const int sb_ = (int)xsc[mf & 1];                                                                \
+            _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) {                                               \
+                const v8i_t afr = {(int)WCUR.w[nf][0], (int)WCUR.w[nf][1], (int)WCUR.w[nf][2], (int)WCUR.w[nf][3], 0, 0, 0, 0}; \
+                if (nf == 0) acc[mf][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][0], 4, 0, 0, (int)WCUR.s, 0, sb_); \
+                else if (nf == 1) acc[mf][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][1], 4, 0, 1, (int)WCUR.s, 0, sb_); \
+                else if (nf == 2) acc[mf][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][2], 4, 0, 2, (int)WCUR.s, 0, sb_); \
+                else acc[mf][3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][3], 4, 0, 3, (int)WCUR.s, 0, sb_); \
+            }                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+        /* only this K-step's 5 LDS-DMA ops (needed two                                                      \
+           barriers from now) stay in flight; the weights of K-step kt + 2 (older) are forced too, which is  \
+           harmless: they were issued a full K-step ago at the next wait */                                  \
+        __builtin_amdgcn_s_waitcnt(0x0070 | 5);                                                              \
+        __builtin_amdgcn_s_barrier();                                                                        \
+    }
+
+    int abuf = 0;
+    {
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) { MSQ_MX_STEP(kt, w0, w1) MSQ_MX_STEP(kt + 1, w1, w0) }
+        if (kt < KT) MSQ_MX_STEP(kt, w0, w1)
+    }
+#undef MSQ_MX_STEP
+    __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
+    __builtin_amdgcn_s_barrier();
+    store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Small-M (decode) kernel: M <= 16 (MG = 1; the template still takes MG 16-row groups).  HBM-bound: the job is to stream the packed weight once at full
 // rate.  One wave = one task = KC consecutive 64x64 packed tiles of one 64-column strip; per tile it
 // converts the 8 fragments and issues 8*MG MFMAs against the activation fragments, which it reads
@@ -1120,6 +1267,25 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
     if (rc) return rc;
     return msq_qlinear_bf16(xq, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, w_block, in_kind, out_kind,
                             gws, workspace_bytes - (gws - (char*)workspace), stream);
+}
+
+// MX-native W4A8 GEMM on pre-packed operands (msq_mx_pack_a8 / msq_mx_pack_w4)
+int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream) {
+    if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: negative M");
+    if (N <= 0 || K <= 0 || (N % BN) || (K % 128)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: N must be a multiple of 256 and K of 128");
+    if (!x_codes || !x_scales || !w_codes || !w_scales || !Y) return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: null buffer");
+    if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
+    if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
+    const int MT = (int)((M + 127) / 128), NTB = (int)(N / BN);
+    const dim3 grid((unsigned)(MT * NTB)), blk(256);
+    const size_t lds = 3 * 128 * 128 + 3 * 1024;              // three code tiles + three scale tiles
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == 0) hipLaunchKernelGGL(k_mxgemm<float>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
+                                         (const uint8_t*)w_scales, bias, (float*)Y, (int)M, (int)N, (int)K);
+    else hipLaunchKernelGGL(k_mxgemm<uint16_t>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
+                            (const uint8_t*)w_scales, bias, (uint16_t*)Y, (int)M, (int)N, (int)K);
+    return check_launch2("msq_qlinear_mx_w4a8");
 }
 
 }  // extern "C"

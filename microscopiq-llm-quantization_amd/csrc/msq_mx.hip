@@ -1,0 +1,158 @@
+// msq_mx.hip -- operand packing for the MX-native W4A8 GEMM (msq_gemm.hip k_mxgemm): plain OCP-MX block
+// quantisation (number_system/mx/mx_ops.py:332-457 _quantize_mx, native semantics cpp/mx.cuh / shared_exp.cuh,
+// block 32 along K, round to nearest = half away) emitting CODES + E8M0 scale bytes instead of fake-quant values:
+//   activations  X [M,K] f32 -> e4m3 codes [M][K] (row-major bytes) + scales [M][K/32]
+//   weights      W [N,K] f32 -> e2m1 codes in the operand order of v_mfma_scale_f32_16x16x128_f8f6f4
+//                (tile = 64 n x 128 k; slot nf = 16 n: lane (n % 16, (k % 128) / 32) holds 32 k = 16 bytes)
+//                + one scale byte per (lane, nf)
+// The codes come from the hardware converts (RNE of x | 1ulp == round half away, see msq_outlier_core.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+#include "msq_host.h"
+
+using namespace msq;
+
+extern "C" void msq_set_error_(const char* msg);
+
+namespace {
+
+// shared scale byte of a block (cpp/shared_exp.cuh:14-53 with scale_bits 8): biased max exponent - elem emax,
+// clamped to [0, 254]; 255 (NaN) when the block holds Inf / NaN
+MSQ_D int mx_scale_byte(int max_biased_exp, int elem_emax, int& status) {
+    if (max_biased_exp == 255) { status |= MSQ_STATUS_NAN; return 255; }
+    int e = max_biased_exp - elem_emax;
+    if (e - 127 > 127) { status |= MSQ_STATUS_NAN; return 255; }
+    if (e - 127 < -127) e = 0;
+    return e;
+}
+
+// A wave owns 64 consecutive blocks of 32 floats = one contiguous 8 KiB run: coalesced 16-byte loads, transpose
+// through LDS (row stride 36 words), one block per lane.  FP4: weights, codes scattered into the MFMA tile order;
+// otherwise activations, e4m3 codes written back row-major through the same LDS tile.
+template <bool FP4>
+__global__ void __launch_bounds__(256)
+k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t rows, int64_t K,
+          int flush, int* status_flag) {
+    constexpr int BS = 32, LDS_STRIDE = BS + 4;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nblk = K / BS, nblocks = rows * nblk;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (g0 >= nblocks) return;
+    const bool full = (g0 + 64 <= nblocks);
+    const int64_t g = g0 + lane;
+    float* tl = tile[wv];
+    float a[BS];
+    if (full) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + g0 * BS);
+#pragma unroll
+        for (int t = 0; t < BS / 4; ++t) {
+            const int f = lane + 64 * t;
+            const int row = f / (BS / 4), c4 = f % (BS / 4);
+            *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = s4[f];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int c = 0; c < BS / 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
+            a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) a[b] = (g < nblocks) ? src[g * BS + b] : 0.f;
+    }
+    int status = 0;
+    int se = 0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
+    const bool fl = (se == 0) && flush;
+    const int sb = mx_scale_byte(se, FP4 ? 2 : 8, status);
+    const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
+    const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
+    uint32_t cw[FP4 ? 4 : 8];
+#pragma unroll
+    for (int p = 0; p < BS / 2; ++p) {
+        typedef short v2s_t __attribute__((ext_vector_type(2)));
+        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | 1u), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | 1u);
+        if (FP4) {
+            uint32_t w = (p & 3) ? cw[p >> 2] : 0u;
+            if ((p & 3) == 0) w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 0);
+            else if ((p & 3) == 1) w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 1);
+            else if ((p & 3) == 2) w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 2);
+            else w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 3);
+            cw[p >> 2] = w;
+        } else {
+            x0 = __builtin_amdgcn_fmed3f(x0, -bound, bound); x1 = __builtin_amdgcn_fmed3f(x1, -bound, bound);   // e4m3 does not saturate
+            v2s_t cur = __builtin_bit_cast(v2s_t, (p & 1) ? cw[p >> 1] : 0u);
+            if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, false);
+            else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, true);
+            cw[p >> 1] = __builtin_bit_cast(uint32_t, cur);
+        }
+    }
+    // -0 codes are fine for the MFMA (no OR-combination here)
+    if (g < nblocks) {
+        const int64_t r = g / nblk, kb = g % nblk;
+        if (FP4) {
+            const int64_t KT = K / 128;
+            const int64_t t = (r / 64) * KT + kb / 4;
+            const int nf = (int)((r % 64) / 16), ln = (int)((kb % 4) * 16 + (r % 16));
+            *reinterpret_cast<uint4*>(codes + ((t * 4 + nf) * 64 + ln) * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            scales[(t * 64 + ln) * 4 + nf] = (uint8_t)sb;
+        } else {
+            scales[g] = (uint8_t)sb;
+        }
+    }
+    if (!FP4) {
+        if (full) {                                             // 8 words per block back through LDS, coalesced 16-byte stores
+            constexpr int HS = 12;                              // words per row (8 used; 48-byte rows keep 16-byte alignment)
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* tw = reinterpret_cast<uint32_t*>(tl);
+            *reinterpret_cast<uint4*>(tw + lane * HS) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            *reinterpret_cast<uint4*>(tw + lane * HS + 4) = make_uint4(cw[FP4 ? 0 : 4], cw[FP4 ? 1 : 5], cw[FP4 ? 2 : 6], cw[FP4 ? 3 : 7]);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            uint4* dst = reinterpret_cast<uint4*>(codes + g0 * BS);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int f = lane + 64 * t;                    // 16-byte piece index: block f / 2, half f % 2
+                dst[f] = *reinterpret_cast<const uint4*>(tw + (f >> 1) * HS + (f & 1) * 4);
+            }
+        } else if (g < nblocks) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) reinterpret_cast<uint32_t*>(codes + g * BS)[w] = cw[FP4 ? 0 : w];
+        }
+    }
+    if (status && status_flag) atomicOr(status_flag, status);
+}
+
+}  // namespace
+
+extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                              int flush_fp32_subnorms, void* stream) {
+    if (M < 0 || K < 0) { msq_set_error_("msq_mx_pack_a8: negative size"); return MSQ_ERR_BAD_ARG; }
+    if (M == 0 || K == 0) return MSQ_OK;
+    if (K % 128) { msq_set_error_("msq_mx_pack_a8: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8: null buffer"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = M * (K / 32);
+    hipLaunchKernelGGL((k_mx_pack<false>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+                       (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+extern "C" int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
+                              int flush_fp32_subnorms, void* stream) {
+    if (N <= 0 || K <= 0 || (N % 64) || (K % 128)) { msq_set_error_("msq_mx_pack_w4: N must be a multiple of 64 and K of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!W || !codes || !scales) { msq_set_error_("msq_mx_pack_w4: null buffer"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = N * (K / 32);
+    hipLaunchKernelGGL((k_mx_pack<true>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       (uint8_t*)codes, (uint8_t*)scales, N, K, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}

@@ -238,6 +238,79 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     return y.reshape(*x.shape[:-1], P.N)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# MX-native W4A8 (BASELINE config 3): plain OCP-MX operands, no outlier split, multiplied by the scaled fp8 / fp4 MFMA
+# ---------------------------------------------------------------------------------------------------------
+class MXPackedWeight:
+    """e2m1 codes in MFMA operand order + E8M0 block scales of one [N, K] weight (4.25 bits per weight)."""
+
+    def __init__(self, codes, scales, N, K):
+        self.codes, self.scales, self.N, self.K = codes, scales, N, K
+
+    @property
+    def nbytes(self):
+        return int(self.codes.numel() + self.scales.numel())
+
+    @property
+    def bits_per_element(self):
+        return 8.0 * self.nbytes / (self.N * self.K)
+
+
+def _mx_status(status, what):
+    if int(status.item()) & 1:
+        raise AssertionError("%s: a block holds Inf / NaN or its shared exponent overflows" % what)
+
+
+def mx_pack_weight(W, flush_fp32_subnorms=False):
+    """W [N, K] -> MX-FP4 (e2m1, block 32 along K, scale_bits 8, round nearest: mx_ops.py:332-457)."""
+    if not W.is_cuda:
+        raise MsqError("mx_pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
+    Wf = W.detach().contiguous().float()
+    N, K = Wf.shape
+    codes = torch.empty(N * K // 2, dtype=torch.uint8, device=Wf.device)
+    scales = torch.empty(N * K // 32, dtype=torch.uint8, device=Wf.device)
+    status = torch.zeros(1, dtype=torch.int32, device=Wf.device)
+    check(lib().msq_mx_pack_w4(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, int(bool(flush_fp32_subnorms)),
+                               current_stream(Wf.device)), "msq_mx_pack_w4")
+    _mx_status(status, "mx_pack_weight")
+    return MXPackedWeight(codes, scales, N, K)
+
+
+def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
+    """x [..., K] -> MX-FP8 (e4m3) codes [M, K] + scales [M, K / 32]."""
+    if not x.is_cuda:
+        raise MsqError("mx_pack_act needs a CUDA/HIP tensor (no CPU fallback)")
+    K = x.shape[-1]
+    xf = x.reshape(-1, K).float().contiguous()
+    M = xf.shape[0]
+    codes = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    scales = torch.empty(M, K // 32, dtype=torch.uint8, device=x.device)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device) if check_status else None
+    check(lib().msq_mx_pack_a8(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, int(bool(flush_fp32_subnorms)),
+                               current_stream(x.device)), "msq_mx_pack_a8")
+    if check_status:
+        _mx_status(status, "mx_pack_act")
+    return codes, scales
+
+
+def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False):
+    """y = MXFP8(x) . MXFP4(W)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4: one pass packs the activations,
+    the GEMM consumes codes and scale bytes directly."""
+    K = x.shape[-1]
+    if K != P.K:
+        raise MsqError("qlinear_mx_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
+    xc, xs = mx_pack_act(x, check_status=check_status)
+    M = xc.shape[0]
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
+    y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y),
+                                    0 if out_dtype == torch.float32 else 2, M, P.N, K, current_stream(x.device)),
+          "msq_qlinear_mx_w4a8")
+    return y.reshape(*x.shape[:-1], P.N)
+
+
 class QuantLinear(nn.Module):
     """Packed Linear.  ``pack(linear, quantizer)`` consumes an nn.Linear and an MXQuantizer
     (the GPTQ-style contract implied by llm/opt.py:255-264); state_dict round-trips the

@@ -266,6 +266,54 @@ def test_act_quant_wide_rows_vs_oracle(msq, O):
             assert int(st.item()) == 0 and _eq(xq.float().cpu().numpy(), Xo).all(), (M, K, variant)
 
 
+def _mx_unpack_w4(P):
+    """Decode MXPackedWeight planes on the host (layout of include/msq.h): returns dense [N, K] float64."""
+    codes = P.codes.cpu().numpy().reshape(P.N // 64, P.K // 128, 4, 64, 16)
+    scales = P.scales.cpu().numpy().reshape(P.N // 64, P.K // 128, 64, 4)
+    lut = np.array([0, .5, 1, 1.5, 2, 3, 4, 6, -0., -.5, -1, -1.5, -2, -3, -4, -6])
+    W = np.zeros((P.N, P.K))
+    for nf in range(4):
+        for ln in range(64):
+            r, kg = ln % 16, ln // 16
+            by = codes[:, :, nf, ln, :]                                  # [NT, KT, 16]
+            nib = np.stack([by & 15, by >> 4], axis=-1).reshape(by.shape[0], by.shape[1], 32)
+            val = lut[nib] * np.exp2(scales[:, :, ln, nf].astype(np.float64) - 127.0)[..., None]
+            for nt in range(P.N // 64):
+                for kt in range(P.K // 128):
+                    W[nt * 64 + nf * 16 + r, kt * 128 + kg * 32: kt * 128 + kg * 32 + 32] = val[nt, kt]
+    return W
+
+
+@pytest.mark.parametrize("M", [1, 16, 200, 300])
+def test_mx_native_w4a8_vs_oracle(msq, O, M):
+    """MX-native W4A8 (plain OCP-MX operands on v_mfma_scale_f32_16x16x128_f8f6f4): the packed operands decode to
+    the oracle's quantize_mx values bit for bit (a9: mx_ops.py:332-457), the GEMM equals the oracle's linear on them.
+    Tolerance 1e-4 * max|y|: the scaled MFMA sums the 128 products of one instruction with about 15 bits
+    relative to the largest term (scripts/experiments/mx_mfma_probe.hip), fp32 across instructions."""
+    g = torch.Generator().manual_seed(21)
+    N, K = 256, 512
+    W = torch.randn(N, K, generator=g) * 0.02
+    W[torch.rand(N, K, generator=g) < 0.01] *= 20
+    X = torch.randn(M, K, generator=g)
+    X[torch.rand(M, K, generator=g) < 0.02] *= 10
+    bias = torch.randn(N, generator=g)
+    P = msq.qlinear.mx_pack_weight(W.to(dev()))
+    assert abs(P.bits_per_element - 4.25) < 1e-9
+    Wo = O.quantize_mx(W.numpy(), 8, "fp4_e2m1", axis=-1, block_size=32)
+    assert (_mx_unpack_w4(P) == Wo.astype(np.float64)).all()
+    xc, xs = msq.qlinear.mx_pack_act(X.to(dev()), check_status=True)
+    Xo = O.quantize_mx(X.numpy(), 8, "fp8_e4m3", axis=-1, block_size=32)
+    e = xc.cpu().numpy().astype(np.int32)
+    sgn = np.where(e & 0x80, -1.0, 1.0); ex = (e >> 3) & 15; mant = e & 7
+    dec = sgn * np.where(ex > 0, (1 + mant / 8.0) * np.exp2(ex - 7.0), mant / 8.0 * 2.0 ** -6)
+    dec = dec * np.repeat(np.exp2(xs.cpu().numpy().astype(np.float64) - 127.0), 32, axis=1)
+    assert (dec == Xo.astype(np.float64)).all()
+    ref = O.linear(Xo, Wo, bias.numpy())
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2.0 ** -8)):
+        y = msq.qlinear.qlinear_mx_w4a8(X.to(dev()), P, bias.to(dev()), dt).float().cpu().numpy()
+        assert np.abs(y - ref).max() <= tol * np.abs(ref).max() + 1e-6, (str(dt), float(np.abs(y - ref).max()), float(np.abs(ref).max()))
+
+
 def test_act_quant_rejects_wide_formats(msq):
     x = torch.randn(4, 64, device=dev())
     with pytest.raises(msq._lib.MsqError):
