@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
 
 
 def synth_weight(N, K, dev, seed=0):
@@ -88,7 +89,7 @@ def main():
     ap.add_argument("--outlier", default="posit8_es1")
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama70b_rowparallel"])
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama70b_rowparallel"])
     ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
                     help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +125,17 @@ def main():
                 "X[%d,%d] x W[%d,%d]^T" % (args.outlier, M, K, N, K))
     W = synth_weight(N, K, dev, seed=rank)
     w4a8 = args.workload == "llama7b_w4a8"
-    if w4a8:
+    mxw4a8 = args.workload == "llama7b_mx_w4a8"
+    if mxw4a8:
+        # BASELINE config 3 on the CDNA4 MX matrix path: plain OCP-MX operands (mx_ops.py:332-457, block 32), MX-FP4
+        # weights x MX-FP8 (e4m3) activations on v_mfma_scale_f32_16x16x128_f8f6f4; a step = activation pack (fp32 in,
+        # one pass) + GEMM
+        name = ("Llama-2-7B W4A8 on the MX matrix path (MX-FP4 weights x MX-FP8 activations, scaled MFMA, no dequantisation), "
+                "act-pack + GEMM X[%d,%d] x W[%d,%d]^T" % (M, K, N, K))
+        args.inlier, args.outlier = "fp4_e2m1 (plain MX)", "none"
+        P = qlinear.mx_pack_weight(W)
+        X = torch.randn(M, K, device=dev)
+    elif w4a8:
         # BASELINE config 3 = MXLinear(w=fp4_e2m1, a=fp8_e4m3, block 32) semantics (mx_ops variant, std_dev 5):
         # a step = activation quantisation of X (fp32 in, one pass) + the fused dequant-GEMM
         name = ("Llama-2-7B W4A8 (MX-FP4 weights + FP8-e4m3 activations, MXLinear semantics), act-quant + fused "
@@ -140,6 +151,8 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        if mxw4a8:
+            return qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
         if w4a8:
             return qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5,
                                         a_block_size=args.block, a_variant=1)
@@ -184,18 +197,18 @@ def main():
         "metric": "fused dequant-GEMM TFLOPS (% MFMA peak) + PPL delta, Llama-7B W4 1xMI355X",
         "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "mxfp8 x mxfp4 (fp32 accumulate)" if mxw4a8 else "bf16", "data": "synthetic",
         "config": {"workload": name, "M": M, "N": N, "K": K, "block": args.block, "inlier": args.inlier,
                    "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element, "clock_ramp_launches": RAMP,
                    "layout": {(1, 2): "planes", (1, 3): "planes", (1, 4): "planes", (0, 4): "bf16", (0, 5): "unified",
-                              (0, 6): "unified+ext"}.get((P.in_kind, P.out_kind)),
+                              (0, 6): "unified+ext"}.get((getattr(P, "in_kind", -1), getattr(P, "out_kind", -1)), "mx operand order"),
                    "parallelism": ("replicas x%d" % world) if args.workload != "llama70b_rowparallel"
                    else ("row-parallel K/%d + RCCL all-reduce" % world)},
-        "pct_of_mfma_peak": 100.0 * (value / world) / PEAK_BF16_TFLOPS,
+        "pct_of_mfma_peak": 100.0 * (value / world) / (PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS),
         "ppl_delta": None,
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                     "kernel": "k_qgemm", "kernel_ms": kern_ms, "flops_per_launch": flops_step},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / (PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS), "traffic": None,
+                     "kernel": "k_mxgemm (+ k_mx_pack)" if mxw4a8 else "k_qgemm", "kernel_ms": kern_ms, "flops_per_launch": flops_step},
     }
     # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
     # scripts/profile_gpu.sh, scripts/summarize_profiles.py); they cannot be collected from inside this run.
