@@ -702,7 +702,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     struct WSet { u32x4_t w[4]; uint32_t s; };
-    WSet w0, w1;
+    WSet w0, w1, w2;
     auto load_w = [&](WSet& ws, int kt) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
@@ -712,7 +712,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     const int kl = KT - 1;
     stage_A(0, 0);
     if (KT > 1) stage_A(1, 1);
-    load_w(w0, 0);
+    load_w(w0, 0); load_w(w1, kl < 1 ? kl : 1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -723,7 +723,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
-        load_w(WLOAD, k1);                   /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
+        load_w(WLOAD, k2);                   /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         stage_A(k2, buf2);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -747,18 +747,18 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             }                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
-        /* only this K-step's 5 LDS-DMA ops (needed two                                                      \
-           barriers from now) stay in flight; the weights of K-step kt + 2 (older) are forced too, which is  \
-           harmless: they were issued a full K-step ago at the next wait */                                  \
-        __builtin_amdgcn_s_waitcnt(0x0070 | 5);                                                              \
+        /* this K-step's 5 weight loads and 5 LDS-DMA ops (all for K-step kt + 2) stay in flight; everything \
+           issued in the previous K-step -- the tile and the weights of K-step kt + 1 -- has landed */       \
+        __builtin_amdgcn_s_waitcnt(0x0070 | 10);                                                             \
         __builtin_amdgcn_s_barrier();                                                                        \
     }
 
     int abuf = 0;
     {
         int kt = 0;
-        for (; kt + 1 < KT; kt += 2) { MSQ_MX_STEP(kt, w0, w1) MSQ_MX_STEP(kt + 1, w1, w0) }
-        if (kt < KT) MSQ_MX_STEP(kt, w0, w1)
+        for (; kt + 2 < KT; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
+        if (kt < KT) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
+        if (kt < KT) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
     }
 #undef MSQ_MX_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS

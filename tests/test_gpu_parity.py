@@ -314,6 +314,26 @@ def test_mx_native_w4a8_vs_oracle(msq, O, M):
         assert np.abs(y - ref).max() <= tol * np.abs(ref).max() + 1e-6, (str(dt), float(np.abs(y - ref).max()), float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_mx_native_llama_shapes_repeatable(msq, N, K):
+    """MX-native GEMM at the Llama-7B layer shapes: equal to a dense fp32 GEMM on the decoded operands within the
+    stated tolerance and bit-identical run after run (LDS-DMA tiles + scale bytes cross waves: race detector)."""
+    g = torch.Generator(device=dev()).manual_seed(6)
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    P = msq.qlinear.mx_pack_weight(W)
+    Wd = torch.from_numpy(_mx_unpack_w4(P)).float().to(dev()) if N * K <= 4096 * 4096 else None
+    for M in (3, 130, 2048):
+        X = torch.randn(M, K, generator=g, device=dev())
+        Y0 = msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32)
+        if Wd is not None:
+            Xq = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32)
+            ref = Xq @ Wd.t()
+            assert (Y0 - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6
+        for _ in range(20):
+            assert torch.equal(msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32), Y0)
+
+
 def test_act_quant_rejects_wide_formats(msq):
     x = torch.randn(4, 64, device=dev())
     with pytest.raises(msq._lib.MsqError):
