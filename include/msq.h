@@ -248,8 +248,10 @@ int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, 
                    int flush_fp32_subnorms, void* stream);
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
+int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 only for small M (split-K) */
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
-                        const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+                        const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

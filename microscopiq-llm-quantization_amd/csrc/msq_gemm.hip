@@ -639,7 +639,8 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 template <typename YT>
 __global__ void __launch_bounds__(256, 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
-         const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K) {
+         const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+         int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BMX = 128, KS = 128, A_TILE = BMX * KS;         // 16 KiB per activation buffer
     const int tid = threadIdx.x, lane = tid & 63;
@@ -648,9 +649,13 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     const int c = lane & 15, g = lane >> 4;
     const int MT = (M + BMX - 1) / BMX, NTB = N / BN;
     const int KT = K / KS;
-    const int bid = (int)blockIdx.x;
+    const int ks = (int)(blockIdx.x % (unsigned)ksplit);           // split-K (small M): K-steps [kt_lo, kt_hi), fp32 partial tile
+    const int bid = (int)(blockIdx.x / (unsigned)ksplit);
+    const int kchunk = (KT + ksplit - 1) / ksplit;
+    const int kt_lo = ks * kchunk;
+    const int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
     int bm, bn;
-    if ((NTB & 7) == 0) {                                          // XCD-aware order, as k_qgemm3
+    if ((NTB & 7) == 0 && ksplit == 1) {                           // XCD-aware order, as k_qgemm3
         const int xcd = bid & 7, i = bid >> 3;
         const int npx = NTB >> 3, per_group = 8 * npx, full = MT >> 3;
         int rg, j, R;
@@ -709,10 +714,11 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             ws.w[nf] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni(((tile_row32 + (uint32_t)kt) * 4u + nf) * 1024u), 0));
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
-    const int kl = KT - 1;
-    stage_A(0, 0);
-    if (KT > 1) stage_A(1, 1);
-    load_w(w0, 0); load_w(w1, kl < 1 ? kl : 1);
+    const int kl = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);   // an empty split runs a harmless prologue
+    const int kf0 = (kt_lo < KT) ? kt_lo : KT - 1, kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
+    stage_A(kf0, 0);
+    stage_A(kf1, 1);
+    load_w(w0, kf0); load_w(w1, kf1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -755,15 +761,16 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 
     int abuf = 0;
     {
-        int kt = 0;
-        for (; kt + 2 < KT; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
-        if (kt < KT) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
-        if (kt < KT) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
+        int kt = kt_lo;
+        for (; kt + 2 < kt_hi; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
+        if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
+        if (kt < kt_hi) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
     }
 #undef MSQ_MX_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
-    store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
+    if (ksplit > 1) store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
+    else store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1269,23 +1276,49 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
                             gws, workspace_bytes - (gws - (char*)workspace), stream);
 }
 
-// MX-native W4A8 GEMM on pre-packed operands (msq_mx_pack_a8 / msq_mx_pack_w4)
+// MX-native W4A8 GEMM on pre-packed operands (msq_mx_pack_a8 / msq_mx_pack_w4).  Few row tiles (small M): K is
+// split over power-of-two many work items so that about one block per CU streams the weight; fp32 partial tiles
+// go through `workspace` (msq_qlinear_mx_w4a8_workspace_bytes; NULL = single pass).
+static int pick_mx_ksplit(int64_t M, int64_t N, int64_t K) {
+    const int64_t blocks = ((M + 127) / 128) * (N / BN), KT = K / 128;
+    if (blocks >= 192 || KT < 4) return 1;
+    int64_t ks = 1;
+    while (ks * blocks < 256) ks *= 2;
+    if (ks > KT / 2) ks = KT / 2;
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : (int)ks;
+}
+int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % 128)) return 0;
+    const int ks = pick_mx_ksplit(M, N, K);
+    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+}
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
-                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream) {
+                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: negative M");
     if (N <= 0 || K <= 0 || (N % BN) || (K % 128)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: N must be a multiple of 256 and K of 128");
     if (!x_codes || !x_scales || !w_codes || !w_scales || !Y) return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: null buffer");
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
     const int MT = (int)((M + 127) / 128), NTB = (int)(N / BN);
-    const dim3 grid((unsigned)(MT * NTB)), blk(256);
+    int ksplit = pick_mx_ksplit(M, N, K);
+    if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;
+    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
     const size_t lds = 3 * 128 * 128 + 3 * 1024;              // three code tiles + three scale tiles
     hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
     if (y_dtype == 0) hipLaunchKernelGGL(k_mxgemm<float>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
-                                         (const uint8_t*)w_scales, bias, (float*)Y, (int)M, (int)N, (int)K);
+                                         (const uint8_t*)w_scales, bias, (float*)Y, (int)M, (int)N, (int)K, ksplit, partial);
     else hipLaunchKernelGGL(k_mxgemm<uint16_t>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
-                            (const uint8_t*)w_scales, bias, (uint16_t*)Y, (int)M, (int)N, (int)K);
-    return check_launch2("msq_qlinear_mx_w4a8");
+                            (const uint8_t*)w_scales, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, ksplit, partial);
+    int rc = check_launch2("msq_qlinear_mx_w4a8");
+    if (rc || ksplit == 1) return rc;
+    const int64_t MN = M * N;
+    const dim3 rgrid((unsigned)((MN / 4 + 255) / 256));
+    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
+    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
+    return check_launch2("msq_qlinear_mx_w4a8(split-K reduce)");
 }
 
 }  // extern "C"

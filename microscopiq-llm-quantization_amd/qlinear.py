@@ -305,9 +305,11 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
         raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
     y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
     b = bias.detach().float().contiguous() if bias is not None else None
+    wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y),
-                                    0 if out_dtype == torch.float32 else 2, M, P.N, K, current_stream(x.device)),
-          "msq_qlinear_mx_w4a8")
+                                    0 if out_dtype == torch.float32 else 2, M, P.N, K, ptr(ws), wsb,
+                                    current_stream(x.device)), "msq_qlinear_mx_w4a8")
     return y.reshape(*x.shape[:-1], P.N)
 
 

@@ -125,8 +125,9 @@ def sec_mx():
             X = torch.randn(M, K, device=dev)
             xc, xs = qlinear.mx_pack_act(X)
             y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, N, K); ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
             def gemm():
-                check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), None, ptr(y), 2, M, N, K, current_stream(dev)), "gemm")
+                check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), None, ptr(y), 2, M, N, K, ptr(ws), wsb, current_stream(dev)), "gemm")
             tg = t(gemm); tp = t(lambda: qlinear.mx_pack_act(X)); te = t(lambda: qlinear.qlinear_mx_w4a8(X, P))
             print(f"N{N:5d} K{K:5d} M{M:5d}: GEMM {tg*1e3:7.1f} us {2*M*N*K/tg/1e9:7.1f} TF | act pack {tp*1e3:6.1f} us {M*K*(5+1/32)/tp/1e6:5.0f} GB/s | "
                   f"end to end {te*1e3:7.1f} us {2*M*N*K/te/1e9:7.1f} TF", flush=True)
