@@ -213,8 +213,10 @@ def main():
     # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
     # scripts/profile_gpu.sh, scripts/summarize_profiles.py); they cannot be collected from inside this run.
     tag = {"posit8_es1": "posit", "fp8_e4m3": "fp8"}.get(args.outlier)
+    if mxw4a8:
+        tag = "mx_w4a8"
     prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % tag) if tag else None
-    if prof and os.path.exists(prof) and args.workload == "llama7b_w4_fused_gemm" and (M, H) == (2048, 4096):
+    if prof and os.path.exists(prof) and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8") and (M, H) == (2048, 4096):
         try:
             pj = json.load(open(prof))
             out["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")

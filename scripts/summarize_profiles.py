@@ -23,7 +23,7 @@ def main(tag):
             w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                         r["MaxNs"], r["StdDev"]])
     summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python3 bench.py ..."}
-    dom = [r for r in rows if "k_qgemm" in r["Name"]][0]
+    dom = [r for r in rows if "k_qgemm" in r["Name"] or "k_mxgemm" in r["Name"]][0]
     summary["dominant_kernel"] = dom["Name"][:100]
     summary["dominant_kernel_avg_us"] = float(dom["AverageNs"]) / 1e3
     summary["dominant_kernel_calls"] = int(dom["Calls"])
@@ -33,7 +33,7 @@ def main(tag):
     kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     if kt:
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                for r in csv.DictReader(open(kt[0])) if "k_qgemm" in r["Kernel_Name"]]
+                for r in csv.DictReader(open(kt[0])) if "k_qgemm" in r["Kernel_Name"] or "k_mxgemm" in r["Kernel_Name"]]
         durs.sort()
         last = [d for _, d in durs][-int(bj["steps"]):]
         summary["dominant_kernel_avg_us_timed_region"] = sum(last) / len(last) / 1e3
@@ -44,7 +44,7 @@ def main(tag):
         f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
         if not f:
             continue
-        rr = [r for r in csv.DictReader(open(f[0])) if "k_qgemm" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        rr = [r for r in csv.DictReader(open(f[0])) if ("k_qgemm" in r["Kernel_Name"] or "k_mxgemm" in r["Kernel_Name"]) and r["Counter_Name"] == name]
         vals = [float(r["Counter_Value"]) for r in rr]
         summary[name + "_KB_per_launch_raw"] = sum(vals) / len(vals)
         meta = rr[0]
@@ -57,7 +57,8 @@ def main(tag):
         summary["traffic_bytes_per_launch"] = fetch + write
         summary["traffic_note"] = "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes); fabric-side counters, Infinity-Cache hits included"
         cfg = bj["config"]
-        alg = cfg["M"] * cfg["K"] * 2 + cfg["N"] * cfg["K"] * cfg["packed_bits_per_weight"] / 8 + cfg["M"] * cfg["N"] * 2
+        x_bytes = (1 + 1 / 32) if "mx" in cfg.get("layout", "") else 2          # MX path: e4m3 codes + scale bytes
+        alg = cfg["M"] * cfg["K"] * x_bytes + cfg["N"] * cfg["K"] * cfg["packed_bits_per_weight"] / 8 + cfg["M"] * cfg["N"] * 2
         summary["algorithmic_bytes_per_launch"] = alg
     with open(os.path.join(dst, tag + "_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
