@@ -313,6 +313,35 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
     return y.reshape(*x.shape[:-1], P.N)
 
 
+class MXLinearW4A8(nn.Module):
+    """Linear whose weight lives as MX-FP4 codes (4.25 bits/weight) and whose forward quantises the activations
+    to MX-FP8 and multiplies on the scaled MFMA (plain OCP-MX semantics: quantize_mx_op on both operands,
+    number_system/mx/mx_ops.py:460-490, block 32 along in_features)."""
+
+    def __init__(self, in_features, out_features, bias=True, out_dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.in_features, self.out_features, self.out_dtype = in_features, out_features, out_dtype
+        self.register_buffer("w_codes", torch.zeros(out_features * in_features // 2, dtype=torch.uint8, device=device))
+        self.register_buffer("w_scales", torch.zeros(out_features * in_features // 32, dtype=torch.uint8, device=device))
+        if bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, device=device))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_linear(cls, linear, out_dtype=torch.bfloat16):
+        m = cls(linear.in_features, linear.out_features, linear.bias is not None, out_dtype, linear.weight.device)
+        P = mx_pack_weight(linear.weight.data)
+        m.w_codes.copy_(P.codes); m.w_scales.copy_(P.scales)
+        if m.bias is not None:
+            m.bias.copy_(linear.bias.data.float())
+        return m
+
+    def forward(self, x):
+        P = MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features)
+        return qlinear_mx_w4a8(x, P, self.bias, self.out_dtype)
+
+
 class QuantLinear(nn.Module):
     """Packed Linear.  ``pack(linear, quantizer)`` consumes an nn.Linear and an MXQuantizer
     (the GPTQ-style contract implied by llm/opt.py:255-264); state_dict round-trips the

@@ -334,6 +334,20 @@ def test_mx_native_llama_shapes_repeatable(msq, N, K):
             assert torch.equal(msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32), Y0)
 
 
+def test_mx_linear_module(msq):
+    lin = torch.nn.Linear(512, 256).to(dev())
+    m = msq.qlinear.MXLinearW4A8.from_linear(lin)
+    x = torch.randn(2, 5, 512, device=dev())
+    y = m(x)
+    Xq = msq.mx_ops._quantize_mx(x, 8, "fp8_e4m3", axes=[-1], block_size=32)
+    Wq = msq.mx_ops._quantize_mx(lin.weight.data, 8, "fp4_e2m1", axes=[-1], block_size=32)
+    ref = torch.nn.functional.linear(Xq, Wq, lin.bias.data)
+    assert y.shape == (2, 5, 256) and (y.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    m2 = msq.qlinear.MXLinearW4A8(512, 256, True, device=dev())
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2(x), y)
+
+
 def test_act_quant_rejects_wide_formats(msq):
     x = torch.randn(4, 64, device=dev())
     with pytest.raises(msq._lib.MsqError):
