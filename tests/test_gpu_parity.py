@@ -790,6 +790,43 @@ def test_harness_quantlinear_swap_keeps_ppl(msq):
     assert abs(ppl_packed2 - ppl_fake2) / ppl_fake2 < 0.05 / 5.5, (ppl_packed2, ppl_fake2)
 
 
+def test_harness_mx_native_w4a8_ppl(msq):
+    """Model-level check of the MX-native W4A8 path: a tiny Llama whose decoder Linears are swapped for MXLinearW4A8
+    (scaled-MFMA GEMM on MX-FP4 x MX-FP8 operands) has the perplexity of the same model with the two plain MX fake-quant
+    steps done explicitly (quantize_mx on the weight in place + on the activation in a forward pre-hook, dense fp32
+    F.linear).  Relative bound 0.05 / 5.5 as in the bf16-path test."""
+    from msq.harness import find_layers
+    from msq.harness.data_utils import _Enc
+    from msq.harness.evalppl import perplexity
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    g = torch.Generator().manual_seed(1)
+    tokens = _Enc(torch.randint(0, 512, (1, 64 * 6), generator=g))
+    torch.manual_seed(0)
+    ref = LlamaForCausalLM(cfg).eval().to(dev())
+    torch.manual_seed(0)
+    fast = LlamaForCausalLM(cfg).eval().to(dev())
+    hooks = []
+    for layer in ref.model.layers:
+        for name, lin in find_layers(layer).items():
+            lin.weight.data = msq.mx_ops._quantize_mx(lin.weight.data.float(), 8, "fp4_e2m1", axes=[-1], block_size=32)
+            hooks.append(lin.register_forward_pre_hook(
+                lambda mod, args: (msq.mx_ops._quantize_mx(args[0].float(), 8, "fp8_e4m3", axes=[-1], block_size=32),)))
+    for layer in fast.model.layers:
+        for name, lin in find_layers(layer).items():
+            parent = layer
+            parts = name.split(".")
+            for p_ in parts[:-1]:
+                parent = getattr(parent, p_)
+            setattr(parent, parts[-1], msq.qlinear.MXLinearW4A8.from_linear(lin, out_dtype=torch.float32))
+    ppl_ref = perplexity(ref, tokens, dev(), 64)
+    ppl_fast = perplexity(fast, tokens, dev(), 64)
+    for h in hooks:
+        h.remove()
+    assert abs(ppl_fast - ppl_ref) / ppl_ref < 0.05 / 5.5, (ppl_fast, ppl_ref)
+
+
 # ---------------------------------------------------------------- f1 GPTQ + MicroScopiQ pruning (llm/gptq.py)
 def test_gptq_solver_vs_reference_fixture(msq):
     """The GPTQ solver with the fused per-column MicroScopiQ quantiser against the reference's CPU solver on
