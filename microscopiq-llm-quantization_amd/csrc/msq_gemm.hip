@@ -774,6 +774,79 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 }
 
 // ---------------------------------------------------------------------------
+// MX-native decode kernel (M <= 16): streams the 4.25-bit weight once.  One wave = one task = KC consecutive
+// 64(n) x 128(k) packed tiles of one 64-column strip: per tile 4 weight fragments (16 B per lane each) + one scale
+// dword, 4 scaled MFMAs against the activation fragment, which is read straight from global memory (X codes are
+// <= 16 rows: L2-resident).  The next tile's weights are in flight while the current one is consumed; fp32 partial
+// tiles per k-chunk, summed by k_splitk_reduce.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
+         const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int KT = K / 128;
+    const int nks = (KT + kc - 1) / kc;
+    const int nkb = (nks + 3) / 4;                             // the block's four waves take four consecutive k-chunks
+    const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb;
+    const int ks = kb * 4 + wid;
+    const int kt_lo = ks * kc < KT ? ks * kc : KT;
+    const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
+    const int64_t tile_row = (int64_t)strip * KT;
+    const int mrow = c < M ? c : M - 1;                        // rows >= M are clamped; their results are never stored
+    const uint8_t* xrow = Xc + (int64_t)mrow * K + g * 16;
+    const uint8_t* xsrow = Xs + (int64_t)mrow * (K / 32) + g;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    struct WT { u32x4_t w[4]; uint32_t s; };
+    auto load_w = [&](WT& t, int64_t tile) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) t.w[nf] = *reinterpret_cast<const u32x4_t*>(Wc + ((tile * 4 + nf) * 64 + lane) * 16);
+        t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4);
+    };
+    WT cur, nxt;
+    if (kt_lo < kt_hi) load_w(cur, tile_row + kt_lo);
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
+        load_w(nxt, tile_row + ktn);
+        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(xrow + (int64_t)kt * 128);        // k = 16 g ..
+        const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(xrow + (int64_t)kt * 128 + 64);   // k = 64 + 16 g ..
+        const int sb = (int)xsrow[kt * 4];
+        const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const v8i_t afr = {(int)cur.w[nf][0], (int)cur.w[nf][1], (int)cur.w[nf][2], (int)cur.w[nf][3], 0, 0, 0, 0};
+            if (nf == 0) acc[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[0], 4, 0, 0, (int)cur.s, 0, sb);
+            else if (nf == 1) acc[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[1], 4, 0, 1, (int)cur.s, 0, sb);
+            else if (nf == 2) acc[2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[2], 4, 0, 2, (int)cur.s, 0, sb);
+            else acc[3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[3], 4, 0, 3, (int)cur.s, 0, sb);
+        }
+        cur = nxt;
+    }
+    // the four k-chunks meet in LDS (fixed order: wave 0 + 1 + 2 + 3), one partial plane per block
+    if (wid > 0) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wid - 1][nf * 4 + e][lane] = acc[nf][e];
+    }
+    __syncthreads();
+    // D[lane, e] = C[n = 4 g + e][m = c]
+    if (wid == 0 && c < M) {
+        float* pbase = partial + ((int64_t)kb * M + c) * N + strip * 64 + g * 4;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((acc[nf][e] + red[0][nf * 4 + e][lane]) + red[1][nf * 4 + e][lane]) + red[2][nf * 4 + e][lane];
+            *reinterpret_cast<float4*>(pbase + nf * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Small-M (decode) kernel: M <= 16 (MG = 1; the template still takes MG 16-row groups).  HBM-bound: the job is to stream the packed weight once at full
 // rate.  One wave = one task = KC consecutive 64x64 packed tiles of one 64-column strip; per tile it
 // converts the 8 fragments and issues 8*MG MFMAs against the activation fragments, which it reads
@@ -1288,8 +1361,17 @@ static int pick_mx_ksplit(int64_t M, int64_t N, int64_t K) {
     if (ks > 16) ks = 16;
     return ks < 1 ? 1 : (int)ks;
 }
+// decode path (M <= 16): K-steps per wave so that there are ~3000 waves (4 per block) and at most 32 k-chunks
+static int pick_mx_kc(int64_t N, int64_t K) {
+    const int64_t KT = K / 128, strips = N / 64;
+    int64_t kc = (strips * KT + 3071) / 3072;
+    if (kc < 1) kc = 1;
+    while ((KT + kc - 1) / kc > 32) ++kc;
+    return (int)kc;
+}
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % 128)) return 0;
+    if (M <= 16) { const int kc = pick_mx_kc(N, K); return (((K / 128 + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_mx_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -1301,12 +1383,27 @@ int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w
     if (!x_codes || !x_scales || !w_codes || !w_scales || !Y) return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: null buffer");
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 16 && workspace) {
+        const int kc = pick_mx_kc(N, K);
+        const int nks = (int)(((K / 128 + kc - 1) / kc + 3) / 4);        // partial planes: one per four k-chunks
+        if (workspace_bytes >= (int64_t)nks * M * N * 4) {
+            hipLaunchKernelGGL(k_mxgemv, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
+                               (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
+            int rc0 = check_launch2("msq_qlinear_mx_w4a8(decode)");
+            if (rc0) return rc0;
+            const int64_t MN0 = M * N;
+            const dim3 rg((unsigned)((MN0 / 4 + 255) / 256));
+            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks);
+            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks);
+            return check_launch2("msq_qlinear_mx_w4a8(decode reduce)");
+        }
+    }
     const int MT = (int)((M + 127) / 128), NTB = (int)(N / BN);
     int ksplit = pick_mx_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
     const size_t lds = 3 * 128 * 128 + 3 * 1024;              // three code tiles + three scale tiles
-    hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     if (y_dtype == 0) hipLaunchKernelGGL(k_mxgemm<float>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
                                          (const uint8_t*)w_scales, bias, (float*)Y, (int)M, (int)N, (int)K, ksplit, partial);

@@ -323,7 +323,7 @@ def test_mx_native_llama_shapes_repeatable(msq, N, K):
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
     P = msq.qlinear.mx_pack_weight(W)
     Wd = torch.from_numpy(_mx_unpack_w4(P)).float().to(dev()) if N * K <= 4096 * 4096 else None
-    for M in (3, 130, 2048):
+    for M in (1, 3, 16, 17, 130, 2048):            # <= 16: decode kernel; then split-K and plain GEMM
         X = torch.randn(M, K, generator=g, device=dev())
         Y0 = msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32)
         if Wd is not None:
