@@ -852,22 +852,21 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // converts the 8 fragments and issues 8*MG MFMAs against the activation fragments, which it reads
 // straight from global memory (the whole X is <= 512 KiB and stays in L2).  Next tile's packed data
 // is in flight while the current one is consumed; 12 waves per CU keep ~80 KiB of loads in flight.
-// Every task writes an fp32 partial tile, k_splitk_reduce sums them.
+// The four waves of a block sum their k-chunks in LDS and write one fp32 partial tile, k_splitk_reduce sums those.
 // ---------------------------------------------------------------------------
 template <int IN_KIND, int OUT_KIND, int MG>
 __global__ void __launch_bounds__(256)
 k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
         const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc) {
-    const int lane = threadIdx.x & 63;
+    __shared__ float red[3][16 * MG][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / TILE_K;
-    const int nks = (KT + kc - 1) / kc;                        // k-chunks per strip = number of partial planes
-    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t ntasks = (int64_t)(N / TILE_N) * nks;
-    if (task >= ntasks) return;
-    // consecutive tasks walk k-chunks of the same strip: neighbouring waves share the X rows in L1/L2
-    const int strip = (int)(task / nks), ks = (int)(task % nks);
-    const int kt_lo = ks * kc;
+    const int nks = (KT + kc - 1) / kc;                        // k-chunks per strip
+    const int nkb = (nks + 3) / 4;                             // the block's four waves take four consecutive k-chunks
+    const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb; //   of one strip and share its X rows in L1
+    const int ks = kb * 4 + wid;
+    const int kt_lo = ks * kc < KT ? ks * kc : KT;             // chunks past the end are empty
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
     const int64_t tile_row = (int64_t)strip * KT;
 
@@ -883,7 +882,7 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
     for (int j = 0; j < MG; ++j) { int m = j * 16 + c; m = m < M ? m : M - 1; xrow[j] = X + (int64_t)m * K + g * 8; }
 
     TileRegs cur, nxt;
-    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + kt_lo, lane, scl_groups);
+    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + (kt_lo < KT ? kt_lo : KT - 1), lane, scl_groups);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
         load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups);
@@ -904,8 +903,19 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
             }
         cur = nxt;
     }
+    // the four k-chunks meet in LDS (fixed order: wave 0 + 1 + 2 + 3): one partial plane per block
+    if (wid > 0) {
+#pragma unroll
+        for (int j = 0; j < MG; ++j)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wid - 1][(j * 4 + nf) * 4 + e][lane] = acc[nf][j][e];
+    }
+    __syncthreads();
+    if (wid != 0) return;
     // D[n = 4 g + r][m = c]: 4 consecutive n of row m
-    float* pbase = partial + (int64_t)ks * M * N;
+    float* pbase = partial + (int64_t)kb * M * N;
 #pragma unroll
     for (int j = 0; j < MG; ++j) {
         const int m = j * 16 + c;
@@ -913,7 +923,13 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int n = strip * TILE_N + nf * 16 + g * 4;
-            *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(acc[nf][j][0], acc[nf][j][1], acc[nf][j][2], acc[nf][j][3]);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = (j * 4 + nf) * 4 + e;
+                v[e] = ((acc[nf][j][e] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+            }
+            *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -1224,7 +1240,7 @@ static int pick_kc(int64_t N, int64_t K) {
 
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
-    if (M <= gemv_max_m()) { const int kc = pick_kc(N, K); return ((K / BK + kc - 1) / kc) * M * N * 4; }
+    if (M <= gemv_max_m()) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -1247,10 +1263,9 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     if (M <= gemv_max_m() && workspace) {
         const int kc = pick_kc(N, K);
-        const int nks = (int)((K / BK + kc - 1) / kc);
+        const int nks = (int)(((K / BK + kc - 1) / kc + 3) / 4);         // partial planes: one per four k-chunks
         if (workspace_bytes >= (int64_t)nks * M * N * 4) {
-            const int64_t ntasks = (N / TILE_N) * nks;
-            const dim3 vgrid((unsigned)((ntasks + 3) / 4)), vblk(256);
+            const dim3 vgrid((unsigned)((N / TILE_N) * nks)), vblk(256);
 #define MSQ_GV(IK, OK)                                                                                                  \
             hipLaunchKernelGGL((k_qgemv<IK, OK, 1>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc)
             if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
