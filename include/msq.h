@@ -248,8 +248,21 @@ int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, 
                    int flush_fp32_subnorms, void* stream);
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
-int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 only for small M (split-K) */
+int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode, split-K) */
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
+                        const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* MicroScopiQ weights on the same path -- NEW: the fake-quant VALUES of any quantiser of this library (inliers +
+ * outliers of utils/quant.py:147-266, the mx_ops variant, GPTQ output) as ONE e4m3 code per weight + one E8M0 scale
+ * per 32 k (8.25 bits/weight, scale rule of MSQ-U1) in the fp8 operand order of the scaled MFMA: lane (n % 16, kg)
+ * holds k = 16 kg .. +15 and 64 + 16 kg .. +15 of the 128-k tile, stored as two 1 KiB half-slots per (tile, nf).
+ * Every code is decoded back and compared with the value: status_flag receives MSQ_STATUS_INEXACT when a value is
+ * not representable (the caller then keeps the MSQ-T1 / MSQ-U1 planes and msq_qlinear_bf16).
+ *   msq_mx_pack_w8: Wq [N,K] f32 -> codes [N*K] bytes + scales [N*K/32] bytes.  N % 64 == 0, K % 128 == 0.
+ *   msq_qlinear_mx_w8a8: as msq_qlinear_mx_w4a8 with that weight operand (same workspace size). */
+int msq_mx_pack_w8(const float* Wq, void* codes, void* scales, int* status_flag, int64_t N, int64_t K, void* stream);
+int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
                         const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
                         void* workspace, int64_t workspace_bytes, void* stream);
 

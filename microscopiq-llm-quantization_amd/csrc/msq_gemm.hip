@@ -636,7 +636,14 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 // ---------------------------------------------------------------------------
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
-template <typename YT>
+// W8: the weight operand holds e4m3 codes (fake-quant values of any quantiser packed exactly by msq_mx_pack_w8,
+// 8.25 bits/weight: MicroScopiQ inliers + outliers) instead of e2m1: 32 B per lane and 16 n in two half-slots, the
+// same MFMA rate (an fp8 operand on either side sets it).  The three-deep weight ring would need 99 VGPRs next
+// to the 128 accumulators, so the fp8 ring is two deep: the weights of K-step kt + 1 are requested at the top of
+// K-step kt, AFTER the LDS-DMA of this step (the kernel is at the register limit: an address reloaded from
+// scratch before the LDS-DMA must not have to wait for weight loads issued just before it), and everything is
+// awaited at the end of the K-step.
+template <typename YT, bool W8>
 __global__ void __launch_bounds__(256, 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
@@ -666,20 +673,22 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     } else { bm = bid % MT; bn = bid / MT; }
     const int m0 = bm * BMX, n0 = bn * BN;
     const int64_t wtiles = (int64_t)(N / 64) * KT;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * 4096);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * (W8 ? 8192 : 4096));
     const __amdgpu_buffer_rsrc_t wsr = make_rsrc(Ws, wtiles * 256);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xc, (int64_t)M * K);
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(Xs, (int64_t)M * (K / 32));
     const uint32_t tile_row32 = (uint32_t)((n0 / 64 + wn) * KT);
     const int lane16 = lane * 16;
     // activation staging: piece = 4 wid + p covers rows 8 piece .. +7, 16-byte chunk (lane & 7) ^ ((row >> 1) & 7)
-    int aoff[4];
+    // Two lane offsets only (pieces 0 and 1; piece p + 2 lies 16 rows = 16 K bytes further, the chunk swizzle repeats
+    // every 16 rows): rows >= M are NOT clamped, their offset is >= M K = the descriptor's size and the hardware
+    // range check makes the load a no-op / zero fill; those rows of the result are never stored.
+    int aoff[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 2; ++p) {
         const int row = (wid * 4 + p) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gr = m0 + row; gr = gr < M ? gr : M - 1;
-        aoff[p] = (int)((int64_t)gr * K + chunk * 16);
+        aoff[p] = (int)((int64_t)(m0 + row) * K + chunk * 16);
     }
     // the 4 scale bytes of (row, K-step) travel with the tile: every wave copies one dword per row for its 32 rows
     // (lanes 32-63 repeat lanes 0-31 into the upper half of the wave's 256 bytes: no wave-dependent branch, the
@@ -687,10 +696,12 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     constexpr int XS_BASE = 3 * A_TILE;
     int xs_goff = m0 + wid * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
     auto stage_A = [&](int kt, int buf) {
+        int k16 = 16 * K;
+        asm volatile("" : "+s"(k16));                             // keeps the two derived offsets out of registers across K-steps
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 4 + p) * 1024),
-                                                     16, aoff[p], uni((uint32_t)kt * KS), 0, 0);
+                                                     16, p < 2 ? aoff[p] : aoff[p - 2] + k16, uni((uint32_t)kt * KS), 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem + XS_BASE + buf * 1024 + wid * 256),
                                                  4, xs_goff, uni((uint32_t)kt * 4u), 0, 0);
     };
@@ -706,19 +717,25 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    struct WSet { u32x4_t w[4]; uint32_t s; };
+    constexpr int WV = W8 ? 2 : 1;                               // 16-byte pieces per lane and 16 n
+    struct WSet { u32x4_t w[4][WV]; uint32_t s; };
     WSet w0, w1, w2;
     auto load_w = [&](WSet& ws, int kt) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
-            ws.w[nf] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni(((tile_row32 + (uint32_t)kt) * 4u + nf) * 1024u), 0));
+#pragma unroll
+            for (int h = 0; h < WV; ++h)
+                ws.w[nf][h] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni((((tile_row32 + (uint32_t)kt) * 4u + nf) * WV + h) * 1024u), 0));
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
+    constexpr int CBSZ = W8 ? 0 : 4;                             // A-operand format: e4m3 / e2m1
+    constexpr int N_WAIT_MX = W8 ? 0 : 10;
     const int kl = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);   // an empty split runs a harmless prologue
     const int kf0 = (kt_lo < KT) ? kt_lo : KT - 1, kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
     stage_A(kf0, 0);
     stage_A(kf1, 1);
-    load_w(w0, kf0); load_w(w1, kf1);
+    load_w(w0, kf0);
+    if (!W8) load_w(w1, kf1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -729,42 +746,53 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
-        load_w(WLOAD, k2);                   /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
+        if (!W8) load_w(WLOAD, k2);          /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         stage_A(k2, buf2);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (W8) load_w(WLOAD, k1);           /* fp8 ring: LDS-DMA first, the weights of K-step kt + 1 last */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         u32x4_t xl[2], xh[2];                                                                                \
         xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh);             \
         uint32_t xsc[2];                                                                                     \
         xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024);                                \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
+            if (W8) { xl[mf & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + mf * 2048);                                       \
+                      xh[mf & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + mf * 2048);                                       \
+                      xsc[mf & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + (mf >> 1) * 256 + (mf & 1) * 64); } \
+            else if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + (mf + 1) * 2048);                  \
                               xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }   \
             const u32x4_t lo = xl[mf & 1], hi = xh[mf & 1];                                                  \
             const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
             const int sb_ = (int)xsc[mf & 1];                                                                \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) {                                               \
-                const v8i_t afr = {(int)WCUR.w[nf][0], (int)WCUR.w[nf][1], (int)WCUR.w[nf][2], (int)WCUR.w[nf][3], 0, 0, 0, 0}; \
-                if (nf == 0) acc[mf][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][0], 4, 0, 0, (int)WCUR.s, 0, sb_); \
-                else if (nf == 1) acc[mf][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][1], 4, 0, 1, (int)WCUR.s, 0, sb_); \
-                else if (nf == 2) acc[mf][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][2], 4, 0, 2, (int)WCUR.s, 0, sb_); \
-                else acc[mf][3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][3], 4, 0, 3, (int)WCUR.s, 0, sb_); \
+                const u32x4_t wl_ = WCUR.w[nf][0], wh_ = WCUR.w[nf][WV - 1];                                  \
+                const v8i_t afr = {(int)wl_[0], (int)wl_[1], (int)wl_[2], (int)wl_[3], W8 ? (int)wh_[0] : 0, W8 ? (int)wh_[1] : 0, W8 ? (int)wh_[2] : 0, W8 ? (int)wh_[3] : 0}; \
+                if (nf == 0) acc[mf][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][0], CBSZ, 0, 0, (int)WCUR.s, 0, sb_); \
+                else if (nf == 1) acc[mf][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][1], CBSZ, 0, 1, (int)WCUR.s, 0, sb_); \
+                else if (nf == 2) acc[mf][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][2], CBSZ, 0, 2, (int)WCUR.s, 0, sb_); \
+                else acc[mf][3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[mf][3], CBSZ, 0, 3, (int)WCUR.s, 0, sb_); \
             }                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
         /* this K-step's 5 weight loads and 5 LDS-DMA ops (all for K-step kt + 2) stay in flight; everything \
            issued in the previous K-step -- the tile and the weights of K-step kt + 1 -- has landed */       \
-        __builtin_amdgcn_s_waitcnt(0x0070 | 10);                                                             \
+        __builtin_amdgcn_s_waitcnt(0x0070 | N_WAIT_MX);                                                      \
         __builtin_amdgcn_s_barrier();                                                                        \
     }
 
     int abuf = 0;
     {
         int kt = kt_lo;
-        for (; kt + 2 < kt_hi; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
-        if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
-        if (kt < kt_hi) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
+        if constexpr (W8) {
+            for (; kt + 1 < kt_hi; kt += 2) { MSQ_MX_STEP(kt, w0, w1) MSQ_MX_STEP(kt + 1, w1, w0) }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w1) ++kt; }
+        } else {
+            for (; kt + 2 < kt_hi; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
+        }
     }
 #undef MSQ_MX_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
@@ -780,6 +808,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // <= 16 rows: L2-resident).  The next tile's weights are in flight while the current one is consumed; fp32 partial
 // tiles per k-chunk, summed by k_splitk_reduce.
 // ---------------------------------------------------------------------------
+template <bool W8>
 __global__ void __launch_bounds__(256)
 k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc) {
@@ -800,10 +829,13 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     f32x4_t acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    struct WT { u32x4_t w[4]; uint32_t s; };
+    constexpr int WV = W8 ? 2 : 1, CBSZ = W8 ? 0 : 4;
+    struct WT { u32x4_t w[4][WV]; uint32_t s; };
     auto load_w = [&](WT& t, int64_t tile) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) t.w[nf] = *reinterpret_cast<const u32x4_t*>(Wc + ((tile * 4 + nf) * 64 + lane) * 16);
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int h = 0; h < WV; ++h) t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf) * WV + h) * 64 + lane) * 16);
         t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4);
     };
     WT cur, nxt;
@@ -817,11 +849,12 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const v8i_t afr = {(int)cur.w[nf][0], (int)cur.w[nf][1], (int)cur.w[nf][2], (int)cur.w[nf][3], 0, 0, 0, 0};
-            if (nf == 0) acc[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[0], 4, 0, 0, (int)cur.s, 0, sb);
-            else if (nf == 1) acc[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[1], 4, 0, 1, (int)cur.s, 0, sb);
-            else if (nf == 2) acc[2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[2], 4, 0, 2, (int)cur.s, 0, sb);
-            else acc[3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[3], 4, 0, 3, (int)cur.s, 0, sb);
+            const u32x4_t wl = cur.w[nf][0], wh = cur.w[nf][WV - 1];
+            const v8i_t afr = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], W8 ? (int)wh[0] : 0, W8 ? (int)wh[1] : 0, W8 ? (int)wh[2] : 0, W8 ? (int)wh[3] : 0};
+            if (nf == 0) acc[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[0], CBSZ, 0, 0, (int)cur.s, 0, sb);
+            else if (nf == 1) acc[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[1], CBSZ, 0, 1, (int)cur.s, 0, sb);
+            else if (nf == 2) acc[2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[2], CBSZ, 0, 2, (int)cur.s, 0, sb);
+            else acc[3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[3], CBSZ, 0, 3, (int)cur.s, 0, sb);
         }
         cur = nxt;
     }
@@ -1390,9 +1423,9 @@ int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int ks = pick_mx_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
-int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
-                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
-                        void* stream) {
+static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                     void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: negative M");
     if (N <= 0 || K <= 0 || (N % BN) || (K % 128)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: N must be a multiple of 256 and K of 128");
     if (!x_codes || !x_scales || !w_codes || !w_scales || !Y) return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: null buffer");
@@ -1403,8 +1436,10 @@ int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w
         const int kc = pick_mx_kc(N, K);
         const int nks = (int)(((K / 128 + kc - 1) / kc + 3) / 4);        // partial planes: one per four k-chunks
         if (workspace_bytes >= (int64_t)nks * M * N * 4) {
-            hipLaunchKernelGGL(k_mxgemv, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
-                               (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
+            if (w8) hipLaunchKernelGGL(k_mxgemv<true>, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
+                                       (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
+            else hipLaunchKernelGGL(k_mxgemv<false>, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
+                                    (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
             int rc0 = check_launch2("msq_qlinear_mx_w4a8(decode)");
             if (rc0) return rc0;
             const int64_t MN0 = M * N;
@@ -1420,10 +1455,11 @@ int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
     const size_t lds = 3 * 128 * 128 + 3 * 1024;              // three code tiles + three scale tiles
     float* partial = (float*)workspace;
-    if (y_dtype == 0) hipLaunchKernelGGL(k_mxgemm<float>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
-                                         (const uint8_t*)w_scales, bias, (float*)Y, (int)M, (int)N, (int)K, ksplit, partial);
-    else hipLaunchKernelGGL(k_mxgemm<uint16_t>, grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes,
-                            (const uint8_t*)w_scales, bias, (uint16_t*)Y, (int)M, (int)N, (int)K, ksplit, partial);
+#define MSQ_MXL(YT, W8V) hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+                                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial)
+    if (y_dtype == 0) { if (w8) MSQ_MXL(float, true); else MSQ_MXL(float, false); }
+    else { if (w8) MSQ_MXL(uint16_t, true); else MSQ_MXL(uint16_t, false); }
+#undef MSQ_MXL
     int rc = check_launch2("msq_qlinear_mx_w4a8");
     if (rc || ksplit == 1) return rc;
     const int64_t MN = M * N;
@@ -1431,6 +1467,16 @@ int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w
     if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
     else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
     return check_launch2("msq_qlinear_mx_w4a8(split-K reduce)");
+}
+int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+    return mx_linear(false, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
+}
+int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+    return mx_linear(true, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

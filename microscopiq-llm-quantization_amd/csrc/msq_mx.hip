@@ -6,6 +6,10 @@
 //                (tile = 64 n x 128 k; slot nf = 16 n: lane (n % 16, (k % 128) / 32) holds 32 k = 16 bytes)
 //                + one scale byte per (lane, nf)
 // The codes come from the hardware converts (RNE of x | 1ulp == round half away, see msq_outlier_core.h).
+//   fake-quant values Wq [N,K] f32 (MicroScopiQ inliers + outliers, GPTQ output, ...) -> e4m3 codes in the fp8
+//                operand order (same tile; lane (n % 16, kg) holds k = 16 kg .. +15 and 64 + 16 kg .. +15 = 2 x 16
+//                bytes, stored as two 1 KiB half-slots) + one scale byte per (lane, nf), scale rule of MSQ-U1
+//                (msq_pack_unified.hip); every code is decoded back and compared: MSQ_STATUS_INEXACT otherwise.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,10 +36,12 @@ MSQ_D int mx_scale_byte(int max_biased_exp, int elem_emax, int& status) {
 // A wave owns 64 consecutive blocks of 32 floats = one contiguous 8 KiB run: coalesced 16-byte loads, transpose
 // through LDS (row stride 36 words), one block per lane.  FP4: weights, codes scattered into the MFMA tile order;
 // otherwise activations, e4m3 codes written back row-major through the same LDS tile.
-template <bool FP4>
+// MODE 0: activations (e4m3, row-major), 1: weights (e2m1, operand order), 2: exact values (e4m3, operand order)
+template <int MODE>
 __global__ void __launch_bounds__(256)
 k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t rows, int64_t K,
           int flush, int* status_flag) {
+    constexpr bool FP4 = (MODE == 1), VAL = (MODE == 2);
     constexpr int BS = 32, LDS_STRIDE = BS + 4;
     __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -69,15 +75,28 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
     int se = 0;
 #pragma unroll
     for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
-    const bool fl = (se == 0) && flush;
-    const int sb = mx_scale_byte(se, FP4 ? 2 : 8, status);
+    const bool fl = (se == 0) && flush && !VAL;
+    int sb = mx_scale_byte(se, FP4 ? 2 : 8, status);
+    if (VAL) {                                                   // MSQ-U1 rule: max |v| 2^-s in [256, 448] or (448, 512) -> s + 1
+        float mx = 0.f;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) { const float t = __builtin_fabsf(a[b]); mx = t > mx ? t : mx; }
+        int su = 0;
+        if (mx > 0.f && se != 255) {
+            su = ilog2f(mx) - 8;
+            if (__builtin_ldexpf(mx, -su) > 448.f) su += 1;
+        }
+        su = su < -126 ? -126 : su;
+        if (su > 127) { su = 127; status |= MSQ_STATUS_INEXACT; }
+        sb = su + 127;
+    }
     const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
     const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
     uint32_t cw[FP4 ? 4 : 8];
 #pragma unroll
     for (int p = 0; p < BS / 2; ++p) {
         typedef short v2s_t __attribute__((ext_vector_type(2)));
-        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | 1u), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | 1u);
+        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | (VAL ? 0u : 1u)), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | (VAL ? 0u : 1u));
         if (FP4) {
             uint32_t w = (p & 3) ? cw[p >> 2] : 0u;
             if ((p & 3) == 0) w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 0);
@@ -91,6 +110,12 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
             if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, false);
             else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, true);
             cw[p >> 1] = __builtin_bit_cast(uint32_t, cur);
+            if (VAL) {                                           // decode as the hardware does and compare
+                const uint32_t u0 = f2u(a[2 * p]), u1 = f2u(a[2 * p + 1]);
+                const uint32_t d = ((p & 1) == 0) ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(cw[p >> 1], s_op, false))
+                                                  : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(cw[p >> 1], s_op, true));
+                if ((((u0 | u1) & 0xFFFFu) != 0u || d != ((u0 >> 16) | (u1 & 0xFFFF0000u))) && se != 255) status |= MSQ_STATUS_INEXACT;
+            }
         }
     }
     // -0 codes are fine for the MFMA (no OR-combination here)
@@ -102,11 +127,21 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
             const int nf = (int)((r % 64) / 16), ln = (int)((kb % 4) * 16 + (r % 16));
             *reinterpret_cast<uint4*>(codes + ((t * 4 + nf) * 64 + ln) * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
             scales[(t * 64 + ln) * 4 + nf] = (uint8_t)sb;
+        } else if (VAL) {
+            // block kb % 4 = b holds k = 32 b .. 32 b + 31 of the 128-k tile: its first 16 codes belong to lane
+            // (r, kg = 2 (b & 1)), the next 16 to kg + 1, both in half b >> 1; the scale byte to lane (r, b)
+            const int64_t KT = K / 128;
+            const int64_t t = (r / 64) * KT + kb / 4;
+            const int nf = (int)((r % 64) / 16), b = (int)(kb % 4), r16 = (int)(r % 16);
+            uint8_t* slot = codes + (((t * 4 + nf) * 2 + (b >> 1)) * 64) * 16;
+            *reinterpret_cast<uint4*>(slot + ((2 * (b & 1)) * 16 + r16) * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            *reinterpret_cast<uint4*>(slot + ((2 * (b & 1) + 1) * 16 + r16) * 16) = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+            scales[(t * 64 + b * 16 + r16) * 4 + nf] = (uint8_t)sb;
         } else {
             scales[g] = (uint8_t)sb;
         }
     }
-    if (!FP4) {
+    if (MODE == 0) {
         if (full) {                                             // 8 words per block back through LDS, coalesced 16-byte stores
             constexpr int HS = 12;                              // words per row (8 used; 48-byte rows keep 16-byte alignment)
             __builtin_amdgcn_wave_barrier();
@@ -138,7 +173,7 @@ extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* st
     if (K % 128) { msq_set_error_("msq_mx_pack_a8: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
-    hipLaunchKernelGGL((k_mx_pack<false>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+    hipLaunchKernelGGL((k_mx_pack<0>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                        (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
@@ -150,8 +185,19 @@ extern "C" int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* st
     if (N <= 0 || K <= 0 || (N % 64) || (K % 128)) { msq_set_error_("msq_mx_pack_w4: N must be a multiple of 64 and K of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!W || !codes || !scales) { msq_set_error_("msq_mx_pack_w4: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = N * (K / 32);
-    hipLaunchKernelGGL((k_mx_pack<true>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+    hipLaunchKernelGGL((k_mx_pack<1>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
                        (uint8_t*)codes, (uint8_t*)scales, N, K, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+extern "C" int msq_mx_pack_w8(const float* Wq, void* codes, void* scales, int* status_flag, int64_t N, int64_t K, void* stream) {
+    if (N <= 0 || K <= 0 || (N % 64) || (K % 128)) { msq_set_error_("msq_mx_pack_w8: N must be a multiple of 64 and K of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!Wq || !codes || !scales) { msq_set_error_("msq_mx_pack_w8: null buffer"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = N * (K / 32);
+    hipLaunchKernelGGL((k_mx_pack<2>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wq,
+                       (uint8_t*)codes, (uint8_t*)scales, N, K, 0, status_flag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;

@@ -242,10 +242,11 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
 # MX-native W4A8 (BASELINE config 3): plain OCP-MX operands, no outlier split, multiplied by the scaled fp8 / fp4 MFMA
 # ---------------------------------------------------------------------------------------------------------
 class MXPackedWeight:
-    """e2m1 codes in MFMA operand order + E8M0 block scales of one [N, K] weight (4.25 bits per weight)."""
+    """Codes in the operand order of the scaled MFMA + E8M0 block scales of one [N, K] weight: ``w_fmt`` "e2m1"
+    (plain MX-FP4, 4.25 bits per weight) or "e4m3" (exactly packed fake-quant values, 8.25 bits per weight)."""
 
-    def __init__(self, codes, scales, N, K):
-        self.codes, self.scales, self.N, self.K = codes, scales, N, K
+    def __init__(self, codes, scales, N, K, w_fmt="e2m1"):
+        self.codes, self.scales, self.N, self.K, self.w_fmt = codes, scales, N, K, w_fmt
 
     @property
     def nbytes(self):
@@ -274,6 +275,28 @@ def mx_pack_weight(W, flush_fp32_subnorms=False):
                                current_stream(Wf.device)), "msq_mx_pack_w4")
     _mx_status(status, "mx_pack_weight")
     return MXPackedWeight(codes, scales, N, K)
+
+
+def mx_pack_values(Wq, allow_inexact=False):
+    """Fake-quant VALUES [N, K] (MicroScopiQ inliers + outliers, the mx_ops variant, GPTQ output ...) -> one e4m3
+    code per weight + one E8M0 scale per 32 k in the fp8 operand order of the scaled MFMA (msq_mx_pack_w8).  Every
+    code is decoded back and compared on the GPU: raises MsqError when a value is not representable (e.g. posit8
+    outliers with 4 fraction bits, blocks spanning more than e4m3's range) unless ``allow_inexact``."""
+    if not Wq.is_cuda:
+        raise MsqError("mx_pack_values needs a CUDA/HIP tensor (no CPU fallback)")
+    Wf = Wq.detach().contiguous().float()
+    N, K = Wf.shape
+    codes = torch.empty(N * K, dtype=torch.uint8, device=Wf.device)
+    scales = torch.empty(N * K // 32, dtype=torch.uint8, device=Wf.device)
+    status = torch.zeros(1, dtype=torch.int32, device=Wf.device)
+    check(lib().msq_mx_pack_w8(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, current_stream(Wf.device)),
+          "msq_mx_pack_w8")
+    st = int(status.item())
+    if st & 1:
+        raise AssertionError("mx_pack_values: the values hold Inf / NaN")
+    if (st & 2) and not allow_inexact:              # MSQ_STATUS_INEXACT
+        raise MsqError("mx_pack_values: values not representable as e4m3 x 2^s per 32-block (MSQ_STATUS_INEXACT)")
+    return MXPackedWeight(codes, scales, N, K, "e4m3")
 
 
 def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
@@ -307,9 +330,9 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
     b = bias.detach().float().contiguous() if bias is not None else None
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
-    check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y),
-                                    0 if out_dtype == torch.float32 else 2, M, P.N, K, ptr(ws), wsb,
-                                    current_stream(x.device)), "msq_qlinear_mx_w4a8")
+    fn = lib().msq_qlinear_mx_w8a8 if P.w_fmt == "e4m3" else lib().msq_qlinear_mx_w4a8
+    check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), 0 if out_dtype == torch.float32 else 2,
+             M, P.N, K, ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_mx_w%sa8" % ("8" if P.w_fmt == "e4m3" else "4"))
     return y.reshape(*x.shape[:-1], P.N)
 
 
@@ -318,10 +341,11 @@ class MXLinearW4A8(nn.Module):
     to MX-FP8 and multiplies on the scaled MFMA (plain OCP-MX semantics: quantize_mx_op on both operands,
     number_system/mx/mx_ops.py:460-490, block 32 along in_features)."""
 
-    def __init__(self, in_features, out_features, bias=True, out_dtype=torch.bfloat16, device=None):
+    def __init__(self, in_features, out_features, bias=True, out_dtype=torch.bfloat16, device=None, w_fmt="e2m1"):
         super().__init__()
-        self.in_features, self.out_features, self.out_dtype = in_features, out_features, out_dtype
-        self.register_buffer("w_codes", torch.zeros(out_features * in_features // 2, dtype=torch.uint8, device=device))
+        self.in_features, self.out_features, self.out_dtype, self.w_fmt = in_features, out_features, out_dtype, w_fmt
+        nb = out_features * in_features // (2 if w_fmt == "e2m1" else 1)
+        self.register_buffer("w_codes", torch.zeros(nb, dtype=torch.uint8, device=device))
         self.register_buffer("w_scales", torch.zeros(out_features * in_features // 32, dtype=torch.uint8, device=device))
         if bias:
             self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, device=device))
@@ -337,8 +361,20 @@ class MXLinearW4A8(nn.Module):
             m.bias.copy_(linear.bias.data.float())
         return m
 
+    @classmethod
+    def from_values(cls, Wq, bias=None, out_dtype=torch.bfloat16):
+        """Fake-quant values of any quantiser (e.g. quant.outlier_fakequant / GPTQ output): MicroScopiQ weights with
+        their outliers, exact, on the scaled-MFMA path with MX-FP8 activations."""
+        N, K = Wq.shape
+        m = cls(K, N, bias is not None, out_dtype, Wq.device, w_fmt="e4m3")
+        P = mx_pack_values(Wq)
+        m.w_codes.copy_(P.codes); m.w_scales.copy_(P.scales)
+        if bias is not None:
+            m.bias.copy_(bias.detach().float())
+        return m
+
     def forward(self, x):
-        P = MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features)
+        P = MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features, self.w_fmt)
         return qlinear_mx_w4a8(x, P, self.bias, self.out_dtype)
 
 

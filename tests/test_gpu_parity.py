@@ -314,6 +314,80 @@ def test_mx_native_w4a8_vs_oracle(msq, O, M):
         assert np.abs(y - ref).max() <= tol * np.abs(ref).max() + 1e-6, (str(dt), float(np.abs(y - ref).max()), float(np.abs(ref).max()))
 
 
+def _e4m3_decode(e):
+    e = e.astype(np.int32)
+    sgn = np.where(e & 0x80, -1.0, 1.0); ex = (e >> 3) & 15; mant = e & 7
+    return sgn * np.where(ex > 0, (1 + mant / 8.0) * np.exp2(ex - 7.0), mant / 8.0 * 2.0 ** -6)
+
+
+def _mx_unpack_w8(P):
+    """Decode the e4m3 weight operand (include/msq.h: msq_mx_pack_w8) on the host: dense [N, K] float64."""
+    NT, KT = P.N // 64, P.K // 128
+    codes = P.codes.cpu().numpy().reshape(NT, KT, 4, 2, 64, 16)     # [tile][nf][half][lane][16 codes]
+    scales = P.scales.cpu().numpy().reshape(NT, KT, 64, 4)           # [tile][lane (r, block)][nf]
+    W = np.zeros((NT, 64, KT, 128))
+    for nf in range(4):
+        for ln in range(64):
+            r, kg = ln % 16, ln // 16
+            for half in range(2):
+                k0 = 64 * half + 16 * kg
+                sc = scales[:, :, (k0 // 32) * 16 + r, nf].astype(np.float64)
+                W[:, nf * 16 + r, :, k0:k0 + 16] = _e4m3_decode(codes[:, :, nf, half, ln, :]) * np.exp2(sc - 127.0)[..., None]
+    return W.reshape(P.N, P.K)
+
+
+@pytest.mark.parametrize("fo", ["fp8_e4m3", "fp4_e2m1", "posit8_es1"])
+@pytest.mark.parametrize("M", [1, 16, 200, 300])
+def test_mx_msq_weights_vs_oracle(msq, O, M, fo):
+    """MicroScopiQ weights (oracle fake-quant values: e2m1 inliers + outliers, a3-a7) packed exactly as e4m3 codes
+    + E8M0 scales for the scaled MFMA, MX-FP8 activations (a9): operands bit-exact vs the oracle, GEMM within
+    1e-4 * max|y| of the oracle's linear.  posit8_es1 outliers carry 4 fraction bits: the pack must refuse them."""
+    g = torch.Generator().manual_seed(33)
+    N, K = 256, 512
+    W = torch.randn(N, K, generator=g) * 0.02
+    W[torch.rand(N, K, generator=g) < 0.01] *= 20
+    X = torch.randn(M, K, generator=g)
+    X[torch.rand(M, K, generator=g) < 0.02] *= 10
+    bias = torch.randn(N, generator=g)
+    Wo = O.outlier_fakequant(W.numpy(), 8, 8, "fp4_e2m1", fo, 2, -1, 32)["out"]
+    if fo == "posit8_es1":
+        with pytest.raises(msq._lib.MsqError):
+            msq.qlinear.mx_pack_values(_t(Wo))
+        return
+    P = msq.qlinear.mx_pack_values(_t(Wo))
+    assert abs(P.bits_per_element - 8.25) < 1e-9
+    assert (_mx_unpack_w8(P) == Wo.astype(np.float64)).all()
+    Xo = O.quantize_mx(X.numpy(), 8, "fp8_e4m3", axis=-1, block_size=32)
+    ref = O.linear(Xo, Wo, bias.numpy())
+    # accumulation tolerance: the MFMA aligns the 128 products of one instruction to the largest one; with outlier
+    # weights in the block the small terms lose low bits: measured <= 2^-12.5 of the sum of |products|
+    # (scripts/experiments/mx_accuracy.py); bound 2^-11 elementwise.  bf16 output: + half an ulp of the result.
+    ab = np.abs(Xo).astype(np.float64) @ np.abs(Wo).astype(np.float64).T
+    for dt, rnd in ((torch.float32, 0.0), (torch.bfloat16, 2.0 ** -8)):
+        y = msq.qlinear.qlinear_mx_w4a8(X.to(dev()), P, bias.to(dev()), dt).float().cpu().numpy()
+        assert (np.abs(y - ref) <= 2.0 ** -11 * ab + rnd * np.abs(ref) + 1e-6).all(), (M, str(dt), float(np.abs(y - ref).max()))
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 11008)])
+def test_mx_msq_weights_llama_shapes_repeatable(msq, N, K):
+    g = torch.Generator(device=dev()).manual_seed(8)
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    Wq = msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    P = msq.qlinear.mx_pack_values(Wq)
+    if N * K <= 4096 * 4096:
+        assert torch.equal(torch.from_numpy(_mx_unpack_w8(P)).float().to(dev()), Wq)
+    for M in (1, 16, 17, 130, 2048):
+        X = torch.randn(M, K, generator=g, device=dev())
+        Y0 = msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32)
+        Xq = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32)
+        ref = Xq.double() @ Wq.double().t()
+        ab = Xq.double().abs() @ Wq.double().abs().t()
+        assert bool(((Y0.double() - ref).abs() <= 2.0 ** -11 * ab + 1e-6).all())
+        for _ in range(20):
+            assert torch.equal(msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32), Y0)
+
+
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
 def test_mx_native_llama_shapes_repeatable(msq, N, K):
     """MX-native GEMM at the Llama-7B layer shapes: equal to a dense fp32 GEMM on the decoded operands within the
