@@ -36,7 +36,7 @@ def synth_weight(N, K, dev, seed=0):
     return W
 
 
-def cpu_baseline(M, N, K, bs, fi, fo):
+def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False):
     """The oracle (a scalar C port of the reference's CPU fake-quant + the dense linear it feeds)
     timed on the host on a bounded sample of the same workload.  Reported, never optimised."""
     import numpy as np
@@ -46,7 +46,7 @@ def cpu_baseline(M, N, K, bs, fi, fo):
     Ws = (rng.randn(rows, K) * 0.02).astype(np.float32)
     Ws[rng.rand(rows, K) < 0.005] *= 16
     t0 = time.perf_counter()
-    r = O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs)
+    r = {"out": O.quantize_mx(Ws, 8, "fp4_e2m1", axis=-1, block_size=bs)} if plain_mx else O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs)
     t_q = time.perf_counter() - t0
     ms, ns = 512, 1024                           # linear sample: [512, K] x [1024, K]^T (~2-4 s)
     Xs = rng.randn(ms, K).astype(np.float32)
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--outlier", default="posit8_es1")
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama70b_rowparallel"])
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
     ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
                     help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +126,19 @@ def main():
     W = synth_weight(N, K, dev, seed=rank)
     w4a8 = args.workload == "llama7b_w4a8"
     mxw4a8 = args.workload == "llama7b_mx_w4a8"
-    if mxw4a8:
+    msqmx = args.workload == "llama7b_msq_w4a8_mx"
+    if msqmx:
+        # BASELINE config 3 with the MicroScopiQ weight itself on the MX matrix path: the fake-quant values (MX-FP4
+        # inliers + fp8_e4m3 outliers, utils/quant.py:147-266) packed exactly as one e4m3 code per weight + E8M0 scale
+        # per 32 k (8.25 bits/weight), MX-FP8 activations; a step = activation pack (fp32 in, one pass) + GEMM
+        args.outlier = "fp8_e4m3"
+        name = ("Llama-2-7B MicroScopiQ W4A8 on the MX matrix path (MX-FP4 inliers + fp8_e4m3 outliers as one exact e4m3 "
+                "operand x MX-FP8 activations, scaled MFMA, no dequantisation), act-pack + GEMM X[%d,%d] x W[%d,%d]^T" % (M, K, N, K))
+        from msq import quant
+        P = qlinear.mx_pack_values(quant.outlier_fakequant(W, 8, 8, args.inlier, args.outlier, 2, -1, args.block)["out"])
+        X = torch.randn(M, K, device=dev)
+        mxw4a8 = True
+    elif mxw4a8:
         # BASELINE config 3 on the CDNA4 MX matrix path: plain OCP-MX operands (mx_ops.py:332-457, block 32), MX-FP4
         # weights x MX-FP8 (e4m3) activations on v_mfma_scale_f32_16x16x128_f8f6f4; a step = activation pack (fp32 in,
         # one pass) + GEMM
@@ -197,7 +209,7 @@ def main():
         "metric": "fused dequant-GEMM TFLOPS (% MFMA peak) + PPL delta, Llama-7B W4 1xMI355X",
         "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "mxfp8 x mxfp4 (fp32 accumulate)" if mxw4a8 else "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("mxfp8 x e4m3 codes (fp32 accumulate)" if msqmx else "mxfp8 x mxfp4 (fp32 accumulate)") if mxw4a8 else "bf16", "data": "synthetic",
         "config": {"workload": name, "M": M, "N": N, "K": K, "block": args.block, "inlier": args.inlier,
                    "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element, "clock_ramp_launches": RAMP,
                    "layout": {(1, 2): "planes", (1, 3): "planes", (1, 4): "planes", (0, 4): "bf16", (0, 5): "unified",
@@ -214,9 +226,9 @@ def main():
     # scripts/profile_gpu.sh, scripts/summarize_profiles.py); they cannot be collected from inside this run.
     tag = {"posit8_es1": "posit", "fp8_e4m3": "fp8"}.get(args.outlier)
     if mxw4a8:
-        tag = "mx_w4a8"
+        tag = "msq_w4a8_mx" if msqmx else "mx_w4a8"
     prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % tag) if tag else None
-    if prof and os.path.exists(prof) and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8") and (M, H) == (2048, 4096):
+    if prof and os.path.exists(prof) and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx") and (M, H) == (2048, 4096):
         try:
             pj = json.load(open(prof))
             out["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")
@@ -225,7 +237,7 @@ def main():
         except Exception:
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier)
+        out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier, plain_mx=(mxw4a8 and not msqmx))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

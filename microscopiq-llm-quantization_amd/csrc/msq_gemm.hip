@@ -757,10 +757,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         uint32_t xsc[2];                                                                                     \
         xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024);                                \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (W8) { xl[mf & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + mf * 2048);                                       \
-                      xh[mf & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + mf * 2048);                                       \
-                      xsc[mf & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + (mf >> 1) * 256 + (mf & 1) * 64); } \
-            else if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
+            if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + (mf + 1) * 2048);                  \
                               xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }   \
             const u32x4_t lo = xl[mf & 1], hi = xh[mf & 1];                                                  \
