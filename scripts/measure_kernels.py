@@ -11,7 +11,7 @@ import torch
 
 import msq
 from msq import _lib as pkg
-from msq import qlinear
+from msq import qlinear, quant
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -113,28 +113,38 @@ def sec_w4a8():
     print(f"qlinear_w4a8 (MXLinear semantics) M{M} N{N} K{K}: {ms*1e3:6.1f} us  {2*M*N*K/ms/1e9:6.1f} TF")
 
 
-def sec_mx():
-    print("# MX-native W4A8 (msq_mx_pack_a8 + msq_qlinear_mx_w4a8: MX-FP4 x MX-FP8 on the scaled MFMA), X f32, bf16 out;")
-    print("#   flops = 2 M N K; act pack algorithmic bytes = numel * (4 + 1 + 1/32)")
+def sec_mx(w8=False):
     from msq._lib import lib, ptr, check, current_stream
+    if w8:
+        print("# MicroScopiQ weights on the MX matrix path (msq_mx_pack_w8 + msq_qlinear_mx_w8a8: fake-quant values fp4_e2m1 + fp8_e4m3")
+        print("#   outliers as one exact e4m3 operand, 8.25 bits/weight, x MX-FP8 activations), X f32, bf16 out; flops = 2 M N K")
+    else:
+        print("# MX-native W4A8 (msq_mx_pack_a8 + msq_qlinear_mx_w4a8: MX-FP4 x MX-FP8 on the scaled MFMA), X f32, bf16 out;")
+        print("#   flops = 2 M N K; act pack algorithmic bytes = numel * (4 + 1 + 1/32)")
+    fn = lib().msq_qlinear_mx_w8a8 if w8 else lib().msq_qlinear_mx_w4a8
     for (N, K) in [(16384, 4096), (4096, 4096), (11008, 4096), (4096, 11008)]:
         W = synth(N, K)
-        P = qlinear.mx_pack_weight(W)
-        tpw = t(lambda: qlinear.mx_pack_weight(W), 10)
+        if w8:
+            W = quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+            P = qlinear.mx_pack_values(W)
+            tpw = t(lambda: qlinear.mx_pack_values(W), 10)
+        else:
+            P = qlinear.mx_pack_weight(W)
+            tpw = t(lambda: qlinear.mx_pack_weight(W), 10)
         for M in (16, 128, 2048, 8192):
             X = torch.randn(M, K, device=dev)
             xc, xs = qlinear.mx_pack_act(X)
             y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, N, K); ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
             def gemm():
-                check(lib().msq_qlinear_mx_w4a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), None, ptr(y), 2, M, N, K, ptr(ws), wsb, current_stream(dev)), "gemm")
+                check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), None, ptr(y), 2, M, N, K, ptr(ws), wsb, current_stream(dev)), "gemm")
             tg = t(gemm); tp = t(lambda: qlinear.mx_pack_act(X)); te = t(lambda: qlinear.qlinear_mx_w4a8(X, P))
             print(f"N{N:5d} K{K:5d} M{M:5d}: GEMM {tg*1e3:7.1f} us {2*M*N*K/tg/1e9:7.1f} TF | act pack {tp*1e3:6.1f} us {M*K*(5+1/32)/tp/1e6:5.0f} GB/s | "
                   f"end to end {te*1e3:7.1f} us {2*M*N*K/te/1e9:7.1f} TF", flush=True)
-        print(f"N{N:5d} K{K:5d} weight pack (offline): {tpw*1e3:6.0f} us {N*K*(4+0.53125)/tpw/1e6:5.0f} GB/s, {P.bits_per_element:.2f} bits/weight")
+        print(f"N{N:5d} K{K:5d} weight pack (offline): {tpw*1e3:6.0f} us {N*K*(4+P.bits_per_element/8)/tpw/1e6:5.0f} GB/s, {P.bits_per_element:.2f} bits/weight")
 
 
-SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8, "mx": sec_mx}
+SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8, "mx": sec_mx, "mx8": lambda: sec_mx(True)}
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)
     print("device:", torch.cuda.get_device_name(0))

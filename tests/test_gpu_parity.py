@@ -901,6 +901,51 @@ def test_harness_mx_native_w4a8_ppl(msq):
     assert abs(ppl_fast - ppl_ref) / ppl_ref < 0.05 / 5.5, (ppl_fast, ppl_ref)
 
 
+def test_harness_msq_weights_on_mx_path_ppl(msq):
+    """The MicroScopiQ weight itself (MX-FP4 inliers + fp8_e4m3 outliers, utils/quant.py:147-266) on the scaled-MFMA
+    path with MX-FP8 activations: perplexity of the tiny Llama with MXLinearW4A8.from_values modules vs the same model
+    with the weight fake-quantised in place and the activation quantised in a forward pre-hook (dense fp32 F.linear)."""
+    from msq.harness import find_layers
+    from msq.harness.data_utils import _Enc
+    from msq.harness.evalppl import perplexity
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    g = torch.Generator().manual_seed(1)
+    tokens = _Enc(torch.randint(0, 512, (1, 64 * 6), generator=g))
+    torch.manual_seed(0)
+    ref = LlamaForCausalLM(cfg).eval().to(dev())
+    torch.manual_seed(0)
+    fast = LlamaForCausalLM(cfg).eval().to(dev())
+    hooks = []
+    fq = lambda w: msq.quant.outlier_fakequant(w.float(), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    for layer in ref.model.layers:
+        for name, lin in find_layers(layer).items():
+            lin.weight.data = fq(lin.weight.data)
+            hooks.append(lin.register_forward_pre_hook(
+                lambda mod, args: (msq.mx_ops._quantize_mx(args[0].float(), 8, "fp8_e4m3", axes=[-1], block_size=32),)))
+    for layer in fast.model.layers:
+        for name, lin in find_layers(layer).items():
+            parent = layer
+            parts = name.split(".")
+            for p_ in parts[:-1]:
+                parent = getattr(parent, p_)
+            m = msq.qlinear.MXLinearW4A8.from_values(fq(lin.weight.data), lin.bias, out_dtype=torch.float32)
+            assert m.w_fmt == "e4m3" and m.w_codes.numel() == lin.weight.numel()
+            setattr(parent, parts[-1], m)
+    ppl_ref = perplexity(ref, tokens, dev(), 64)
+    ppl_fast = perplexity(fast, tokens, dev(), 64)
+    for h in hooks:
+        h.remove()
+    assert abs(ppl_fast - ppl_ref) / ppl_ref < 0.05 / 5.5, (ppl_fast, ppl_ref)
+    sd = fast.state_dict()                                        # the module round-trips through its state_dict
+    m2 = msq.qlinear.MXLinearW4A8(256, 256, False, torch.float32, dev(), w_fmt="e4m3")
+    src = fast.model.layers[0].self_attn.q_proj
+    m2.load_state_dict(src.state_dict())
+    x = torch.randn(3, 256, device=dev())
+    assert torch.equal(m2(x), src(x)) and any(k.endswith("w_codes") for k in sd)
+
+
 # ---------------------------------------------------------------- f1 GPTQ + MicroScopiQ pruning (llm/gptq.py)
 def test_gptq_solver_vs_reference_fixture(msq):
     """The GPTQ solver with the fused per-column MicroScopiQ quantiser against the reference's CPU solver on
