@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmsq_hip.so")
+_SO = os.environ.get("MSQ_LIB_OVERRIDE") or os.path.join(_HERE, "libmsq_hip.so")   # override: ablation builds (scripts/experiments)
 _lib = None
 
 MSQ_OK = 0

@@ -25,6 +25,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MSQ_MXABL
+#define MSQ_MXABL 0      /* ablation of k_mxgemm (scripts/experiments/build_mx_ablation.sh): 1 no LDS fragment reads, 2 no weight loads, 4 no LDS-DMA, 8 no barrier, 16 no stores */
+#endif
 #ifndef MSQ_ABL
 #define MSQ_ABL 0
 #endif
@@ -746,23 +749,23 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
-        if (!W8) load_w(WLOAD, k2);          /* issue order (vmcnt is in-order): weights, then LDS-DMA */     \
+        if (!W8 && !(MSQ_MXABL & 2)) load_w(WLOAD, k2);   /* issue order (vmcnt is in-order): weights, then LDS-DMA */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        stage_A(k2, buf2);                                                                                   \
+        if (!(MSQ_MXABL & 4)) stage_A(k2, buf2);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (W8) load_w(WLOAD, k1);           /* fp8 ring: LDS-DMA first, the weights of K-step kt + 1 last */ \
+        if (W8 && !(MSQ_MXABL & 2)) load_w(WLOAD, k1);    /* fp8 ring: LDS-DMA first, the weights of K-step kt + 1 last */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         u32x4_t xl[2], xh[2];                                                                                \
         xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh);             \
         uint32_t xsc[2];                                                                                     \
         xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024);                                \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 1 < 8) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
+            if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + (mf + 1) * 2048);                  \
                               xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }   \
-            const u32x4_t lo = xl[mf & 1], hi = xh[mf & 1];                                                  \
+            const u32x4_t lo = xl[(MSQ_MXABL & 1) ? 0 : (mf & 1)], hi = xh[(MSQ_MXABL & 1) ? 0 : (mf & 1)];  \
             const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
-            const int sb_ = (int)xsc[mf & 1];                                                                \
+            const int sb_ = (int)xsc[(MSQ_MXABL & 1) ? 0 : (mf & 1)];                                        \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) {                                               \
                 const u32x4_t wl_ = WCUR.w[nf][0], wh_ = WCUR.w[nf][WV - 1];                                  \
                 const v8i_t afr = {(int)wl_[0], (int)wl_[1], (int)wl_[2], (int)wl_[3], W8 ? (int)wh_[0] : 0, W8 ? (int)wh_[1] : 0, W8 ? (int)wh_[2] : 0, W8 ? (int)wh_[3] : 0}; \
@@ -776,7 +779,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         /* this K-step's 5 weight loads and 5 LDS-DMA ops (all for K-step kt + 2) stay in flight; everything \
            issued in the previous K-step -- the tile and the weights of K-step kt + 1 -- has landed */       \
         __builtin_amdgcn_s_waitcnt(0x0070 | N_WAIT_MX);                                                      \
-        __builtin_amdgcn_s_barrier();                                                                        \
+        if (!(MSQ_MXABL & 8)) __builtin_amdgcn_s_barrier();                                                  \
     }
 
     int abuf = 0;
@@ -794,6 +797,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #undef MSQ_MX_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
+    if (MSQ_MXABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     if (ksplit > 1) store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
     else store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
 }
