@@ -755,14 +755,21 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (W8 && !(MSQ_MXABL & 2)) load_w(WLOAD, k1);    /* fp8 ring: LDS-DMA first, the weights of K-step kt + 1 last */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* fp8 ring: the kernel sits at the register limit and hipcc parks loop-invariant LDS addresses in scratch; a  \
+           reload after the weight loads would wait for them (in-order vmcnt).  The three addresses are re-derived from \
+           the lane id instead (volatile asm: not hoisted), 10 VALU per K-step */                                      \
+        int rdl_ = rdl, rdh_ = rdh, xs_rd_ = xs_rd;                                                           \
+        if (W8) { int l_; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_)); \
+                  const int c_ = l_ & 15, g_ = l_ >> 4, sw_ = (c_ >> 1) & 7;                                  \
+                  rdl_ = c_ * 128 + ((g_ ^ sw_) << 4); rdh_ = rdl_ ^ 64; xs_rd_ = XS_BASE + c_ * 4 + g_; }    \
         u32x4_t xl[2], xh[2];                                                                                \
-        xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh);             \
+        xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl_); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh_);           \
         uint32_t xsc[2];                                                                                     \
-        xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024);                                \
+        xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd_ + buf * 1024);                               \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl + (mf + 1) * 2048);                  \
-                              xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh + (mf + 1) * 2048);                  \
-                              xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }   \
+            if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl_ + (mf + 1) * 2048);                 \
+                              xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh_ + (mf + 1) * 2048);                 \
+                              xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd_ + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }  \
             const u32x4_t lo = xl[(MSQ_MXABL & 1) ? 0 : (mf & 1)], hi = xh[(MSQ_MXABL & 1) ? 0 : (mf & 1)];  \
             const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
             const int sb_ = (int)xsc[(MSQ_MXABL & 1) ? 0 : (mf & 1)];                                        \
