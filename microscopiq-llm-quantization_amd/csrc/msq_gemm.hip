@@ -643,9 +643,10 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // 8.25 bits/weight: MicroScopiQ inliers + outliers) instead of e2m1: 32 B per lane and 16 n in two half-slots, the
 // same MFMA rate (an fp8 operand on either side sets it).  The three-deep weight ring would need 99 VGPRs next
 // to the 128 accumulators, so the fp8 ring is two deep: the weights of K-step kt + 1 are requested at the top of
-// K-step kt, AFTER the LDS-DMA of this step (the kernel is at the register limit: an address reloaded from
-// scratch before the LDS-DMA must not have to wait for weight loads issued just before it), and everything is
-// awaited at the end of the K-step.
+// K-step kt and awaited at its end (vmcnt(5): the LDS-DMA of this step, issued after them, stays in flight).  The
+// kernel sits at the register limit; hipcc used to park loop-invariant LDS addresses in scratch and a reload behind
+// the weight loads made every K-step wait for the loads it had just issued (in-order vmcnt): those addresses are
+// re-derived from the lane id inside the loop instead (no spills).
 template <typename YT, bool W8>
 __global__ void __launch_bounds__(256, 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
@@ -732,7 +733,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
     constexpr int CBSZ = W8 ? 0 : 4;                             // A-operand format: e4m3 / e2m1
-    constexpr int N_WAIT_MX = W8 ? 0 : 10;
+    constexpr int N_WAIT_MX = W8 ? 5 : 10;
     const int kl = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);   // an empty split runs a harmless prologue
     const int kf0 = (kt_lo < KT) ? kt_lo : KT - 1, kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
     stage_A(kf0, 0);
@@ -749,11 +750,9 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
-        if (!W8 && !(MSQ_MXABL & 2)) load_w(WLOAD, k2);   /* issue order (vmcnt is in-order): weights, then LDS-DMA */ \
+        if (!(MSQ_MXABL & 2)) load_w(WLOAD, W8 ? k1 : k2);   /* issue order (vmcnt is in-order): weights, then LDS-DMA */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (!(MSQ_MXABL & 4)) stage_A(k2, buf2);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (W8 && !(MSQ_MXABL & 2)) load_w(WLOAD, k1);    /* fp8 ring: LDS-DMA first, the weights of K-step kt + 1 last */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         /* fp8 ring: the kernel sits at the register limit and hipcc parks loop-invariant LDS addresses in scratch; a  \
            reload after the weight loads would wait for them (in-order vmcnt).  The three addresses are re-derived from \
