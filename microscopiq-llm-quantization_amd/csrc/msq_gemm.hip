@@ -815,11 +815,11 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // <= 16 rows: L2-resident).  The next tile's weights are in flight while the current one is consumed; fp32 partial
 // tiles per k-chunk, summed by k_splitk_reduce.
 // ---------------------------------------------------------------------------
-template <bool W8>
+template <bool W8, int MG>
 __global__ void __launch_bounds__(256)
 k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc) {
-    __shared__ float red[3][16][64];
+    __shared__ float red[3][16 * MG][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / 128;
@@ -830,12 +830,20 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     const int kt_lo = ks * kc < KT ? ks * kc : KT;
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
     const int64_t tile_row = (int64_t)strip * KT;
-    const int mrow = c < M ? c : M - 1;                        // rows >= M are clamped; their results are never stored
-    const uint8_t* xrow = Xc + (int64_t)mrow * K + g * 16;
-    const uint8_t* xsrow = Xs + (int64_t)mrow * (K / 32) + g;
-    f32x4_t acc[4];
+    // MG groups of 16 activation rows; rows >= M are clamped, their results are never stored
+    const uint8_t* xrow[MG];
+    const uint8_t* xsrow[MG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MG; ++j) {
+        int m = j * 16 + c; m = m < M ? m : M - 1;
+        xrow[j] = Xc + (int64_t)m * K + g * 16;
+        xsrow[j] = Xs + (int64_t)m * (K / 32) + g;
+    }
+    f32x4_t acc[4][MG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int WV = W8 ? 2 : 1, CBSZ = W8 ? 0 : 4;
     struct WT { u32x4_t w[4][WV]; uint32_t s; };
     auto load_w = [&](WT& t, int64_t tile) {
@@ -850,37 +858,54 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
         load_w(nxt, tile_row + ktn);
-        const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(xrow + (int64_t)kt * 128);        // k = 16 g ..
-        const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(xrow + (int64_t)kt * 128 + 64);   // k = 64 + 16 g ..
-        const int sb = (int)xsrow[kt * 4];
-        const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        v8i_t bfr[MG];
+        int sb[MG];
+#pragma unroll
+        for (int j = 0; j < MG; ++j) {
+            const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(xrow[j] + (int64_t)kt * 128);        // k = 16 g ..
+            const u32x4_t hi = *reinterpret_cast<const u32x4_t*>(xrow[j] + (int64_t)kt * 128 + 64);   // k = 64 + 16 g ..
+            sb[j] = (int)xsrow[j][kt * 4];
+            bfr[j] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const u32x4_t wl = cur.w[nf][0], wh = cur.w[nf][WV - 1];
             const v8i_t afr = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], W8 ? (int)wh[0] : 0, W8 ? (int)wh[1] : 0, W8 ? (int)wh[2] : 0, W8 ? (int)wh[3] : 0};
-            if (nf == 0) acc[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[0], CBSZ, 0, 0, (int)cur.s, 0, sb);
-            else if (nf == 1) acc[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[1], CBSZ, 0, 1, (int)cur.s, 0, sb);
-            else if (nf == 2) acc[2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[2], CBSZ, 0, 2, (int)cur.s, 0, sb);
-            else acc[3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr, acc[3], CBSZ, 0, 3, (int)cur.s, 0, sb);
+#pragma unroll
+            for (int j = 0; j < MG; ++j) {
+                if (nf == 0) acc[0][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[0][j], CBSZ, 0, 0, (int)cur.s, 0, sb[j]);
+                else if (nf == 1) acc[1][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[1][j], CBSZ, 0, 1, (int)cur.s, 0, sb[j]);
+                else if (nf == 2) acc[2][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[2][j], CBSZ, 0, 2, (int)cur.s, 0, sb[j]);
+                else acc[3][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[3][j], CBSZ, 0, 3, (int)cur.s, 0, sb[j]);
+            }
         }
         cur = nxt;
     }
     // the four k-chunks meet in LDS (fixed order: wave 0 + 1 + 2 + 3), one partial plane per block
     if (wid > 0) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+        for (int j = 0; j < MG; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[wid - 1][nf * 4 + e][lane] = acc[nf][e];
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wid - 1][(j * 4 + nf) * 4 + e][lane] = acc[nf][j][e];
     }
     __syncthreads();
-    // D[lane, e] = C[n = 4 g + e][m = c]
-    if (wid == 0 && c < M) {
-        float* pbase = partial + ((int64_t)kb * M + c) * N + strip * 64 + g * 4;
+    if (wid != 0) return;
+    // D[lane, e] = C[n = 4 g + e][m = 16 j + c]
+#pragma unroll
+    for (int j = 0; j < MG; ++j) {
+        const int m = j * 16 + c;
+        if (m >= M) continue;
+        float* pbase = partial + ((int64_t)kb * M + m) * N + strip * 64 + g * 4;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((acc[nf][e] + red[0][nf * 4 + e][lane]) + red[1][nf * 4 + e][lane]) + red[2][nf * 4 + e][lane];
+            for (int e = 0; e < 4; ++e) {
+                const int r = (j * 4 + nf) * 4 + e;
+                v[e] = ((acc[nf][j][e] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+            }
             *reinterpret_cast<float4*>(pbase + nf * 16) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
@@ -1268,8 +1293,17 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
 
 // small-M path: tiles per task so that there are ~3000 tasks (12 waves x 256 CUs) but at most 32 partial planes
 // measured (scripts/experiments/gemv_thr.py): the decode kernel wins up to M = 16, the split-K GEMM from M = 32 on
-#define MSQ_GEMV_MAX_M 16
-static int gemv_max_m() { return MSQ_GEMV_MAX_M; }
+// Decode kernel or (split-K) GEMM.  Measured from HIP graphs (scripts/experiments/mx_midm_check.py): with the LDS
+// reduction of four k-chunks the decode kernel wins for every Llama-7B shape up to M = 32 (two 16-row groups per wave);
+// with four groups (M <= 64) every wave re-reads 64 activation rows per tile from L2 and the partial planes grow with
+// M N: it still wins for the 4096 x 4096 projections (14.6 vs 19.3 us), not for N = 16384 or K = 11008.
+// MSQ_GEMV_MAX_M (tuning only) replaces the rule by M <= value.
+static bool use_gemv(int64_t M, int64_t N, int64_t K) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("MSQ_GEMV_MAX_M"); v = e ? atoi(e) : -1; if (v > 64) v = 64; }
+    if (v >= 0) return M <= v;
+    return M <= 32 || (M <= 64 && N <= 4096 && K <= 4096);
+}
 static int pick_kc(int64_t N, int64_t K) {
     const int64_t KT = K / BK, strips = N / TILE_N;
     int64_t kc = (strips * KT + 3071) / 3072;
@@ -1280,7 +1314,7 @@ static int pick_kc(int64_t N, int64_t K) {
 
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
-    if (M <= gemv_max_m()) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }
+    if (use_gemv(M, N, K)) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -1301,13 +1335,14 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     hipStream_t st0 = (hipStream_t)stream;
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
-    if (M <= gemv_max_m() && workspace) {
+    if (use_gemv(M, N, K) && workspace) {
         const int kc = pick_kc(N, K);
         const int nks = (int)(((K / BK + kc - 1) / kc + 3) / 4);         // partial planes: one per four k-chunks
         if (workspace_bytes >= (int64_t)nks * M * N * 4) {
             const dim3 vgrid((unsigned)((N / TILE_N) * nks)), vblk(256);
-#define MSQ_GV(IK, OK)                                                                                                  \
-            hipLaunchKernelGGL((k_qgemv<IK, OK, 1>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc)
+#define MSQ_GV1(IK, OK, MGV)                                                                                            \
+            hipLaunchKernelGGL((k_qgemv<IK, OK, MGV>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc)
+#define MSQ_GV(IK, OK) do { if (M <= 16) MSQ_GV1(IK, OK, 1); else if (M <= 32) MSQ_GV1(IK, OK, 2); else MSQ_GV1(IK, OK, 4); } while (0)
             if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
@@ -1316,6 +1351,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8X) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_U8X);
             else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds");
 #undef MSQ_GV
+#undef MSQ_GV1
             rc = check_launch2("msq_qlinear_bf16(gemv)");
             if (rc) return rc;
             const int64_t MN0 = M * N;
@@ -1416,7 +1452,16 @@ static int pick_mx_ksplit(int64_t M, int64_t N, int64_t K) {
     if (ks > 16) ks = 16;
     return ks < 1 ? 1 : (int)ks;
 }
-// decode path (M <= 16): K-steps per wave so that there are ~3000 waves (4 per block) and at most 32 k-chunks
+// decode kernel or GEMM, as use_gemv: up to M = 32 always, up to 64 for N <= 4096 (13.1 vs 17.6 us at 4096 x 4096,
+// 16.3 vs 17.4 at K = 11008; 22.1 vs 18.1 at N = 16384).  MSQ_MX_GEMV_MAX_M (tuning only): M <= value.
+static bool use_mx_gemv(int64_t M, int64_t N, int64_t K) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("MSQ_MX_GEMV_MAX_M"); v = e ? atoi(e) : -1; if (v > 64) v = 64; }
+    if (v >= 0) return M <= v;
+    (void)K;
+    return M <= 32 || (M <= 64 && N <= 4096);
+}
+// decode path: K-steps per wave so that there are ~3000 waves (4 per block) and at most 32 k-chunks
 static int pick_mx_kc(int64_t N, int64_t K) {
     const int64_t KT = K / 128, strips = N / 64;
     int64_t kc = (strips * KT + 3071) / 3072;
@@ -1426,7 +1471,7 @@ static int pick_mx_kc(int64_t N, int64_t K) {
 }
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % 128)) return 0;
-    if (M <= 16) { const int kc = pick_mx_kc(N, K); return (((K / 128 + kc - 1) / kc + 3) / 4) * M * N * 4; }
+    if (use_mx_gemv(M, N, K)) { const int kc = pick_mx_kc(N, K); return (((K / 128 + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_mx_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -1439,14 +1484,16 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
     hipStream_t st = (hipStream_t)stream;
-    if (M <= 16 && workspace) {
+    if (use_mx_gemv(M, N, K) && workspace) {
         const int kc = pick_mx_kc(N, K);
         const int nks = (int)(((K / 128 + kc - 1) / kc + 3) / 4);        // partial planes: one per four k-chunks
         if (workspace_bytes >= (int64_t)nks * M * N * 4) {
-            if (w8) hipLaunchKernelGGL(k_mxgemv<true>, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
-                                       (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
-            else hipLaunchKernelGGL(k_mxgemv<false>, dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales,
-                                    (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc);
+#define MSQ_MXV(W8V, MGV) hipLaunchKernelGGL((k_mxgemv<W8V, MGV>), dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
+                                             (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc)
+            if (M <= 16) { if (w8) MSQ_MXV(true, 1); else MSQ_MXV(false, 1); }
+            else if (M <= 32) { if (w8) MSQ_MXV(true, 2); else MSQ_MXV(false, 2); }
+            else { if (w8) MSQ_MXV(true, 4); else MSQ_MXV(false, 4); }
+#undef MSQ_MXV
             int rc0 = check_launch2("msq_qlinear_mx_w4a8(decode)");
             if (rc0) return rc0;
             const int64_t MN0 = M * N;

@@ -284,7 +284,7 @@ def _mx_unpack_w4(P):
     return W
 
 
-@pytest.mark.parametrize("M", [1, 16, 200, 300])
+@pytest.mark.parametrize("M", [1, 16, 24, 40, 64, 200, 300])
 def test_mx_native_w4a8_vs_oracle(msq, O, M):
     """MX-native W4A8 (plain OCP-MX operands on v_mfma_scale_f32_16x16x128_f8f6f4): the packed operands decode to
     the oracle's quantize_mx values bit for bit (a9: mx_ops.py:332-457), the GEMM equals the oracle's linear on them.
@@ -337,7 +337,7 @@ def _mx_unpack_w8(P):
 
 
 @pytest.mark.parametrize("fo", ["fp8_e4m3", "fp4_e2m1", "posit8_es1"])
-@pytest.mark.parametrize("M", [1, 16, 200, 300])
+@pytest.mark.parametrize("M", [1, 16, 24, 40, 64, 200, 300])
 def test_mx_msq_weights_vs_oracle(msq, O, M, fo):
     """MicroScopiQ weights (oracle fake-quant values: e2m1 inliers + outliers, a3-a7) packed exactly as e4m3 codes
     + E8M0 scales for the scaled MFMA, MX-FP8 activations (a9): operands bit-exact vs the oracle, GEMM within
@@ -377,7 +377,7 @@ def test_mx_msq_weights_llama_shapes_repeatable(msq, N, K):
     P = msq.qlinear.mx_pack_values(Wq)
     if N * K <= 4096 * 4096:
         assert torch.equal(torch.from_numpy(_mx_unpack_w8(P)).float().to(dev()), Wq)
-    for M in (1, 16, 17, 130, 2048):
+    for M in (1, 16, 17, 32, 33, 64, 130, 2048):        # decode kernel with 1 / 2 / 4 row groups, split-K, plain GEMM
         X = torch.randn(M, K, generator=g, device=dev())
         Y0 = msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32)
         Xq = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32)
@@ -397,7 +397,7 @@ def test_mx_native_llama_shapes_repeatable(msq, N, K):
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
     P = msq.qlinear.mx_pack_weight(W)
     Wd = torch.from_numpy(_mx_unpack_w4(P)).float().to(dev()) if N * K <= 4096 * 4096 else None
-    for M in (1, 3, 16, 17, 130, 2048):            # <= 16: decode kernel; then split-K and plain GEMM
+    for M in (1, 3, 16, 17, 32, 33, 64, 130, 2048):    # decode kernel with 1 / 2 / 4 row groups, split-K, plain GEMM
         X = torch.randn(M, K, generator=g, device=dev())
         Y0 = msq.qlinear.qlinear_mx_w4a8(X, P, None, torch.float32)
         if Wd is not None:
@@ -558,7 +558,7 @@ def test_unified_pack_unpack_equals_fakequant(msq, O, fi, fo, bs, kind):
 
 
 @pytest.mark.parametrize("fi,fo,bs,kind", UCFGS[:3])
-@pytest.mark.parametrize("M", [1, 16, 65, 300, 513])
+@pytest.mark.parametrize("M", [1, 16, 24, 40, 64, 65, 300, 513])
 def test_unified_fused_gemm_vs_oracle_linear(msq, O, fi, fo, bs, kind, M):
     g = torch.Generator().manual_seed(2)
     W = torch.randn(256, 512, generator=g) * 0.02
@@ -594,7 +594,7 @@ def test_unified_layout_limits(msq):
 
 
 @pytest.mark.parametrize("fi,fo,bs", CFGS[:4])
-@pytest.mark.parametrize("M", [1, 16, 300, 513])
+@pytest.mark.parametrize("M", [1, 16, 24, 40, 64, 300, 513])
 def test_fused_gemm_vs_oracle_linear(msq, O, fi, fo, bs, M):
     """Tolerance: fp32 accumulation of K=512 products of bf16 x exact weights; the oracle accumulates in
     double, so |err| <= K * 2^-24 * sum|x.w| -- bounded here by 2e-5 * max|y| + 1e-6."""
@@ -648,7 +648,7 @@ def test_fused_gemm_llama_shapes_repeatable(msq, N, K, layout):
     W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
     P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3" if N != 11008 else "posit8_es1", 2, 32, layout=layout)
     Wu = msq.qlinear.unpack_weight(P, torch.float32)
-    for M in (1, 7, 16, 65, 128, 1000, 2048):                       # decode kernel (flag-synchronised reduction), split-K, full tiles
+    for M in (1, 7, 16, 17, 32, 48, 64, 65, 128, 1000, 2048):       # decode kernel (1 / 2 / 4 row groups, LDS + split-K reduction), split-K GEMM, full tiles
         X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
         Yr = X.float() @ Wu.t()
         Y0 = msq.qlinear.qlinear(X, P, None, torch.float32)
