@@ -11,6 +11,9 @@ and loads its own file, `shard` / `world_size` are recorded).
               "layers": {"<module name>": {"in_features", "out_features", "block_size", "layout",
                                             "in_kind", "out_kind", "inlier_elem_format",
                                             "outlier_elem_format", "bias", "out_dtype"}}}
+
+MX-operand layers (MXLinearW4A8: codes in the operand order of the scaled MFMA) are listed with
+``"layout": "mx-operand"`` and ``"w_fmt"`` ("e2m1" plain MX-FP4, "e4m3" exactly packed fake-quant values).
 """
 import json
 
@@ -18,13 +21,13 @@ import torch
 import torch.nn as nn
 
 from ._lib import MsqError
-from .qlinear import QuantLinear
+from .qlinear import MXLinearW4A8, QuantLinear
 
 FORMAT, VERSION = "msq-packed", 1
 
 
 def _packed_layers(model):
-    return {name: m for name, m in model.named_modules() if isinstance(m, QuantLinear)}
+    return {name: m for name, m in model.named_modules() if isinstance(m, (QuantLinear, MXLinearW4A8))}
 
 
 def save_packed(model, path, shard=0, world_size=1):
@@ -32,6 +35,10 @@ def save_packed(model, path, shard=0, world_size=1):
     from safetensors.torch import save_file
     layers = {}
     for name, m in _packed_layers(model).items():
+        if isinstance(m, MXLinearW4A8):
+            layers[name] = dict(in_features=m.in_features, out_features=m.out_features, layout="mx-operand", w_fmt=m.w_fmt,
+                                bias=m.bias is not None, out_dtype=str(m.out_dtype).replace("torch.", ""))
+            continue
         layers[name] = dict(in_features=m.in_features, out_features=m.out_features, block_size=m.block_size,
                             layout=m.layout, in_kind=m.in_kind, out_kind=m.out_kind,
                             inlier_elem_format=m.inlier_elem_format, outlier_elem_format=m.outlier_elem_format,
@@ -73,11 +80,15 @@ def load_packed(model, path, device=None, strict=True):
         old = modules.get(name)
         if old is None:
             raise MsqError("checkpoint layer %r does not exist in the model" % name)
-        if isinstance(old, (nn.Linear, QuantLinear)):
+        if isinstance(old, (nn.Linear, QuantLinear, MXLinearW4A8)):
             if (old.in_features, old.out_features) != (d["in_features"], d["out_features"]):
                 raise MsqError("checkpoint layer %r has shape %dx%d, the model %dx%d" % (
                     name, d["out_features"], d["in_features"], old.out_features, old.in_features))
         dev = device if device is not None else next(old.parameters(), next(old.buffers(), torch.zeros(0))).device
+        if d.get("layout") == "mx-operand":
+            _swap(model, name, MXLinearW4A8(d["in_features"], d["out_features"], d["bias"], getattr(torch, d["out_dtype"]), dev,
+                                            w_fmt=d["w_fmt"]))
+            continue
         if d["inlier_elem_format"] == "values":          # packed from dense values (QuantLinear.from_dense)
             q = QuantLinear.empty_single_plane(d["in_features"], d["out_features"], d["bias"], d["out_kind"],
                                                getattr(torch, d["out_dtype"]), dev)

@@ -44,17 +44,36 @@ def quantize_layers_nearest(layers, dev, quant_cfg=None, log=None):
 
 
 @torch.no_grad()
-def pack_layers(layers):
+def pack_layers(layers, path="bf16"):
     """After quantize_layers_nearest / the GPTQ pass: swap every (already fake-quantised) Linear inside the decoder
     layers for a packed QuantLinear (what ``opt_pack3`` / ``make_quant3`` were meant to do, llm/opt.py:255-264).
     The weights are stored in the smallest exact single-plane kind (8.25 bits/weight for the harness default
     int2 / fp4 configuration) and the forward runs the fused dequant-GEMM.  Layers whose shape the kernel
-    does not take (out_features % 256, in_features % 64) stay dense.  Returns (packed, kept_dense)."""
-    from ..qlinear import make_quant
+    does not take (out_features % 256, in_features % 64) stay dense.  Returns (packed, kept_dense).
+
+    ``path="mx"``: W4A8 on the MX matrix path instead -- the fake-quant values become one exact e4m3 operand
+    (MXLinearW4A8.from_values, 8.25 bits/weight), the forward quantises the activations to MX-FP8 (plain OCP-MX,
+    block 32) and multiplies on the scaled MFMA.  Needs in_features % 128; a layer whose values do not fit
+    e4m3 x 2^s per 32-block (e.g. posit outliers) stays on the bf16-activation QuantLinear."""
+    from .._lib import MsqError
+    from ..qlinear import MXLinearW4A8, make_quant
     packed = dense = 0
     for layer in layers:
         names = {}
         for name, lin in find_layers(layer, layers=[nn.Linear]).items():
+            if path == "mx" and lin.out_features % 256 == 0 and lin.in_features % 128 == 0 and lin.weight.is_cuda:
+                try:
+                    m = MXLinearW4A8.from_values(lin.weight.data, lin.bias, out_dtype=lin.weight.dtype if lin.weight.dtype == torch.bfloat16 else torch.float32)
+                except MsqError:
+                    m = None
+                if m is not None:
+                    parent = layer
+                    parts = name.split(".")
+                    for p_ in parts[:-1]:
+                        parent = getattr(parent, p_)
+                    setattr(parent, parts[-1], m)
+                    packed += 1
+                    continue
             if lin.out_features % 256 == 0 and lin.in_features % 64 == 0 and lin.weight.is_cuda:
                 names[name] = None
                 packed += 1

@@ -758,6 +758,37 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     assert torch.equal(dst[0].dequantize(), src[0].dequantize())
 
 
+def test_mx_operand_checkpoint_and_pack_layers(msq, tmp_path):
+    """pack_layers(path="mx") turns fake-quantised Linears into MXLinearW4A8 modules (posit outliers do not fit e4m3 and
+    stay on QuantLinear); the checkpoint format round-trips both module kinds bit-identically."""
+    from msq import checkpoint
+    from msq.harness.evalppl import pack_layers
+    torch.manual_seed(0)
+    def build():
+        return torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.GELU(), torch.nn.Linear(512, 256, bias=False),
+                                   torch.nn.GELU(), torch.nn.Linear(256, 256)).to(dev())
+    src = build()
+    with torch.no_grad():
+        src[0].weight.copy_(msq.quant.outlier_fakequant(src[0].weight.data, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"])
+        src[2].weight.copy_(msq.quant.outlier_fakequant(src[2].weight.data, 8, 8, "fp4_e2m1", "posit8_es1", 2, -1, 32)["out"])
+        src[4].weight.copy_(msq.mx_ops._quantize_mx_outlier_v1(src[4].weight.data, 8, 8, "fp4_e2m1", "fp4_e2m1", "max", 5, [1], 32))
+    x = torch.randn(9, 256, device=dev())
+    dense = src(x)
+    packed, kept = pack_layers([src], path="mx")
+    assert (packed, kept) == (3, 0)
+    assert isinstance(src[0], msq.qlinear.MXLinearW4A8) and isinstance(src[4], msq.qlinear.MXLinearW4A8)
+    assert isinstance(src[2], msq.qlinear.QuantLinear)             # posit outliers: not an e4m3 operand
+    y = src(x)
+    assert (y - dense).abs().max() <= 0.05 * dense.abs().max()      # MX-FP8 activation quantisation, nothing else
+    path = str(tmp_path / "mx.safetensors")
+    hdr = checkpoint.save_packed(src, path)
+    assert hdr["layers"]["0"] == dict(in_features=256, out_features=512, layout="mx-operand", w_fmt="e4m3", bias=True, out_dtype="float32")
+    dst = build()
+    checkpoint.load_packed(dst, path)
+    assert isinstance(dst[0], msq.qlinear.MXLinearW4A8) and isinstance(dst[2], msq.qlinear.QuantLinear)
+    assert torch.equal(dst(x), y)
+
+
 def test_c_abi_error_codes(msq):
     L = msq._lib.lib()
     x = torch.zeros(64, device=dev())
