@@ -92,6 +92,8 @@ def main():
                     choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
     ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
                     help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
+    ap.add_argument("--mx", action="store_true",
+                    help="llama70b_rowparallel on the MX matrix path (MicroScopiQ e4m3 weight operand x MX-FP8 activations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,8 +116,8 @@ def main():
     if args.workload == "llama70b_rowparallel":
         H, N = 8192, 8192                                  # Llama-2-70B down_proj: K = 28672 split over ranks
         K_full = 28672
-        if K_full % (world * 64):
-            raise SystemExit("K=28672 must split into 64-multiples over the ranks")
+        if K_full % (world * (128 if args.mx else 64)):
+            raise SystemExit("K=28672 must split into 64-multiples (128 with --mx) over the ranks")
         K = K_full // world
         name = "Llama-2-70B W4 row-parallel QuantLinear down_proj [8192 x 28672], K split over %d GPU(s)" % world
     else:
@@ -126,8 +128,17 @@ def main():
     W = synth_weight(N, K, dev, seed=rank)
     w4a8 = args.workload == "llama7b_w4a8"
     mxw4a8 = args.workload == "llama7b_mx_w4a8"
-    msqmx = args.workload == "llama7b_msq_w4a8_mx"
-    if msqmx:
+    msqmx = args.workload == "llama7b_msq_w4a8_mx" or (args.workload == "llama70b_rowparallel" and args.mx)
+    if msqmx and args.workload == "llama70b_rowparallel":
+        # K splits on a multiple of 128: the activation's 32-blocks and the weight's packed tiles stay whole, every
+        # shard's operands equal the unsharded ones; one RCCL all-reduce of the bf16 partial outputs per step
+        args.outlier = "fp8_e4m3"
+        name += " on the MX matrix path (e4m3 weight operand x MX-FP8 activations)"
+        from msq import quant
+        P = qlinear.mx_pack_values(quant.outlier_fakequant(W, 8, 8, args.inlier, args.outlier, 2, -1, args.block)["out"])
+        X = torch.randn(M, K, device=dev)
+        mxw4a8 = True
+    elif msqmx:
         # BASELINE config 3 with the MicroScopiQ weight itself on the MX matrix path: the fake-quant values (MX-FP4
         # inliers + fp8_e4m3 outliers, utils/quant.py:147-266) packed exactly as one e4m3 code per weight + E8M0 scale
         # per 32 k (8.25 bits/weight), MX-FP8 activations; a step = activation pack (fp32 in, one pass) + GEMM
@@ -164,7 +175,10 @@ def main():
 
     def step():
         if mxw4a8:
-            return qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
+            y = qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
+            if args.workload == "llama70b_rowparallel" and world > 1:
+                dist.all_reduce(y)
+            return y
         if w4a8:
             return qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5,
                                         a_block_size=args.block, a_variant=1)

@@ -758,6 +758,31 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     assert torch.equal(dst[0].dequantize(), src[0].dequantize())
 
 
+def test_mx_row_parallel_shards_equal_unsharded(msq):
+    """70B row-parallel on the MX path: a K split on a multiple of 128 cuts neither a 32-block of the activations nor
+    a packed weight tile, so every shard's operands are slices of the unsharded ones and the shard outputs add up to
+    the unsharded output (the all-reduce of RowParallelQuantLinear; here summed on one GPU)."""
+    g = torch.Generator(device=dev()).manual_seed(12)
+    N, K, M, G = 512, 1024, 96, 2
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.01] *= 16
+    X = torch.randn(M, K, generator=g, device=dev())
+    Wq = msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    xc, xs = msq.qlinear.mx_pack_act(X)
+    full = msq.qlinear.qlinear_mx_w4a8(X, msq.qlinear.mx_pack_values(Wq), None, torch.float32)
+    acc = torch.zeros_like(full)
+    for r in range(G):
+        k0, k1 = msq.qlinear.RowParallelQuantLinear.shard_bounds(K, G, r, 128)
+        xcs, xss = msq.qlinear.mx_pack_act(X[:, k0:k1].contiguous())
+        assert torch.equal(xcs, xc[:, k0:k1]) and torch.equal(xss, xs[:, k0 // 32:k1 // 32])
+        shard = msq.qlinear.MXLinearW4A8.from_values(Wq[:, k0:k1].contiguous(), None, out_dtype=torch.float32)
+        rp = msq.qlinear.RowParallelQuantLinear(shard, 1, 0)          # world size 1: no collective, the sum is done below
+        acc += rp(X[:, k0:k1].contiguous())
+    ref = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32).double() @ Wq.double().t()
+    bound = 2.0 ** -11 * (msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32).double().abs() @ Wq.double().abs().t()) + 1e-6
+    assert bool(((acc.double() - ref).abs() <= bound).all()) and bool(((full.double() - ref).abs() <= bound).all())
+
+
 def test_mx_operand_checkpoint_and_pack_layers(msq, tmp_path):
     """pack_layers(path="mx") turns fake-quantised Linears into MXLinearW4A8 modules (posit outliers do not fit e4m3 and
     stay on QuantLinear); the checkpoint format round-trips both module kinds bit-identically."""
