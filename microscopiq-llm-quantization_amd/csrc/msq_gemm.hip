@@ -815,18 +815,22 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // <= 16 rows: L2-resident).  The next tile's weights are in flight while the current one is consumed; fp32 partial
 // tiles per k-chunk, summed by k_splitk_reduce.
 // ---------------------------------------------------------------------------
-template <bool W8, int MG>
-__global__ void __launch_bounds__(256)
+// WAVES (4 or 16) waves per block take consecutive k-chunks of one strip and meet in LDS.  When one block covers all
+// of K (nkb == 1, `direct`) wave 0 adds the bias and writes Y itself: one launch, no partial planes, no reduce kernel.
+template <bool W8, int MG, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
-         const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc) {
-    __shared__ float red[3][16 * MG][64];
+         const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc,
+         int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16) {
+    extern __shared__ __attribute__((aligned(16))) char smem_v[];
+    float (*red)[16 * MG][64] = reinterpret_cast<float (*)[16 * MG][64]>(smem_v);      // [WAVES - 1][16 MG][64]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / 128;
     const int nks = (KT + kc - 1) / kc;
-    const int nkb = (nks + 3) / 4;                             // the block's four waves take four consecutive k-chunks
+    const int nkb = (nks + WAVES - 1) / WAVES;                 // the block's waves take WAVES consecutive k-chunks
     const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb;
-    const int ks = kb * 4 + wid;
+    const int ks = kb * WAVES + wid;
     const int kt_lo = ks * kc < KT ? ks * kc : KT;
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
     const int64_t tile_row = (int64_t)strip * KT;
@@ -853,11 +857,15 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             for (int h = 0; h < WV; ++h) t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf) * WV + h) * 64 + lane) * 16);
         t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4);
     };
-    WT cur, nxt;
+    // tiles in flight ahead of the one being multiplied: 1 with four waves per block (~3000 waves in the grid), 2 with
+    // sixteen (fewer, longer waves)
+    constexpr bool DEEP2 = (WAVES == 16);
+    WT cur, nxt, nx2;
     if (kt_lo < kt_hi) load_w(cur, tile_row + kt_lo);
+    if (DEEP2 && kt_lo < kt_hi) load_w(nxt, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : kt_lo));
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
-        load_w(nxt, tile_row + ktn);
+        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; load_w(nx2, tile_row + ktn); }
+        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; load_w(nxt, tile_row + ktn); }
         v8i_t bfr[MG];
         int sb[MG];
 #pragma unroll
@@ -880,6 +888,7 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             }
         }
         cur = nxt;
+        if (DEEP2) nxt = nx2;
     }
     // the four k-chunks meet in LDS (fixed order: wave 0 + 1 + 2 + 3), one partial plane per block
     if (wid > 0) {
@@ -897,16 +906,28 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     for (int j = 0; j < MG; ++j) {
         const int m = j * 16 + c;
         if (m >= M) continue;
-        float* pbase = partial + ((int64_t)kb * M + m) * N + strip * 64 + g * 4;
+        const int n0 = strip * 64 + g * 4;
+        float* pbase = partial + ((int64_t)kb * M + m) * N + n0;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = (j * 4 + nf) * 4 + e;
-                v[e] = ((acc[nf][j][e] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+                float t = acc[nf][j][e];
+#pragma unroll
+                for (int w = 0; w < WAVES - 1; ++w) t += red[w][r][lane];           // fixed order: k-chunk 0 + 1 + 2 + ...
+                v[e] = t;
             }
-            *reinterpret_cast<float4*>(pbase + nf * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            if (!direct) { *reinterpret_cast<float4*>(pbase + nf * 16) = make_float4(v[0], v[1], v[2], v[3]); continue; }
+            const int n = n0 + nf * 16;
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (!y_bf16) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
         }
     }
 }
@@ -1461,6 +1482,18 @@ static bool use_mx_gemv(int64_t M, int64_t N, int64_t K) {
     (void)K;
     return M <= 32 || (M <= 64 && N <= 4096);
 }
+// single-launch decode: 16 waves per block = 16 k-chunks of one strip, summed in LDS, output written by wave 0.
+// Needs M <= 32 (LDS: 15 x 16 MG x 64 floats); used where it measured faster than decode + reduce
+// (scripts/experiments/mx_decode_check.py: N >= 8192 and K <= 4096: 6.0 vs 8.1 us at N16384 M1, 4.8 vs 6.6 at N11008;
+// e4m3 operand 12.8 vs 14.6); returns the K-steps per wave or 0.
+// MSQ_MX_GEMV_DIRECT=0 (tuning only) disables it.
+static int mx_direct_kc(int64_t M, int64_t N, int64_t K) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MSQ_MX_GEMV_DIRECT"); on = e ? atoi(e) : 1; }
+    if (!on || M > 32 || N < 8192) return 0;                    // fewer than 128 blocks: per-CU bandwidth bound (measured)
+    const int kc = (int)((K / 128 + 15) / 16);
+    return kc <= 2 ? kc : 0;                                     // long K: few long waves lose to ~3000 short ones (measured)
+}
 // decode path: K-steps per wave so that there are ~3000 waves (4 per block) and at most 32 k-chunks
 static int pick_mx_kc(int64_t N, int64_t K) {
     const int64_t KT = K / 128, strips = N / 64;
@@ -1471,7 +1504,7 @@ static int pick_mx_kc(int64_t N, int64_t K) {
 }
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % 128)) return 0;
-    if (use_mx_gemv(M, N, K)) { const int kc = pick_mx_kc(N, K); return (((K / 128 + kc - 1) / kc + 3) / 4) * M * N * 4; }
+    if (use_mx_gemv(M, N, K)) { if (mx_direct_kc(M, N, K)) return 0; const int kc = pick_mx_kc(N, K); return (((K / 128 + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_mx_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
@@ -1484,15 +1517,27 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
     hipStream_t st = (hipStream_t)stream;
-    if (use_mx_gemv(M, N, K) && workspace) {
-        const int kc = pick_mx_kc(N, K);
-        const int nks = (int)(((K / 128 + kc - 1) / kc + 3) / 4);        // partial planes: one per four k-chunks
-        if (workspace_bytes >= (int64_t)nks * M * N * 4) {
-#define MSQ_MXV(W8V, MGV) hipLaunchKernelGGL((k_mxgemv<W8V, MGV>), dim3((unsigned)((N / 64) * nks)), dim3(256), 0, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
-                                             (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc)
-            if (M <= 16) { if (w8) MSQ_MXV(true, 1); else MSQ_MXV(false, 1); }
-            else if (M <= 32) { if (w8) MSQ_MXV(true, 2); else MSQ_MXV(false, 2); }
-            else { if (w8) MSQ_MXV(true, 4); else MSQ_MXV(false, 4); }
+    if (use_mx_gemv(M, N, K)) {
+        const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+        const int kcd = mx_direct_kc(M, N, K);                           // > 0: one block of 16 waves covers all of K
+        const int kc = kcd ? kcd : pick_mx_kc(N, K);
+        const int waves = kcd ? 16 : 4;
+        const int nks = kcd ? 1 : (int)(((K / 128 + kc - 1) / kc + 3) / 4);   // partial planes: one per four k-chunks
+        if (kcd || (workspace && workspace_bytes >= (int64_t)nks * M * N * 4)) {
+            const size_t ldsv = (size_t)(waves - 1) * 16 * mg * 64 * 4;
+#define MSQ_MXV(W8V, MGV, WV)                                                                                          \
+            do { static bool attr_set = false;                                                                         \
+                 if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_set = true; } \
+                 hipLaunchKernelGGL((k_mxgemv<W8V, MGV, WV>), dim3((unsigned)((N / 64) * nks)), dim3(64 * WV), ldsv, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
+                                    (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+            if (kcd) {
+                if (mg == 1) { if (w8) MSQ_MXV(true, 1, 16); else MSQ_MXV(false, 1, 16); }
+                else { if (w8) MSQ_MXV(true, 2, 16); else MSQ_MXV(false, 2, 16); }
+                return check_launch2("msq_qlinear_mx_w4a8(decode, single launch)");
+            }
+            if (mg == 1) { if (w8) MSQ_MXV(true, 1, 4); else MSQ_MXV(false, 1, 4); }
+            else if (mg == 2) { if (w8) MSQ_MXV(true, 2, 4); else MSQ_MXV(false, 2, 4); }
+            else { if (w8) MSQ_MXV(true, 4, 4); else MSQ_MXV(false, 4, 4); }
 #undef MSQ_MXV
             int rc0 = check_launch2("msq_qlinear_mx_w4a8(decode)");
             if (rc0) return rc0;
