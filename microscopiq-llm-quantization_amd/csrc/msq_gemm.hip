@@ -940,18 +940,22 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // is in flight while the current one is consumed; 12 waves per CU keep ~80 KiB of loads in flight.
 // The four waves of a block sum their k-chunks in LDS and write one fp32 partial tile, k_splitk_reduce sums those.
 // ---------------------------------------------------------------------------
-template <int IN_KIND, int OUT_KIND, int MG>
-__global__ void __launch_bounds__(256)
+// WAVES = 16 (unified layouts, `direct`): one block covers all of K, wave 0 adds the bias and writes Y itself -- one
+// launch, no partial planes, no reduce kernel (as k_mxgemv).
+template <int IN_KIND, int OUT_KIND, int MG, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
-        const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc) {
-    __shared__ float red[3][16 * MG][64];
+        const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc,
+        int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16) {
+    extern __shared__ __attribute__((aligned(16))) char smem_v[];
+    float (*red)[16 * MG][64] = reinterpret_cast<float (*)[16 * MG][64]>(smem_v);      // [WAVES - 1][16 MG][64]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / TILE_K;
     const int nks = (KT + kc - 1) / kc;                        // k-chunks per strip
-    const int nkb = (nks + 3) / 4;                             // the block's four waves take four consecutive k-chunks
+    const int nkb = (nks + WAVES - 1) / WAVES;                 // the block's waves take WAVES consecutive k-chunks
     const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb; //   of one strip and share its X rows in L1
-    const int ks = kb * 4 + wid;
+    const int ks = kb * WAVES + wid;
     const int kt_lo = ks * kc < KT ? ks * kc : KT;             // chunks past the end are empty
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
     const int64_t tile_row = (int64_t)strip * KT;
@@ -967,11 +971,13 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 #pragma unroll
     for (int j = 0; j < MG; ++j) { int m = j * 16 + c; m = m < M ? m : M - 1; xrow[j] = X + (int64_t)m * K + g * 8; }
 
-    TileRegs cur, nxt;
+    constexpr bool DEEP2 = (WAVES == 16);                      // tiles in flight ahead: 2 with few long waves, else 1
+    TileRegs cur, nxt, nx2;
     load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + (kt_lo < KT ? kt_lo : KT - 1), lane, scl_groups);
+    if (DEEP2) load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : (kt_lo < KT ? kt_lo : KT - 1)), lane, scl_groups);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt;
-        load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups);
+        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; load_tile<IN_KIND, OUT_KIND>(nx2, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
+        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
         bf16x8_t xf[2][MG];
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
@@ -988,6 +994,7 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
                     acc[nf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[kf][j], acc[nf][j], 0, 0, 0);
             }
         cur = nxt;
+        if (DEEP2) nxt = nx2;
     }
     // the four k-chunks meet in LDS (fixed order: wave 0 + 1 + 2 + 3): one partial plane per block
     if (wid > 0) {
@@ -1013,9 +1020,19 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = (j * 4 + nf) * 4 + e;
-                v[e] = ((acc[nf][j][e] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+                float t = acc[nf][j][e];
+#pragma unroll
+                for (int w = 0; w < WAVES - 1; ++w) t += red[w][r][lane];           // fixed order: k-chunk 0 + 1 + 2 + ...
+                v[e] = t;
             }
-            *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (!direct) { *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]); continue; }
+            if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+            if (!y_bf16) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                bf16x2_t lo, hi;
+                lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
         }
     }
 }
@@ -1325,6 +1342,15 @@ static bool use_gemv(int64_t M, int64_t N, int64_t K) {
     if (v >= 0) return M <= v;
     return M <= 32 || (M <= 64 && N <= 4096 && K <= 4096);
 }
+// single-launch decode (unified layouts): as mx_direct_kc; 64-k tiles: K <= 4096 = at most 4 tiles per wave.
+// MSQ_GEMV_DIRECT=0 (tuning only) disables it.
+static int direct_kc(int64_t M, int64_t N, int64_t K) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MSQ_GEMV_DIRECT"); on = e ? atoi(e) : 1; }
+    if (!on || M > 32 || N < 8192) return 0;
+    const int kc = (int)((K / BK + 15) / 16);
+    return kc <= 4 ? kc : 0;
+}
 static int pick_kc(int64_t N, int64_t K) {
     const int64_t KT = K / BK, strips = N / TILE_N;
     int64_t kc = (strips * KT + 3071) / 3072;
@@ -1356,14 +1382,25 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     hipStream_t st0 = (hipStream_t)stream;
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
-    if (use_gemv(M, N, K) && workspace) {
-        const int kc = pick_kc(N, K);
-        const int nks = (int)(((K / BK + kc - 1) / kc + 3) / 4);         // partial planes: one per four k-chunks
-        if (workspace_bytes >= (int64_t)nks * M * N * 4) {
-            const dim3 vgrid((unsigned)((N / TILE_N) * nks)), vblk(256);
-#define MSQ_GV1(IK, OK, MGV)                                                                                            \
-            hipLaunchKernelGGL((k_qgemv<IK, OK, MGV>), vgrid, vblk, 0, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc)
-#define MSQ_GV(IK, OK) do { if (M <= 16) MSQ_GV1(IK, OK, 1); else if (M <= 32) MSQ_GV1(IK, OK, 2); else MSQ_GV1(IK, OK, 4); } while (0)
+    if (use_gemv(M, N, K)) {
+        const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+        const int kcd = unified ? direct_kc(M, N, K) : 0;                // > 0: one block of 16 waves covers all of K
+        const int kc = kcd ? kcd : pick_kc(N, K);
+        const int nks = kcd ? 1 : (int)(((K / BK + kc - 1) / kc + 3) / 4);    // partial planes: one per four k-chunks
+        if (kcd || (workspace && workspace_bytes >= (int64_t)nks * M * N * 4)) {
+            const dim3 vgrid((unsigned)((N / TILE_N) * nks));
+            const size_t ldsv = (size_t)((kcd ? 16 : 4) - 1) * 16 * mg * 64 * 4;
+#define MSQ_GV1(IK, OK, MGV, WV)                                                                                        \
+            do { static bool attr_set = false;                                                                         \
+                 if (!attr_set) { hipFuncSetAttribute((const void*)k_qgemv<IK, OK, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_set = true; } \
+                 hipLaunchKernelGGL((k_qgemv<IK, OK, MGV, WV>), vgrid, dim3(64 * WV), ldsv, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, \
+                                    (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+#define MSQ_GV(IK, OK) do { if (mg == 1) MSQ_GV1(IK, OK, 1, 4); else if (mg == 2) MSQ_GV1(IK, OK, 2, 4); else MSQ_GV1(IK, OK, 4, 4); } while (0)
+            if (kcd) {
+                if (out_kind == MSQ_PLANE_U8) { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 2, 16); }
+                else { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8X, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8X, 2, 16); }
+                return check_launch2("msq_qlinear_bf16(decode, single launch)");
+            }
             if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_BF16) MSQ_GV(MSQ_PLANE_NONE, MSQ_PLANE_BF16);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_FP8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_FP8);
             else if (in_kind == MSQ_PLANE_FP4 && out_kind == MSQ_PLANE_BF8) MSQ_GV(MSQ_PLANE_FP4, MSQ_PLANE_BF8);
