@@ -14,7 +14,8 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]     # gpurun_out/ accumulates earlier runs
+    ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(ks)))
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
@@ -30,7 +31,7 @@ def main(tag):
     bj = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
     # the stats average covers every launch (clock-ramp and warm-up launches included); the bench's timed region is
     # the LAST `steps` launches of the dominant kernel: average those from the kernel trace
-    kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    kt = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     if kt:
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in csv.DictReader(open(kt[0])) if "k_qgemm" in r["Kernel_Name"] or "k_mxgemm" in r["Kernel_Name"]]
@@ -41,7 +42,7 @@ def main(tag):
     summary["bench_under_profiler"] = {k: bj[k] for k in ("value", "ms_per_step")}
     summary["bench_roofline_kernel_ms_under_profiler"] = bj["roofline"]["kernel_ms"]
     for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
         if not f:
             continue
         rr = [r for r in csv.DictReader(open(f[0])) if ("k_qgemm" in r["Kernel_Name"] or "k_mxgemm" in r["Kernel_Name"]) and r["Counter_Name"] == name]
