@@ -758,6 +758,41 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     assert torch.equal(dst[0].dequantize(), src[0].dequantize())
 
 
+def test_mx_operand_pack_edge_cases(msq, O):
+    """msq_mx_pack_w8 / msq_qlinear_mx_w8a8 at the edges: all-zero and tiny blocks, a block spanning more than e4m3's
+    range (reported, never rounded silently), Inf, bad shapes, M = 0."""
+    L = msq._lib.lib()
+    W = torch.zeros(64, 128, device=dev())
+    P = msq.qlinear.mx_pack_values(W)                                     # zeros: codes 0
+    assert int(P.codes.max().item()) == 0
+    W[0, :32] = 2.0 ** -120; W[1, 32:64] = -(2.0 ** 100)                   # tiny and huge blocks are exact with their own scale
+    W[2, 64] = 1.0; W[2, 65] = 2.0 ** -9; W[2, 66] = 448.0                 # full e4m3 span inside one block: 2^-9 ... 448 x 2^0
+    P = msq.qlinear.mx_pack_values(W)
+    assert (_mx_unpack_w8(P) == W.double().cpu().numpy()).all()
+    Wb = W.clone(); Wb[3, 96] = 1.0; Wb[3, 97] = 2.0 ** -20                # 2^-20 next to 1.0 (scale 2^-8): below the subnormal step 2^-17
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.mx_pack_values(Wb)
+    Pi = msq.qlinear.mx_pack_values(Wb, allow_inexact=True)                 # explicit opt-in: every other value still exact
+    d = _mx_unpack_w8(Pi); ref = Wb.double().cpu().numpy(); ref[3, 97] = 0.0
+    assert (d == ref).all()
+    Wn = W.clone(); Wn[5, 5] = float("inf")
+    with pytest.raises(AssertionError):
+        msq.qlinear.mx_pack_values(Wn)
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.mx_pack_values(torch.zeros(60, 128, device=dev()))     # N % 64
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.mx_pack_values(torch.zeros(64, 96, device=dev()))      # K % 128
+    Pw = msq.qlinear.mx_pack_values(torch.randn(256, 128, device=dev()).to(torch.bfloat16).float().mul(0).add(1.0))
+    y = msq.qlinear.qlinear_mx_w4a8(torch.zeros(0, 128, device=dev()), Pw, None, torch.float32)
+    assert y.shape == (0, 256)
+    with pytest.raises(msq._lib.MsqError):
+        msq.qlinear.qlinear_mx_w4a8(torch.zeros(4, 256, device=dev()), Pw)   # in_features mismatch
+    assert L.msq_qlinear_mx_w8a8(None, None, None, None, None, None, 0, 4, 256, 128, None, 0, None) == -1   # null buffers
+    assert L.msq_mx_pack_w8(None, None, None, None, 64, 128, None) == -1
+    x = torch.ones(1, 128, device=dev())
+    assert torch.equal(msq.qlinear.qlinear_mx_w4a8(x, Pw, None, torch.float32), torch.full((1, 256), 128.0, device=dev()))
+
+
 def test_mx_row_parallel_shards_equal_unsharded(msq):
     """70B row-parallel on the MX path: a K split on a multiple of 128 cuts neither a 32-block of the activations nor
     a packed weight tile, so every shard's operands are slices of the unsharded ones and the shard outputs add up to
