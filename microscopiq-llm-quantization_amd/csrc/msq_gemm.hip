@@ -1314,6 +1314,23 @@ static int pick_wm(int64_t M, int64_t N) {
 }
 
 // split-K factor: enough blocks to fill the 256 CUs when M is small (decode / short prefill)
+// Split-K for grids that do not fill the chip (MX GEMM): cost model fitted to HIP-graph replays at M = 65 ... 512 on
+// the four Llama-7B shapes (scripts/experiments/mx_ks_sweep.py).  A block spends `tau` us per K-step, all
+// blocks run concurrently up to 512 (two per CU), the partial planes cost ks M N 8 bytes (fp32 written + read back) at
+// ~8 TB/s while they stay cache-resident (<= 32 MB), ~6.5 TB/s up to 128 MB, ~3.6 TB/s beyond; one split writes Y
+// directly.  Power-of-two splits with at least `min_steps` K-steps per chunk.
+static int splitk_by_cost(int64_t blocks, int64_t KT, int64_t M, int64_t N, double tau, int max_ks, int min_steps) {
+    int best = 1;
+    double best_t = 1e30;
+    for (int ks = 1; ks <= max_ks && (int64_t)ks * min_steps <= KT; ks *= 2) {
+        const double rounds = (double)((blocks * ks + 511) / 512);
+        const double pbytes = (double)ks * (double)M * (double)N * 4.0;
+        const double bw = pbytes <= 32e6 ? 8.0e6 : (pbytes <= 128e6 ? 6.5e6 : 3.6e6);       // bytes per us
+        const double t = tau * (double)((KT + ks - 1) / ks) * rounds + (ks > 1 ? 2.0 * pbytes / bw : 0.0);
+        if (t < best_t) { best_t = t; best = ks; }
+    }
+    return best;
+}
 static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("MSQ_GEMM_KS"); return e ? atoi(e) : 0; }();
     const int wm = pick_wm(M, N);
@@ -1321,7 +1338,8 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
     const int64_t KT = K / BK;
     if (forced > 0) return forced < KT ? forced : (int)KT;
     if (blocks >= 192 || KT < 8) return 1;
-    // measured (scripts/experiments/ks_sweep.py): best is about one block per CU, power-of-two splits (even K chunks)
+    // measured (scripts/experiments/ks_sweep.py, ks_sweep_graph.py): best is about one block per CU, power-of-two
+    // splits (even K chunks); the cost model below was tried here too and lost where pick_wm takes 256-row blocks
     int64_t ks = 1;
     while (ks * blocks < 256) ks *= 2;
     if (ks > KT / 4) ks = KT / 4;
@@ -1329,8 +1347,6 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
     return ks < 1 ? 1 : (int)ks;
 }
 
-// small-M path: tiles per task so that there are ~3000 tasks (12 waves x 256 CUs) but at most 32 partial planes
-// measured (scripts/experiments/gemv_thr.py): the decode kernel wins up to M = 16, the split-K GEMM from M = 32 on
 // Decode kernel or (split-K) GEMM.  Measured from HIP graphs (scripts/experiments/mx_midm_check.py): with the LDS
 // reduction of four k-chunks the decode kernel wins for every Llama-7B shape up to M = 32 (two 16-row groups per wave);
 // with four groups (M <= 64) every wave re-reads 64 activation rows per tile from L2 and the partial planes grow with
@@ -1501,14 +1517,14 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
 // MX-native W4A8 GEMM on pre-packed operands (msq_mx_pack_a8 / msq_mx_pack_w4).  Few row tiles (small M): K is
 // split over power-of-two many work items so that about one block per CU streams the weight; fp32 partial tiles
 // go through `workspace` (msq_qlinear_mx_w4a8_workspace_bytes; NULL = single pass).
+// Split-K of the MX GEMM (splitk_by_cost): a 128-k step takes ~0.77 us per block.  The earlier rule (fill 256 blocks,
+// chunks of >= 2 K-steps) over-split short K: 4096 x 4096 M128 22.9 -> 17.1-18.9 us, N11008 M512 40.3 -> 30.2 us.
 static int pick_mx_ksplit(int64_t M, int64_t N, int64_t K) {
+    static const int forced = [] { const char* e = getenv("MSQ_MX_GEMM_KS"); return e ? atoi(e) : 0; }();   // tuning only
     const int64_t blocks = ((M + 127) / 128) * (N / BN), KT = K / 128;
+    if (forced > 0) return forced < KT ? forced : (int)KT;
     if (blocks >= 192 || KT < 4) return 1;
-    int64_t ks = 1;
-    while (ks * blocks < 256) ks *= 2;
-    if (ks > KT / 2) ks = KT / 2;
-    if (ks > 16) ks = 16;
-    return ks < 1 ? 1 : (int)ks;
+    return splitk_by_cost(blocks, KT, M, N, 0.77, 16, 2);
 }
 // decode kernel or GEMM, as use_gemv: up to M = 32 always, up to 64 for N <= 4096 (13.1 vs 17.6 us at 4096 x 4096,
 // 16.3 vs 17.4 at K = 11008; 22.1 vs 18.1 at N = 16384).  MSQ_MX_GEMV_MAX_M (tuning only): M <= value.
