@@ -246,6 +246,8 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
  * ------------------------------------------------------------------------- */
 int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
                    int flush_fp32_subnorms, void* stream);
+int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                        int flush_fp32_subnorms, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode, split-K) */

@@ -37,7 +37,8 @@ MSQ_D int mx_scale_byte(int max_biased_exp, int elem_emax, int& status) {
 // through LDS (row stride 36 words), one block per lane.  FP4: weights, codes scattered into the MFMA tile order;
 // otherwise activations, e4m3 codes written back row-major through the same LDS tile.
 // MODE 0: activations (e4m3, row-major), 1: weights (e2m1, operand order), 2: exact values (e4m3, operand order)
-template <int MODE>
+// XBF16: the source holds bfloat16 (activations of a bf16 model: every bf16 is an fp32 value, same results as casting first)
+template <int MODE, bool XBF16 = false>
 __global__ void __launch_bounds__(256)
 k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t rows, int64_t K,
           int flush, int* status_flag) {
@@ -52,13 +53,26 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
     const int64_t g = g0 + lane;
     float* tl = tile[wv];
     float a[BS];
+    const uint16_t* srch = reinterpret_cast<const uint16_t*>(src);
     if (full) {
+        if (XBF16) {
+            const uint4* s8 = reinterpret_cast<const uint4*>(srch + g0 * BS);     // 8 bf16 per 16-byte load
+#pragma unroll
+            for (int t = 0; t < BS / 8; ++t) {
+                const int f = lane + 64 * t;
+                const int row = f / (BS / 8), c8 = f % (BS / 8);
+                const uint4 v = s8[f];
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8) = make_float4(u2f(v.x << 16), u2f(v.x & 0xFFFF0000u), u2f(v.y << 16), u2f(v.y & 0xFFFF0000u));
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4) = make_float4(u2f(v.z << 16), u2f(v.z & 0xFFFF0000u), u2f(v.w << 16), u2f(v.w & 0xFFFF0000u));
+            }
+        } else {
         const float4* s4 = reinterpret_cast<const float4*>(src + g0 * BS);
 #pragma unroll
         for (int t = 0; t < BS / 4; ++t) {
             const int f = lane + 64 * t;
             const int row = f / (BS / 4), c4 = f % (BS / 4);
             *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = s4[f];
+        }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -69,7 +83,7 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
         }
     } else {
 #pragma unroll
-        for (int b = 0; b < BS; ++b) a[b] = (g < nblocks) ? src[g * BS + b] : 0.f;
+        for (int b = 0; b < BS; ++b) a[b] = (g < nblocks) ? (XBF16 ? u2f((uint32_t)srch[g * BS + b] << 16) : src[g * BS + b]) : 0.f;
     }
     int status = 0;
     int se = 0;
@@ -198,6 +212,21 @@ extern "C" int msq_mx_pack_w8(const float* Wq, void* codes, void* scales, int* s
     const int64_t nblocks = N * (K / 32);
     hipLaunchKernelGGL((k_mx_pack<2>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wq,
                        (uint8_t*)codes, (uint8_t*)scales, N, K, 0, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+// as msq_mx_pack_a8 with bfloat16 activations (x_dtype of include/msq.h: 2)
+extern "C" int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                                   int flush_fp32_subnorms, void* stream) {
+    if (M < 0 || K < 0) { msq_set_error_("msq_mx_pack_a8_bf16: negative size"); return MSQ_ERR_BAD_ARG; }
+    if (M == 0 || K == 0) return MSQ_OK;
+    if (K % 128) { msq_set_error_("msq_mx_pack_a8_bf16: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = M * (K / 32);
+    hipLaunchKernelGGL((k_mx_pack<0, true>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)X,
+                       (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;

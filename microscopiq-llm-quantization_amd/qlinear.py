@@ -304,13 +304,15 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
     if not x.is_cuda:
         raise MsqError("mx_pack_act needs a CUDA/HIP tensor (no CPU fallback)")
     K = x.shape[-1]
-    xf = x.reshape(-1, K).float().contiguous()
+    bf = x.dtype == torch.bfloat16                       # read as is (every bf16 is an fp32 value: same codes)
+    xf = x.reshape(-1, K).contiguous() if bf else x.reshape(-1, K).float().contiguous()
     M = xf.shape[0]
     codes = torch.empty(M, K, dtype=torch.uint8, device=x.device)
     scales = torch.empty(M, K // 32, dtype=torch.uint8, device=x.device)
     status = torch.zeros(1, dtype=torch.int32, device=x.device) if check_status else None
-    check(lib().msq_mx_pack_a8(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, int(bool(flush_fp32_subnorms)),
-                               current_stream(x.device)), "msq_mx_pack_a8")
+    fn = lib().msq_mx_pack_a8_bf16 if bf else lib().msq_mx_pack_a8
+    check(fn(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, int(bool(flush_fp32_subnorms)),
+             current_stream(x.device)), "msq_mx_pack_a8")
     if check_status:
         _mx_status(status, "mx_pack_act")
     return codes, scales

@@ -758,6 +758,18 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     assert torch.equal(dst[0].dequantize(), src[0].dequantize())
 
 
+def test_mx_pack_act_bf16_input(msq):
+    """bf16 activations are packed without a cast pass: same codes and scales as the fp32 route (ragged M: the tail
+    blocks take the scalar path)."""
+    g = torch.Generator(device=dev()).manual_seed(4)
+    for M, K in ((1, 128), (7, 384), (65, 4096), (300, 512)):
+        x = (torch.randn(M, K, generator=g, device=dev()) * 3).to(torch.bfloat16)
+        x[0, :32] = 0
+        c0, s0 = msq.qlinear.mx_pack_act(x.float(), check_status=True)
+        c1, s1 = msq.qlinear.mx_pack_act(x, check_status=True)
+        assert torch.equal(c0, c1) and torch.equal(s0, s1), (M, K)
+
+
 def test_mx_operand_pack_edge_cases(msq, O):
     """msq_mx_pack_w8 / msq_qlinear_mx_w8a8 at the edges: all-zero and tiny blocks, a block spanning more than e4m3's
     range (reported, never rounded silently), Inf, bad shapes, M = 0."""
