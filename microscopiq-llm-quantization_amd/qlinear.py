@@ -321,21 +321,27 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
 def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False):
     """y = MXFP8(x) . MXFP4(W)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4: one pass packs the activations,
     the GEMM consumes codes and scale bytes directly."""
-    K = x.shape[-1]
+    if isinstance(x, (tuple, list)):                     # activations already packed by mx_pack_act: q / k / v or
+        xc, xs = x                                       # gate / up projections of one input share the pack
+        K, lead, xdev = xc.shape[-1], tuple(xc.shape[:-1]), xc.device
+        xc, xs = xc.reshape(-1, K), xs.reshape(-1, K // 32)
+    else:
+        K, lead, xdev = x.shape[-1], tuple(x.shape[:-1]), x.device
     if K != P.K:
         raise MsqError("qlinear_mx_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
-    xc, xs = mx_pack_act(x, check_status=check_status)
+    if not isinstance(x, (tuple, list)):
+        xc, xs = mx_pack_act(x, check_status=check_status)
     M = xc.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
-    y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
+    y = torch.empty(M, P.N, dtype=out_dtype, device=xdev)
     b = bias.detach().float().contiguous() if bias is not None else None
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
+    ws = torch.empty(wsb, dtype=torch.uint8, device=xdev) if wsb > 0 else None
     fn = lib().msq_qlinear_mx_w8a8 if P.w_fmt == "e4m3" else lib().msq_qlinear_mx_w4a8
     check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), 0 if out_dtype == torch.float32 else 2,
-             M, P.N, K, ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_mx_w%sa8" % ("8" if P.w_fmt == "e4m3" else "4"))
-    return y.reshape(*x.shape[:-1], P.N)
+             M, P.N, K, ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w%sa8" % ("8" if P.w_fmt == "e4m3" else "4"))
+    return y.reshape(*lead, P.N)
 
 
 class MXLinearW4A8(nn.Module):

@@ -420,6 +420,9 @@ def test_mx_linear_module(msq):
     m2 = msq.qlinear.MXLinearW4A8(512, 256, True, device=dev())
     m2.load_state_dict(m.state_dict())
     assert torch.equal(m2(x), y)
+    packed = msq.qlinear.mx_pack_act(x)                    # one activation pack shared by several projections
+    assert torch.equal(m(packed).reshape(2, 5, 256), y) and torch.equal(m2(packed).reshape(2, 5, 256), y)
+    assert torch.equal(m(x.to(torch.bfloat16)), m(x.to(torch.bfloat16).float()))      # bf16 activations: no cast pass
 
 
 def test_act_quant_rejects_wide_formats(msq):
