@@ -30,6 +30,12 @@ P4 = {n: qlinear.mx_pack_weight(w) for n, w in Wq.items()}
 P8 = {n: qlinear.mx_pack_values(w) for n, w in Wq.items()}
 PU = {n: qlinear.pack_values(w) for n, w in Wq.items()}
 WB = {n: w.to(torch.bfloat16) for n, w in Wq.items()}
+# q/k/v and gate/up concatenated along out_features (blocks run along in_features: the packed values are unchanged)
+cat = dict(qkv=torch.cat([Wq["q"], Wq["k"], Wq["v"]]), gateup=torch.cat([Wq["gate"], Wq["up"]]))
+P4c = {n: qlinear.mx_pack_weight(w) for n, w in cat.items()}
+P8c = {n: qlinear.mx_pack_values(w) for n, w in cat.items()}
+PUc = {n: qlinear.pack_values(w) for n, w in cat.items()}
+WBc = {n: w.to(torch.bfloat16) for n, w in cat.items()}
 for M in (1, 16, 32):
     x = torch.randn(M, H, device=dev).to(torch.bfloat16); xi = torch.randn(M, I, device=dev).to(torch.bfloat16)
     def mx(P):
@@ -47,6 +53,17 @@ for M in (1, 16, 32):
     def bl():
         for n in ("q", "k", "v", "o", "gate", "up"): x @ WB[n].t()
         xi @ WB["down"].t()
+    def mxc(P, Pc):
+        def f():
+            qlinear.qlinear_mx_w4a8(x, Pc["qkv"]); qlinear.qlinear_mx_w4a8(x, P["o"])
+            qlinear.qlinear_mx_w4a8(x, Pc["gateup"]); qlinear.qlinear_mx_w4a8(xi, P["down"])
+        return f
+    def u1c():
+        qlinear.qlinear(x, PUc["qkv"]); qlinear.qlinear(x, PU["o"]); qlinear.qlinear(x, PUc["gateup"]); qlinear.qlinear(xi, PU["down"])
+    def blc():
+        x @ WBc["qkv"].t(); x @ WB["o"].t(); x @ WBc["gateup"].t(); xi @ WB["down"].t()
+    rc = [graphed(f) * 1e3 for f in (mxc(P4, P4c), mxc(P8, P8c), u1c, blc)]
+    print(f"M{M:3d}: q/k/v and gate/up concatenated (4 Linears): MX-FP4 {rc[0]:6.1f} us | MicroScopiQ e4m3 operand {rc[1]:6.1f} us | MSQ-U1 bf16-act {rc[2]:6.1f} us | hipBLASLt bf16 {rc[3]:6.1f} us", flush=True)
     r = [graphed(f) * 1e3 for f in (mx(P4), mx(P8), u1, bl)]
     wb = sum(N * K for N, K in shapes.values())
     print(f"M{M:3d}: seven Linears of one layer: MX-FP4 {r[0]:6.1f} us | MicroScopiQ e4m3 operand {r[1]:6.1f} us | MSQ-U1 bf16-act {r[2]:6.1f} us | "
