@@ -11,7 +11,7 @@ d = sys.argv[1]
 vals = collections.defaultdict(list)
 for f in glob.glob(os.path.join(d, "p*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_qgemm" in r["Kernel_Name"]:
+        if "k_qgemm" in r["Kernel_Name"] or "k_mxgemm" in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
 for k in sorted(avg):
