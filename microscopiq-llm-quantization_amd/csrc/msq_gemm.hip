@@ -25,6 +25,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MSQ_MX_XBUFS
+#define MSQ_MX_XBUFS 3      /* 4 = four activation buffers staged three K-steps ahead: measured equal (101.0 vs 101.2 us), kept at 3 */
+#endif
 #ifndef MSQ_MXABL
 #define MSQ_MXABL 0      /* ablation of k_mxgemm (scripts/experiments/build_mx_ablation.sh): 1 no LDS fragment reads, 2 no weight loads, 4 no LDS-DMA, 8 no barrier, 16 no stores */
 #endif
@@ -697,7 +700,9 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     // the 4 scale bytes of (row, K-step) travel with the tile: every wave copies one dword per row for its 32 rows
     // (lanes 32-63 repeat lanes 0-31 into the upper half of the wave's 256 bytes: no wave-dependent branch, the
     // same number of vector-memory ops in every wave)
-    constexpr int XS_BASE = 3 * A_TILE;
+    // activation buffers: 3 staged two K-steps ahead (MSQ_MX_XBUFS = 4: the fp4 kernel stages three ahead; no gain)
+    constexpr int XBUFS = W8 ? 3 : MSQ_MX_XBUFS;
+    constexpr int XS_BASE = XBUFS * A_TILE;
     int xs_goff = m0 + wid * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
     auto stage_A = [&](int kt, int buf) {
         int k16 = 16 * K;
@@ -733,11 +738,12 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
     constexpr int CBSZ = W8 ? 0 : 4;                             // A-operand format: e4m3 / e2m1
-    constexpr int N_WAIT_MX = W8 ? 5 : 10;
+    constexpr int N_WAIT_MX = W8 ? 5 : (XBUFS == 4 ? 15 : 10);
     const int kl = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);   // an empty split runs a harmless prologue
     const int kf0 = (kt_lo < KT) ? kt_lo : KT - 1, kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
     stage_A(kf0, 0);
     stage_A(kf1, 1);
+    if (XBUFS == 4) stage_A((kf1 + 1 <= kl) ? kf1 + 1 : kl, 2);
     load_w(w0, kf0);
     if (!W8) load_w(w1, kf1);
     __builtin_amdgcn_s_waitcnt(0);
@@ -746,13 +752,13 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #define MSQ_MX_STEP(KT_CUR, WCUR, WLOAD)                                                                      \
     {                                                                                                        \
         const int kt_ = (KT_CUR);                                                                            \
-        const int buf = abuf, buf2 = (abuf == 0) ? 2 : abuf - 1;                                             \
-        abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
+        const int buf = abuf, buf2 = (XBUFS == 4) ? ((abuf + 3) & 3) : ((abuf == 0) ? 2 : abuf - 1);         \
+        abuf = (XBUFS == 4) ? ((abuf + 1) & 3) : ((abuf == 2) ? 0 : abuf + 1);                               \
         const char* abase = smem + buf * A_TILE;                                                             \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
         if (!(MSQ_MXABL & 2)) load_w(WLOAD, W8 ? k1 : k2);   /* issue order (vmcnt is in-order): weights, then LDS-DMA */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (!(MSQ_MXABL & 4)) stage_A(k2, buf2);                                                             \
+        if (!(MSQ_MXABL & 4)) stage_A((XBUFS == 4) ? ((kt_ + 3 <= kl) ? kt_ + 3 : kl) : k2, buf2);           \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         /* fp8 ring: the kernel sits at the register limit and hipcc parks loop-invariant LDS addresses in scratch; a  \
            reload after the weight loads would wait for them (in-order vmcnt).  The three addresses are re-derived from \
@@ -1605,10 +1611,13 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
     int ksplit = pick_mx_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
-    const size_t lds = 3 * 128 * 128 + 3 * 1024;              // three code tiles + three scale tiles
+    const size_t lds = (size_t)(w8 ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
     float* partial = (float*)workspace;
-#define MSQ_MXL(YT, W8V) hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial)
+#define MSQ_MXL(YT, W8V)                                                                                              \
+    do { static bool attr_set = false;                                                                                 \
+         if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+         hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } while (0)
     if (y_dtype == 0) { if (w8) MSQ_MXL(float, true); else MSQ_MXL(float, false); }
     else { if (w8) MSQ_MXL(uint16_t, true); else MSQ_MXL(uint16_t, false); }
 #undef MSQ_MXL
