@@ -25,6 +25,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MSQ_MX_PIN_READS
+#define MSQ_MX_PIN_READS 0   /* 1: sched_barrier between the LDS prefetch of group mf + 1 and the MFMAs of group mf (hipcc sinks the reads below them); same-box A/B 99.7 vs 99.5 us: the second wave of the SIMD already covers the wait */
+#endif
 #ifndef MSQ_MX_XBUFS
 #define MSQ_MX_XBUFS 3      /* 4 = four activation buffers staged three K-steps ahead: measured equal (101.0 vs 101.2 us), kept at 3 */
 #endif
@@ -775,6 +778,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl_ + (mf + 1) * 2048);                 \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh_ + (mf + 1) * 2048);                 \
                               xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd_ + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }  \
+            if (!W8 && MSQ_MX_PIN_READS) __builtin_amdgcn_sched_barrier(0);   /* hipcc otherwise sinks these reads below the MFMAs of this group and waits for them at once (fp8 ring: the pin costs registers -> a scratch reload in the loop, slower) */ \
             const u32x4_t lo = xl[(MSQ_MXABL & 1) ? 0 : (mf & 1)], hi = xh[(MSQ_MXABL & 1) ? 0 : (mf & 1)];  \
             const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
             const int sb_ = (int)xsc[(MSQ_MXABL & 1) ? 0 : (mf & 1)];                                        \
