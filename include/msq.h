@@ -201,9 +201,12 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
 /* fused unpack-dequant-GEMM: Y[M,N] = X[M,K] (bf16) . W^T (+ bias f32 [N] or NULL), fp32 accumulate on
  * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 2 = bf16.  Replaces the dense F.linear the reference
  * runs on the fake-quantised weight (number_system/mx/linear.py:91, llm/llama.py:255-256).
- * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0 (M <= 16 takes the decode kernel).
- * When M is small the kernel splits K over several workgroups (so that all 256 CUs stream the weight) and
- * reduces fp32 partial tiles from `workspace` (msq_qlinear_workspace_bytes(); NULL = single pass). */
+ * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0.  M <= 32 (<= 64 for the 4096 x 4096 class) takes the decode
+ * kernel: one wave per (64 columns, k-chunk), k-chunks summed in LDS; for the unified layouts with N >= 8192 and
+ * K <= 4096 one launch writes Y directly, otherwise fp32 partial tiles go through `workspace`.
+ * For larger M with a grid that does not fill the chip the GEMM splits K over several workgroups and reduces fp32
+ * partial tiles from `workspace` (msq_qlinear_workspace_bytes(); NULL or too small = single pass, never an error).
+ * Results are bit-identical from run to run on every path (fixed summation order). */
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
@@ -250,7 +253,7 @@ int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int* status_fl
                         int flush_fp32_subnorms, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
-int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode, split-K) */
+int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode with partial planes, split-K); 0 for the single-launch decode */
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
                         const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
                         void* workspace, int64_t workspace_bytes, void* stream);
