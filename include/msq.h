@@ -130,7 +130,10 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
  *   num_outliers  int8 [ceil(nblk/block)*post] (utils/quant.py:66; needs pre == 1)
  *   status_flag   int (device): MSQ_STATUS_* bits OR-ed in
  *   workspace     device scratch of msq_outlier_workspace_bytes() bytes (variant 1 only, else NULL)
- * in/out dtype: 0 = f32 (bit-exact vs the reference), 1 = f16, 2 = bf16 (computed in f32). */
+ * in/out dtype: 0 = f32 (bit-exact vs the reference); 2 = bf16 tensors (read as f32 values, computed in f32, one
+ *   round-to-nearest-even on the way out: the same bits as upcasting, running dtype 0 and casting back), built for
+ *   round-to-nearest with float / int inlier formats, variant 0; 1 = f16 and the remaining combinations return
+ *   MSQ_ERR_UNSUPPORTED (the Python shim upcasts). */
 int64_t msq_outlier_workspace_bytes(int64_t pre, int64_t axis_len, int64_t post, int block, int variant);
 int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in, float* e_out,
                           int8_t* num_outliers, int* status_flag, void* workspace,

@@ -12,6 +12,14 @@ template <> struct IO<float> {
     static MSQ_D void st(float* p, int64_t i, float v) { p[i] = v; }
 };
 
+// bfloat16 tensors: read as is (every bf16 is an fp32 value), written with round-to-nearest-even like torch's .to(bfloat16)
+// (exact whenever the formats have <= 8 significant bits)
+struct bf16io_t { uint16_t v; };
+template <> struct IO<bf16io_t> {
+    static MSQ_D float ld(const bf16io_t* p, int64_t i) { return u2f((uint32_t)p[i].v << 16); }
+    static MSQ_D void st(bf16io_t* p, int64_t i, float v) { p[i].v = __builtin_bit_cast(uint16_t, (__bf16)v); }
+};
+
 template <int BS>
 MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS + 31) / 32], float se_in,
                                 float se_out, int status, int64_t p, int64_t nb, int64_t q) {
@@ -82,7 +90,7 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     const int64_t nblocks = A.pre * A.nblk;
     const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;      // first block of this wave
     if (g0 >= nblocks) return;
-    const bool fast = (A.axis_len % BS == 0) && (g0 + 64 <= nblocks) && (sizeof(T) == 4);
+    const bool fast = (A.axis_len % BS == 0) && (g0 + 64 <= nblocks);
     float a[BS];
     const int64_t g = g0 + lane;
     const int64_t p = g / A.nblk, nb = g % A.nblk;
@@ -90,12 +98,24 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     const int64_t base = p * A.axis_len + a0;
     float* tl = tile[wv];
     if (fast) {
+        if constexpr (sizeof(T) == 2) {                           // 8 bf16 per 16-byte load
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(in) + g0 * BS);
+#pragma unroll
+            for (int t = 0; t < BS / 8; ++t) {
+                const int f = lane + 64 * t;
+                const int row = f / (BS / 8), c8 = f % (BS / 8);
+                const uint4 v = src[f];
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8) = make_float4(u2f(v.x << 16), u2f(v.x & 0xFFFF0000u), u2f(v.y << 16), u2f(v.y & 0xFFFF0000u));
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4) = make_float4(u2f(v.z << 16), u2f(v.z & 0xFFFF0000u), u2f(v.w << 16), u2f(v.w & 0xFFFF0000u));
+            }
+        } else {
         const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + g0 * BS);
 #pragma unroll
         for (int t = 0; t < BS / 4; ++t) {
             const int f = lane + 64 * t;                         // float4 index inside the 64xBS tile
             const int row = f / (BS / 4), c4 = f % (BS / 4);
             *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
+        }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
@@ -129,12 +149,26 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
                 make_float4(a[c * 4 + 0], a[c * 4 + 1], a[c * 4 + 2], a[c * 4 + 3]);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        if constexpr (sizeof(T) == 2) {
+            uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + g0 * BS);
+#pragma unroll
+            for (int t = 0; t < BS / 8; ++t) {
+                const int f = lane + 64 * t;
+                const int row = f / (BS / 8), c8 = f % (BS / 8);
+                const float4 x = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c8 * 8);
+                const float4 y = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4);
+                auto pk = [](float lo, float hi) -> uint32_t {
+                    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16); };
+                dst[f] = make_uint4(pk(x.x, x.y), pk(x.z, x.w), pk(y.x, y.y), pk(y.z, y.w));
+            }
+        } else {
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + g0 * BS);
 #pragma unroll
         for (int t = 0; t < BS / 4; ++t) {
             const int f = lane + 64 * t;
             const int row = f / (BS / 4), c4 = f % (BS / 4);
             dst[f] = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c4 * 4);
+        }
         }
     } else if (g < nblocks) {
 #pragma unroll
@@ -152,15 +186,15 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
 }
 
 // launch one of the two kernels for the compile-time FAST variant; returns false for an unsupported block size
-template <int FAST>
+template <int FAST, typename T = float>
 static inline bool launch_outlier_variant(const void* in, void* out, const OutlierArgs& A, int block, hipStream_t st) {
     const int64_t nthreads = A.pre * A.nblk * A.post;
     int64_t g = (nthreads + 255) / 256; if (g < 1) g = 1;
     const dim3 grid((unsigned)g), blk(256);
 #define MSQ_OL(BS)                                                                                          \
     case BS:                                                                                                \
-        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, float, FAST>), grid, blk, 0, st, (const float*)in, (float*)out, A);  \
-        else hipLaunchKernelGGL((k_outlier_strided<BS, float, FAST>), grid, blk, 0, st, (const float*)in, (float*)out, A);             \
+        if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T, FAST>), grid, blk, 0, st, (const T*)in, (T*)out, A);  \
+        else hipLaunchKernelGGL((k_outlier_strided<BS, T, FAST>), grid, blk, 0, st, (const T*)in, (T*)out, A);             \
         return true;
     switch (block) { MSQ_OL(8) MSQ_OL(16) MSQ_OL(32) MSQ_OL(64) MSQ_OL(128) default: return false; }
 #undef MSQ_OL

@@ -380,16 +380,21 @@ static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
 }
 
 // implemented in msq_quant_hw.hip (hardware-convert variants, own translation unit)
-extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, void* stream);
+extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
 
-static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st) {
+// dtype 2 (bf16 tensors) is built for round-to-nearest with float / int inliers (the hardware-convert variants and
+// the nearest-specialised arithmetic one); everything else is f32 only (the host shim upcasts)
+static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st, int dtype = 0) {
     bool ok;
+    if (dtype != 0 && !(dtype == 2 && A.fi.kind == 0 && A.rmode == 0))
+        return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: this dtype / format / rounding combination is f32 only; the host shim upcasts");
     if (A.fi.kind == 0) {                                      // float/int inliers; outliers float/int or posit
         if (A.rmode == 0) {
             const int ih = hw_codec_kind(A.fi), oh = hw_codec_kind(A.fo);
-            if (ih && oh) return msq_launch_outlier_hw_(in, out, &A, block, 1, (void*)st);            // both through the converts
-            if (ih && A.fo.kind == 1) return msq_launch_outlier_hw_(in, out, &A, block, 2, (void*)st); // inliers only, posit outliers
-            ok = launch_outlier_variant<1>(in, out, A, block, st);
+            if (ih && oh) return msq_launch_outlier_hw_(in, out, &A, block, 1, dtype, (void*)st);            // both through the converts
+            if (ih && A.fo.kind == 1) return msq_launch_outlier_hw_(in, out, &A, block, 2, dtype, (void*)st); // inliers only, posit outliers
+            if (dtype == 2) ok = launch_outlier_variant<1, bf16io_t>(in, out, A, block, st);
+            else ok = launch_outlier_variant<1>(in, out, A, block, st);
         } else ok = launch_outlier_variant<2>(in, out, A, block, st);
     } else ok = launch_outlier_variant<0>(in, out, A, block, st);   // posit inliers: generic maths
     if (!ok) return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
@@ -571,8 +576,8 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
         A.vmean = vmean; A.vstd = vstd;
     }
     int rc;
-    if (dtype == 0) rc = launch_outlier(in, out, A, block, st);
-    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: only dtype 0 (f32) is built; the host shim upcasts f16/bf16");
+    if (dtype == 0 || dtype == 2) rc = launch_outlier(in, out, A, block, st, dtype);
+    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: dtype 1 (f16) is not built; the host shim upcasts");
     if (rc) return rc;
     return check_launch("msq_outlier_fakequant");
 }

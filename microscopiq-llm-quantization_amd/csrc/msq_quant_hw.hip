@@ -15,9 +15,13 @@ using namespace msq;
 extern "C" void msq_set_error_(const char* msg);
 
 // mode 1: inliers and outliers through the converts; mode 2: inliers through the converts, posit outliers
-extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, void* stream) {
-    const bool ok = (mode == 1) ? launch_outlier_variant<3>(in, out, *A, block, (hipStream_t)stream)
-                                : launch_outlier_variant<4>(in, out, *A, block, (hipStream_t)stream);
+// dtype 0 = f32, 2 = bf16 tensors
+extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream) {
+    bool ok;
+    if (dtype == 2) ok = (mode == 1) ? launch_outlier_variant<3, bf16io_t>(in, out, *A, block, (hipStream_t)stream)
+                                     : launch_outlier_variant<4, bf16io_t>(in, out, *A, block, (hipStream_t)stream);
+    else ok = (mode == 1) ? launch_outlier_variant<3>(in, out, *A, block, (hipStream_t)stream)
+                          : launch_outlier_variant<4>(in, out, *A, block, (hipStream_t)stream);
     if (!ok) { msq_set_error_("msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128"); return MSQ_ERR_UNSUPPORTED; }
     return MSQ_OK;
 }

@@ -61,7 +61,12 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
     assert (inlier_scale_bits > 0 and outlier_scale_bits > 0)            # utils/quant.py:168
     orig_dtype = A.dtype
     x = A.contiguous()
-    if x.dtype != torch.float32:
+    # bf16 tensors go through natively (read as fp32 values, computed in fp32, one RNE rounding on the way out:
+    # the same result as the upcast / downcast shim) where the kernels are built for it: round-to-nearest with
+    # float / int inliers, quant.py variant; everything else (fp16, other rounding modes, posit inliers) is upcast
+    native_bf16 = (x.dtype == torch.bfloat16 and round == "nearest" and variant == VARIANT_QUANT
+                   and not str(inlier_elem_format).startswith("posit"))
+    if x.dtype != torch.float32 and not native_bf16:
         x = x.float()
     axis = axis % x.ndim
     pre, axis_len, post = _pap(x.shape, axis)
@@ -84,14 +89,14 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
     wsb = L.msq_outlier_workspace_bytes(pre, axis_len, post, blk, variant)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb > 0 else None
     check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), ptr(n_out), ptr(status),
-                                  ptr(ws), wsb, 0, pre, axis_len, post, blk, format_id(inlier_elem_format),
+                                  ptr(ws), wsb, 2 if native_bf16 else 0, pre, axis_len, post, blk, format_id(inlier_elem_format),
                                   format_id(outlier_elem_format), int(inlier_scale_bits), int(outlier_scale_bits),
                                   float(std_dev), int(RoundingMode[round]), int(bool(flush_fp32_subnorms)),
                                   int(variant), current_stream(dev)), "msq_outlier_fakequant")
     if CHECK_NAN and int(status.item()) & 1:
         # utils/quant.py:225-250 / mx_ops.py:66: a shared scale overflowed to NaN
         raise AssertionError("outlier_val / inlier_val / shared_exp contains NaN values")
-    r = {"out": out if orig_dtype == torch.float32 else out.to(orig_dtype)}
+    r = {"out": out if out.dtype == orig_dtype else out.to(orig_dtype)}
     if want_mask:
         r["mask"] = mask
     if want_exps:
