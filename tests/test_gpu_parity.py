@@ -761,6 +761,35 @@ def test_packed_checkpoint_roundtrip_gpu(msq, tmp_path):
     assert torch.equal(dst[0].dequantize(), src[0].dequantize())
 
 
+def test_bench_shape_gemms_against_dense_reference(msq):
+    """BASELINE.json's full size (X[2048,4096] x W[16384,4096]^T, the bench.py workloads): every 16th output row of the
+    three GEMM paths against a float64 GEMM on the dequantised operands, with each path's stated tolerance."""
+    g = torch.Generator(device=dev()).manual_seed(2)
+    M, N, K = 2048, 16384, 4096
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    X = torch.randn(M, K, generator=g, device=dev())
+    rows = torch.arange(0, M, 16, device=dev())
+    # (1) default bench: fp4 + posit8 outliers, MSQ-U1 + extension bit, bf16 activations
+    Wq = msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, -1, 32)["out"]
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="auto")
+    assert (P.in_kind, P.out_kind) == (0, 6)
+    xb = X.to(torch.bfloat16)
+    y = msq.qlinear.qlinear(xb, P, None, torch.float32)[rows].double()
+    ref = xb[rows].double() @ Wq.double().t()
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+    # (2) MX-FP4 x MX-FP8 and (3) MicroScopiQ e4m3 operand x MX-FP8 on the scaled MFMA
+    Xq = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32)[rows].double()
+    W4 = msq.mx_ops._quantize_mx(W, 8, "fp4_e2m1", axes=[-1], block_size=32).double()
+    y4 = msq.qlinear.qlinear_mx_w4a8(X, msq.qlinear.mx_pack_weight(W), None, torch.float32)[rows].double()
+    ref4 = Xq @ W4.t()
+    assert (y4 - ref4).abs().max().item() <= 1e-4 * ref4.abs().max().item() + 1e-6
+    W8 = msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    y8 = msq.qlinear.qlinear_mx_w4a8(X, msq.qlinear.mx_pack_values(W8), None, torch.float32)[rows].double()
+    ref8 = Xq @ W8.double().t()
+    assert bool(((y8 - ref8).abs() <= 2.0 ** -11 * (Xq.abs() @ W8.double().abs().t()) + 1e-6).all())
+
+
 def test_fakequant_bf16_native_equals_upcast(msq):
     """bf16 tensors through the fused fake-quant without the cast passes (dtype 2 of msq_outlier_fakequant): the same
     bits as computing on the upcast tensor and rounding the result to bf16 once; both block layouts, ragged tails,
