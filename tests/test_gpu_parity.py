@@ -788,6 +788,24 @@ def test_bench_shape_gemms_against_dense_reference(msq):
     y8 = msq.qlinear.qlinear_mx_w4a8(X, msq.qlinear.mx_pack_values(W8), None, torch.float32)[rows].double()
     ref8 = Xq @ W8.double().t()
     assert bool(((y8 - ref8).abs() <= 2.0 ** -11 * (Xq.abs() @ W8.double().abs().t()) + 1e-6).all())
+    # decode sizes at the same N, K: the single-launch kernels (N >= 8192, K <= 4096) with bias, f32 and bf16 output
+    bias = torch.randn(N, generator=g, device=dev())
+    P4, P8 = msq.qlinear.mx_pack_weight(W), msq.qlinear.mx_pack_values(W8)
+    for Md in (1, 16, 17, 32):
+        xd = X[:Md]
+        xq = msq.mx_ops._quantize_mx(xd, 8, "fp8_e4m3", axes=[-1], block_size=32).double()
+        r = xd.to(torch.bfloat16).double() @ Wq.double().t() + bias.double()
+        yd = msq.qlinear.qlinear(xd.to(torch.bfloat16), P, bias, torch.float32).double()
+        assert (yd - r).abs().max().item() <= 2e-5 * r.abs().max().item() + 1e-6, Md
+        yb = msq.qlinear.qlinear(xd.to(torch.bfloat16), P, bias, torch.bfloat16).double()
+        assert (yb - r).abs().max().item() <= 2.0 ** -8 * r.abs().max().item(), Md
+        r4 = xq @ W4.t() + bias.double()
+        y4d = msq.qlinear.qlinear_mx_w4a8(xd, P4, bias, torch.float32).double()
+        assert (y4d - r4).abs().max().item() <= 1e-4 * r4.abs().max().item() + 1e-6, Md
+        assert (msq.qlinear.qlinear_mx_w4a8(xd, P4, bias, torch.bfloat16).double() - r4).abs().max().item() <= 2.0 ** -8 * r4.abs().max().item(), Md
+        r8 = xq @ W8.double().t() + bias.double()
+        y8d = msq.qlinear.qlinear_mx_w4a8(xd, P8, bias, torch.float32).double()
+        assert bool(((y8d - r8).abs() <= 2.0 ** -11 * (xq.abs() @ W8.double().abs().t()) + 1e-6).all()), Md
 
 
 def test_fakequant_bf16_native_equals_upcast(msq):
