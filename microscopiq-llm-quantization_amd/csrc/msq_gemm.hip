@@ -1,5 +1,9 @@
-// msq_gemm.hip -- packed ("GEMM-ready", tile-major MSQ-T1) weight format, its
-// repack / unpack kernels and the fused unpack-dequant-GEMM for gfx950.
+// msq_gemm.hip -- packed ("GEMM-ready", tile-major) weight formats MSQ-T1 / MSQ-U1, their repack / unpack kernels and
+// the GEMMs of the hot path for gfx950:
+//   k_qgemm3      fused unpack-dequant-GEMM, bf16 activations (msq_qlinear_bf16)
+//   k_mxgemm      MX-native GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: MX-FP8 activations x MX-FP4 codes or an exact
+//                 e4m3 weight operand (msq_qlinear_mx_w4a8 / _w8a8)
+//   k_qgemv, k_mxgemv   weight-streaming decode kernels of both paths (M <= 32 / 64), k_splitk_reduce
 //
 // Design: the weight operand never touches LDS.  Every wavefront streams
 // its own 64(n) x 64(k) packed tiles straight from global memory (L2-resident across
