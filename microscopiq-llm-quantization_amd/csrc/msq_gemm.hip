@@ -831,19 +831,23 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // ---------------------------------------------------------------------------
 // WAVES (4 or 16) waves per block take consecutive k-chunks of one strip and meet in LDS.  When one block covers all
 // of K (nkb == 1, `direct`) wave 0 adds the bias and writes Y itself: one launch, no partial planes, no reduce kernel.
-template <bool W8, int MG, int WAVES>
+// NFB = 16-column fragments per block: 4 (the whole 64-column strip) or 2 (half strips: twice the blocks for the
+// narrow projections, where 64 blocks leave three quarters of the CUs without work)
+template <bool W8, int MG, int WAVES, int NFB = 4>
 __global__ void __launch_bounds__(64 * WAVES)
 k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc,
          int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16) {
     extern __shared__ __attribute__((aligned(16))) char smem_v[];
-    float (*red)[16 * MG][64] = reinterpret_cast<float (*)[16 * MG][64]>(smem_v);      // [WAVES - 1][16 MG][64]
+    float (*red)[4 * NFB * MG][64] = reinterpret_cast<float (*)[4 * NFB * MG][64]>(smem_v);      // [WAVES - 1][4 NFB MG][64]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / 128;
     const int nks = (KT + kc - 1) / kc;
     const int nkb = (nks + WAVES - 1) / WAVES;                 // the block's waves take WAVES consecutive k-chunks
-    const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb;
+    const int sidx = blockIdx.x / nkb, kb = blockIdx.x % nkb;
+    const int strip = (NFB == 4) ? sidx : (sidx >> 1);
+    const int nf0 = (NFB == 4) ? 0 : (sidx & 1) * 2;           // first fragment of this block inside the strip
     const int ks = kb * WAVES + wid;
     const int kt_lo = ks * kc < KT ? ks * kc : KT;
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
@@ -857,19 +861,19 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         xrow[j] = Xc + (int64_t)m * K + g * 16;
         xsrow[j] = Xs + (int64_t)m * (K / 32) + g;
     }
-    f32x4_t acc[4][MG];
+    f32x4_t acc[NFB][MG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NFB; ++i)
 #pragma unroll
         for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int WV = W8 ? 2 : 1, CBSZ = W8 ? 0 : 4;
-    struct WT { u32x4_t w[4][WV]; uint32_t s; };
+    struct WT { u32x4_t w[NFB][WV]; uint32_t s; };
     auto load_w = [&](WT& t, int64_t tile) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+        for (int nf = 0; nf < NFB; ++nf)
 #pragma unroll
-            for (int h = 0; h < WV; ++h) t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf) * WV + h) * 64 + lane) * 16);
-        t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4);
+            for (int h = 0; h < WV; ++h) t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16);
+        t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4) >> (8 * nf0);       // byte nf of the dword = fragment nf0 + nf
     };
     // tiles in flight ahead of the one being multiplied: 1 with four waves per block (~3000 waves in the grid), 2 with
     // sixteen (fewer, longer waves)
@@ -890,15 +894,15 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             bfr[j] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
         }
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NFB; ++nf) {
             const u32x4_t wl = cur.w[nf][0], wh = cur.w[nf][WV - 1];
             const v8i_t afr = {(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3], W8 ? (int)wh[0] : 0, W8 ? (int)wh[1] : 0, W8 ? (int)wh[2] : 0, W8 ? (int)wh[3] : 0};
 #pragma unroll
             for (int j = 0; j < MG; ++j) {
                 if (nf == 0) acc[0][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[0][j], CBSZ, 0, 0, (int)cur.s, 0, sb[j]);
                 else if (nf == 1) acc[1][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[1][j], CBSZ, 0, 1, (int)cur.s, 0, sb[j]);
-                else if (nf == 2) acc[2][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[2][j], CBSZ, 0, 2, (int)cur.s, 0, sb[j]);
-                else acc[3][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[3][j], CBSZ, 0, 3, (int)cur.s, 0, sb[j]);
+                else if (nf == 2) acc[2 % NFB][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[2 % NFB][j], CBSZ, 0, 2, (int)cur.s, 0, sb[j]);
+                else acc[3 % NFB][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afr, bfr[j], acc[3 % NFB][j], CBSZ, 0, 3, (int)cur.s, 0, sb[j]);
             }
         }
         cur = nxt;
@@ -909,9 +913,9 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #pragma unroll
         for (int j = 0; j < MG; ++j)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NFB; ++nf)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) red[wid - 1][(j * 4 + nf) * 4 + e][lane] = acc[nf][j][e];
+                for (int e = 0; e < 4; ++e) red[wid - 1][(j * NFB + nf) * 4 + e][lane] = acc[nf][j][e];
     }
     __syncthreads();
     if (wid != 0) return;
@@ -920,14 +924,14 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     for (int j = 0; j < MG; ++j) {
         const int m = j * 16 + c;
         if (m >= M) continue;
-        const int n0 = strip * 64 + g * 4;
+        const int n0 = strip * 64 + nf0 * 16 + g * 4;
         float* pbase = partial + ((int64_t)kb * M + m) * N + n0;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NFB; ++nf) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = (j * 4 + nf) * 4 + e;
+                const int r = (j * NFB + nf) * 4 + e;
                 float t = acc[nf][j][e];
 #pragma unroll
                 for (int w = 0; w < WAVES - 1; ++w) t += red[w][r][lane];           // fixed order: k-chunk 0 + 1 + 2 + ...
@@ -1557,7 +1561,10 @@ static bool use_mx_gemv(int64_t M, int64_t N, int64_t K) {
 static int mx_direct_kc(int64_t M, int64_t N, int64_t K) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MSQ_MX_GEMV_DIRECT"); on = e ? atoi(e) : 1; }
-    if (!on || M > 32 || N < 8192) return 0;                    // fewer than 128 blocks: per-CU bandwidth bound (measured)
+    static int half = -1;
+    if (half < 0) { const char* e = getenv("MSQ_MX_GEMV_HALF"); half = e ? atoi(e) : 1; }      // tuning only
+    // fewer than 128 blocks are per-CU bandwidth bound (measured): below N = 8192 the blocks take half strips (N / 32)
+    if (!on || M > 32 || N < (half ? 4096 : 8192)) return 0;
     const int kc = (int)((K / 128 + 15) / 16);
     return kc <= 2 ? kc : 0;                                     // long K: few long waves lose to ~3000 short ones (measured)
 }
@@ -1597,6 +1604,18 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
                  if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_set = true; } \
                  hipLaunchKernelGGL((k_mxgemv<W8V, MGV, WV>), dim3((unsigned)((N / 64) * nks)), dim3(64 * WV), ldsv, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
                                     (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+            if (kcd && N < 8192) {                                       // half strips: N / 32 blocks
+                const size_t ldsh = (size_t)15 * 8 * mg * 64 * 4;
+#define MSQ_MXH(W8V, MGV)                                                                                               \
+                do { static bool attr_set = false;                                                                     \
+                     if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_set = true; } \
+                     hipLaunchKernelGGL((k_mxgemv<W8V, MGV, 16, 2>), dim3((unsigned)(N / 32)), dim3(1024), ldsh, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
+                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, 1, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+                if (mg == 1) { if (w8) MSQ_MXH(true, 1); else MSQ_MXH(false, 1); }
+                else { if (w8) MSQ_MXH(true, 2); else MSQ_MXH(false, 2); }
+#undef MSQ_MXH
+                return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, half strips)");
+            }
             if (kcd) {
                 if (mg == 1) { if (w8) MSQ_MXV(true, 1, 16); else MSQ_MXV(false, 1, 16); }
                 else { if (w8) MSQ_MXV(true, 2, 16); else MSQ_MXV(false, 2, 16); }
