@@ -240,24 +240,6 @@ MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_p
         t.out[s] = *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * OS + s) * 64 + lane) * 16);
 }
 
-// unified layouts: fragment pair h (fragments 2 h, 2 h + 1) of a tile as LOCAL fragments 0, 1 (half strips of the
-// decode kernel): the two code slots go to out[kf * 2], the scale bytes are shifted down by two and the extension
-// bits rotated by 8 h (their position is (3 + 16 (j & 1) + 4 nf + (j >> 1)) mod 32), so that tile_frag(t, 0 / 1, kf)
-// works unchanged and no register array is indexed dynamically
-template <int OUT_KIND>
-MSQ_D void load_tile_half(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_plane, const uint8_t* scl_plane,
-                          int64_t tile, int lane, int h) {
-    const uint2 sc = *reinterpret_cast<const uint2*>(scl_plane + (tile * 16 + (lane & 15)) * 8);
-    t.scl[0] = sc.x >> (16 * h); t.scl[1] = sc.y >> (16 * h);
-    if (OUT_KIND == MSQ_PLANE_U8X) {
-        const uint32_t e0 = *reinterpret_cast<const uint32_t*>(inl_plane + ((tile * 2 + 0) * 64 + lane) * 4);
-        const uint32_t e1 = *reinterpret_cast<const uint32_t*>(inl_plane + ((tile * 2 + 1) * 64 + lane) * 4);
-        t.ext[0] = __builtin_amdgcn_alignbit(e0, e0, 8 * h); t.ext[1] = __builtin_amdgcn_alignbit(e1, e1, 8 * h);
-    } else { t.ext[0] = 0; t.ext[1] = 0; }
-    t.out[0] = *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * 4 + 0 + h) * 64 + lane) * 16);
-    t.out[2] = *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * 4 + 2 + h) * 64 + lane) * 16);
-}
-
 // ---------------------------------------------------------------------------
 // unpack: planes -> dense W[N][K] (f32 or bf16), same converts as the GEMM.
 // ---------------------------------------------------------------------------
@@ -978,30 +960,27 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // ---------------------------------------------------------------------------
 // WAVES = 16 (unified layouts, `direct`): one block covers all of K, wave 0 adds the bias and writes Y itself -- one
 // launch, no partial planes, no reduce kernel (as k_mxgemv).
-// NFB = 2: half strips (one fragment pair per block; unified layouts, single-launch form): twice the blocks for N < 8192
-template <int IN_KIND, int OUT_KIND, int MG, int WAVES, int NFB = 4>
+template <int IN_KIND, int OUT_KIND, int MG, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
         const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc,
         int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16) {
     extern __shared__ __attribute__((aligned(16))) char smem_v[];
-    float (*red)[4 * NFB * MG][64] = reinterpret_cast<float (*)[4 * NFB * MG][64]>(smem_v);      // [WAVES - 1][4 NFB MG][64]
+    float (*red)[16 * MG][64] = reinterpret_cast<float (*)[16 * MG][64]>(smem_v);      // [WAVES - 1][16 MG][64]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int KT = K / TILE_K;
     const int nks = (KT + kc - 1) / kc;                        // k-chunks per strip
     const int nkb = (nks + WAVES - 1) / WAVES;                 // the block's waves take WAVES consecutive k-chunks
-    const int sidx = blockIdx.x / nkb, kb = blockIdx.x % nkb;  //   of one strip and share its X rows in L1
-    const int strip = (NFB == 4) ? sidx : (sidx >> 1);
-    const int hp = (NFB == 4) ? 0 : (sidx & 1), nf0 = hp * 2;  // fragment pair of a half strip
+    const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb; //   of one strip and share its X rows in L1
     const int ks = kb * WAVES + wid;
     const int kt_lo = ks * kc < KT ? ks * kc : KT;             // chunks past the end are empty
     const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
     const int64_t tile_row = (int64_t)strip * KT;
 
-    f32x4_t acc[NFB][MG];
+    f32x4_t acc[4][MG];
 #pragma unroll
-    for (int i = 0; i < NFB; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -1011,16 +990,12 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
     for (int j = 0; j < MG; ++j) { int m = j * 16 + c; m = m < M ? m : M - 1; xrow[j] = X + (int64_t)m * K + g * 8; }
 
     constexpr bool DEEP2 = (WAVES == 16);                      // tiles in flight ahead: 2 with few long waves, else 1
-    auto ld = [&](TileRegs& t, int64_t tile) {
-        if constexpr (NFB == 2) load_tile_half<OUT_KIND>(t, inl_plane, out_plane, scl_plane, tile, lane, hp);
-        else load_tile<IN_KIND, OUT_KIND>(t, inl_plane, out_plane, scl_plane, tile, lane, scl_groups);
-    };
     TileRegs cur, nxt, nx2;
-    ld(cur, tile_row + (kt_lo < KT ? kt_lo : KT - 1));
-    if (DEEP2) ld(nxt, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : (kt_lo < KT ? kt_lo : KT - 1)));
+    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + (kt_lo < KT ? kt_lo : KT - 1), lane, scl_groups);
+    if (DEEP2) load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : (kt_lo < KT ? kt_lo : KT - 1)), lane, scl_groups);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; ld(nx2, tile_row + ktn); }
-        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; ld(nxt, tile_row + ktn); }
+        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; load_tile<IN_KIND, OUT_KIND>(nx2, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
+        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
         bf16x8_t xf[2][MG];
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
@@ -1030,8 +1005,8 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int nf = 0; nf < NFB; ++nf) {
-                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, tile_frag<IN_KIND, OUT_KIND>(cur, nf, kf));   // half strips: local fragments
+            for (int nf = 0; nf < 4; ++nf) {
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, tile_frag<IN_KIND, OUT_KIND>(cur, nf, kf));
 #pragma unroll
                 for (int j = 0; j < MG; ++j)
                     acc[nf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[kf][j], acc[nf][j], 0, 0, 0);
@@ -1044,9 +1019,9 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 #pragma unroll
         for (int j = 0; j < MG; ++j)
 #pragma unroll
-            for (int nf = 0; nf < NFB; ++nf)
+            for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) red[wid - 1][(j * NFB + nf) * 4 + e][lane] = acc[nf][j][e];
+                for (int e = 0; e < 4; ++e) red[wid - 1][(j * 4 + nf) * 4 + e][lane] = acc[nf][j][e];
     }
     __syncthreads();
     if (wid != 0) return;
@@ -1057,12 +1032,12 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
         const int m = j * 16 + c;
         if (m >= M) continue;
 #pragma unroll
-        for (int nf = 0; nf < NFB; ++nf) {
-            const int n = strip * TILE_N + (nf0 + nf) * 16 + g * 4;
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = strip * TILE_N + nf * 16 + g * 4;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = (j * NFB + nf) * 4 + e;
+                const int r = (j * 4 + nf) * 4 + e;
                 float t = acc[nf][j][e];
 #pragma unroll
                 for (int w = 0; w < WAVES - 1; ++w) t += red[w][r][lane];           // fixed order: k-chunk 0 + 1 + 2 + ...
@@ -1406,9 +1381,7 @@ static bool use_gemv(int64_t M, int64_t N, int64_t K) {
 static int direct_kc(int64_t M, int64_t N, int64_t K) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MSQ_GEMV_DIRECT"); on = e ? atoi(e) : 1; }
-    static int half = -1;
-    if (half < 0) { const char* e = getenv("MSQ_GEMV_HALF"); half = e ? atoi(e) : 1; }          // tuning only
-    if (!on || M > 32 || N < (half ? 4096 : 8192)) return 0;    // below N = 8192: half strips (N / 32 blocks)
+    if (!on || M > 32 || N < 8192) return 0;
     const int kc = (int)((K / BK + 15) / 16);
     return kc <= 4 ? kc : 0;
 }
@@ -1457,18 +1430,6 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
                  hipLaunchKernelGGL((k_qgemv<IK, OK, MGV, WV>), vgrid, dim3(64 * WV), ldsv, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, \
                                     (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
 #define MSQ_GV(IK, OK) do { if (mg == 1) MSQ_GV1(IK, OK, 1, 4); else if (mg == 2) MSQ_GV1(IK, OK, 2, 4); else MSQ_GV1(IK, OK, 4, 4); } while (0)
-            if (kcd && N < 8192) {                                       // half strips: N / 32 blocks
-                const size_t ldsh = (size_t)15 * 8 * mg * 64 * 4;
-#define MSQ_GVH(OK, MGV)                                                                                                \
-                do { static bool attr_set = false;                                                                     \
-                     if (!attr_set) { hipFuncSetAttribute((const void*)k_qgemv<MSQ_PLANE_NONE, OK, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_set = true; } \
-                     hipLaunchKernelGGL((k_qgemv<MSQ_PLANE_NONE, OK, MGV, 16, 2>), dim3((unsigned)(N / 32)), dim3(1024), ldsh, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, \
-                                        (const uint8_t*)scale_plane, (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, 1, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
-                if (out_kind == MSQ_PLANE_U8) { if (mg == 1) MSQ_GVH(MSQ_PLANE_U8, 1); else MSQ_GVH(MSQ_PLANE_U8, 2); }
-                else { if (mg == 1) MSQ_GVH(MSQ_PLANE_U8X, 1); else MSQ_GVH(MSQ_PLANE_U8X, 2); }
-#undef MSQ_GVH
-                return check_launch2("msq_qlinear_bf16(decode, single launch, half strips)");
-            }
             if (kcd) {
                 if (out_kind == MSQ_PLANE_U8) { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 2, 16); }
                 else { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8X, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8X, 2, 16); }
