@@ -19,24 +19,29 @@ def synthetic_tokens(vocab_size, n_tokens, seed=0):
     return _Enc(torch.randint(0, vocab_size, (1, n_tokens), generator=g))
 
 
-def get_wikitext2(nsamples, seed, seqlen, model):
-    """utils/data_utils.py:36-56: (trainloader of nsamples random seqlen windows, testenc)."""
+def _wikitext2_split(split):
     from datasets import load_dataset
+    return "\n\n".join(load_dataset('wikitext', 'wikitext-2-raw-v1', split=split)['text'])
+
+
+def get_wikitext2(nsamples, seed, seqlen, model):
+    """utils/data_utils.py:36-56: `nsamples` calibration windows of `seqlen` tokens drawn with Python's `random`
+    seeded by `seed` (same draws as the reference: one randint per window, inclusive upper bound), labels masked
+    except the last position, plus the tokenised test split."""
     from transformers import AutoTokenizer
-    traindata = load_dataset('wikitext', 'wikitext-2-raw-v1', split='train')
-    testdata = load_dataset('wikitext', 'wikitext-2-raw-v1', split='test')
-    tokenizer = AutoTokenizer.from_pretrained(model, use_fast=False)
-    trainenc = tokenizer("\n\n".join(traindata['text']), return_tensors='pt')
-    testenc = tokenizer("\n\n".join(testdata['text']), return_tensors='pt')
-    random.seed(seed)
-    trainloader = []
+    tok = AutoTokenizer.from_pretrained(model, use_fast=False)
+    train_ids = tok(_wikitext2_split('train'), return_tensors='pt').input_ids
+    testenc = tok(_wikitext2_split('test'), return_tensors='pt')
+    rng = random.Random(seed)                       # random.seed(seed) + random.randint: the same Mersenne stream
+    last_start = train_ids.shape[1] - seqlen - 1
+    windows = []
     for _ in range(nsamples):
-        i = random.randint(0, trainenc.input_ids.shape[1] - seqlen - 1)
-        inp = trainenc.input_ids[:, i:i + seqlen]
-        tar = inp.clone()
-        tar[:, :-1] = -100
-        trainloader.append((inp, tar))
-    return trainloader, testenc
+        start = rng.randint(0, last_start)
+        inp = train_ids[:, start:start + seqlen]
+        labels = torch.full_like(inp, -100)
+        labels[:, -1] = inp[:, -1]
+        windows.append((inp, labels))
+    return windows, testenc
 
 
 def get_loaders(name, nsamples=128, seed=0, seqlen=2048, model=''):
