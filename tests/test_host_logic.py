@@ -223,6 +223,29 @@ def test_packed_checkpoint_roundtrip_cpu(msq, tmp_path):
     for k, v in src.state_dict().items():
         assert torch.equal(v, dst.state_dict()[k]), k
 
+    # MX-operand modules (MXLinearW4A8: codes in the operand order of the scaled MFMA) round-trip the same way
+    from msq.qlinear import MXLinearW4A8
+
+    class MxNet(torch.nn.Module):
+        def __init__(self, packed):
+            super().__init__()
+            self.p = MXLinearW4A8(128, 256, True, torch.float32, w_fmt="e2m1") if packed else torch.nn.Linear(128, 256)
+            self.q = MXLinearW4A8(256, 256, False, torch.bfloat16, w_fmt="e4m3") if packed else torch.nn.Linear(256, 256, bias=False)
+
+    ms = MxNet(True)
+    for m in (ms.p, ms.q):
+        m.w_codes.copy_(torch.randint(0, 256, m.w_codes.shape, generator=g, dtype=torch.uint8))
+        m.w_scales.copy_(torch.randint(0, 256, m.w_scales.shape, generator=g, dtype=torch.uint8))
+    assert ms.p.w_codes.numel() == 128 * 256 // 2 and ms.q.w_codes.numel() == 256 * 256
+    mpath = str(tmp_path / "mx.safetensors")
+    mh = checkpoint.save_packed(ms, mpath)
+    assert mh["layers"]["p"]["layout"] == "mx-operand" and mh["layers"]["q"]["w_fmt"] == "e4m3" and mh["layers"]["q"]["out_dtype"] == "bfloat16"
+    md = MxNet(False)
+    checkpoint.load_packed(md, mpath)
+    assert isinstance(md.p, MXLinearW4A8) and md.q.w_fmt == "e4m3" and md.q.out_dtype == torch.bfloat16 and md.q.bias is None
+    for k, v in ms.state_dict().items():
+        assert torch.equal(v, md.state_dict()[k]), k
+
     class Other(torch.nn.Module):
         def __init__(self):
             super().__init__()
