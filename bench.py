@@ -8,15 +8,23 @@ H = 4096, M = B.S = 2048 tokens, W = [4H, H] = [16384, 4096], MX-FP4 (e2m1) inli
 outliers (posit8_es1 by default, --outlier fp8_e4m3 for the all-HW-convert variant), block 32
 along K, scale bits 8/8, std_dev 2, heavy-tailed synthetic weights (0.5 % of entries x16).
 
-N > 1: the 7B path does not shard ("7B = replicas only"): every rank runs an
-independent replica on its own GPU, no data-path collective, value = sum over ranks ("weak").
---workload llama70b_rowparallel shards K over the ranks with one RCCL all-reduce per step.
+N > 1: one process per GPU.  Launched either by the driver (`python -m torch.distributed.run ... bench.py
+--gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or directly as
+`python bench.py --gpus N`: the parent then starts N fresh rank processes itself BEFORE it imports torch or
+touches a GPU (plain subprocess children, never an exec of a process that has initialised HIP), relays rank 0's
+JSON line and exits with the worst return code.
+The 7B path does not shard ("7B = replicas only"): every rank runs an independent replica on
+its own GPU, no data-path collective, value = sum over ranks ("weak").
+--workload llama70b_rowparallel shards K over the ranks (RowParallelQuantLinear): the partial products are
+summed with reduce-scatter + all-gather over RCCL, chunked so that chunk i communicates while chunk i + 1
+multiplies.
 
 Prints ONE JSON line (rank 0).  The timed region starts with all inputs resident in HBM.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +34,71 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
+ROUND_TAG = "r02"
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--H", type=int, default=4096)
+    ap.add_argument("--inlier", default="fp4_e2m1")
+    ap.add_argument("--outlier", default="posit8_es1")
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
+    ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
+                    help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
+    ap.add_argument("--mx", action="store_true",
+                    help="llama70b_rowparallel on the MX matrix path (MicroScopiQ e4m3 weight operand x MX-FP8 activations)")
+    ap.add_argument("--comm", default="rs_ag", choices=["rs_ag", "all_reduce"],
+                    help="llama70b_rowparallel: how the partial outputs are summed")
+    ap.add_argument("--chunks", type=int, default=0, help="llama70b_rowparallel: row chunks overlapped with the collective (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU-only plumbing check (tests): gloo backend, the step is a no-op; exercises rank start-up, "
+                         "barriers, max-over-ranks timing and the JSON line without a GPU")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1 started by hand: the parent is a launcher only.  Nothing in this function imports torch.
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    import socket
+    n = args.gpus
+    with socket.socket() as s:                     # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MSQ_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=None, text=True))
+    worst = 0
+    lines = []
+    for r, p in enumerate(procs):
+        out, _ = p.communicate()
+        rc = p.returncode
+        if rc != 0:
+            worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+        for ln in (out or "").splitlines():
+            if r == 0 and ln.startswith("{"):
+                lines.append(ln)
+            else:
+                sys.stderr.write("[rank %d] %s\n" % (r, ln))
+    if worst == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines (expected 1)\n" % len(lines))
+        worst = 1
+    for ln in lines[-1:]:
+        print(ln)
+    sys.stdout.flush()
+    return worst
 
 
 def synth_weight(N, K, dev, seed=0):
@@ -36,45 +109,62 @@ def synth_weight(N, K, dev, seed=0):
     return W
 
 
-def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False):
-    """The oracle (a scalar C port of the reference's CPU fake-quant + the dense linear it feeds)
-    timed on the host on a bounded sample of the same workload.  Reported, never optimised."""
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False, budget_s=10.0):
+    """The oracle (a C restatement of the reference's CPU fake-quant + the dense linear it feeds, OpenMP over
+    independent blocks / output elements) timed on ALL physical host cores on a bounded sample of the same workload.
+    Reported, never optimised.  `value` is the all-core figure of the linear; the fake-quant of the whole weight and
+    torch's own CPU F.linear (what the reference itself executes, number_system/mx/linear.py:91) ride beside it."""
     import numpy as np
     from oracle import oracle as O
+    cores = physical_cores()
+    threads = O.set_threads(cores)
     rng = np.random.RandomState(0)
-    rows = N                                     # fake-quant sample: the whole [N, K] weight (~10 s)
-    Ws = (rng.randn(rows, K) * 0.02).astype(np.float32)
-    Ws[rng.rand(rows, K) < 0.005] *= 16
+    Ws = (rng.randn(N, K) * 0.02).astype(np.float32)         # fake-quant sample: the whole [N, K] weight
+    Ws[rng.rand(N, K) < 0.005] *= 16
     t0 = time.perf_counter()
     r = {"out": O.quantize_mx(Ws, 8, "fp4_e2m1", axis=-1, block_size=bs)} if plain_mx else O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs)
     t_q = time.perf_counter() - t0
-    ms, ns = 512, 1024                           # linear sample: [512, K] x [1024, K]^T (~2-4 s)
-    Xs = rng.randn(ms, K).astype(np.float32)
+    Xs = rng.randn(M, K).astype(np.float32)
+    # linear sample: probe, then as many of the N output columns as fit the time budget (all M rows)
+    t0 = time.perf_counter()
+    O.linear(Xs[:256], r["out"][:1024])
+    rate = 2.0 * 256 * 1024 * K / max(time.perf_counter() - t0, 1e-6)
+    ns = int(min(N, max(256, rate * budget_s / (2.0 * M * K)))) // 256 * 256
+    ns = max(ns, 256)
     t0 = time.perf_counter()
     O.linear(Xs, r["out"][:ns])
     t_l = time.perf_counter() - t0
-    # the reference itself runs torch F.linear on the host cores (number_system/mx/linear.py:91)
-    torch_tf, threads = None, None
+    torch_tf, tthreads = None, None
     try:
         import torch
-        threads = torch.get_num_threads()
+        tthreads = torch.get_num_threads()
         Xt = torch.randn(1024, K); Wt = torch.from_numpy(r["out"])
         torch.nn.functional.linear(Xt, Wt)
         t0 = time.perf_counter()
         for _ in range(3):
             torch.nn.functional.linear(Xt, Wt)
-        torch_tf = 3 * 2.0 * 1024 * rows * K / (time.perf_counter() - t0) / 1e12
+        torch_tf = 3 * 2.0 * 1024 * N * K / (time.perf_counter() - t0) / 1e12
         del Wt
     except Exception:
         pass
     return {
-        "value": 2.0 * ms * ns * K / t_l / 1e12, "unit": "TFLOP/s", "cores": 1, "kind": "port",
-        "sample": "oracle dense linear X[%d,%d].Wq[%d,%d]^T (double accumulate, 1 thread) after oracle "
-                  "fake-quant of W[%d,%d]" % (ms, K, ns, K, rows, K),
-        "fakequant_s_per_weight": t_q * (N / rows),
-        "fakequant_sample_s": t_q,
-        "torch_cpu_fp32_linear_tflops": torch_tf, "torch_cpu_threads": threads,
-        "host_cpus": os.cpu_count(),
+        "value": 2.0 * M * ns * K / t_l / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
+        "sample": "oracle dense linear X[%d,%d].Wq[%d,%d]^T (double accumulate, OpenMP over outputs, %d threads, %.1f s) after "
+                  "the oracle fake-quant of the whole W[%d,%d] (%d threads, %.2f s)" % (M, K, ns, K, threads, t_l, N, K, threads, t_q),
+        "fakequant_s_per_weight": t_q, "fakequant_GBps": 2.0 * N * K * 4 / t_q / 1e9,
+        "torch_cpu_fp32_linear_tflops": torch_tf, "torch_cpu_threads": tthreads,
+        "host_cpus": os.cpu_count(), "host_physical_cores": cores,
     }
 
 
@@ -106,24 +196,62 @@ def ppl_proxy(dev, fi, fo, bs):
             "equivalent_delta_at_ppl_5.5": 5.5 * abs(ppl_packed - ppl_fake) / ppl_fake}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--M", type=int, default=2048)
-    ap.add_argument("--H", type=int, default=4096)
-    ap.add_argument("--inlier", default="fp4_e2m1")
-    ap.add_argument("--outlier", default="posit8_es1")
-    ap.add_argument("--block", type=int, default=32)
-    ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
-    ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
-                    help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
-    ap.add_argument("--mx", action="store_true",
-                    help="llama70b_rowparallel on the MX matrix path (MicroScopiQ e4m3 weight operand x MX-FP8 activations)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def ppl_delta_from_env(dev, fi, fo, bs):
+    """Metric half (ii), WikiText-2 PPL delta vs the CPU reference, when a checkpoint and the dataset are on local
+    disk:  MSQ_PPL_MODEL = a HuggingFace Llama checkpoint directory, MSQ_WIKITEXT2_DIR = a directory holding
+    wiki.train.raw / wiki.test.raw (or the HF `wikitext-2-raw-v1` parquet / arrow files); optional
+    MSQ_PPL_NSAMPLES bounds the number of test windows.  PPL_ref = the model with every decoder Linear replaced by the
+    ORACLE's CPU fake-quant (the reference's arithmetic) and evaluated densely; PPL_ours = the same checkpoint through
+    the HIP quantiser, packed, fused dequant-GEMM.  Returns None when the environment does not name both."""
+    model_dir, data_dir = os.environ.get("MSQ_PPL_MODEL"), os.environ.get("MSQ_WIKITEXT2_DIR")
+    if not (model_dir and data_dir):
+        return None
+    import copy
+    import numpy as np
+    import torch
+    import msq
+    from msq.harness import find_layers, llama
+    from msq.harness.data_utils import get_wikitext2, _Enc
+    from msq.harness.evalppl import perplexity
+    from oracle import oracle as O
+    model = llama.get_llama(model_dir).eval()
+    seqlen = int(os.environ.get("MSQ_PPL_SEQLEN", model.seqlen))
+    model.seqlen = seqlen
+    _, testenc = get_wikitext2(0, 0, seqlen, model_dir, data_dir=data_dir)
+    ids = testenc.input_ids
+    ns = os.environ.get("MSQ_PPL_NSAMPLES")
+    if ns:
+        ids = ids[:, :int(ns) * seqlen]
+    tokens = _Enc(ids)
+    qc = dict(inlier_elem_format=fi, outlier_elem_format=fo, axes=[-1], block_size=bs)
+    ref = copy.deepcopy(model)
+    O.set_threads(physical_cores())
+    for layer in ref.model.layers:                       # CPU reference arithmetic (oracle), evaluated densely
+        for name, lin in find_layers(layer).items():
+            W = lin.weight.data
+            Wq = O.outlier_fakequant(W.float().numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
+            lin.weight.data = torch.from_numpy(Wq).to(W.dtype)
+    ppl_ref = perplexity(ref.to(dev), tokens, dev, seqlen)
+    del ref
+    model.to(dev)
+    q = msq.quant.MXQuantizer(); q.configure(8, 8, **qc)
+    kept = 0
+    for layer in model.model.layers:
+        names = {n: q for n, l in find_layers(layer).items() if l.out_features % 256 == 0 and l.in_features % 64 == 0}
+        kept += len(find_layers(layer)) - len(names)
+        msq.qlinear.make_quant(layer, names)
+    ppl_ours = perplexity(model, tokens, dev, seqlen)
+    return {"ppl_cpu_reference": ppl_ref, "ppl_hip_packed_fused": ppl_ours, "delta": ppl_ours - ppl_ref,
+            "windows": int(ids.numel() // seqlen), "seqlen": seqlen, "layers_kept_dense": kept,
+            "model": os.path.basename(os.path.normpath(model_dir))}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher: start the ranks before anything here touches torch / HIP
+        sys.exit(spawn_ranks(args, argv))
 
     import torch
     import torch.distributed as dist
@@ -133,15 +261,21 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if not args.stub:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo" if args.stub else "nccl", rank=rank, world_size=world)
+    sys.stderr.write("bench.py rank %d / world %d (local rank %d, pid %d, backend %s)\n" %
+                     (rank, world, local_rank, os.getpid(), ("gloo" if args.stub else "nccl") if world > 1 else "none"))
+    if args.stub:
+        return stub_main(args, rank, world)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     from msq import qlinear
 
     M = args.M
-    if args.workload == "llama70b_rowparallel":
+    rowpar = args.workload == "llama70b_rowparallel"
+    if rowpar:
         H, N = 8192, 8192                                  # Llama-2-70B down_proj: K = 28672 split over ranks
         K_full = 28672
         if K_full % (world * (128 if args.mx else 64)):
@@ -156,16 +290,27 @@ def main():
     W = synth_weight(N, K, dev, seed=rank)
     w4a8 = args.workload == "llama7b_w4a8"
     mxw4a8 = args.workload == "llama7b_mx_w4a8"
-    msqmx = args.workload == "llama7b_msq_w4a8_mx" or (args.workload == "llama70b_rowparallel" and args.mx)
-    if msqmx and args.workload == "llama70b_rowparallel":
-        # K splits on a multiple of 128: the activation's 32-blocks and the weight's packed tiles stay whole, every
-        # shard's operands equal the unsharded ones; one RCCL all-reduce of the bf16 partial outputs per step
-        args.outlier = "fp8_e4m3"
-        name += " on the MX matrix path (e4m3 weight operand x MX-FP8 activations)"
+    msqmx = args.workload == "llama7b_msq_w4a8_mx" or (rowpar and args.mx)
+    rp = None
+    if rowpar:
+        # K splits on a multiple of 64 (128 on the MX path): the 32-blocks and the packed tiles stay whole, every shard's
+        # operands equal the unsharded ones; partial outputs summed by reduce-scatter + all-gather (RCCL over xGMI),
+        # row-chunked so that the collective of chunk i overlaps the GEMM of chunk i + 1
         from msq import quant
-        P = qlinear.mx_pack_values(quant.outlier_fakequant(W, 8, 8, args.inlier, args.outlier, 2, -1, args.block)["out"])
-        X = torch.randn(M, K, device=dev)
-        mxw4a8 = True
+        if args.mx:
+            args.outlier = "fp8_e4m3"
+            name += " on the MX matrix path (e4m3 weight operand x MX-FP8 activations)"
+            shard = qlinear.MXLinearW4A8.from_values(quant.outlier_fakequant(W, 8, 8, args.inlier, args.outlier, 2, -1, args.block)["out"],
+                                                     None, out_dtype=torch.bfloat16)
+            P = qlinear.MXPackedWeight(shard.w_codes, shard.w_scales, N, K, "e4m3")
+            X = torch.randn(M, K, device=dev)
+            mxw4a8 = True
+        else:
+            P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block, layout=args.layout)
+            shard = qlinear.QuantLinear.from_packed(P, None, out_dtype=torch.bfloat16)
+            X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        rp = qlinear.RowParallelQuantLinear(shard, world, rank, None, comm=args.comm, chunks=args.chunks,
+                                            reduce_dtype=torch.bfloat16)
     elif msqmx:
         # BASELINE config 3 with the MicroScopiQ weight itself on the MX matrix path: the fake-quant values (MX-FP4
         # inliers + fp8_e4m3 outliers, utils/quant.py:147-266) packed exactly as one e4m3 code per weight + E8M0 scale
@@ -202,18 +347,14 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        if rp is not None:
+            return rp(X)
         if mxw4a8:
-            y = qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
-            if args.workload == "llama70b_rowparallel" and world > 1:
-                dist.all_reduce(y)
-            return y
+            return qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
         if w4a8:
             return qlinear.qlinear_w4a8(X, P, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5,
                                         a_block_size=args.block, a_variant=1)
-        y = qlinear.qlinear(X, P, None, torch.bfloat16)
-        if args.workload == "llama70b_rowparallel" and world > 1:
-            dist.all_reduce(y)
-        return y
+        return qlinear.qlinear(X, P, None, torch.bfloat16)
 
     # Bring the GPU out of its idle power state before the contract's W warm-up steps: the first ~50 launches
     # after an idle phase run at lower clocks (measured: W = 20 -> 1219 TFLOP/s, W = 100 -> 1270 with nothing
@@ -237,7 +378,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream (torch's current stream = the stream handed to the C ABI)
     if world > 1:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,6 +388,7 @@ def main():
     total_flops = flops_step * args.steps * world
     value = total_flops / wall / 1e12
     achieved = flops_step / (kern_ms * 1e-3) / 1e12
+    peak = PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS
     out = {
         "metric": "fused dequant-GEMM TFLOPS (% MFMA peak) + PPL delta, Llama-7B W4 1xMI355X",
         "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,12 +398,12 @@ def main():
                    "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element, "clock_ramp_launches": RAMP,
                    "layout": {(1, 2): "planes", (1, 3): "planes", (1, 4): "planes", (0, 4): "bf16", (0, 5): "unified",
                               (0, 6): "unified+ext"}.get((getattr(P, "in_kind", -1), getattr(P, "out_kind", -1)), "mx operand order"),
-                   "parallelism": ("replicas x%d" % world) if args.workload != "llama70b_rowparallel"
-                   else ("row-parallel K/%d + RCCL all-reduce" % world)},
-        "pct_of_mfma_peak": 100.0 * (value / world) / (PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS),
+                   "parallelism": ("replicas x%d" % world) if not rowpar
+                   else ("row-parallel K/%d + RCCL %s, %d row chunk(s)" % (world, args.comm, rp.chunks_for(M)))},
+        "pct_of_mfma_peak": 100.0 * (value / world) / peak,
         "ppl_delta": None,
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / (PEAK_FP8_TFLOPS if mxw4a8 else PEAK_BF16_TFLOPS), "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None,
                      "kernel": "k_mxgemm (+ k_mx_pack)" if mxw4a8 else "k_qgemm", "kernel_ms": kern_ms, "flops_per_launch": flops_step},
     }
     # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
@@ -269,26 +411,75 @@ def main():
     tag = {"posit8_es1": "posit", "fp8_e4m3": "fp8"}.get(args.outlier)
     if mxw4a8:
         tag = "msq_w4a8_mx" if msqmx else "mx_w4a8"
-    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % tag) if tag else None
-    if prof and os.path.exists(prof) and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx") and (M, H) == (2048, 4096):
-        try:
-            pj = json.load(open(prof))
-            out["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")
-            out["roofline"]["traffic_source"] = "profiles/r01_%s_summary.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" % tag
-            out["roofline"]["algorithmic_bytes"] = pj.get("algorithmic_bytes_per_launch")
-        except Exception:
-            pass
+    if tag and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx") and (M, H) == (2048, 4096):
+        for rt in (ROUND_TAG, "r01"):
+            prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rt, tag))
+            if not os.path.exists(prof):
+                continue
+            try:
+                pj = json.load(open(prof))
+                out["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/%s_%s_summary.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE)" % (rt, tag)
+                out["roofline"]["algorithmic_bytes"] = pj.get("algorithmic_bytes_per_launch")
+                break
+            except Exception:
+                pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "llama7b_w4_fused_gemm":
+        import contextlib
         try:
-            import contextlib
             with contextlib.redirect_stdout(sys.stderr):              # the harness prints progress: keep stdout to ONE JSON line
                 out["ppl_proxy"] = ppl_proxy(dev, args.inlier, args.outlier, args.block)
         except Exception as e:                                     # the stand-in must never take the bench line down
             out["ppl_proxy"] = {"error": repr(e)[:200]}
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                pd = ppl_delta_from_env(dev, args.inlier, args.outlier, args.block)
+            if pd is not None:
+                out["ppl_delta"] = pd["delta"]
+                out["ppl_wikitext2"] = pd
+        except Exception as e:
+            out["ppl_wikitext2"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier, plain_mx=(mxw4a8 and not msqmx))
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def stub_main(args, rank, world):
+    """--stub: the contract's control flow (warm-up, barrier, K timed steps, barrier, MAX over ranks, one JSON line
+    from rank 0) with a no-op step on the CPU.  Lets the CPU tests prove that `bench.py --gpus N` starts N ranks with
+    the right RANK / WORLD_SIZE and that the line reports n_gpus = N."""
+    import torch
+    import torch.distributed as dist
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"]), os.getpid()))
+    else:
+        seen = [(0, 0, 1, os.getpid())]
+    x = torch.zeros(1)
+    for _ in range(args.warmup):
+        x += 1
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x += 1
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub (no GPU work)", "value": 0.0, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "stub", "ranks_seen": seen}}))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

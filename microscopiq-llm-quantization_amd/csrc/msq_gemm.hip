@@ -1093,6 +1093,20 @@ k_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bia
 // ===========================================================================
 // C ABI
 // ===========================================================================
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remember it per device (one bit per
+// device ordinal, atomically; ordinals >= 64 simply set the attribute on every launch), not once per process.
+#include <atomic>
+struct DevOnce { std::atomic<uint64_t> mask{0}; };
+static inline bool attr_needed(const DevOnce& o) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    return !(o.mask.load(std::memory_order_acquire) & (1ull << d));
+}
+static inline void attr_done(DevOnce& o) {
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) o.mask.fetch_or(1ull << d, std::memory_order_release);
+}
+
 static thread_local char g_err2[256] = "";
 extern "C" const char* msq_last_error(void);
 static int fail2(int code, const char* msg);
@@ -1414,6 +1428,12 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
     if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
+    {   // activations and packed planes are addressed with 32-bit buffer offsets (make_rsrc clamps num_records)
+        int64_t ib = 0, ob = 0, sb = 0;
+        msq_packed_sizes(N, K, block, in_kind, out_kind, &ib, &ob, &sb, nullptr);
+        if (M * K * 2 > 0xFFFFFFFFll || ib > 0xFFFFFFFFll || ob > 0xFFFFFFFFll || sb > 0xFFFFFFFFll)
+            return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: activations (M*K*2 bytes) and every packed plane must stay below 4 GiB; split M (or N) on the host");
+    }
     hipStream_t st0 = (hipStream_t)stream;
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     if (use_gemv(M, N, K)) {
@@ -1425,8 +1445,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             const dim3 vgrid((unsigned)((N / TILE_N) * nks));
             const size_t ldsv = (size_t)((kcd ? 16 : 4) - 1) * 16 * mg * 64 * 4;
 #define MSQ_GV1(IK, OK, MGV, WV)                                                                                        \
-            do { static bool attr_set = false;                                                                         \
-                 if (!attr_set) { hipFuncSetAttribute((const void*)k_qgemv<IK, OK, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_set = true; } \
+            do { static DevOnce once_;                                                                         \
+                 if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv<IK, OK, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_done(once_); } \
                  hipLaunchKernelGGL((k_qgemv<IK, OK, MGV, WV>), vgrid, dim3(64 * WV), ldsv, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, \
                                     (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
 #define MSQ_GV(IK, OK) do { if (mg == 1) MSQ_GV1(IK, OK, 1, 4); else if (mg == 2) MSQ_GV1(IK, OK, 2, 4); else MSQ_GV1(IK, OK, 4, 4); } while (0)
@@ -1463,8 +1483,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const int groups = groups0;
     float* partial = (float*)workspace;
 #define MSQ_LAUNCH1(KERN, IK, OK, YT, WMV)                                                                             \
-    do { static bool attr_set = false;                                                                                 \
-         if (!attr_set) { hipFuncSetAttribute((const void*)KERN<IK, OK, YT, WMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    do { static DevOnce once_;                                                                                 \
+         if (attr_needed(once_)) { hipFuncSetAttribute((const void*)KERN<IK, OK, YT, WMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((KERN<IK, OK, YT, WMV>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,  \
                 (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
 #define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
@@ -1600,15 +1620,15 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
         if (kcd || (workspace && workspace_bytes >= (int64_t)nks * M * N * 4)) {
             const size_t ldsv = (size_t)(waves - 1) * 16 * mg * 64 * 4;
 #define MSQ_MXV(W8V, MGV, WV)                                                                                          \
-            do { static bool attr_set = false;                                                                         \
-                 if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_set = true; } \
+            do { static DevOnce once_;                                                                         \
+                 if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_done(once_); } \
                  hipLaunchKernelGGL((k_mxgemv<W8V, MGV, WV>), dim3((unsigned)((N / 64) * nks)), dim3(64 * WV), ldsv, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
                                     (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
             if (kcd && N < 8192) {                                       // half strips: N / 32 blocks
                 const size_t ldsh = (size_t)15 * 8 * mg * 64 * 4;
 #define MSQ_MXH(W8V, MGV)                                                                                               \
-                do { static bool attr_set = false;                                                                     \
-                     if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_set = true; } \
+                do { static DevOnce once_;                                                                     \
+                     if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_done(once_); } \
                      hipLaunchKernelGGL((k_mxgemv<W8V, MGV, 16, 2>), dim3((unsigned)(N / 32)), dim3(1024), ldsh, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
                                         (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, 1, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
                 if (mg == 1) { if (w8) MSQ_MXH(true, 1); else MSQ_MXH(false, 1); }
@@ -1641,8 +1661,8 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
     const size_t lds = (size_t)(w8 ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
     float* partial = (float*)workspace;
 #define MSQ_MXL(YT, W8V)                                                                                              \
-    do { static bool attr_set = false;                                                                                 \
-         if (!attr_set) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    do { static DevOnce once_;                                                                                 \
+         if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
                             (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } while (0)
     if (y_dtype == 0) { if (w8) MSQ_MXL(float, true); else MSQ_MXL(float, false); }

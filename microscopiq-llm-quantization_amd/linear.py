@@ -55,13 +55,28 @@ def pack_mx_weight(weight, mx_specs):
 
 
 def _forward_packed(input, P, bias, mx_specs):
-    """Same dataflow as _forward with the weight side precomputed and the two middle steps fused."""
-    from .qlinear import qlinear_w4a8
+    """Same dataflow as _forward with the weight side precomputed.  The reference quantises the activations along
+    ``axes=[1]`` (linear.py:66-73).  For a 2-D input [M, K] that is the feature axis and the two middle steps run
+    fused (activation quantiser + dequant-GEMM, msq_qlinear_w4a8).  For [B, S, K] and beyond axis 1 is NOT the last
+    axis (it is the sequence axis): the activations then go through the same quantiser call as ``_forward``
+    (quantize_mx_outlier_op, axes=[1]) and only the GEMM uses the packed weight, so pack() never changes which
+    elements share a block."""
+    from .formats import _get_format_params
+    from .qlinear import qlinear, qlinear_w4a8
+    from ._lib import MsqError
     bf_in = quantize_elemwise_op(input, mx_specs=mx_specs, round=mx_specs["round_output"])
     sb = _mx_scale_bits(mx_specs)
-    output = qlinear_w4a8(bf_in, P, None, torch.float32, a_elem_format=mx_specs["a_elem_format"], a_scale_bits=sb,
-                          a_std_dev=5, a_block_size=mx_specs["block_size"], a_round=mx_specs["round_mx_output"],
-                          a_flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], a_variant=1)
+    if input.ndim == 2:
+        output = qlinear_w4a8(bf_in, P, None, torch.float32, a_elem_format=mx_specs["a_elem_format"], a_scale_bits=sb,
+                              a_std_dev=5, a_block_size=mx_specs["block_size"], a_round=mx_specs["round_mx_output"],
+                              a_flush_fp32_subnorms=mx_specs["mx_flush_fp32_subnorms"], a_variant=1)
+    else:
+        if _get_format_params(mx_specs["a_elem_format"])[1] > 9:     # mbits counts sign + implicit bit: bf16 holds 9
+            raise MsqError("MXLinear.pack(): a_elem_format %s is not exact in bf16 (fused GEMM operand)" % mx_specs["a_elem_format"])
+        qis_input = quantize_mx_outlier_op(bf_in, mx_specs, inlier_elem_format=mx_specs['a_elem_format'],
+                                           outlier_elem_format=mx_specs['a_elem_format'], axes=[1],
+                                           round=mx_specs["round_mx_output"])
+        output = qlinear(qis_input, P, None, torch.float32)
     output = quantize_elemwise_op(output, mx_specs=mx_specs, round=mx_specs["round_output"])
     if bias is not None:
         bf_bias = quantize_elemwise_op(bias, mx_specs=mx_specs, round=mx_specs["round_weight"])

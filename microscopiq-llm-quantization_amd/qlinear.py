@@ -154,7 +154,16 @@ def unpack_weight(P, dtype=torch.float32):
     return W
 
 
-def qlinear(x, P, bias=None, out_dtype=torch.bfloat16):
+def _out_buffer(out, M, N, out_dtype, dev, who):
+    """Caller-provided result buffer (a contiguous [M, N] view, e.g. a row slice of a larger tensor) or a fresh one."""
+    if out is None:
+        return torch.empty(M, N, dtype=out_dtype, device=dev)
+    if tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous() or out.device != dev:
+        raise MsqError("%s: out must be a contiguous [%d, %d] %s tensor on %s" % (who, M, N, out_dtype, dev))
+    return out
+
+
+def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
     """y = x . Wq^T (+ bias): the fused unpack-dequant-GEMM.  x: [..., K] (cast to bf16)."""
     if not x.is_cuda:
         raise MsqError("qlinear needs CUDA/HIP tensors (no CPU fallback)")
@@ -168,7 +177,7 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16):
     M = xb.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear: out_dtype must be float32 or bfloat16")
-    y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
+    y = _out_buffer(out, M, P.N, out_dtype, x.device, "qlinear")
     b = None
     if bias is not None:
         b = bias.detach().float().contiguous()
@@ -318,7 +327,7 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
     return codes, scales
 
 
-def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False):
+def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False, out=None):
     """y = MXFP8(x) . MXFP4(W)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4: one pass packs the activations,
     the GEMM consumes codes and scale bytes directly."""
     if isinstance(x, (tuple, list)):                     # activations already packed by mx_pack_act: q / k / v or
@@ -334,7 +343,7 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
     M = xc.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
-    y = torch.empty(M, P.N, dtype=out_dtype, device=xdev)
+    y = _out_buffer(out, M, P.N, out_dtype, xdev, "qlinear_mx_w4a8")
     b = bias.detach().float().contiguous() if bias is not None else None
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=xdev) if wsb > 0 else None
@@ -381,9 +390,16 @@ class MXLinearW4A8(nn.Module):
             m.bias.copy_(bias.detach().float())
         return m
 
-    def forward(self, x):
-        P = MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features, self.w_fmt)
-        return qlinear_mx_w4a8(x, P, self.bias, self.out_dtype)
+    def _packed(self):
+        return MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features, self.w_fmt)
+
+    def forward(self, x, out=None):
+        y = qlinear_mx_w4a8(x, self._packed(), self.bias, self.out_dtype, out=out)
+        # an fp16 / bf16 model gets its own dtype back (as QuantLinear.forward); pre-packed activations (a tuple of
+        # codes and scales) carry no dtype: those callers take out_dtype
+        if out is None and torch.is_tensor(x) and x.is_floating_point() and x.dtype != torch.float32 and y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        return y
 
 
 class QuantLinear(nn.Module):
@@ -500,11 +516,32 @@ class QuantLinear(nn.Module):
             m.bias = None
         return m
 
+    @classmethod
+    def from_packed(cls, P, bias=None, out_dtype=torch.bfloat16):
+        """Module around an existing PackedWeight (the planes are adopted, not copied)."""
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.in_features, m.out_features, m.block_size = P.K, P.N, P.block
+        m.inlier_elem_format = m.outlier_elem_format = "packed"
+        m.out_dtype = out_dtype
+        m.layout = "unified" if P.out_kind in (PLANE_U8, PLANE_U8X) else "planes"
+        m.in_kind, m.out_kind = P.in_kind, P.out_kind
+        dev = P.out.device
+        m.register_buffer("inl_plane", P.inl if P.inl is not None else torch.zeros(0, dtype=torch.uint8, device=dev))
+        m.register_buffer("out_plane", P.out)
+        m.register_buffer("scale_plane", P.scl if P.scl is not None else torch.zeros(0, dtype=torch.uint8, device=dev))
+        if bias is not None:
+            m.register_buffer("bias", bias.detach().float().clone())
+        else:
+            m.bias = None
+        return m
+
     def dequantize(self, dtype=torch.float32):
         return unpack_weight(self._packed(), dtype)
 
-    def forward(self, x):
-        return qlinear(x, self._packed(), self.bias, self.out_dtype).to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
+    def forward(self, x, out=None):
+        y = qlinear(x, self._packed(), self.bias, self.out_dtype, out=out)
+        return y if out is not None else y.to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
 
 
 def make_quant(module, quantizers, name='', layout="auto"):
@@ -525,43 +562,110 @@ def make_quant(module, quantizers, name='', layout="auto"):
 
 
 class RowParallelQuantLinear(nn.Module):
-    """K-split QuantLinear: rank r owns in_features [r*K/G, (r+1)*K/G); forward all-reduces the
-    fp32 partial outputs (torch.distributed: backend "nccl" == RCCL over xGMI on MI355X, "gloo"
-    on CPU for tests -- there the partial product must be supplied by `partial_fn`)."""
+    """K-split (row-parallel) packed Linear for the 70B configuration: rank r owns in_features
+    [r K/G, (r+1) K/G) as a packed shard (``QuantLinear``, or ``MXLinearW4A8`` on the MX matrix path) and the ranks'
+    partial products are summed over ``torch.distributed`` (backend "nccl" == RCCL over xGMI on MI355X).
 
-    def __init__(self, shard, world_size, rank, process_group=None, partial_fn=None):
+    Communication.  xGMI is point-to-point, so a ring all-reduce is bound by one link (2 (G-1)/G S / 153 GB/s = 383 us
+    for the 33.5 MB bf16 output of down_proj at M = 2048) while reduce-scatter + all-gather over all seven links move
+    2 S / (G 153 GB/s) = 55 us -- still the same order as the shard's GEMM (~96 us).  The forward therefore
+      * sums with ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` (``comm="rs_ag"``; ``"all_reduce"`` keeps the
+        single collective, and is what non-NCCL backends such as gloo get), and
+      * cuts the M rows into chunks: the GEMM of chunk i + 1 runs on the compute stream while RCCL's stream moves
+        chunk i (async collectives; every chunk is a contiguous row slice of the one output tensor, so nothing is
+        copied and the GEMM writes straight into the buffer the collective reduces in place).
+    ``reduce_dtype`` is the wire / accumulation dtype of the sum (float32: exact fp32 sum in rank order up to RCCL's
+    reduction tree; bfloat16 halves the bytes)."""
+
+    def __init__(self, shard, world_size, rank, process_group=None, comm="rs_ag", chunks=0, reduce_dtype=torch.float32,
+                 single_rank_collectives=False):
         super().__init__()
-        self.shard = shard                    # QuantLinear over the local K slice (bias only on rank 0)
+        if comm not in ("rs_ag", "all_reduce"):
+            raise MsqError("RowParallelQuantLinear: comm must be 'rs_ag' or 'all_reduce'")
+        self.shard = shard                    # packed Linear over the local K slice (bias only on rank 0)
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
-        self.partial_fn = partial_fn
+        self.comm, self.chunks, self.reduce_dtype = comm, int(chunks), reduce_dtype
+        self.single_rank_collectives = bool(single_rank_collectives)   # run the collectives with one rank too (profiling on one GPU)
 
     @staticmethod
-    def shard_bounds(in_features, world_size, rank, block_size):
-        """[k0, k1) of a rank; the split must fall on a 64-multiple (tile) and a block multiple."""
+    def shard_bounds(in_features, world_size, rank, block_size, multiple=64):
+        """[k0, k1) of a rank; the split must fall on a tile multiple (64; 128 on the MX path) and a block multiple."""
         if in_features % world_size:
             raise MsqError("in_features must divide evenly over the ranks")
         per = in_features // world_size
-        if per % 64 or per % block_size:
-            raise MsqError("per-rank in_features (%d) must be a multiple of 64 and of the block size" % per)
+        if per % multiple or per % block_size:
+            raise MsqError("per-rank in_features (%d) must be a multiple of %d and of the block size" % (per, multiple))
         return rank * per, (rank + 1) * per
 
     @classmethod
-    def from_linear(cls, linear, quantizer, world_size, rank, process_group=None):
-        k0, k1 = cls.shard_bounds(linear.in_features, world_size, rank, quantizer.block_size)
-        local = nn.Linear(k1 - k0, linear.out_features, bias=(linear.bias is not None and rank == 0),
-                          device=linear.weight.device, dtype=linear.weight.dtype)
-        with torch.no_grad():
-            local.weight.copy_(linear.weight[:, k0:k1])
-            if local.bias is not None:
-                local.bias.copy_(linear.bias)
-        return cls(QuantLinear.from_linear(local, quantizer, out_dtype=torch.float32), world_size, rank,
-                   process_group)
+    def from_linear(cls, linear, quantizer, world_size, rank, process_group=None, path="bf16", **kw):
+        """Quantise and pack this rank's K slice of a dense Linear.  ``path="bf16"``: fused dequant-GEMM shard
+        (QuantLinear); ``"mx"``: the fake-quant values as an exact e4m3 operand with MX-FP8 activations
+        (MXLinearW4A8.from_values).  Blocks run along K, so every shard's masks and scales equal the unsharded ones."""
+        k0, k1 = cls.shard_bounds(linear.in_features, world_size, rank, quantizer.block_size, 128 if path == "mx" else 64)
+        has_bias = linear.bias is not None and rank == 0
+        Wl = linear.weight.data[:, k0:k1].contiguous()
+        kw.setdefault("reduce_dtype", torch.float32)
+        if path == "mx":
+            from .quant import outlier_fakequant
+            axes = quantizer.axes if isinstance(quantizer.axes, (list, tuple)) else [quantizer.axes]
+            if [a % 2 for a in axes] != [1]:
+                raise MsqError("RowParallelQuantLinear: blocks must run along in_features (axes=[-1])")
+            Wq = outlier_fakequant(Wl.float(), quantizer.inlier_scale_bits, quantizer.outlier_scale_bits,
+                                   quantizer.inlier_elem_format, quantizer.outlier_elem_format, quantizer.std_dev, -1,
+                                   quantizer.block_size, quantizer.round, quantizer.flush_fp32_subnorms)["out"]
+            shard = MXLinearW4A8.from_values(Wq, linear.bias.data if has_bias else None, out_dtype=kw["reduce_dtype"])
+        elif path == "bf16":
+            local = nn.Linear(k1 - k0, linear.out_features, bias=has_bias, device=linear.weight.device, dtype=linear.weight.dtype)
+            with torch.no_grad():
+                local.weight.copy_(Wl)
+                if has_bias:
+                    local.bias.copy_(linear.bias)
+            shard = QuantLinear.from_linear(local, quantizer, out_dtype=kw["reduce_dtype"])
+        else:
+            raise MsqError("RowParallelQuantLinear.from_linear: path must be 'bf16' or 'mx'")
+        return cls(shard, world_size, rank, process_group, **kw)
+
+    def chunks_for(self, M):
+        """Row chunks the forward overlaps with the collective: the configured count, or one per 512 rows up to four."""
+        if self.world_size == 1 and not self.single_rank_collectives:
+            return 1
+        n = self.chunks if self.chunks > 0 else max(1, min(4, M // 512))
+        return max(1, min(n, (M + 127) // 128))
 
     def forward(self, x_local):
-        """x_local: [..., K/G] (this rank's slice of the activations)."""
+        """x_local: [..., K/G] (this rank's slice of the activations) -> the full sum [..., N] in ``reduce_dtype``."""
         import torch.distributed as dist
-        y = self.partial_fn(x_local) if self.partial_fn is not None else self.shard(x_local)
-        y = y.float()
-        if self.world_size > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.process_group)
-        return y
+        lead = tuple(x_local.shape[:-1])
+        x2 = x_local.reshape(-1, x_local.shape[-1])
+        M, N, G = x2.shape[0], self.shard.out_features, self.world_size
+        y = torch.empty(M, N, dtype=self.reduce_dtype, device=x2.device)
+        direct = isinstance(self.shard, (QuantLinear, MXLinearW4A8)) and getattr(self.shard, "out_dtype", None) == self.reduce_dtype
+
+        def partial(r0, r1):                     # the shard's GEMM on rows [r0, r1), written into y[r0:r1]
+            if direct:
+                self.shard(x2[r0:r1], out=y[r0:r1])
+            else:
+                y[r0:r1].copy_(self.shard(x2[r0:r1]))
+
+        if G == 1 and not self.single_rank_collectives:
+            partial(0, M)
+            return y.reshape(*lead, N)
+        pg = self.process_group
+        use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
+        nch = self.chunks_for(M)
+        rows = (((M + nch - 1) // nch) + 127) // 128 * 128
+        pending = []
+        for r0 in range(0, M, rows):
+            r1 = min(M, r0 + rows)
+            partial(r0, r1)
+            yc = y[r0:r1]
+            if use_rs and (r1 - r0) % G == 0:
+                part = torch.empty((r1 - r0) // G, N, dtype=self.reduce_dtype, device=y.device)
+                pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
+                pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
+            else:
+                pending.append(dist.all_reduce(yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
+        for h in pending:
+            h.wait()
+        return y.reshape(*lead, N)

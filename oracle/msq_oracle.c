@@ -492,8 +492,6 @@ int msq_oracle_outlier_fakequant(const float* in, float* out, uint8_t* mask, flo
     if (block <= 0) block = (int)axis_len;
     const int64_t nblk = (axis_len + block - 1) / block;
     int status = 0;
-    float* a = (float*)malloc(sizeof(float) * block * 6);
-    float *absa = a + block, *mk = a + 2 * block, *inl = a + 3 * block, *outl = a + 4 * block, *tmp = a + 5 * block;
     const float k = (float)std_dev; /* python scalar * fp32 tensor -> fp32 mul */
 
     /* variant 1 (mx_ops.py:248,62-66): statistics of the SIGNED values over the
@@ -502,7 +500,12 @@ int msq_oracle_outlier_fakequant(const float* in, float* out, uint8_t* mask, flo
     if (variant == MSQ_VARIANT_MXOPS) {
         vmean = (float*)malloc(sizeof(float) * pre * block * post);
         vstd = (float*)malloc(sizeof(float) * pre * block * post);
+        /* threads split the independent (p, b) statistics; every value is computed by one thread in the
+         * reference's order, so the result does not depend on the thread count */
+#pragma omp parallel reduction(| : status) private(col)
+        {
         col = (float*)malloc(sizeof(float) * nblk);
+#pragma omp for collapse(2) schedule(static)
         for (int64_t p = 0; p < pre; ++p) for (int b = 0; b < block; ++b) for (int64_t q = 0; q < post; ++q) {
             for (int64_t nb = 0; nb < nblk; ++nb) {
                 int64_t ai = nb * block + b;
@@ -515,8 +518,18 @@ int msq_oracle_outlier_fakequant(const float* in, float* out, uint8_t* mask, flo
             vstd[(p * block + b) * post + q] = std_welford(col, nblk, 1, 1);
             if (vstd[(p * block + b) * post + q] != vstd[(p * block + b) * post + q]) status |= 1;
         }
+        free(col);
+        }
+        col = NULL;
     }
 
+    /* blocks are independent (utils/quant.py works on the whole tensor at once): OpenMP threads take whole
+     * (p, nb) slabs with private scratch; per-element arithmetic and order are untouched */
+#pragma omp parallel reduction(| : status)
+    {
+    float* a = (float*)malloc(sizeof(float) * block * 6);
+    float *absa = a + block, *mk = a + 2 * block, *inl = a + 3 * block, *outl = a + 4 * block, *tmp = a + 5 * block;
+#pragma omp for collapse(2) schedule(static)
     for (int64_t p = 0; p < pre; ++p) for (int64_t nb = 0; nb < nblk; ++nb) for (int64_t q = 0; q < post; ++q) {
         /* gather block with zero padding (a3) */
         for (int b = 0; b < block; ++b) {
@@ -587,7 +600,9 @@ int msq_oracle_outlier_fakequant(const float* in, float* out, uint8_t* mask, flo
         if (e_in_o) e_in_o[(p * nblk + nb) * post + q] = se_in;
         if (e_out_o) e_out_o[(p * nblk + nb) * post + q] = se_out;
     }
-    free(a); free(vmean); free(vstd); free(col);
+    free(a);
+    }
+    free(vmean); free(vstd); free(col);
     return status;
 }
 
@@ -688,6 +703,7 @@ void msq_oracle_reduce_inner(const float* in, float* out, int64_t outer, int64_t
  * accumulated in double (checker-grade, used with a tolerance). */
 void msq_oracle_linear(const float* x, const float* w, const float* bias, float* y, int64_t M,
                        int64_t N, int64_t K) {
+#pragma omp parallel for collapse(2) schedule(static)
     for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) {
         double s = 0.0;
         for (int64_t kk = 0; kk < K; ++kk) s += (double)x[m * K + kk] * (double)w[n * K + kk];
@@ -695,6 +711,14 @@ void msq_oracle_linear(const float* x, const float* w, const float* bias, float*
         y[m * N + n] = (float)s;
     }
 }
+
+/* thread count of the OpenMP regions above (0 = all cores); returns the count in effect */
+#ifdef _OPENMP
+#include <omp.h>
+int msq_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int msq_oracle_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* test hook: the per-block mean / std exactly as the a4 mask path computes them
  * for a tensor with `post` contiguous non-reduced columns. */

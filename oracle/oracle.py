@@ -35,6 +35,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n=0):
+    """OpenMP threads of the fake-quant / linear loops (0 = leave as is); returns the count in effect."""
+    return int(lib().msq_oracle_set_threads(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 

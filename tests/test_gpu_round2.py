@@ -1,0 +1,130 @@
+"""Round-2 GPU tests: advisor findings (dtype of the MX-path modules inside an fp16 model, MXLinear.pack() on 3-D
+inputs, argument guards of the C ABI) and the new hot-path pieces of this round."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def msq():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import msq as m
+    m._lib.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _tiny_llama(dtype):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).eval().to(dtype).to(dev())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("path", ["mx", "bf16"])
+def test_pack_layers_in_half_precision_model(msq, dtype, path):
+    """Llama-2 / OPT checkpoints load as fp16 (get_llama, torch_dtype='auto'): every packed projection must hand the
+    model's dtype back, otherwise the first dense Linear behind it fails with a dtype mismatch (advisor, round 1)."""
+    from msq.harness import find_layers
+    from msq.harness.data_utils import _Enc
+    from msq.harness.evalppl import pack_layers, perplexity, quantize_layers_nearest
+    tokens = _Enc(torch.randint(0, 512, (1, 64 * 4), generator=torch.Generator().manual_seed(1)))
+    m = _tiny_llama(dtype)
+    quantize_layers_nearest(m.model.layers, dev(), dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3",
+                                                        axes=[-1], block_size=32))
+    ppl_dense = perplexity(m, tokens, dev(), 64)
+    packed, dense = pack_layers(m.model.layers, path=path)
+    assert packed == 14 and dense == 0
+    kinds = {type(l).__name__ for layer in m.model.layers for l in layer.modules()}
+    assert ("MXLinearW4A8" in kinds) == (path == "mx")
+    x = torch.randn(2, 5, 256, device=dev(), dtype=dtype)
+    y = m.model.layers[0].self_attn.q_proj(x)
+    assert y.dtype == dtype and y.shape == (2, 5, 256)
+    ppl = perplexity(m, tokens, dev(), 64)                         # runs end to end: no dtype mismatch at lm_head / SDPA
+    # bf16-activation path: same weights, bf16 rounding of activations only; MX path adds MX-FP8 activations
+    assert abs(ppl - ppl_dense) / ppl_dense < (0.02 if path == "bf16" else 0.05), (ppl, ppl_dense)
+
+
+def test_mxlinear_pack_3d_input_matches_unpacked(msq):
+    """MXLinear quantises activations along axes=[1] (number_system/mx/linear.py:66-73): for [B, S, K] that is the
+    SEQUENCE axis.  pack() must keep that: same outlier masks / scales as the unpacked module (advisor, round 1)."""
+    sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8,
+                                      "block_size": 32, "bfloat": 16, "custom_cuda": True})
+    torch.manual_seed(3)
+    lin = msq.linear.MXLinear(128, 256, True, mx_specs=sp).to(dev())
+    X = torch.randn(3, 64, 128, device=dev())
+    X[torch.rand(3, 64, 128, device=dev()) < 0.02] *= 10
+    with torch.no_grad():
+        y_ref = lin(X)
+        # the activation operand the unpacked forward builds (blocks of 32 along S)
+        bf_in = msq.elemwise_ops.quantize_elemwise_op(X, mx_specs=lin.mx_specs, round=lin.mx_specs["round_output"])
+        q_seq = msq.mx_ops.quantize_mx_outlier_op(bf_in, lin.mx_specs, inlier_elem_format="fp8_e4m3",
+                                                  outlier_elem_format="fp8_e4m3", axes=[1], round=lin.mx_specs["round_mx_output"])
+        q_feat = msq.mx_ops.quantize_mx_outlier_op(bf_in, lin.mx_specs, inlier_elem_format="fp8_e4m3",
+                                                   outlier_elem_format="fp8_e4m3", axes=[2], round=lin.mx_specs["round_mx_output"])
+        assert not torch.equal(q_seq, q_feat)                      # the two groupings really differ on this input
+        y_packed = lin.pack()(X)
+        y2 = lin(X[0])                                             # 2-D input: axis 1 is the feature axis, fused path
+    assert y_packed.shape == y_ref.shape == (3, 64, 256)
+    err = (y_packed - y_ref).abs()
+    tol = y_ref.abs() * 2.0 ** -7 + 1e-6                           # one bf16 ulp of the re-rounded output (fp32 sum order)
+    assert bool((err <= tol).all()), float(err.max())
+    assert float((err > 0).float().mean()) <= 0.01
+    lin._packed = None
+    with torch.no_grad():
+        y2_ref = lin(X[0])
+    e2 = (y2 - y2_ref).abs()
+    assert bool((e2 <= y2_ref.abs() * 2.0 ** -7 + 1e-6).all())
+
+
+def test_qlinear_rejects_over_4gib_operands(msq):
+    """msq_qlinear_bf16 addresses activations and packed planes with 32-bit buffer offsets: operands above 4 GiB must be
+    refused with MSQ_ERR_UNSUPPORTED, not wrap around silently (advisor, round 1).  No memory is touched: the check
+    happens before any launch, so the pointers may be small dummies."""
+    L = msq._lib.lib()
+    d = torch.zeros(1024, dtype=torch.uint8, device=dev())
+    p = msq._lib.ptr
+    # M * K * 2 bytes > 4 GiB
+    rc = L.msq_qlinear_bf16(p(d), None, p(d), p(d), None, p(d), 2, 1 << 20, 256, 4096, 32, 0, 5, None, 0, None)
+    assert rc == -2, rc
+    assert b"4 GiB" in L.msq_last_error()
+    # a packed plane > 4 GiB: N * K bytes for the unified layout
+    rc = L.msq_qlinear_bf16(p(d), None, p(d), p(d), None, p(d), 2, 16, 1 << 17, 1 << 16, 32, 0, 5, None, 0, None)
+    assert rc == -2, rc
+
+
+def test_decode_kernels_on_second_stream_and_repeated(msq):
+    """The single-launch decode kernels need 120 KiB of dynamic LDS: the attribute is set per device inside the
+    library (no process-wide flag).  Repeated calls from two streams must keep returning identical results."""
+    g = torch.Generator(device=dev()).manual_seed(5)
+    W = torch.randn(8192, 4096, generator=g, device=dev()) * 0.02
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="unified")
+    x = torch.randn(4, 4096, generator=g, device=dev()).to(torch.bfloat16)
+    y0 = msq.qlinear.qlinear(x, P, None, torch.float32)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        y1 = msq.qlinear.qlinear(x, P, None, torch.float32)
+    s.synchronize()
+    assert torch.equal(y0, y1)
+    ref = x.float() @ msq.qlinear.unpack_weight(P).t()
+    assert float((y0 - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6

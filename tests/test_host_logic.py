@@ -161,7 +161,7 @@ rank, world = int(sys.argv[1]), 2
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
 dist.init_process_group("gloo", rank=rank, world_size=world)
 rng = np.random.RandomState(0)
-N, K, M = 64, 256, 8
+N, K, M = 64, 256, 300
 W = (rng.randn(N, K) * 0.02).astype(np.float32); X = rng.randn(M, K).astype(np.float32)
 bias = rng.randn(N).astype(np.float32)
 k0, k1 = RowParallelQuantLinear.shard_bounds(K, world, rank, 32)
@@ -169,12 +169,20 @@ k0, k1 = RowParallelQuantLinear.shard_bounds(K, world, rank, 32)
 full = O.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
 loc = O.outlier_fakequant(np.ascontiguousarray(W[:, k0:k1]), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
 assert (loc == full[:, k0:k1]).all()
-def partial(x):            # CPU stand-in for the HIP shard (tests only): oracle linear on the local slice
-    return torch.from_numpy(O.linear(x.numpy(), loc, bias if rank == 0 else None))
-rp = RowParallelQuantLinear(None, world, rank, None, partial_fn=partial)
-y = rp(torch.from_numpy(np.ascontiguousarray(X[:, k0:k1])))
+class OracleShard(torch.nn.Module):        # CPU stand-in for the HIP shard (lives in the test only): oracle linear on the K slice
+    out_features = N
+    def forward(self, x):
+        return torch.from_numpy(O.linear(x.numpy(), loc, bias if rank == 0 else None))
 ref = O.linear(X, full, bias)
-assert np.abs(y.numpy() - ref).max() < 1e-5, np.abs(y.numpy() - ref).max()
+xl = torch.from_numpy(np.ascontiguousarray(X[:, k0:k1]))
+for comm, chunks in (("rs_ag", 0), ("all_reduce", 1), ("rs_ag", 3)):   # gloo has no reduce-scatter: rs_ag falls back per chunk
+    rp = RowParallelQuantLinear(OracleShard(), world, rank, None, comm=comm, chunks=chunks)
+    y = rp(xl)
+    assert y.shape == (M, N) and y.dtype == torch.float32
+    assert np.abs(y.numpy() - ref).max() < 1e-5, (comm, chunks, np.abs(y.numpy() - ref).max())
+assert RowParallelQuantLinear(OracleShard(), world, rank, chunks=0).chunks_for(2048) == 4
+assert RowParallelQuantLinear(OracleShard(), world, rank, chunks=0).chunks_for(300) == 1
+assert RowParallelQuantLinear(OracleShard(), 1, 0).chunks_for(4096) == 1
 dist.barrier(); dist.destroy_process_group()
 print("RANK_OK", rank)
 '''
@@ -189,6 +197,38 @@ def test_row_parallel_two_ranks_gloo(msq, tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o
+
+
+def test_bench_gpus_flag_spawns_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two fresh rank processes itself --
+    before torch is imported in the parent -- and relay ONE JSON line that reports n_gpus = 2 (--stub: gloo, no GPU)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    seen = sorted(tuple(t[:3]) for t in j["config"]["ranks_seen"])
+    assert seen == [(0, 0, 2), (1, 1, 2)], seen                      # (RANK, LOCAL_RANK, WORLD_SIZE) of each child
+    assert len({t[3] for t in j["config"]["ranks_seen"]}) == 2       # two distinct processes
+    assert "rank 0 / world 2" in p.stderr and "rank 1 / world 2" in p.stderr
+    # the launcher itself never imports torch
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def spawn_ranks"):src.index("def synth_weight")]
+    assert "import torch" not in body
+
+
+def test_bench_torchrun_env_is_honoured(tmp_path):
+    """Started the driver's way (RANK / WORLD_SIZE already in the environment) bench.py must NOT spawn again."""
+    import json
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29431")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip())["n_gpus"] == 1
 
 
 def test_packed_checkpoint_roundtrip_cpu(msq, tmp_path):
