@@ -133,8 +133,18 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
  * in/out dtype: 0 = f32 (bit-exact vs the reference); 2 = bf16 tensors (read as f32 values, computed in f32, one
  *   round-to-nearest-even on the way out: the same bits as upcasting, running dtype 0 and casting back), built for
  *   round-to-nearest with float / int inlier formats, variant 0; 1 = f16 and the remaining combinations return
- *   MSQ_ERR_UNSUPPORTED (the Python shim upcasts). */
+ *   MSQ_ERR_UNSUPPORTED (the Python shim upcasts).
+ *   MSQ_DTYPE_F16_NATIVE / MSQ_DTYPE_BF16_NATIVE = fp16 / bf16 tensors COMPUTED IN THAT DTYPE: every torch op of
+ *   utils/quant.py:147-266 rounded back to the tensor dtype as ATen's CPU half kernels do -- what the reference's RTN
+ *   harness executes on an fp16 checkpoint (llm/llama.py:238) -- bit-exact vs the reference on half tensors
+ *   (variant 0, float / int element formats, no num_outliers; otherwise MSQ_ERR_UNSUPPORTED). */
+#define MSQ_DTYPE_F16_NATIVE 0x11
+#define MSQ_DTYPE_BF16_NATIVE 0x12
 int64_t msq_outlier_workspace_bytes(int64_t pre, int64_t axis_len, int64_t post, int block, int variant);
+/* floor(log2(v)) as torch evaluates it on a Half (dtype 1) / BFloat16 (dtype 2) tensor: floor(R(log2f(v))), which
+ * rounds values just under a power of two up to the next exponent (utils/quant.py:525-529 and elemwise_ops.py:139 on
+ * half tensors).  v: non-negative values of that dtype held as f32.  Diagnostic entry (exhaustively tested). */
+int msq_floor_log2_lowp(const float* v, float* out, int64_t n, int dtype, void* stream);
 int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in, float* e_out,
                           int8_t* num_outliers, int* status_flag, void* workspace,
                           int64_t workspace_bytes, int dtype, int64_t pre,

@@ -380,7 +380,8 @@ static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
 }
 
 // implemented in msq_quant_hw.hip (hardware-convert variants, own translation unit)
-extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
+extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* stream);   // msq_quant_lowp.hip
+int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
 
 // dtype 2 (bf16 tensors) is built for round-to-nearest with float / int inliers (the hardware-convert variants and
 // the nearest-specialised arithmetic one); everything else is f32 only (the host shim upcasts)
@@ -403,7 +404,7 @@ static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, 
 
 extern "C" {
 
-int msq_version(void) { return 100; }
+int msq_version(void) { return 200; }
 const char* msq_last_error(void) { return g_err; }
 
 int msq_format_id(const char* name) { return msq_host::format_id(name); }
@@ -576,8 +577,16 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
         A.vmean = vmean; A.vstd = vstd;
     }
     int rc;
+    if (dtype == MSQ_DTYPE_F16_NATIVE || dtype == MSQ_DTYPE_BF16_NATIVE) {
+        // compute in the tensor dtype, every op rounded as ATen's CPU half kernels do (llm/llama.py:238)
+        if (variant != MSQ_VARIANT_QUANT || fi.kind != 0 || fo.kind != 0 || num_outliers)
+            return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: native half-precision compute covers utils/quant.py:147-266 with float / int element formats");
+        if (!msq_launch_outlier_lowp_(in, out, &A, block, dtype & 3, (void*)st))
+            return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
+        return check_launch("msq_outlier_fakequant(native half)");
+    }
     if (dtype == 0 || dtype == 2) rc = launch_outlier(in, out, A, block, st, dtype);
-    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: dtype 1 (f16) is not built; the host shim upcasts");
+    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: dtype 1 (f16 computed in f32) is not built; use MSQ_DTYPE_F16_NATIVE or upcast");
     if (rc) return rc;
     return check_launch("msq_outlier_fakequant");
 }

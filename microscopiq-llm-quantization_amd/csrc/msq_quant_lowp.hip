@@ -1,0 +1,248 @@
+// msq_quant_lowp.hip -- the MicroScopiQ fake-quant computed IN the tensor dtype (fp16 / bf16).
+//
+// The reference's RTN harness hands the checkpoint weight to quantize_mx_outlier_v1 in its own dtype
+// (llm/llama.py:238, fp16 for Llama-2 / OPT), so every torch op of utils/quant.py:147-266 and
+// number_system/mx/elemwise_ops.py:84-174 runs on a Half / BFloat16 CPU tensor: ATen evaluates each op in fp32 and
+// rounds the result back to the tensor dtype, op by op.  The kernels here reproduce that sequence literally -- R()
+// is the per-op rounding (v_cvt_f16_f32 / bf16 RNE) -- so that the result is bit-identical to the reference's for
+// fp16 / bf16 inputs as well (oracle: msq_oracle_outlier_fakequant_lowp; goldens: tests/golden/outlier_lowp.npz).
+// What differs from "compute in fp32, round once":
+//   * mean = R(fp32 sum in ATen's order / n); std = R((float) double Welford);  bounds R(mean -+ R(k std));
+//   * floor(log2(x)) = floor(R(log2f(x))): results within half a T-ulp below an integer round UP to it, i.e. values
+//     just under a power of two get the next exponent (21 % of all bf16 values).  floor_log2_lowp() is a closed rule
+//     that matches torch for every positive fp16 / bf16 value (tests/golden/log2_lowp.npz, exhaustive);
+//   * 2^e, every scaling, the +0.5 of the rounding and the final recombination are rounded to T;
+//   * FP32_MIN_NORMAL underflows to 0 in fp16: an all-zero block has log2(0) = -inf -> clamp -> -20.
+// One quantisation block per lane, register resident; the element loop is a straight-line float pipeline (VALU
+// bound, ~200 instructions per element), read once / written once.  Offline step of the harness, not a GEMM-path
+// kernel: 6.5 G weights of Llama-2-7B take well under a second.
+// Compiled with -ffp-contract=off (no fused multiply-adds: every op rounds on its own).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+#include "msq_host.h"
+#include "msq_outlier_core.h"
+
+using namespace msq;
+
+template <int DT> MSQ_D float Rr(float x) {
+    if (DT == 1) return (float)(_Float16)x;          // v_cvt_f16_f32: RNE, fp16 subnormals kept, overflow -> Inf
+    return (float)(__bf16)x;                         // RNE on the upper 16 bits
+}
+template <int DT> MSQ_D float ld16(const uint16_t* p, int64_t i) {
+    if (DT == 1) return (float)__builtin_bit_cast(_Float16, p[i]);
+    return u2f((uint32_t)p[i] << 16);
+}
+template <int DT> MSQ_D void st16(uint16_t* p, int64_t i, float v) {   // v is already a T value
+    if (DT == 1) p[i] = __builtin_bit_cast(uint16_t, (_Float16)v);
+    else p[i] = (uint16_t)(f2u(v) >> 16);
+}
+
+// floor(R(log2f(v))) for a non-negative T value v (see the header comment).  c[jb + 1] = 2^(-2^(jb - p)), p = 11 / 8
+// significand bits: the significand m in [0.5, 1) of v rounds up to the next integer exponent iff m > c.
+template <int DT> MSQ_D float floor_log2_lowp(float v) {
+    if (v != v) return v;
+    if (v == 0.f) return u2f(0xFF800000u);
+    if (__builtin_isinf(v)) return v;
+    const int e = __builtin_amdgcn_frexp_expf(v);       // v = m 2^e, m in [0.5, 1)
+    const float m = __builtin_amdgcn_frexp_mantf(v);
+    const int k = e - 1, u = e;
+    if (u == 0) return (float)k;
+    const int au = u < 0 ? -u : u;
+    int jb = 31 - __builtin_clz((unsigned)au);
+    if (u > 0 && (au & (au - 1)) == 0) jb -= 1;
+    float c;
+    if (DT == 1) {
+        const float t[9] = {0.9998307824134827f, 0.9996616244316101f, 0.999323308467865f, 0.9986470937728882f, 0.9972960352897644f,
+                            0.9945994019508362f, 0.9892280101776123f, 0.9785720705986023f, 0.9576032757759094f};
+        c = t[jb + 1];
+    } else {
+        const float t[9] = {0.9986470937728882f, 0.9972960352897644f, 0.9945994019508362f, 0.9892280101776123f, 0.9785720705986023f,
+                            0.9576032757759094f, 0.9170040488243103f, 0.8408964276313782f, 0.7071067690849304f};
+        c = t[jb + 1];
+    }
+    return (m > c) ? (float)u : (float)k;
+}
+template <int DT> MSQ_D float pow2_lowp(float e) { return Rr<DT>(exp2f_int(e)); }     // R(powf(2, e))
+
+// elemwise_ops.py:47-78
+template <int DT> MSQ_D float round_mantissa_lowp(float a, int rmode) {
+    if (a != a) return a;
+    const float s = (a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f);
+    const float m = __builtin_fabsf(a);
+    if (rmode == 1) return Rr<DT>(s * __builtin_floorf(m));
+    if (rmode == 0) return Rr<DT>(s * __builtin_floorf(Rr<DT>(m + 0.5f)));
+    const float t = Rr<DT>(m - 0.5f);
+    float r = __builtin_fmodf(t, 2.0f);
+    if (r != 0.f && r < 0.f) r += 2.0f;
+    r = Rr<DT>(r);
+    const float tie = (r == 0.f) ? 1.f : 0.f;
+    return Rr<DT>(s * Rr<DT>(__builtin_floorf(Rr<DT>(m + 0.5f)) - tie));
+}
+// elemwise_ops.py:84-174 (saturate_normals, allow_denorm: utils/quant.py:218-221), every op rounded to T
+template <int DT> MSQ_D float core_lowp(float a, const Fmt& f, int rmode) {
+    float out = a, pe = 0.f, p2 = 1.f;
+    const bool have_pe = f.ebits != 0;
+    if (have_pe) {
+        const float t = Rr<DT>(__builtin_fabsf(a) + ((a == 0.f) ? 1.f : 0.f));
+        pe = floor_log2_lowp<DT>(t);
+        const float min_exp = (float)(2 - (1 << (f.ebits - 1)));
+        pe = (pe == pe && pe < min_exp) ? min_exp : pe;
+        p2 = pow2_lowp<DT>(pe);
+    }
+    const float sh = pow2i(f.mbits - 2);
+    if (have_pe) out = Rr<DT>(Rr<DT>(out / p2) * sh);
+    else out = Rr<DT>(out * sh);
+    out = round_mantissa_lowp<DT>(out, rmode);
+    if (have_pe) out = Rr<DT>(Rr<DT>(out / sh) * p2);
+    else out = Rr<DT>(out / sh);
+    const float mn = Rr<DT>(f.max_norm);
+    if (out == out) { out = out < -mn ? -mn : out; out = out > mn ? mn : out; }
+    if (__builtin_isinf(a)) out = a;
+    return out;
+}
+template <int DT> MSQ_D float shared_exp_lowp(float mx) {
+    if (mx != mx) return mx;
+    const float t = Rr<DT>(pow2i(-126) * ((mx == 0.f) ? 1.f : 0.f));
+    return floor_log2_lowp<DT>(Rr<DT>(mx + t));
+}
+
+template <int BS, int DT>
+MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
+                             const OutlierArgs& A, int order) {
+    int status = 0;
+    float lo, hi;
+    {
+        float ab[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(a[b]);
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        const float mean = Rr<DT>(s / (float)BS);                       // utils/quant.py:477 (fp32 sum, one rounding)
+        const float sd = Rr<DT>(std_twopass_checked<BS>(ab, 0));        // :478 (double Welford -> float -> T)
+        const float ks = Rr<DT>(A.k * sd);
+        lo = Rr<DT>(mean - ks); hi = Rr<DT>(mean + ks);                 // :489-490
+    }
+#pragma unroll
+    for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
+    float mx_in = 0.f;
+    float inl[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        const bool m = (a[b] < lo) || (a[b] > hi);                      // :492
+        mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
+        const float mf = m ? 1.f : 0.f;
+        inl[b] = a[b] * (1.0f - mf);                                    // :192 (exact: x * 1 or x * 0)
+        a[b] = a[b] * mf;                                               // :193
+        const float t = __builtin_fabsf(inl[b]);
+        mx_in = (t > mx_in || t != t) ? t : mx_in;
+    }
+    float se_in = shared_exp_lowp<DT>(mx_in);                           // :196-198
+    const bool fl = A.flush && !(se_in > -127.f);
+    se_in = Rr<DT>(se_in - (float)A.fi.emax);                           // :207
+    se_in = clamp_scale_exp(se_in, A.in_sb, 0);                         // :208-211
+    const float sc_in = pow2_lowp<DT>(se_in);
+    float mx_out = 0.f;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        float v = inl[b];
+        if (fl) v = v * 0.f;
+        v = Rr<DT>(v / sc_in);                                          // :214
+        a[b] = Rr<DT>(a[b] * sc_in);                                    // :216
+        v = core_lowp<DT>(v, A.fi, A.rmode);                            // :218-221
+        v = Rr<DT>(v * sc_in);                                          // :224
+        if (v != v || a[b] != a[b]) status |= MSQ_STATUS_NAN;           // :225-226
+        inl[b] = v;
+        const float t = __builtin_fabsf(a[b]);
+        mx_out = (t > mx_out || t != t) ? t : mx_out;
+    }
+    float se_out = shared_exp_lowp<DT>(mx_out);                         // :229-231
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    se_out = Rr<DT>(se_out - (float)A.fo.emax);                         // :237
+    se_out = clamp_scale_exp(se_out, A.out_sb, 0);                      // :239-242
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    const float sc_out = pow2_lowp<DT>(se_out);
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        float o = Rr<DT>(a[b] / sc_out);                                // :247
+        if (o != o) status |= MSQ_STATUS_NAN;                           // :250
+        o = core_lowp<DT>(o, A.fo, A.rmode);                            // :252-255
+        o = Rr<DT>(Rr<DT>(o * sc_out) / sc_in);                         // :258
+        a[b] = Rr<DT>(inl[b] + o);                                      // :262
+    }
+    se_in_o = se_in; se_out_o = se_out;
+    return status;
+}
+
+// lane <-> (p, nb, q), q fastest.  post > 1: each of the BS row accesses of a wave is one contiguous 128-byte segment;
+// post == 1: every lane walks its own contiguous block (the cache lines are shared by neighbouring lanes).
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A) {
+    const int64_t total = A.pre * A.nblk * A.post;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = t % A.post;
+    const int64_t nb = (t / A.post) % A.nblk;
+    const int64_t p = t / (A.post * A.nblk);
+    const int64_t a0 = nb * BS;
+    const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    float a[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+        a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;     // zero padding, :563-583
+    int order = 1;                                           // reduced dim contiguous
+    if (A.post > 1) {
+        const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
+        order = (q < lim) ? 0 : 2;
+    }
+    uint32_t mkw[(BS + 31) / 32];
+    float se_in, se_out;
+    const int status = outlier_block_lowp<BS, DT>(a, mkw, se_in, se_out, A, order);
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        if (a0 + b < A.axis_len) {
+            st16<DT>(out, base + (int64_t)b * A.post, a[b]);
+            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+    }
+    if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
+    if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
+    if (status && A.status) atomicOr(A.status, status);
+}
+
+// test hook kernels: the two rules the exhaustive fixtures pin
+template <int DT>
+__global__ void __launch_bounds__(256) k_floor_log2_lowp(const float* __restrict__ v, float* __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = floor_log2_lowp<DT>(v[i]);
+}
+
+// called from msq_outlier_fakequant (msq_quant.hip) for dtype MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE
+extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* stream) {
+    const OutlierArgs& A = *(const OutlierArgs*)args;
+    const int64_t n = A.pre * A.nblk * A.post;
+    int64_t g = (n + 255) / 256; if (g < 1) g = 1;
+    const dim3 grid((unsigned)g), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MSQ_LP(BS)                                                                                                     \
+    case BS:                                                                                                           \
+        if (dt == 1) hipLaunchKernelGGL((k_outlier_lowp<BS, 1>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
+        else hipLaunchKernelGGL((k_outlier_lowp<BS, 2>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A);   \
+        return 1;
+    switch (block) { MSQ_LP(8) MSQ_LP(16) MSQ_LP(32) MSQ_LP(64) MSQ_LP(128) default: return 0; }
+#undef MSQ_LP
+}
+
+extern "C" int msq_floor_log2_lowp(const float* v, float* out, int64_t n, int dtype, void* stream) {
+    if (n <= 0) return MSQ_OK;
+    if (!v || !out || (dtype != 1 && dtype != 2)) return MSQ_ERR_BAD_ARG;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (dtype == 1) hipLaunchKernelGGL(k_floor_log2_lowp<1>, grid, blk, 0, (hipStream_t)stream, v, out, n);
+    else hipLaunchKernelGGL(k_floor_log2_lowp<2>, grid, blk, 0, (hipStream_t)stream, v, out, n);
+    return hipGetLastError() == hipSuccess ? MSQ_OK : MSQ_ERR_LAUNCH;
+}

@@ -633,6 +633,12 @@ class RowParallelQuantLinear(nn.Module):
         n = self.chunks if self.chunks > 0 else max(1, min(4, M // 512))
         return max(1, min(n, (M + 127) // 128))
 
+    def chunk_bounds(self, M):
+        """[(r0, r1)] row chunks of the forward (multiples of the GEMM's 128-row block tile)."""
+        nch = self.chunks_for(M)
+        rows = (((M + nch - 1) // nch) + 127) // 128 * 128
+        return [(r0, min(M, r0 + rows)) for r0 in range(0, M, rows)]
+
     def forward(self, x_local):
         """x_local: [..., K/G] (this rank's slice of the activations) -> the full sum [..., N] in ``reduce_dtype``."""
         import torch.distributed as dist
@@ -653,11 +659,8 @@ class RowParallelQuantLinear(nn.Module):
             return y.reshape(*lead, N)
         pg = self.process_group
         use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
-        nch = self.chunks_for(M)
-        rows = (((M + nch - 1) // nch) + 127) // 128 * 128
         pending = []
-        for r0 in range(0, M, rows):
-            r1 = min(M, r0 + rows)
+        for r0, r1 in self.chunk_bounds(M):
             partial(r0, r1)
             yc = y[r0:r1]
             if use_rs and (r1 - r0) % G == 0:

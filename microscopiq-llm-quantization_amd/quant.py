@@ -50,10 +50,16 @@ def _pap(shape, axis):
 
 def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
                       std_dev=2, axis=0, block_size=0, round="nearest", flush_fp32_subnorms=False,
-                      variant=VARIANT_QUANT, want_mask=False, want_exps=False, want_num_outliers=False):
+                      variant=VARIANT_QUANT, want_mask=False, want_exps=False, want_num_outliers=False,
+                      compute_dtype="input"):
     """One fused launch of the MicroScopiQ fake-quant.  Returns a dict with 'out' and the
-    requested side outputs.  fp16/bf16 inputs are computed in fp32 and rounded back once
-    (the reference computes in the tensor dtype, llm/llama.py:238; DESIGN.md 'dtype')."""
+    requested side outputs.
+
+    fp16 / bf16 tensors: ``compute_dtype="input"`` (default) computes IN the tensor dtype, every op rounded back as
+    ATen's CPU half kernels do -- what the reference does when the RTN harness quantises an fp16 checkpoint
+    (llm/llama.py:238) -- and is bit-exact against the reference on half tensors (utils/quant.py variant, float /
+    int element formats).  ``compute_dtype="float32"`` upcasts, computes in fp32 and rounds once at the end (more
+    accurate, not what the reference does); posit formats, the mx_ops variant and num_outliers always take it."""
     if not isinstance(A, torch.Tensor) or not A.is_cuda:
         raise MsqError("input must be a CUDA/HIP tensor (the MI355X library has no CPU fallback)")
     if round not in RoundingMode.string_enums():
@@ -61,12 +67,17 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
     assert (inlier_scale_bits > 0 and outlier_scale_bits > 0)            # utils/quant.py:168
     orig_dtype = A.dtype
     x = A.contiguous()
+    if compute_dtype not in ("input", "float32"):
+        raise MsqError("compute_dtype must be 'input' or 'float32'")
+    native_half = (compute_dtype == "input" and x.dtype in (torch.float16, torch.bfloat16) and variant == VARIANT_QUANT
+                   and not want_num_outliers and not str(inlier_elem_format).startswith("posit")
+                   and not str(outlier_elem_format).startswith("posit"))
     # bf16 tensors go through natively (read as fp32 values, computed in fp32, one RNE rounding on the way out:
     # the same result as the upcast / downcast shim) where the kernels are built for it: round-to-nearest with
     # float / int inliers, quant.py variant; everything else (fp16, other rounding modes, posit inliers) is upcast
     native_bf16 = (x.dtype == torch.bfloat16 and round == "nearest" and variant == VARIANT_QUANT
                    and not str(inlier_elem_format).startswith("posit"))
-    if x.dtype != torch.float32 and not native_bf16:
+    if x.dtype != torch.float32 and not native_bf16 and not native_half:
         x = x.float()
     axis = axis % x.ndim
     pre, axis_len, post = _pap(x.shape, axis)
@@ -86,10 +97,14 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
         n_out = torch.zeros((((nblk + blk - 1) // blk) * post,), dtype=torch.int8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev) if CHECK_NAN else None
     L = lib()
+    if native_half:
+        dtype_code = 0x11 if x.dtype == torch.float16 else 0x12      # MSQ_DTYPE_F16_NATIVE / MSQ_DTYPE_BF16_NATIVE
+    else:
+        dtype_code = 2 if native_bf16 else 0
     wsb = L.msq_outlier_workspace_bytes(pre, axis_len, post, blk, variant)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb > 0 else None
     check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), ptr(n_out), ptr(status),
-                                  ptr(ws), wsb, 2 if native_bf16 else 0, pre, axis_len, post, blk, format_id(inlier_elem_format),
+                                  ptr(ws), wsb, dtype_code, pre, axis_len, post, blk, format_id(inlier_elem_format),
                                   format_id(outlier_elem_format), int(inlier_scale_bits), int(outlier_scale_bits),
                                   float(std_dev), int(RoundingMode[round]), int(bool(flush_fp32_subnorms)),
                                   int(variant), current_stream(dev)), "msq_outlier_fakequant")

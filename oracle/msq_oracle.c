@@ -607,6 +607,191 @@ int msq_oracle_outlier_fakequant(const float* in, float* out, uint8_t* mask, flo
 }
 
 /* ------------------------------------------------------------------------
+ * a6 on HALF-PRECISION tensors: the RTN harness path quantises the checkpoint in its own dtype
+ * (llm/llama.py:238  W = subset[name].weight.data -- fp16 for Llama-2 / OPT -- passed straight into
+ * quantize_mx_outlier_v1), so every torch op of utils/quant.py:147-266 and elemwise_ops.py:84-174 runs on
+ * Half / BFloat16 CPU tensors: ATen computes each op in fp32 and rounds the result back to the tensor dtype
+ * (RNE), op by op.  This function restates exactly that sequence; R() is the per-op rounding.  Pinned against
+ * the imported reference on fp16 and bf16 tensors (tests/golden/outlier_lowp.npz).  ATen specifics that matter:
+ *   mean  = (sum of the fp32-upcast values in ATen's fp32 order / n) rounded once (ReduceOps.cpp mean: half
+ *           types go cast_fp32 -> sum -> div -> cast back);
+ *   std   = sequential Welford in double, sqrt in double, then double -> float -> T;
+ *   floor(log2(x)) on a T tensor = floor(R(log2f(x))): log2 results within half a T-ulp below an integer round
+ *           UP to it, so values just below a power of two get the next exponent (bf16: 21 % of all values).  The
+ *           rule below (floor_log2_lowp) reproduces torch for EVERY positive fp16 / bf16 value (exhaustive
+ *           fixture tests/golden/log2_lowp.npz);
+ *   2**e  = R(powf(2, e)); FP32_MIN_NORMAL * mask underflows to 0 in fp16, so an all-zero block gives
+ *           log2(0) = -inf -> clamp -> -20.
+ * dtype: 1 = fp16, 2 = bf16.  `in` / `out` hold the values as floats (every input must be representable in T).
+ * posit formats are not part of the reference: returns -2.
+ * ---------------------------------------------------------------------- */
+static float r_f16(float f) {
+    uint32_t u = f2u(f), sg = u & 0x80000000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return f;                       /* NaN */
+    if (a >= 0x477ff000u) return u2f(sg | 0x7f800000u);   /* >= 65520 -> Inf */
+    if (a < 0x38800000u) {                                /* < 2^-14: fp16 subnormal grid, multiples of 2^-24 */
+        float m = rintf(u2f(a) * 16777216.0f);            /* RNE (default rounding mode) */
+        return u2f(sg | f2u(m * (1.0f / 16777216.0f)));
+    }
+    a += 0xfffu + ((a >> 13) & 1u);
+    a &= ~0x1fffu;
+    return u2f(sg | a);
+}
+static float r_bf16(float f) {
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    return u2f(u);
+}
+static float R_(float f, int dtype) { return dtype == 1 ? r_f16(f) : r_bf16(f); }
+
+/* floor(R(log2f(v))) for a non-negative T value v */
+static float floor_log2_lowp(float v, int dtype) {
+    if (v != v) return NAN;
+    if (v == 0.0f) return -INFINITY;
+    if (isinf(v)) return INFINITY;
+    const int p = (dtype == 1) ? 11 : 8;                   /* significand bits of T */
+    int e;
+    const double m = frexp((double)v, &e);                 /* v = m 2^e, m in [0.5, 1) */
+    const int k = e - 1, u = e;                            /* exact floor, and the integer just above log2 v */
+    if (u == 0) return (float)k;
+    const int au = u < 0 ? -u : u;
+    int jb = 0; while ((1 << (jb + 1)) <= au) jb++;        /* floor(log2 |u|) */
+    if (u > 0 && (au & (au - 1)) == 0) jb -= 1;            /* just below a positive power of two: the binade under it */
+    const double h = ldexp(1.0, jb - p);                   /* half a T-ulp of R(log2 v) next to u */
+    return (m > exp2(-h)) ? (float)u : (float)k;
+}
+static float pow2_lowp(float e, int dtype) { return R_(exp2_float(e), dtype); }
+
+static float round_mantissa_lowp(float a, int round_mode, int dt) {
+    if (a != a) return a;
+    const float s = (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f);
+    const float absa = fabsf(a);
+    if (round_mode == MSQ_RD_FLOOR) return R_(s * floorf(absa), dt);
+    if (round_mode == MSQ_RD_NEAREST) return R_(s * floorf(R_(absa + 0.5f, dt)), dt);
+    const float t = R_(absa - 0.5f, dt);
+    float r = fmodf(t, 2.0f);
+    if (r != 0.0f && r < 0.0f) r += 2.0f;
+    r = R_(r, dt);
+    const float maska = (r == 0.0f) ? 1.0f : 0.0f;
+    return R_(s * R_(floorf(R_(absa + 0.5f, dt)) - maska, dt), dt);
+}
+static float quantize_elemwise_core_lowp(float a, int bits, int exp_bits, float max_norm, int round_mode, int dt) {
+    float out = a, pe = 0.0f;
+    const int have_pe = (exp_bits != 0);
+    if (have_pe) {                                           /* elemwise_ops.py:138-144 */
+        const float t = R_(fabsf(a) + ((a == 0.0f) ? 1.0f : 0.0f), dt);
+        pe = floor_log2_lowp(t, dt);
+        const float min_exp = (float)(-(1 << (exp_bits - 1)) + 2);
+        if (pe == pe && pe < min_exp) pe = min_exp;
+    }
+    const float sh = ldexpf(1.0f, bits - 2);
+    if (have_pe) out = R_(R_(out / pow2_lowp(pe, dt), dt) * sh, dt);   /* _safe_lshift :33-37 */
+    else out = R_(out * sh, dt);
+    out = round_mantissa_lowp(out, round_mode, dt);
+    if (have_pe) out = R_(R_(out / sh, dt) * pow2_lowp(pe, dt), dt);   /* _safe_rshift :40-44 */
+    else out = R_(out / sh, dt);
+    const float mn = R_(max_norm, dt);                       /* clamp's scalar bounds are cast to the tensor dtype */
+    if (out == out) { if (out < -mn) out = -mn; if (out > mn) out = mn; }
+    if (a == INFINITY) out = INFINITY;
+    if (a == -INFINITY) out = -INFINITY;
+    return out;
+}
+static float shared_exp_lowp(float mx, int dt) {
+    if (mx != mx) return NAN;
+    const float t = R_(ldexpf(1.0f, -126) * ((mx == 0.0f) ? 1.0f : 0.0f), dt);   /* FP32_MIN_NORMAL * (x == 0).type(dtype) */
+    return floor_log2_lowp(R_(mx + t, dt), dt);
+}
+
+int msq_oracle_outlier_fakequant_lowp(const float* in, float* out, uint8_t* mask, float* e_in_o, float* e_out_o,
+                                      int dtype, int64_t pre, int64_t axis_len, int64_t post, int block,
+                                      const char* inlier_fmt, const char* outlier_fmt, int inlier_scale_bits,
+                                      int outlier_scale_bits, double std_dev, int round_mode,
+                                      int flush_fp32_subnorms) {
+    fmt_t fi, fo; float mn;
+    if (dtype != 1 && dtype != 2) return -2;
+    if (msq_oracle_format_params(inlier_fmt, &fi.ebits, &fi.mbits, &fi.emax, &fi.max_norm, &mn, &fi.kind)) return -1;
+    if (msq_oracle_format_params(outlier_fmt, &fo.ebits, &fo.mbits, &fo.emax, &fo.max_norm, &mn, &fo.kind)) return -1;
+    if (fi.kind == MSQ_KIND_POSIT || fo.kind == MSQ_KIND_POSIT) return -2;
+    if (block <= 0) block = (int)axis_len;
+    const int64_t nblk = (axis_len + block - 1) / block;
+    const int dt = dtype;
+    const float k = (float)std_dev;
+    int status = 0;
+#pragma omp parallel reduction(| : status)
+    {
+    float* a = (float*)malloc(sizeof(float) * block * 5);
+    float *absa = a + block, *mk = a + 2 * block, *inl = a + 3 * block, *outl = a + 4 * block;
+#pragma omp for collapse(2) schedule(static)
+    for (int64_t p = 0; p < pre; ++p) for (int64_t nb = 0; nb < nblk; ++nb) for (int64_t q = 0; q < post; ++q) {
+        for (int b = 0; b < block; ++b) {
+            int64_t ai = nb * block + b;
+            a[b] = (ai < axis_len) ? in[(p * axis_len + ai) * post + q] : 0.0f;
+            absa[b] = fabsf(a[b]);
+        }
+        /* utils/quant.py:477-478, :489-492 */
+        const float mean = R_(sum_ordered(absa, block, sum_order_for(post, q)) / (float)block, dt);
+        const float sd = R_(std_welford(absa, block, 1, 0), dt);
+        const float ks = R_(k * sd, dt);
+        const float lo = R_(mean - ks, dt), hi = R_(mean + ks, dt);
+        float mx_in = 0.0f;
+        for (int b = 0; b < block; ++b) {
+            mk[b] = ((a[b] < lo) || (a[b] > hi)) ? 1.0f : 0.0f;
+            inl[b] = R_(a[b] * R_(1.0f - mk[b], dt), dt);             /* :192 */
+            outl[b] = R_(a[b] * mk[b], dt);                          /* :193 */
+            float t = fabsf(inl[b]); if (t > mx_in || t != t) mx_in = t;
+        }
+        float se_in = shared_exp_lowp(mx_in, dt);                    /* :196-198 */
+        if (flush_fp32_subnorms && !(se_in > -127.0f))
+            for (int b = 0; b < block; ++b) inl[b] = R_(inl[b] * 0.0f, dt);
+        se_in = R_(se_in - (float)fi.emax, dt);                      /* :207 */
+        se_in = clamp_scale_exp(se_in, inlier_scale_bits, MSQ_VARIANT_QUANT);
+        const float sc_in = pow2_lowp(se_in, dt);
+        float mx_out = 0.0f;
+        for (int b = 0; b < block; ++b) {
+            inl[b] = R_(inl[b] / sc_in, dt);                         /* :214 */
+            outl[b] = R_(outl[b] * sc_in, dt);                       /* :216 */
+            inl[b] = quantize_elemwise_core_lowp(inl[b], fi.mbits, fi.ebits, fi.max_norm, round_mode, dt);
+            inl[b] = R_(inl[b] * sc_in, dt);                         /* :224 */
+            if (inl[b] != inl[b] || outl[b] != outl[b]) status |= 1;
+            float t = fabsf(outl[b]); if (t > mx_out || t != t) mx_out = t;
+        }
+        float se_out = shared_exp_lowp(mx_out, dt);                  /* :229-231 */
+        if (se_out != se_out) status |= 1;
+        se_out = R_(se_out - (float)fo.emax, dt);                    /* :237 */
+        se_out = clamp_scale_exp(se_out, outlier_scale_bits, MSQ_VARIANT_QUANT);
+        if (se_out != se_out) status |= 1;
+        const float sc_out = pow2_lowp(se_out, dt);
+        for (int b = 0; b < block; ++b) {
+            float o = R_(outl[b] / sc_out, dt);                      /* :247 */
+            if (o != o) status |= 1;
+            o = quantize_elemwise_core_lowp(o, fo.mbits, fo.ebits, fo.max_norm, round_mode, dt);
+            o = R_(R_(o * sc_out, dt) / sc_in, dt);                  /* :258 */
+            const float r = R_(inl[b] + o, dt);                      /* :262 */
+            int64_t ai = nb * block + b;
+            if (ai >= axis_len) continue;
+            int64_t idx = (p * axis_len + ai) * post + q;
+            if (out) out[idx] = r;
+            if (mask) mask[idx] = (uint8_t)(mk[b] != 0.0f);
+        }
+        if (e_in_o) e_in_o[(p * nblk + nb) * post + q] = se_in;
+        if (e_out_o) e_out_o[(p * nblk + nb) * post + q] = se_out;
+    }
+    free(a);
+    }
+    return status;
+}
+
+/* test hooks of the pieces above */
+void msq_oracle_floor_log2_lowp(const float* v, float* out, int64_t n, int dtype) {
+    for (int64_t i = 0; i < n; ++i) out[i] = floor_log2_lowp(v[i], dtype);
+}
+void msq_oracle_round_lowp(const float* v, float* out, int64_t n, int dtype) {
+    for (int64_t i = 0; i < n; ++i) out[i] = R_(v[i], dtype);
+}
+
+/* ------------------------------------------------------------------------
  * a9  mx_ops.py:332-457  _quantize_mx (custom_cuda=False branch), one axis.
  * plus_eps_defect=1 reproduces `A / (2**e + 1e-6)` (mx_ops.py:444, D2).
  * Returns 1 if any NaN was produced by a scale overflow.
@@ -703,12 +888,37 @@ void msq_oracle_reduce_inner(const float* in, float* out, int64_t outer, int64_t
  * accumulated in double (checker-grade, used with a tolerance). */
 void msq_oracle_linear(const float* x, const float* w, const float* bias, float* y, int64_t M,
                        int64_t N, int64_t K) {
+    /* 4 x 4 register blocks so that the x and w rows are reused out of cache; every output element is still the
+     * same left-to-right double sum over k, so the result does not depend on the blocking or the thread count */
+    const int64_t MB = (M + 3) / 4, NB = (N + 3) / 4;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) {
-        double s = 0.0;
-        for (int64_t kk = 0; kk < K; ++kk) s += (double)x[m * K + kk] * (double)w[n * K + kk];
-        if (bias) s += bias[n];
-        y[m * N + n] = (float)s;
+    for (int64_t nb = 0; nb < NB; ++nb) for (int64_t mb = 0; mb < MB; ++mb) {
+        const int64_t m0 = mb * 4, n0 = nb * 4;
+        const int mr = (int)((M - m0) < 4 ? (M - m0) : 4), nr = (int)((N - n0) < 4 ? (N - n0) : 4);
+        double acc[4][4] = {{0}};
+        if (mr == 4 && nr == 4) {
+            const float *x0 = x + m0 * K, *x1 = x0 + K, *x2 = x1 + K, *x3 = x2 + K;
+            const float *w0 = w + n0 * K, *w1 = w0 + K, *w2 = w1 + K, *w3 = w2 + K;
+            for (int64_t kk = 0; kk < K; ++kk) {
+                const double a0 = x0[kk], a1 = x1[kk], a2 = x2[kk], a3 = x3[kk];
+                const double b0 = w0[kk], b1 = w1[kk], b2 = w2[kk], b3 = w3[kk];
+                acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
+                acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
+                acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2; acc[2][3] += a2 * b3;
+                acc[3][0] += a3 * b0; acc[3][1] += a3 * b1; acc[3][2] += a3 * b2; acc[3][3] += a3 * b3;
+            }
+        } else {
+            for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) {
+                double s = 0.0;
+                for (int64_t kk = 0; kk < K; ++kk) s += (double)x[(m0 + i) * K + kk] * (double)w[(n0 + j) * K + kk];
+                acc[i][j] = s;
+            }
+        }
+        for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) {
+            double s = acc[i][j];
+            if (bias) s += bias[n0 + j];
+            y[(m0 + i) * N + n0 + j] = (float)s;
+        }
     }
 }
 

@@ -106,6 +106,47 @@ def outlier_fakequant(a, inlier_scale_bits, outlier_scale_bits, inlier_fmt, outl
     return r
 
 
+LOWP = {"float16": 1, "fp16": 1, "f16": 1, "bfloat16": 2, "bf16": 2}
+
+
+def outlier_fakequant_lowp(a, dtype, inlier_scale_bits, outlier_scale_bits, inlier_fmt, outlier_fmt, std_dev=2,
+                           axis=0, block_size=0, round="nearest", flush_fp32_subnorms=False):
+    """utils/quant.py:147-266 computed IN the tensor dtype (fp16 / bf16, every op rounded back as ATen's CPU half
+    kernels do): `a` holds the tensor's values as float32.  Returns dict(out, mask, e_in, e_out, status)."""
+    a = _f32(a)
+    pre, axis_len, post = _pap(a.shape, axis)
+    blk = block_size if block_size > 0 else axis_len
+    nblk = (axis_len + blk - 1) // blk
+    out = np.empty_like(a)
+    mask = np.empty(a.shape, dtype=np.uint8)
+    e_in = np.empty((pre, nblk, post), dtype=np.float32)
+    e_out = np.empty((pre, nblk, post), dtype=np.float32)
+    st = lib().msq_oracle_outlier_fakequant_lowp(
+        _p(a), _p(out), _p(mask, C.c_uint8), _p(e_in), _p(e_out), C.c_int(LOWP[str(dtype).replace("torch.", "")]),
+        C.c_int64(pre), C.c_int64(axis_len), C.c_int64(post), C.c_int(blk), inlier_fmt.lower().encode(),
+        outlier_fmt.lower().encode(), C.c_int(inlier_scale_bits), C.c_int(outlier_scale_bits),
+        C.c_double(float(std_dev)), C.c_int(RD[round]), C.c_int(bool(flush_fp32_subnorms)))
+    if st == -1:
+        raise Exception("Undefined elem format", inlier_fmt, outlier_fmt)
+    if st == -2:
+        raise Exception("lowp oracle: fp16 / bf16 with non-posit formats only")
+    return dict(out=out, mask=mask, e_in=e_in, e_out=e_out, status=st)
+
+
+def floor_log2_lowp(v, dtype):
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().msq_oracle_floor_log2_lowp(_p(v), _p(out), C.c_int64(v.size), C.c_int(LOWP[str(dtype).replace("torch.", "")]))
+    return out
+
+
+def round_lowp(v, dtype):
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().msq_oracle_round_lowp(_p(v), _p(out), C.c_int64(v.size), C.c_int(LOWP[str(dtype).replace("torch.", "")]))
+    return out
+
+
 def quantize_mx(a, scale_bits, elem_fmt, axis=-1, block_size=0, round="nearest",
                 flush_fp32_subnorms=False, plus_eps_defect=False):
     a = _f32(a)

@@ -132,12 +132,18 @@ def test_row_parallel_collective_path_single_rank_rccl(msq, layer70):
             shard = msq.qlinear.QuantLinear.from_packed(base.shard._packed(), base.shard.bias, out_dtype=reduce_dtype)
             for M in (M70, 1000):
                 x = X[:M, k0:k1].contiguous()
-                want = msq.qlinear.qlinear(x, shard._packed(), shard.bias, reduce_dtype)
+                whole = msq.qlinear.qlinear(x, shard._packed(), shard.bias, torch.float32)
                 for comm, chunks in (("rs_ag", 0), ("rs_ag", 3), ("all_reduce", 2)):
                     rp = R(shard, 1, 0, None, comm=comm, chunks=chunks, reduce_dtype=reduce_dtype, single_rank_collectives=True)
                     assert rp.chunks_for(M) > 1 or (chunks == 0 and M < 1024)
                     y = rp(x)
                     torch.cuda.synchronize()
+                    # the same GEMM calls on the same row chunks, no collective (a chunk of 512 rows takes the split-K
+                    # schedule, so it is compared with itself, and with the one-call result up to fp32 summation order)
+                    want = torch.cat([msq.qlinear.qlinear(x[r0:r1], shard._packed(), shard.bias, reduce_dtype)
+                                      for r0, r1 in rp.chunk_bounds(M)])
                     assert y.dtype == reduce_dtype and torch.equal(y, want), (comm, chunks, M, reduce_dtype)
+                    tol = (2e-5 if reduce_dtype == torch.float32 else 2.0 ** -7) * float(whole.abs().max())
+                    assert float((y.float() - whole).abs().max()) <= tol
     finally:
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
 """Round-2 GPU tests: advisor findings (dtype of the MX-path modules inside an fp16 model, MXLinear.pack() on 3-D
 inputs, argument guards of the C ABI) and the new hot-path pieces of this round."""
+import json
 import os
 
 import numpy as np
@@ -128,3 +129,79 @@ def test_decode_kernels_on_second_stream_and_repeated(msq):
     assert torch.equal(y0, y1)
     ref = x.float() @ msq.qlinear.unpack_weight(P).t()
     assert float((y0 - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+# ---------------------------------------------------------------- fp16 / bf16 RTN path: compute in the tensor dtype
+def _bits_to_torch(u16, dn):
+    t = torch.from_numpy(u16.view(np.int16).copy())
+    return t.view(torch.float16 if dn == "f16" else torch.bfloat16)
+
+
+def test_lowp_floor_log2_exhaustive_gpu(msq):
+    """The device rule for floor(log2(x)) on half tensors against torch's CPU result for EVERY positive finite fp16 and
+    bf16 value (fixture generated by tests/golden/make_golden_lowp.py)."""
+    z = np.load(os.path.join(G, "log2_lowp.npz"))
+    L = msq._lib.lib()
+    for dn, code, top in (("f16", 1, 0x7C00), ("bf16", 2, 0x7F80)):
+        x = _bits_to_torch(np.arange(1, top, dtype=np.uint16), dn).float().to(dev())
+        out = torch.empty_like(x)
+        msq._lib.check(L.msq_floor_log2_lowp(msq._lib.ptr(x), msq._lib.ptr(out), x.numel(), code,
+                                             msq._lib.current_stream(dev())), "msq_floor_log2_lowp")
+        assert (out.cpu().numpy() == z[dn].astype(np.float32)).all(), dn
+    zero = torch.zeros(4, device=dev()); o = torch.empty(4, device=dev())
+    msq._lib.check(L.msq_floor_log2_lowp(msq._lib.ptr(zero), msq._lib.ptr(o), 4, 1, msq._lib.current_stream(dev())), "log2")
+    assert bool(torch.isinf(o).all()) and bool((o < 0).all())
+
+
+def test_lowp_outlier_fakequant_golden_gpu(msq):
+    """quantize_mx_outlier_v1 on fp16 / bf16 tensors against the reference run on the same half tensors (264 cases:
+    harness default int2 / fp4 along out_features, the BASELINE formats, three rounding modes, scale bits 4, blocks
+    8 ... 128, values just under powers of two, fp16 subnormals): values AND outlier masks bit for bit, AssertionError
+    exactly where the reference's NaN assertion fired."""
+    z = np.load(os.path.join(G, "outlier_lowp.npz"))
+    meta = json.load(open(os.path.join(G, "outlier_lowp_meta.json")))
+    n = na = 0
+    for key, m in sorted(meta.items()):
+        dn, tname, cname = key.split("|")
+        isb, osb, fi, fo, sd, axes, bs, rnd = m["cfg"]
+        A = _bits_to_torch(z[f"in|{dn}|{tname}"], dn).to(dev())
+        if "assert" in m:
+            with pytest.raises(AssertionError):
+                msq.quant.quantize_mx_outlier_v1(A, isb, osb, fi, fo, "max", sd, axes, bs, rnd)
+            na += 1
+            continue
+        r = msq.quant.outlier_fakequant(A, isb, osb, fi, fo, sd, axes[0], bs, rnd, want_mask=True)
+        assert r["out"].dtype == A.dtype
+        got = r["out"].view(torch.int16).cpu().numpy().view(np.uint16)
+        ref = z[f"out|{key}"]
+        nan_both = np.isnan(_bits_to_torch(got, dn).float().numpy()) & np.isnan(_bits_to_torch(ref, dn).float().numpy())
+        assert ((got == ref) | nan_both).all(), (key, int(((got != ref) & ~nan_both).sum()))
+        mask = np.unpackbits(z[f"mask|{key}"])[:A.numel()].reshape(tuple(A.shape))
+        assert (r["mask"].cpu().numpy() == mask).all(), (key, "mask")
+        y = msq.quant.quantize_mx_outlier_v1(A, isb, osb, fi, fo, "max", sd, axes, bs, rnd)     # reference-named entry
+        assert torch.equal(y.view(torch.int16), r["out"].view(torch.int16))
+        n += 1
+    assert n >= 230 and na >= 20
+
+
+@pytest.mark.parametrize("dn", ["f16", "bf16"])
+def test_lowp_llama_sized_weight_vs_oracle(msq, O, dn):
+    """A Llama-2-7B sized projection [4096 x 4096] in the checkpoint dtype through the harness call
+    (llm/llama.py:229-253: int2 / fp4, blocks of 16 along out_features) and the BASELINE format pair: HIP == oracle
+    (compute-in-dtype restatement, pinned on the reference's half-tensor goldens) on all 16.8 M weights."""
+    dt = torch.float16 if dn == "f16" else torch.bfloat16
+    g = torch.Generator(device=dev()).manual_seed(21)
+    W = (torch.randn(4096, 4096, generator=g, device=dev()) * 0.02)
+    W[torch.rand(4096, 4096, generator=g, device=dev()) < 0.005] *= 16
+    W = W.to(dt)
+    Wf = W.float().cpu().numpy()
+    for fi, fo, ax, bs in (("int2", "fp4", 0, 16), ("fp4_e2m1", "fp8_e4m3", -1, 32)):
+        r = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, want_mask=True)
+        o = O.outlier_fakequant_lowp(Wf, dn, 8, 8, fi, fo, 2, ax, bs)
+        assert o["status"] == 0
+        assert (r["mask"].cpu().numpy() == o["mask"]).all()
+        assert (r["out"].float().cpu().numpy() == o["out"]).all()
+        # and it is NOT what "upcast, compute in fp32, round once" gives
+        r32 = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, compute_dtype="float32")["out"]
+        frac = float((r32 != r["out"]).float().mean())
+        assert 0 < frac < 0.05, frac
