@@ -381,7 +381,7 @@ static inline int grid_for(int64_t n, int block, int64_t cap = 1 << 30) {
 
 // implemented in msq_quant_hw.hip (hardware-convert variants, own translation unit)
 extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* stream);   // msq_quant_lowp.hip
-int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
+extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
 
 // dtype 2 (bf16 tensors) is built for round-to-nearest with float / int inliers (the hardware-convert variants and
 // the nearest-specialised arithmetic one); everything else is f32 only (the host shim upcasts)
