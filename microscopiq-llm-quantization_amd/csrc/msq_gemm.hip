@@ -433,19 +433,27 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[8][4], char* wsm, YT* __rest
     }
 }
 
-template <int IN_KIND, int OUT_KIND, typename YT, int WM>
-__global__ void __launch_bounds__(256 * WM, 2)
+// MF = 16-row MFMA fragments per wave along m: 8 (wave tile 128 x 64, two blocks per CU, accumulators in VGPRs) or 16 (wave
+// tile 256 x 64, block 256 x 256, ONE block of four waves per CU: the 256 accumulator registers live in AGPRs and every
+// converted weight fragment feeds 16 MFMAs instead of 8: half the converts, rotates and and-ors per MFMA).
+// WN = waves along n (4: block 256 columns; 8: one block of eight waves per CU covering 512 columns of ONE activation tile --
+// half the LDS-DMA issue per wave and half the activation bytes pulled from L2 per CU and K-step).
+template <int IN_KIND, int OUT_KIND, typename YT, int WM, int MF = 8, int WN = 4>
+__global__ void __launch_bounds__(64 * WN * WM, (MF == 16) ? 1 : (WN == 8 ? 1 : 2))
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int scl_groups, int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR offsets below)
-    constexpr int BMT = 128 * WM;                               // block rows: WM wave rows of 128
+    constexpr int WROWS = 16 * MF;                              // rows of a wave tile
+    constexpr int BMT = WROWS * WM;                             // block rows: WM wave rows
+    constexpr int PPW = BMT / 8 / (WN * WM);                     // 1 KiB staging pieces (8 rows) per wave and K-step
     constexpr int A_TILE = BMT * BK * 2;
-    const int wm = (WM == 2) ? wid >> 2 : 0, wn = wid & 3;
+    const int wm = (WM == 2) ? wid / WN : 0, wn = wid % WN;
+    constexpr int BNW = 64 * WN;                                // block columns
     const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + BMT - 1) / BMT, NTB = N / BN;
+    const int MT = (M + BMT - 1) / BMT, NTB = N / BNW;
     const int ks = (int)(blockIdx.x % (unsigned)ksplit);
     const int bid = (int)(blockIdx.x / (unsigned)ksplit);
     int bm, bn;
@@ -461,7 +469,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         bm = rg * 8 + j % R;
         bn = (j / R) * 8 + xcd;
     } else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * BMT, n0 = bn * BN;
+    const int m0 = bm * BMT, n0 = bn * BNW;
     const int KT = K / BK;
     // split-K: this block covers K-steps [kt_lo, kt_hi) and writes an fp32 partial tile
     const int kchunk = (KT + ksplit - 1) / ksplit;
@@ -490,10 +498,11 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
 
     // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, (int64_t)M * K * 2);
-    int aoff[4];
+    int aoff[8];                                                // PPW <= 8 (a dependent array bound captured by the lambda below makes hipcc drop the host stub)
+    static_assert(PPW <= 8, "staging pieces per wave");
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int piece = wid * 4 + p;
+    for (int p = 0; p < PPW; ++p) {
+        const int piece = wid * PPW + p;
         const int row = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
@@ -501,18 +510,18 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     }
     auto stage_A = [&](int kt, int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 4 + p) * 1024),
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * PPW + p) * 1024),
                                                      16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
     };
     // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
     const int sw = (c >> 1) & 7;
-    const int rd0 = (wm * 128 + c) * 128 + (((0 + g) ^ sw) << 4);
-    const int rd1 = (wm * 128 + c) * 128 + (((4 + g) ^ sw) << 4);
+    const int rd0 = (wm * WROWS + c) * 128 + (((0 + g) ^ sw) << 4);
+    const int rd1 = (wm * WROWS + c) * 128 + (((4 + g) ^ sw) << 4);
 
-    f32x4_t acc[8][4];
+    f32x4_t acc[MF][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -554,18 +563,18 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         bf16x8_t xf[3];                                                                                      \
         xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
         xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
-        _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 2 < 8 && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                  \
+            if (mf + 2 < MF && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
-            if (!(MSQ_ABL & 2)) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);    \
+            if (!(MSQ_ABL & 2) && (mf % (MF / 8)) == 0) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf / (MF / 8)); \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
     // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted
     // one half-step earlier (LOAD1, LOAD2) receive (kt + 2, kf 0) and (kt + 2, kf 1).
     constexpr int N_INFLIGHT = HalfLoads<IN_KIND, OUT_KIND>::n * (DEEP ? 2 : 1);
-    constexpr int N_WAIT_ST = N_INFLIGHT + 4;                  // + the 4 LDS-DMA ops of the tile staged in this K-step
+    constexpr int N_WAIT_ST = N_INFLIGHT + PPW;                // + the LDS-DMA ops of the tile staged in this K-step
     int abuf = 0;
 #define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                       \
     {                                                                                                        \
@@ -623,13 +632,17 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
-    if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
-    if (ksplit > 1)
-        store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * 128, n0 + wn * 64, M, N,
-                                   nullptr, lane);
-    else
-        store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0 + wm * 128, n0 + wn * 64, M, N, bias, lane);
+#pragma unroll
+    for (int h = 0; h < MF / 8; ++h) {                          // 128 rows at a time through the wave's 8 KiB slice
+        const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
+        if (ksplit > 1)
+            store_wave_tile_lds<float>(acch, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N,
+                                       nullptr, lane);
+        else
+            store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N, bias, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1363,9 +1376,18 @@ static int splitk_by_cost(int64_t blocks, int64_t KT, int64_t M, int64_t N, doub
     }
     return best;
 }
-static int pick_ksplit(int64_t M, int64_t N, int64_t K) {
+// wave-tile height (MF x 16 rows): 16 = block 256 x 256 with the accumulators in AGPRs, one block per CU; taken when
+// the grid still has at least two such blocks per CU pair... (measured: see DESIGN.md); MSQ_GEMM_MF forces 8 / 16.
+static int pick_mf(int64_t M, int64_t N, int out_kind) {
+    static const int forced = [] { const char* e = getenv("MSQ_GEMM_MF"); return e ? atoi(e) : 0; }();
+    if (forced == 8 || forced == 16) return (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X) ? forced : 8;
+    (void)M; (void)N;
+    return 8;
+}
+static int pick_ksplit(int64_t M, int64_t N, int64_t K, int mf = 8) {
     static const int forced = [] { const char* e = getenv("MSQ_GEMM_KS"); return e ? atoi(e) : 0; }();
     const int wm = pick_wm(M, N);
+    if (mf == 16) return 1;
     const int64_t blocks = ((M + 128 * wm - 1) / (128 * wm)) * (N / BN);
     const int64_t KT = K / BK;
     if (forced > 0) return forced < KT ? forced : (int)KT;
@@ -1473,12 +1495,14 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             return check_launch2("msq_qlinear_bf16(gemv reduce)");
         }
     }
-    const int wm_sel = pick_wm(M, N);
-    const int MT = (int)((M + 128 * wm_sel - 1) / (128 * wm_sel)), NTB = (int)(N / BN);
-    int ksplit = pick_ksplit(M, N, K);
+    const int mf_sel = pick_mf(M, N, out_kind);
+    const int wm_sel = (mf_sel == 16) ? 1 : pick_wm(M, N);
+    const int brow = 16 * mf_sel * wm_sel;
+    const int MT = (int)((M + brow - 1) / brow), NTB = (int)(N / BN);
+    int ksplit = pick_ksplit(M, N, K, mf_sel);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;   // no scratch: one pass
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256 * wm_sel);
-    const size_t lds = (size_t)3 * 128 * wm_sel * BK * 2;     // three activation buffers
+    const size_t lds = (size_t)3 * brow * BK * 2;             // three activation buffers
     hipStream_t st = (hipStream_t)stream;
     const int groups = groups0;
     float* partial = (float*)workspace;
@@ -1498,6 +1522,37 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
          else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_U8); \
          else if (in_kind == MSQ_PLANE_NONE && out_kind == MSQ_PLANE_U8X) MSQ_LAUNCH(KERN, MSQ_PLANE_NONE, MSQ_PLANE_U8X); \
          else return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: unsupported plane kinds"); } while (0)
+    // Eight waves along n (one block of 128 x 512 per CU instead of two of 128 x 256): the eight waves share ONE activation
+    // tile, so every wave issues half the LDS-DMA pieces and the CU pulls half the activation bytes from L2 per K-step.
+    // Measured (scripts/experiments/shape_ab.py, posit / fp8 outliers): +3.5...7 % / +1...3 % whenever the grid still has
+    // one block per CU (M2048 N16384: 214 -> 206 us; N8192 K28672: 755 -> 719 us), -30 % with half-empty grids.
+    // MSQ_GEMM_WN=4 (tuning only) keeps the four-wave blocks.
+    static const int wn_forced = [] { const char* e = getenv("MSQ_GEMM_WN"); return e ? atoi(e) : 0; }();
+    const bool wn8 = wn_forced == 8 || (wn_forced == 0 && ((M + 127) / 128) * (N / 512) >= 256);
+    if (wn8 && mf_sel == 8 && unified && (N % 512) == 0 && ksplit == 1) {
+        const dim3 grid8((unsigned)(((M + 127) / 128) * (N / 512))), blk8(512);
+        const size_t lds8 = 65536;                                  // max(3 x 16 KiB activation buffers, 8 x 8 KiB epilogue slices)
+#define MSQ_LAUNCH8(OK, YT)                                                                                            \
+        do { static DevOnce once_;                                                                                     \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); attr_done(once_); } \
+             hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 8>), grid8, blk8, lds8, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial); } while (0)
+        if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH8(MSQ_PLANE_U8, float); else MSQ_LAUNCH8(MSQ_PLANE_U8, uint16_t); }
+        else { if (y_dtype == 0) MSQ_LAUNCH8(MSQ_PLANE_U8X, float); else MSQ_LAUNCH8(MSQ_PLANE_U8X, uint16_t); }
+#undef MSQ_LAUNCH8
+        return check_launch2("msq_qlinear_bf16(eight waves along n)");
+    }
+    if (mf_sel == 16) {
+#define MSQ_LAUNCH16(OK, YT)                                                                                           \
+        do { static DevOnce once_;                                                                                     \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
+             hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 16>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
+        if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH16(MSQ_PLANE_U8, float); else MSQ_LAUNCH16(MSQ_PLANE_U8, uint16_t); }
+        else { if (y_dtype == 0) MSQ_LAUNCH16(MSQ_PLANE_U8X, float); else MSQ_LAUNCH16(MSQ_PLANE_U8X, uint16_t); }
+#undef MSQ_LAUNCH16
+        return check_launch2("msq_qlinear_bf16(256-row wave tiles)");
+    }
     MSQ_DISPATCH(k_qgemm3);
 #undef MSQ_DISPATCH
 #undef MSQ_LAUNCH

@@ -196,12 +196,24 @@ def test_lowp_llama_sized_weight_vs_oracle(msq, O, dn):
     W = W.to(dt)
     Wf = W.float().cpu().numpy()
     for fi, fo, ax, bs in (("int2", "fp4", 0, 16), ("fp4_e2m1", "fp8_e4m3", -1, 32)):
-        r = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, want_mask=True)
         o = O.outlier_fakequant_lowp(Wf, dn, 8, 8, fi, fo, 2, ax, bs)
-        assert o["status"] == 0
+        # In fp16 the harness default can hit the reference's own NaN assertion on a handful of blocks (all inliers
+        # zero -> e_in = -20 -> outliers * 2^-20 -> e_out = -26 -> 2^-26 underflows to 0 in fp16 -> x / 0): the
+        # oracle reports it (status 1) and the shim must raise exactly then, like utils/quant.py:225-250.
+        if o["status"] & 1:
+            with pytest.raises(AssertionError):
+                msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs)
+        keep = msq.quant.CHECK_NAN
+        msq.quant.CHECK_NAN = False                                  # compare the tensors themselves, NaNs included
+        try:
+            r = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, want_mask=True)
+        finally:
+            msq.quant.CHECK_NAN = keep
+        got = r["out"].float().cpu().numpy()
         assert (r["mask"].cpu().numpy() == o["mask"]).all()
-        assert (r["out"].float().cpu().numpy() == o["out"]).all()
+        assert ((got == o["out"]) | (np.isnan(got) & np.isnan(o["out"]))).all()
+        assert int(np.isnan(got).sum()) == int(np.isnan(o["out"]).sum())
         # and it is NOT what "upcast, compute in fp32, round once" gives
         r32 = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, compute_dtype="float32")["out"]
-        frac = float((r32 != r["out"]).float().mean())
+        frac = float(((r32 != r["out"]) & ~torch.isnan(r["out"])).float().mean())
         assert 0 < frac < 0.05, frac
