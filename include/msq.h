@@ -284,6 +284,21 @@ int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w
                         const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * KV-cache group quantisation at the GEAR hook (BASELINE config 4).  Replaces
+ * kv_quant/GEARLM/Simulated/compress_function.py:8-38 fake_groupwise_token_asymmetric_quantization (along_tokens = 0:
+ * groups of `group_size` consecutive head.dim entries of one token; group_size must divide H * D) and :41-70
+ * fake_groupwise_channel_asymmetric_quantization_new (along_tokens = 1: groups of `group_size` consecutive tokens of one
+ * channel; group_size must divide S), called from compress_insert_function (:428-517) at the attention hook
+ * (modeling_llama_new.py:944-1030).  in / out: [B, H, S, D] contiguous cache tensors (the reference's permute / view /
+ * float / type(dtype) round trip happens inside); dtype 0 = f32, 1 = f16, 2 = bf16; asymmetric min / max quantisation to
+ * `quantize_bit` bits computed in fp32 with the reference's op order; bit-exact, the NaNs of constant groups included.
+ * The MX variants of the cache use msq_quantize_mx_by_tile / msq_outlier_fakequant on the same axes:
+ * K [pre = B H, axis = S, post = D], V [pre = B H S, axis = D, post = 1].
+ * ------------------------------------------------------------------------- */
+int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                       int quantize_bit, int64_t group_size, int along_tokens, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -922,6 +922,46 @@ void msq_oracle_linear(const float* x, const float* w, const float* bias, float*
     }
 }
 
+/* ------------------------------------------------------------------------
+ * f3  KV-cache group fake-quant of the GEAR tree (kv_quant/GEARLM/Simulated/compress_function.py):
+ *   along_tokens = 0  :8-38   fake_groupwise_token_asymmetric_quantization   (groups along head.dim of one token)
+ *   along_tokens = 1  :41-70  fake_groupwise_channel_asymmetric_quantization_new (groups along the tokens of a channel)
+ * in / out: [B, H, S, D] cache tensors held as float; dtype 0 / 1 / 2 = the tensor was f32 / f16 / bf16 (the result
+ * is cast back with .type(dtype), :34 / :65).  All arithmetic in fp32 in the reference's op order; torch.max / min
+ * propagate NaN; a constant group gives scale 0 and 0 / 0 = NaN, as in the reference.
+ * Returns 0, or -1 when group_size does not divide the grouped extent (the reference raises).
+ * ---------------------------------------------------------------------- */
+static float kv_nmax(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+static float kv_nmin(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+int msq_oracle_kv_group_quant(const float* in, float* out, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                              int quantize_bit, int64_t gs, int along_tokens) {
+    const float levels = (float)((1 << quantize_bit) - 1);
+    const int64_t HD = H * D;
+    if (gs <= 0) return -1;
+    if (along_tokens ? (S % gs) : (HD % gs)) return -1;
+    const int64_t ng = along_tokens ? S / gs : HD / gs;
+    for (int64_t b = 0; b < B; ++b) for (int64_t g = 0; g < ng; ++g)
+        for (int64_t o = 0; o < (along_tokens ? HD : S); ++o) {          /* the non-grouped coordinate */
+            float mx = -INFINITY, mn = INFINITY;
+            for (int64_t i = 0; i < gs; ++i) {
+                const int64_t hd = along_tokens ? o : g * gs + i, s = along_tokens ? g * gs + i : o;
+                const float x = in[((b * H + hd / D) * S + s) * D + hd % D];
+                mx = kv_nmax(mx, x); mn = kv_nmin(mn, x);
+            }
+            const float scale = (mx - mn) / levels;
+            for (int64_t i = 0; i < gs; ++i) {
+                const int64_t hd = along_tokens ? o : g * gs + i, s = along_tokens ? g * gs + i : o;
+                const int64_t a = ((b * H + hd / D) * S + s) * D + hd % D;
+                float v = (in[a] - mn) / scale;
+                v = (v < 0.0f) ? 0.0f : v;                       /* F.relu */
+                v = rintf(v);                                    /* round_(): half to even */
+                v = v * scale + mn;
+                out[a] = dtype ? R_(v, dtype) : v;
+            }
+        }
+    return 0;
+}
+
 /* thread count of the OpenMP regions above (0 = all cores); returns the count in effect */
 #ifdef _OPENMP
 #include <omp.h>

@@ -197,3 +197,20 @@ def posit_decode(code, n, es):
 
 def posit_encode(v, n, es):
     return lib().msq_oracle_posit_encode(float(v), n, es)
+
+
+def kv_group_quant(x, quantize_bit, group_size, along_tokens, dtype="float32"):
+    """GEAR group fake-quant of a [B, H, S, D] cache tensor (values held as float32; `dtype` = the tensor's own dtype,
+    the result is cast back to it): along_tokens=False -> fake_groupwise_token_asymmetric_quantization
+    (compress_function.py:8-38), True -> fake_groupwise_channel_asymmetric_quantization_new (:41-70)."""
+    x = _f32(x)
+    B, H, S, D = x.shape
+    out = np.empty_like(x)
+    dt = {"float32": 0, "f32": 0}.get(str(dtype).replace("torch.", ""), None)
+    if dt is None:
+        dt = LOWP[str(dtype).replace("torch.", "")]
+    rc = lib().msq_oracle_kv_group_quant(_p(x), _p(out), C.c_int(dt), C.c_int64(B), C.c_int64(H), C.c_int64(S), C.c_int64(D),
+                                         C.c_int(quantize_bit), C.c_int64(group_size), C.c_int(bool(along_tokens)))
+    if rc:
+        raise ValueError("group_size should be a factor of the grouped dimension size")
+    return out

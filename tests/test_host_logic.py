@@ -295,3 +295,12 @@ def test_packed_checkpoint_roundtrip_cpu(msq, tmp_path):
     with pytest.raises(msq._lib.MsqError):
         checkpoint.load_packed(Other(), path)
 
+
+def test_gsm8k_scorer_kats(msq):
+    """evaluate_pred_answer (evaluation_gsm8k.py:63-85) restated: every KAT produced by the reference's function."""
+    from msq.harness import gsm8k
+    j = json.load(open(os.path.join(ROOT, "tests", "golden", "gsm8k_scorer.json")))
+    for k in j["kats"]:
+        ok, pred, pl, gold, gl = gsm8k.evaluate_pred_answer(k["pred_str"], k["ans_str"])
+        assert (ok, pred, pl, gold, gl) == (k["is_pred_true"], k["pred"], k["pred_list"], k["gold"], k["gold_list"]), k
+    assert gsm8k.accuracy(["The answer is 18.\nQuestion: what is 3?", "no idea"], ["#### 18", "#### 2"]) == 0.5
