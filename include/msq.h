@@ -299,6 +299,25 @@ int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w
 int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                        int quantize_bit, int64_t group_size, int along_tokens, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Bfloat-rounded vector ops around the MX Linear.  The reference emulates every non-GEMM op as the
+ * torch op followed by quantize_elemwise_op (number_system/mx/vector_ops.py); each entry below is that whole chain as
+ * ONE launch with the rounding Q() = quantize_elemwise (bits, exp_bits, max_norm, rmode, saturate_normals = false,
+ * allow_denorm) applied after every step exactly where the reference applies it (bits = 0: no rounding).
+ *   msq_vec_layernorm  replaces mx.LayerNorm's forward (layernorm.py:18-42 -> norm_utils.py:27-113) over the last axis of
+ *                      x [rows, H]; row sums in ATen's order for a contiguous inner dimension.  H <= 40704.
+ *   msq_vec_gelu       replaces mx.gelu (activations.py:460-512); first_order = the x * sigmoid(1.702 x) variant.
+ *   msq_vec_add        replaces mx.simd_add (simd_ops.py:85-106); b == NULL adds the (unrounded) constant b_scalar.
+ * All tensors f32, contiguous.  The exp inside gelu is the device's expf (torch uses Sleef's): results can differ from the
+ * CPU reference by one unit of the rounded format on isolated elements (none observed on the fixtures).
+ * ------------------------------------------------------------------------- */
+int msq_vec_layernorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H,
+                      float eps, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream);
+int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bits, int exp_bits, float max_norm,
+                 int rmode, int allow_denorm, void* stream);
+int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int64_t n, int bits, int exp_bits,
+                float max_norm, int rmode, int allow_denorm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,169 @@
+// msq_vec.hip -- the bfloat-rounded vector ops that surround the MX Linear in the reference's emulation library
+// (number_system/mx/vector_ops.py: every op = the torch op followed by quantize_elemwise_op):
+//   LayerNorm  layernorm.py:18-42 -> norm_utils.py:27-113 _norm_forward over the last axis (14 rounded ops per element)
+//   gelu       activations.py:460-512 (sigmoid form with bf16 coefficients, 10 rounded ops; first-order variant)
+//   simd_add   simd_ops.py:85-106
+// The reference issues one eager torch kernel per op (and one quantise pass after each): here each function is ONE
+// launch, read once / write once, with the rounding Q() applied in registers after every arithmetic step exactly
+// where the reference applies it, so the results are those of the op-by-op emulation.
+// Q() = the native element codec (quant_bits: cpp/quantize.cuh:88-149 semantics, saturate_normals = false) for
+// (bits, exp_bits, max_norm): bfloat16 = (9, 8, bf16 max), bfloat12 = (5, 8, ...), fp16-style = (bits, 5, ...).
+// LayerNorm: one wavefront per row; the row sums follow ATen's order for a contiguous inner dimension (32 interleaved
+// partial sums = 4 ILP x 8 vector lanes with its cascade levels, combined in ATen's order), so that the mean and
+// variance carry the same fp32 rounding as torch.sum on the CPU.  Compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msq.h"
+#include "msq_device.h"
+
+using namespace msq;
+
+namespace {
+
+struct VQ { int bits, ebits, rmode, dn; float max_norm; };
+MSQ_D float Q(float a, const VQ& q) {
+    return q.bits > 0 ? quant_bits(a, q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0) : a;
+}
+
+MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
+
+// ATen's inner-dimension sum of row[0..n) (oracle sum_inner_v8): lane t < 32 owns the partial sum of elements
+// i * 32 + t (t = 8 k + l), accumulated with multi_row_sum's cascade; the caller's functor gives element values.
+template <typename F>
+MSQ_D float row_sum_inner8(F elem, int64_t n, int lane) {
+    const int64_t vec_size = n / 8, size_ilp = vec_size / 4;
+    float part = 0.f;
+    if (lane < 32) {
+        int lp = ceil_log2_i64(size_ilp > 0 ? size_ilp : 1) / 4; if (lp < 4) lp = 4;
+        const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t i = 0;
+        while (i + step <= size_ilp) {
+            for (int64_t j = 0; j < step; ++j, ++i) acc[0] += elem(i * 32 + lane);
+            for (int j = 1; j < 4; ++j) {
+                acc[j] += acc[j - 1]; acc[j - 1] = 0.f;
+                if ((i & (lmask << (j * lp))) != 0) break;
+            }
+        }
+        for (; i < size_ilp; ++i) acc[0] += elem(i * 32 + lane);
+        for (int j = 1; j < 4; ++j) acc[0] += acc[j];
+        part = acc[0];
+        // vectors beyond the last full group of four go to ILP slot 0 (lanes 0..7)
+        if (lane < 8)
+            for (int64_t v = size_ilp * 4; v < vec_size; ++v) part += elem(v * 8 + lane);
+    }
+    // part[0][l] += part[k][l], k = 1..3, in that order
+    float p0 = part;
+    for (int k = 1; k < 4; ++k) { const float o = __shfl(part, (lane & 7) + 8 * k, 64); p0 += o; }
+    // fin = scalar tail, then + part[0][l] for l = 0..7
+    float fin = 0.f;
+    for (int64_t k = vec_size * 8; k < n; ++k) fin += elem(k);
+    for (int l = 0; l < 8; ++l) fin += __shfl(p0, l, 64);
+    return fin;                                            // identical in every lane
+}
+
+__global__ void __launch_bounds__(64)
+k_vec_layernorm(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+                int64_t rows, int64_t H, float eps, VQ q) {
+    extern __shared__ float xs[];
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + r * H;
+    for (int64_t i = lane; i < H; i += 64) xs[i] = Q(xr[i], q);                       // layernorm.py:24
+    __syncthreads();
+    float mean = Q(row_sum_inner8([&](int64_t i) { return xs[i]; }, H, lane), q);     // vec_reduce_sum
+    mean = Q(mean / (float)H, q);                                                     // vec_div(s, denom)
+    __syncthreads();
+    for (int64_t i = lane; i < H; i += 64) xs[i] = Q(xs[i] - mean, q);                // x_shift
+    __syncthreads();
+    float var = Q(row_sum_inner8([&](int64_t i) { return Q(xs[i] * xs[i], q); }, H, lane), q);
+    var = Q(var / (float)H, q);
+    const float vare = Q(var + eps, q);                                               // norm_utils.py:92
+    const float sd = Q(__builtin_sqrtf(vare), q);
+    const float inv = Q(1.0f / sd, q);
+    float* orow = out + r * H;
+    for (int64_t i = lane; i < H; i += 64) {
+        const float xn = Q(xs[i] * inv, q);
+        const float sc = Q(Q(w[i], q) * xn, q);
+        orow[i] = Q(sc + Q(b[i], q), q);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vec_gelu(const float* __restrict__ x, float* __restrict__ out, int64_t n, int first_order, VQ q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float qi = Q(x[i], q);
+        float s;
+        if (first_order) s = Q(1.703125f * qi, q);
+        else {
+            s = Q(qi * qi, q); s = Q(s * qi, q); s = Q(0.044677734f * s, q);
+            s = Q(s + qi, q); s = Q(1.59375f * s, q);
+        }
+        float phi = Q(expf(-s), q);                                // torch.exp (vec_use_exp2 off)
+        phi = Q(phi + 1.0f, q);
+        phi = Q(1.0f / phi, q);
+        out[i] = Q(qi * phi, q);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vec_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n, int b_is_scalar, float bs, VQ q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = Q(Q(a[i], q) + (b_is_scalar ? bs : Q(b[i], q)), q);                  // simd_ops.py:95-106
+}
+
+}  // namespace
+
+extern "C" void msq_set_error_(const char* msg);
+static int vfail(int code, const char* msg) { msq_set_error_(msg); return code; }
+static int vq_check(int bits, int exp_bits, int rmode) {
+    if (bits != 0 && (bits < 2 || bits > 24)) return vfail(MSQ_ERR_BAD_ARG, "vector op: bits must be 0 (no rounding) or in [2, 24]");
+    if (exp_bits < 0 || exp_bits > 8) return vfail(MSQ_ERR_BAD_ARG, "vector op: exp_bits must be in [0, 8]");
+    if (rmode < 0 || rmode > 2) return vfail(MSQ_ERR_BAD_ARG, "vector op: bad rounding mode");
+    return MSQ_OK;
+}
+static int grid1(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g)); }
+
+extern "C" {
+
+int msq_vec_layernorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H, float eps,
+                      int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
+    if (rows < 0 || H < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_layernorm: negative size");
+    if (rows * H == 0) return MSQ_OK;
+    if (!x || !weight || !bias || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_layernorm: null buffer");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    if (H * 4 > 160 * 1024 - 1024) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_layernorm: a row must fit the CU's LDS (H <= 40704)");
+    const size_t lds = (size_t)H * 4;
+    if (lds > 65536) hipFuncSetAttribute((const void*)k_vec_layernorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_vec_layernorm, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, x, weight, bias, out, rows, H, eps,
+                       VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_layernorm: launch failed");
+}
+
+int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bits, int exp_bits, float max_norm, int rmode,
+                 int allow_denorm, void* stream) {
+    if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_gelu: negative size");
+    if (n == 0) return MSQ_OK;
+    if (!x || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_gelu: null buffer");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    hipLaunchKernelGGL(k_vec_gelu, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, first_order,
+                       VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_gelu: launch failed");
+}
+
+int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int64_t n, int bits, int exp_bits, float max_norm,
+                int rmode, int allow_denorm, void* stream) {
+    if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_add: negative size");
+    if (n == 0) return MSQ_OK;
+    if (!a || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_add: null buffer");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    hipLaunchKernelGGL(k_vec_add, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, b ? 0 : 1, b_scalar,
+                       VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_add: launch failed");
+}
+
+}  // extern "C"

@@ -962,6 +962,66 @@ int msq_oracle_kv_group_quant(const float* in, float* out, int dtype, int64_t B,
     return 0;
 }
 
+/* ------------------------------------------------------------------------
+ * f4  bfloat-rounded vector ops around the MX Linear (number_system/mx/vector_ops.py: every op is the torch op followed
+ * by quantize_elemwise_op, elemwise_ops.py:237-266 -> _quantize_elemwise_core with saturate_normals=False):
+ *   LayerNorm   layernorm.py:18-42 -> norm_utils.py:27-113 _norm_forward (axes = last)
+ *   gelu        activations.py:460-512 (sigmoid form, bf16 coefficients; first_order variant)
+ *   simd_add    simd_ops.py:85-106
+ * (bits, exp_bits, max_norm, round_mode, allow_denorm) describe the rounding Q(): bfloat16 = (9, 8, bf16 max).
+ * The row sums use ATen's order for a contiguous inner dimension (sum_inner_v8).
+ * ---------------------------------------------------------------------- */
+typedef struct { int bits, ebits, rmode, dn; float max_norm; } vq_t;
+static float VQ(float a, const vq_t* q) {
+    if (q->bits <= 0) return a;
+    return quantize_elemwise_core_1(a, q->bits, q->ebits, q->max_norm, q->rmode, 0, q->dn);
+}
+void msq_oracle_vec_layernorm(const float* x, const float* w, const float* b, float* out, int64_t rows, int64_t H,
+                              double eps, int bits, int exp_bits, float max_norm, int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    float* t = (float*)malloc(sizeof(float) * H * 2);
+    float* p = t + H;
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int64_t i = 0; i < H; ++i) t[i] = VQ(x[r * H + i], &q);               /* layernorm.py:24 */
+        float mean = VQ(sum_inner_v8(t, H), &q);                                    /* vec_reduce_sum */
+        mean = VQ(mean / (float)H, &q);                                             /* vec_div(s, denom) */
+        for (int64_t i = 0; i < H; ++i) { t[i] = VQ(t[i] - mean, &q); p[i] = VQ(t[i] * t[i], &q); }
+        float var = VQ(sum_inner_v8(p, H), &q);
+        var = VQ(var / (float)H, &q);
+        const float vare = VQ(var + (float)eps, &q);                                /* norm_utils.py:92 */
+        const float sd = VQ(sqrtf(vare), &q);
+        const float inv = VQ(1.0f / sd, &q);
+        for (int64_t i = 0; i < H; ++i) {
+            const float xn = VQ(t[i] * inv, &q);
+            const float xs = VQ(VQ(w[i], &q) * xn, &q);
+            out[r * H + i] = VQ(xs + VQ(b[i], &q), &q);
+        }
+    }
+    free(t);
+}
+void msq_oracle_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bits, int exp_bits, float max_norm,
+                         int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    for (int64_t i = 0; i < n; ++i) {
+        const float qi = VQ(x[i], &q);
+        float s;
+        if (first_order) s = VQ(1.703125f * qi, &q);
+        else {
+            s = VQ(qi * qi, &q); s = VQ(s * qi, &q); s = VQ(0.044677734f * s, &q);
+            s = VQ(s + qi, &q); s = VQ(1.59375f * s, &q);
+        }
+        float phi = VQ(expf(-s), &q);                                               /* vec_exp, vec_use_exp2 False */
+        phi = VQ(phi + 1.0f, &q);
+        phi = VQ(1.0f / phi, &q);
+        out[i] = VQ(qi * phi, &q);
+    }
+}
+void msq_oracle_vec_add(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm,
+                        int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    for (int64_t i = 0; i < n; ++i) out[i] = VQ(VQ(a[i], &q) + VQ(b[i], &q), &q);
+}
+
 /* thread count of the OpenMP regions above (0 = all cores); returns the count in effect */
 #ifdef _OPENMP
 #include <omp.h>

@@ -214,3 +214,32 @@ def kv_group_quant(x, quantize_bit, group_size, along_tokens, dtype="float32"):
     if rc:
         raise ValueError("group_size should be a factor of the grouped dimension size")
     return out
+
+
+def _vq(bits, exp_bits, max_norm, round, allow_denorm):
+    return (C.c_int(bits), C.c_int(exp_bits), C.c_float(max_norm), C.c_int(RD[round]), C.c_int(bool(allow_denorm)))
+
+
+def vec_layernorm(x, w, b, eps, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    """mx LayerNorm forward (layernorm.py:18-42 / norm_utils.py:27-113) with every op rounded by Q = (bits, exp_bits)."""
+    x = _f32(x); w = _f32(w); b = _f32(b)
+    H = x.shape[-1]
+    out = np.empty_like(x)
+    lib().msq_oracle_vec_layernorm(_p(x), _p(w), _p(b), _p(out), C.c_int64(x.size // H), C.c_int64(H), C.c_double(eps),
+                                   *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out
+
+
+def vec_gelu(x, first_order=False, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().msq_oracle_vec_gelu(_p(x), _p(out), C.c_int64(x.size), C.c_int(bool(first_order)),
+                              *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out
+
+
+def vec_add(a, b, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    a = _f32(a); b = _f32(b)
+    out = np.empty_like(a)
+    lib().msq_oracle_vec_add(_p(a), _p(b), _p(out), C.c_int64(a.size), *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out

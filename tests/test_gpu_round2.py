@@ -217,3 +217,111 @@ def test_lowp_llama_sized_weight_vs_oracle(msq, O, dn):
         r32 = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, ax, bs, compute_dtype="float32")["out"]
         frac = float(((r32 != r["out"]) & ~torch.isnan(r["out"])).float().mean())
         assert 0 < frac < 0.05, frac
+
+
+# ---------------------------------------------------------------- f4 vector ops, a14 direct harness path
+def test_vector_ops_golden_gpu(msq):
+    """mx.LayerNorm / gelu / simd_add as single HIP launches against the reference's CPU outputs (vec_ops.npz).
+    LayerNorm and simd_add: bit-exact (the row sums follow ATen's order).  gelu: the device expf replaces Sleef's, so
+    an element may land one unit of the rounded format away; at most 2 per 6144 are allowed, none has been seen."""
+    z = np.load(os.path.join(G, "vec_ops.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    for sn, sp in (("fp6_bf16", {"bfloat": 16}), ("bf12_even", {"bfloat": 12, "round": "even"})):
+        specs = msq.specs.finalize_mx_specs(dict({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4,
+                                                  "block_size": 32, "custom_cuda": True}, **sp))
+        for H in (128, 200, 1024):
+            ln = msq.vector_ops.LayerNorm(H, mx_specs=specs).to(dev())
+            with torch.no_grad():
+                ln.weight.copy_(t(z[f"ln|{sn}|{H}|w"])); ln.bias.copy_(t(z[f"ln|{sn}|{H}|b"]))
+            y = ln(t(z[f"ln|{sn}|{H}|x"]))
+            assert (y.cpu().numpy() == z[f"ln|{sn}|{H}|y"]).all(), (sn, H)
+        for fo, key in ((False, "y"), (True, "y_first_order")):
+            y = msq.vector_ops.gelu(t(z[f"gelu|{sn}|x"]), mx_specs=specs, first_order_gelu=fo).cpu().numpy()
+            ref = z[f"gelu|{sn}|{key}"]
+            bad = y != ref
+            assert bad.sum() <= 2, (sn, fo, int(bad.sum()))
+            assert (np.abs(y - ref)[bad] <= np.abs(ref[bad]) * 2.0 ** -(7 if sn == "fp6_bf16" else 3)).all()
+        y = msq.vector_ops.simd_add(t(z[f"add|{sn}|a"]), t(z[f"add|{sn}|b"]), mx_specs=specs)
+        assert (y.cpu().numpy() == z[f"add|{sn}|y"]).all()
+    # no specs: plain torch semantics, like the reference
+    a = torch.randn(4, 8, device=dev())
+    assert torch.equal(msq.vector_ops.simd_add(a, a), a + a)
+    with pytest.raises(msq._lib.MsqError):
+        msq.vector_ops.gelu(a.cpu(), mx_specs=specs)
+
+
+def test_scratch3_residual_mlp_golden(msq):
+    """BASELINE config 1's module: the ResidualMLP of examples/scratch_3.py:13-51 (LayerNorm -> MXLinear -> gelu ->
+    MXLinear -> simd_add, run_mx_fp6.sh spec: fp6_e3m2 both ways, scale_bits 4, block 32, bfloat 16) on randn(16, 128)
+    with the reference's parameters: every stage against the reference's CPU intermediate.  The vector ops are exact;
+    the two MXLinears re-round an fp32 GEMM with a different summation order to bfloat16: one bf16 ulp on <= 1 % there."""
+    z = np.load(os.path.join(G, "vec_ops.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32,
+                                      "bfloat": 16, "custom_cuda": True})
+
+    class ResidualMLP(torch.nn.Module):
+        def __init__(self, hidden_size, mx_specs):
+            super().__init__()
+            self.mx_specs = mx_specs
+            self.layernorm = msq.LayerNorm(hidden_size, mx_specs=mx_specs)
+            self.dense_4h = msq.MXLinear(hidden_size, 4 * hidden_size, mx_specs=mx_specs)
+            self.dense_h = msq.MXLinear(4 * hidden_size, hidden_size, mx_specs=mx_specs)
+
+        def forward(self, inputs):
+            inputs, residual = msq.simd_split(inputs)
+            norm_outputs = self.layernorm(inputs)
+            proj_outputs = self.dense_4h(norm_outputs)
+            proj_outputs = msq.gelu(proj_outputs, mx_specs=self.mx_specs)
+            mlp_outputs = self.dense_h(proj_outputs)
+            return msq.simd_add(residual, mlp_outputs, mx_specs=self.mx_specs)
+
+    mlp = ResidualMLP(128, sp).to(dev())
+    mlp.load_state_dict({k[len("mlp|param|"):]: t(z[k]) for k in z.files if k.startswith("mlp|param|")})
+    x = t(z["mlp|x"])
+    with torch.no_grad():
+        norm = mlp.layernorm(x)
+        assert (norm.cpu().numpy() == z["mlp|norm"]).all()
+        proj = mlp.dense_4h(t(z["mlp|norm"]))
+        e = np.abs(proj.cpu().numpy() - z["mlp|proj"])
+        assert (e <= np.abs(z["mlp|proj"]) * 2.0 ** -7 + 1e-6).all() and (e > 0).mean() <= 0.01
+        gl = msq.gelu(t(z["mlp|proj"]), mx_specs=sp)
+        assert (gl.cpu().numpy() != z["mlp|gelu"]).sum() <= 2
+        y = mlp(x).cpu().numpy()
+    e = np.abs(y - z["mlp|y"])
+    assert (e <= np.abs(z["mlp|y"]) * 2.0 ** -6 + 1e-6).all(), float(e.max())
+    assert (e > 0).mean() <= 0.03, float((e > 0).mean())
+
+
+def test_quantize_model_and_opt_direct_eval(msq):
+    """utils/quant_model.py quantize_model + llm/opt_direct.py opt_eval on a tiny OPT (rebuilt from its seed; a checksum of
+    the parameters pins the init): the same 12 Linears become MXLinear, lm_head stays dense, and the perplexity of the
+    swapped model matches the reference's CPU run for the spec opt_direct.py hard-codes (fp4 weights / int4 activations,
+    block 128) and the fp6 spec -- relative 2e-3 (fp32 GEMM summation order through 2 layers; bit-exact quantisers)."""
+    from transformers import OPTConfig, OPTForCausalLM
+    from msq.harness import opt_direct
+    from msq.harness.data_utils import _Enc
+    z = np.load(os.path.join(G, "vec_ops.npz"))
+    cfg = OPTConfig(hidden_size=256, ffn_dim=512, num_hidden_layers=2, num_attention_heads=4, vocab_size=256,
+                    max_position_embeddings=300, word_embed_proj_dim=256, do_layer_norm_before=True)
+    torch.manual_seed(3)
+    model = OPTForCausalLM(cfg).eval()
+    chk = sum(float(v.double().abs().sum()) for v in model.state_dict().values())
+    assert abs(chk - float(z["optd|param_abs_sum"])) <= 1e-6 * chk, "the seeded init differs from the fixture's"
+    model.seqlen = 256
+    tokens = _Enc(torch.from_numpy(z["optd|tokens"]))
+    model = model.to(dev())
+    for sname, sp in (("optdirect", dict(opt_direct.DIRECT_MX_SPECS)),
+                      ("fp6", {"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32, "bfloat": 16})):
+        sp = msq.specs.finalize_mx_specs(dict(sp, custom_cuda=True))
+        qm = msq.quantize_model(model, sp)
+        n_mx = sum(1 for m in qm.modules() if type(m).__name__ == "MXLinear")
+        assert n_mx == int(z[f"optd|{sname}|n_mxlinear"]) == 12
+        assert type(qm.lm_head) is torch.nn.Linear
+        assert all(type(m) is not torch.nn.Linear for n, m in qm.model.decoder.layers.named_modules())
+        with torch.no_grad():
+            logits = qm(tokens.input_ids[:, :256].to(dev())).logits[:, :64].float().cpu().numpy()
+        ref = z[f"optd|{sname}|logits0"]
+        assert np.abs(logits - ref).max() <= 2e-2 * np.abs(ref).max(), float(np.abs(logits - ref).max() / np.abs(ref).max())
+        ppl = opt_direct.opt_eval(qm, tokens, dev())
+        assert abs(ppl - float(z[f"optd|{sname}|ppl"])) / float(z[f"optd|{sname}|ppl"]) < 2e-3, (sname, ppl, float(z[f"optd|{sname}|ppl"]))
