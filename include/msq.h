@@ -318,6 +318,26 @@ int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bit
 int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int64_t n, int bits, int exp_bits,
                 float max_norm, int rmode, int allow_denorm, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * GPTQ column block with MicroScopiQ pruning -- replaces the inner column loop of llm/gptq.py:106-165 (per column:
+ * quantize_mx_outlier_hessian on [O, 1], zero the num_outliers least important entries, error feedback to the columns on
+ * the right) for up to 128 columns as ONE launch.
+ *   Wt  [cols][O]   the block's columns as they stand when the block starts (column-major copy of W[:, c0:c1])
+ *   U   pointer to U[c0][c0] of the upper Cholesky factor of the inverse Hessian (llm/gptq.py:99-103), row stride ldu
+ *   Qt, Et [cols][O] outputs: quantised + pruned columns and error columns (w - q) / d (the caller applies
+ *                   W[:, c1:] -= Et^T . U[c0:c1, c1:], llm/gptq.py:163, with a library GEMM)
+ *   loss (double, device) += sum (w - q)^2 / d^2 / 2;  pruned (u64, device) += entries zeroed by the pruning step
+ * Quantiser = utils/quant.py:23-146 along the output rows (block 8 / 16 / 32 / 64, float / int inlier formats), bit-identical
+ * to msq_outlier_fakequant on the same column; num_outliers follows the reference's every-block-th-block count (:66).
+ * "The n least important" is resolved exactly (radix select on the importance bits); ties go to the LOWEST ROW INDEX
+ * (torch.topk leaves the order among equal values unspecified).  O <= 51200.  status_flag receives MSQ_STATUS_NAN.
+ * ------------------------------------------------------------------------- */
+int64_t msq_gptq_block_workspace_bytes(int64_t O, int cols);
+int msq_gptq_block(const float* Wt, const float* U, int ldu, float* Qt, float* Et, double* loss, unsigned long long* pruned,
+                   int* status_flag, void* workspace, int64_t workspace_bytes, int64_t O, int cols, int block,
+                   int inlier_fmt, int outlier_fmt, int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
+                   int flush_fp32_subnorms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

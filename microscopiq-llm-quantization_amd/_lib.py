@@ -32,6 +32,9 @@ _SIGS = {
     "msq_vec_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_gelu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_add": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "msq_gptq_block_workspace_bytes": (_i64, [_i64, _i32]),
+    "msq_gptq_block": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                 _f32, _i32, _i32, _vp]),
     "msq_kv_group_quant": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _vp]),
     "msq_floor_log2_lowp": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "msq_packed_kinds": (C.c_int, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),

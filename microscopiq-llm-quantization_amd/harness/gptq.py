@@ -2,17 +2,19 @@
 Hessian accumulation :32-58, the column solver :60-184, free :186-193), written for the GPU:
 
 * the running Hessian 2/n X X^T lives on the device and is updated with one GEMM per calibration batch;
-* every column is quantised by ONE fused launch of ``quantize_mx_outlier_hessian`` (utils/quant.py:23-146; the
-  reference issues ~150 eager ops per column);
-* the MicroScopiQ step "zero as many of the least important weights of the column as it holds outliers"
-  (llm/gptq.py:146-153) is done without reading the outlier count back to the host: the column is ordered by
-  importance (stable sort) and the first ``n_outliers`` positions are cleared through a device-side mask.  The
-  reference takes ``topk(..., largest=False)``, whose choice among equal importances is unspecified; ties only
-  occur between equal quantised magnitudes, and the fixture test bounds the effect (>= 97 % identical weights);
-* error feedback inside a column block and the block-to-block update are rank-1 / GEMM updates as in GPTQ.
+* the column loop of a 128-column block (:113-157: quantise the column with quantize_mx_outlier_hessian, zero the
+  `num_outliers` least important entries, feed the error to the columns on the right) is ONE launch of
+  ``msq_gptq_block`` (csrc/msq_gptq.hip): error columns in LDS, lazily rebuilt columns with the reference's rounding
+  sequence, the block quantiser of the fake-quant kernel, exact radix selection for the pruning step.  The reference
+  issues ~150 eager ops per column; round 1 of this build ~25;
+* ties of the pruning choice go to the lowest row index (``torch.topk(..., largest=False)`` leaves the choice among
+  equal importances unspecified; the CPU, CUDA and HIP implementations all differ).  With that rule fixed the solver
+  reproduces the reference's output bit for bit when it is given the same inverse-Hessian factor
+  (tests/golden/gptq_exact.npz);
+* the block-to-block update (:163) stays a library GEMM.
 
-SURVEY.md 8(f1): still one launch group per column; a kernel that walks a whole 128-column block per launch is
-the next step (rows are independent once the pruning choice is made per column)."""
+Quantiser configurations the block kernel does not cover (posit inliers, block 128, groupsize / static_groups
+re-fitting) take the per-column path below (one fused quantiser launch per column, same tie rule)."""
 import math
 import time
 
@@ -85,8 +87,10 @@ class GPTQ:
         return q, n_out
 
     @torch.no_grad()
-    def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False, verbose=True):
-        """`self.quantizer` is an MXQuantizer set by the caller (llm/llama.py:102-113)."""
+    def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False, verbose=True,
+                    hinv=None, per_column=False):
+        """`self.quantizer` is an MXQuantizer set by the caller (llm/llama.py:102-113).  ``hinv`` (tests): use this upper
+        Cholesky factor of the inverse Hessian instead of computing it; ``per_column`` forces the per-column path."""
         t0 = time.time()
         W = _as_matrix(self.layer).clone().float()
         qz = self.quantizer
@@ -99,7 +103,7 @@ class GPTQ:
         if actorder:
             perm = torch.argsort(torch.diag(H), descending=True)
             W, H = W[:, perm], H[perm][:, perm]
-        U = self._inverse_factor(H, percdamp)
+        U = self._inverse_factor(H, percdamp) if hinv is None else hinv.to(self.dev).float().contiguous()
         Q = torch.zeros_like(W)
         loss = torch.zeros((), device=self.dev)
         pruned = torch.zeros((), dtype=torch.int64, device=self.dev)
@@ -109,11 +113,15 @@ class GPTQ:
         from .. import quant as _quant
         check_nan, _quant.CHECK_NAN = _quant.CHECK_NAN, False
         try:
-            self._solve(W, U, Q, qz, blocksize, loss, pruned)
+            if not per_column and self._block_kernel_ok(qz, blocksize):
+                loss, pruned = self._solve_blocks(W, U.contiguous(), Q, qz, blocksize)
+            else:
+                self._solve(W, U, Q, qz, blocksize, loss, pruned)
         finally:
             _quant.CHECK_NAN = check_nan
         torch.cuda.synchronize()
-        if check_nan and bool(torch.isnan(Q).any()):
+        st = getattr(self, "_status", None)
+        if check_nan and ((st is not None and int(st.item()) & 1) or bool(torch.isnan(Q).any())):
             raise AssertionError("outlier_val / inlier_val / shared_exp contains NaN values")
         self.error = float(loss.item())
         self.n_pruned = int(pruned.item())
@@ -123,6 +131,39 @@ class GPTQ:
         if actorder:
             Q = Q[:, torch.argsort(perm)]
         self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
+
+    def _block_kernel_ok(self, qz, blocksize):
+        axes = qz.axes if isinstance(qz.axes, (list, tuple)) else [qz.axes]
+        return (blocksize <= 128 and qz.block_size in (8, 16, 32, 64) and [a % 2 for a in axes] == [0]
+                and not str(qz.inlier_elem_format).startswith("posit") and self.rows <= 51200
+                and qz.shared_exp_method == "max")
+
+    def _solve_blocks(self, W, U, Q, qz, blocksize):
+        """One msq_gptq_block launch per column block + one GEMM for the blocks to the right (llm/gptq.py:106-163)."""
+        from .._lib import check, current_stream, lib, ptr
+        from ..formats import RoundingMode, format_id
+        O, K = W.shape
+        L = lib()
+        loss = torch.zeros((), dtype=torch.float64, device=self.dev)
+        pruned = torch.zeros((), dtype=torch.int64, device=self.dev)
+        status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        wsb = L.msq_gptq_block_workspace_bytes(O, min(blocksize, K))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=self.dev)
+        for c0 in range(0, K, blocksize):
+            c1 = min(c0 + blocksize, K)
+            cols = c1 - c0
+            Wt = W[:, c0:c1].t().contiguous()
+            Qt, Et = torch.empty_like(Wt), torch.empty_like(Wt)
+            check(L.msq_gptq_block(ptr(Wt), U.data_ptr() + (c0 * K + c0) * 4, K, ptr(Qt), ptr(Et), ptr(loss), ptr(pruned),
+                                   ptr(status), ptr(ws), wsb, O, cols, int(qz.block_size), format_id(qz.inlier_elem_format),
+                                   format_id(qz.outlier_elem_format), int(qz.inlier_scale_bits), int(qz.outlier_scale_bits),
+                                   float(qz.std_dev), int(RoundingMode[qz.round]), int(bool(qz.flush_fp32_subnorms)),
+                                   current_stream(self.dev)), "msq_gptq_block")
+            Q[:, c0:c1] = Qt.t()
+            if c1 < K:
+                W[:, c1:] -= Et.t().matmul(U[c0:c1, c1:])                              # llm/gptq.py:163
+        self._status = status
+        return loss, pruned
 
     def _solve(self, W, U, Q, qz, blocksize, loss, pruned):
         for c0 in range(0, self.columns, blocksize):

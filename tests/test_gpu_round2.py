@@ -325,3 +325,87 @@ def test_quantize_model_and_opt_direct_eval(msq):
         assert np.abs(logits - ref).max() <= 2e-2 * np.abs(ref).max(), float(np.abs(logits - ref).max() / np.abs(ref).max())
         ppl = opt_direct.opt_eval(qm, tokens, dev())
         assert abs(ppl - float(z[f"optd|{sname}|ppl"])) / float(z[f"optd|{sname}|ppl"]) < 2e-3, (sname, ppl, float(z[f"optd|{sname}|ppl"]))
+
+
+# ---------------------------------------------------------------- f1 GPTQ column-block kernel
+def _gptq_case(msq, z, name, per_column=False, own_hinv=False):
+    from msq.harness.gptq import GPTQ
+    rows, cols, bs, blocksize = (int(v) for v in z[f"{name}|cfg"])
+    fi, fo = (str(v) for v in z[f"{name}|fmts"])
+    lin = torch.nn.Linear(cols, rows, bias=False).to(dev())
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(z[f"{name}|W"]).to(dev()))
+    gp = GPTQ(lin)
+    gp.quantizer = msq.quant.MXQuantizer()
+    gp.quantizer.configure(8, 8, fi, fo, axes=[0], block_size=bs)
+    X = torch.from_numpy(z[f"{name}|X"]).to(dev())
+    for t in range(X.shape[0]):
+        gp.add_batch(X[t], None)
+    H = gp.H.clone()
+    gp.fasterquant(blocksize=blocksize, percdamp=.01, verbose=False, per_column=per_column,
+                   hinv=None if own_hinv else torch.from_numpy(z[f"{name}|Hinv"]))
+    return lin.weight.detach().cpu().numpy(), gp, H.cpu().numpy()
+
+
+def test_gptq_block_kernel_bit_exact_vs_reference(msq):
+    """msq_gptq_block against the reference's CPU solver (llm/gptq.py, tie rule fixed to 'lowest row index', see
+    tests/golden/make_golden_gptq.py) when it is handed the reference's inverse-Hessian factor:
+    * single column block (no block-to-block GEMM): the quantised, pruned weights are bit-identical -- the lazily rebuilt
+      columns carry exactly the rounding sequence of the reference's running rank-1 updates -- for int2 / fp4 (the harness
+      default: pruning is a no-op, enough zeros), fp4 / fp8 (mixed), fp8 / fp8 (the exact radix selection runs for every
+      column), one and three workgroups, ragged last quantiser block, quantiser blocks of 16 and 32;
+    * the per-column path (round 1's, kept for configurations the kernel does not take) gives the same bits;
+    * several column blocks: the block-to-block update is a GEMM whose summation order differs from the CPU's, so single
+      elements may flip a rounding decision: >= 99 % identical, loss within 1 %."""
+    z = np.load(os.path.join(G, "gptq_exact.npz"))
+    names = sorted({k.split("|")[0] for k in z.files})
+    assert len(names) >= 8
+    for name in names:
+        Q, gp, H = _gptq_case(msq, z, name)
+        ref = z[f"{name}|Q"]
+        assert np.allclose(H, z[f"{name}|H"], rtol=1e-4, atol=1e-5), name
+        if name.startswith("single"):
+            assert (Q == ref).all(), (name, int((Q != ref).sum()))
+            assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-5 * float(z[f"{name}|error"]), name
+            Qc, gpc, _ = _gptq_case(msq, z, name, per_column=True)
+            assert (Qc == ref).all(), (name, "per-column path", int((Qc != ref).sum()))
+            assert gpc.n_pruned == gp.n_pruned
+        else:
+            assert (Q == ref).mean() >= 0.99, (name, float((Q == ref).mean()))
+            assert abs(gp.error - float(z[f"{name}|error"])) <= 0.01 * float(z[f"{name}|error"]), name
+    # the solver's own Cholesky factor (rocSOLVER) instead of the CPU's: same algorithm, fp32 factorisation noise only
+    Q, gp, _ = _gptq_case(msq, z, "single_fp4_fp8", own_hinv=True)
+    assert (Q == z["single_fp4_fp8|Q"]).mean() >= 0.97
+    assert abs(gp.error - float(z["single_fp4_fp8|error"])) <= 0.03 * float(z["single_fp4_fp8|error"])
+
+
+def test_gptq_block_kernel_speed_and_llama_layer(msq):
+    """A Llama-2-7B attention projection (4096 x 4096, 128-column blocks, harness default quantiser): the block kernel
+    and the per-column path agree bit for bit on the whole layer, and the layer takes >= 10x less time than round 1's
+    0.84 s (the bound asserted here is loose: 0.2 s; the measured figure is printed)."""
+    import time
+    from msq.harness.gptq import GPTQ
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(4096, 4096, bias=False).to(dev())
+    with torch.no_grad():
+        lin.weight.mul_(0.5)
+    W0 = lin.weight.data.clone()
+    X = torch.randn(8, 512, 4096, device=dev())
+    outs = []
+    for per_column in (False, True):
+        with torch.no_grad():
+            lin.weight.copy_(W0)
+        gp = GPTQ(lin)
+        gp.quantizer = msq.quant.MXQuantizer()
+        gp.quantizer.configure(8, 8, "int2", "fp4", axes=[0], block_size=16)
+        for t in range(8):
+            gp.add_batch(X[t], None)
+        if per_column:
+            gp.columns_limit = None
+        torch.cuda.synchronize(); t0 = time.time()
+        gp.fasterquant(blocksize=128, percdamp=.01, verbose=False, per_column=per_column)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        outs.append((lin.weight.data.clone(), dt, gp.error))
+        print("GPTQ 4096x4096 layer, %s: %.3f s, error %.4f" % ("per column" if per_column else "block kernel", dt, gp.error))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] < 0.2, outs[0][1]
