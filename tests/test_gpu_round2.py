@@ -413,3 +413,76 @@ def test_gptq_block_kernel_speed_and_llama_layer(msq):
     assert same >= 0.995, same
     assert abs(outs[1][2] - outs[2][2]) <= 1e-3 * outs[2][2]
     assert outs[1][1] < 0.2, outs[1][1]
+
+
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_layer_sequential_gptq_drivers(msq, family):
+    """llama_sequential / opt_sequential (llm/llama.py:62-173, llm/opt.py:26-128) on tiny random models: one quantiser
+    per decoder Linear under the reference's key names, every decoder Linear replaced by values on the quantiser's grid
+    (embeddings and lm_head untouched), calibrated weights lower the model-output error of round-to-nearest, and with
+    true_sequential the first group of layer 0 equals a by-hand calibration of those three projections."""
+    import copy
+    import types
+    from msq.harness import find_layers, sequential
+    from msq.harness.gptq import GPTQ
+    torch.manual_seed(0)
+    if family == "llama":
+        from transformers import LlamaConfig, LlamaForCausalLM
+        model = LlamaForCausalLM(LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                             num_key_value_heads=4, vocab_size=256, max_position_embeddings=128)).eval()
+        layers_of = lambda m: m.model.layers
+        prefix, fn = "model.layers", sequential.llama_sequential
+    else:
+        from transformers import OPTConfig, OPTForCausalLM
+        model = OPTForCausalLM(OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4, vocab_size=256,
+                                         max_position_embeddings=128, word_embed_proj_dim=128)).eval()
+        layers_of = lambda m: m.model.decoder.layers
+        prefix, fn = "model.decoder.layers", sequential.opt_sequential
+    model.seqlen = 64
+    g = torch.Generator().manual_seed(2)
+    data = [(torch.randint(0, 256, (1, 64), generator=g), None) for _ in range(6)]
+    test_ids = torch.randint(0, 256, (4, 64), generator=g).to(dev())
+    ref = copy.deepcopy(model).to(dev())
+    with torch.no_grad():
+        y_ref = ref(test_ids).logits
+    qcfg = dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[0], block_size=16)
+    rtn = copy.deepcopy(model).to(dev())
+    from msq.harness.evalppl import quantize_layers_nearest
+    quantize_layers_nearest(layers_of(rtn), dev(), qcfg)
+    args = types.SimpleNamespace(nsamples=6, true_sequential=(family == "llama"), use_mx=True)
+    cal = copy.deepcopy(model)
+    quantizers = fn(cal, data, dev(), args=args, quant_cfg=qcfg, log=None)
+    names = [n for n in find_layers(layers_of(cal)[0])]
+    assert sorted(quantizers) == sorted("%s.%d.%s" % (prefix, i, n) for i in range(2) for n in names)
+    assert all(isinstance(q, msq.quant.MXQuantizer) for q in quantizers.values())
+    cal = cal.to(dev())
+    for i, layer in enumerate(layers_of(cal)):
+        for n, lin in find_layers(layer).items():
+            W = lin.weight.data
+            assert not torch.equal(W, find_layers(layers_of(ref)[i])[n].weight.data)
+            # on the grid: the packer accepts the values exactly (pack_values raises otherwise)
+            if W.shape[0] % 64 == 0 and W.shape[1] % 64 == 0:
+                msq.qlinear.pack_values(W)
+    assert torch.equal(cal.lm_head.weight, ref.lm_head.weight)
+    with torch.no_grad():
+        e_cal = float(((cal(test_ids).logits - y_ref) ** 2).mean())
+        e_rtn = float(((rtn(test_ids).logits - y_ref) ** 2).mean())
+    assert e_cal < e_rtn, (e_cal, e_rtn)
+    if family == "llama":
+        # by hand: Hessians of q / k / v of layer 0 from hooks on the unquantised model, same solver
+        hand = copy.deepcopy(model).to(dev())
+        l0 = hand.model.layers[0]
+        gp = {}
+        for n in ("self_attn.k_proj", "self_attn.v_proj", "self_attn.q_proj"):
+            lin = find_layers(l0)[n]
+            gp[n] = GPTQ(lin)
+            gp[n].quantizer = msq.quant.MXQuantizer(); gp[n].quantizer.configure(8, 8, **qcfg)
+        hs = [find_layers(l0)[n].register_forward_hook((lambda nm: lambda m, i, o: gp[nm].add_batch(i[0].data, o.data))(n)) for n in gp]
+        with torch.no_grad():
+            for b, _ in data:
+                hand(b.to(dev()))
+        for h in hs:
+            h.remove()
+        for n in gp:
+            gp[n].fasterquant(verbose=False)
+            assert torch.equal(find_layers(l0)[n].weight.data, find_layers(cal.model.layers[0])[n].weight.data), n
