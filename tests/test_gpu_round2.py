@@ -419,7 +419,7 @@ def test_gptq_block_kernel_speed_and_llama_layer(msq):
 def test_layer_sequential_gptq_drivers(msq, family):
     """llama_sequential / opt_sequential (llm/llama.py:62-173, llm/opt.py:26-128) on tiny random models: one quantiser
     per decoder Linear under the reference's key names, every decoder Linear replaced by values on the quantiser's grid
-    (embeddings and lm_head untouched), calibrated weights lower the model-output error of round-to-nearest, and with
+    (embeddings and lm_head untouched), calibrated weights lower the layer-0 output error of round-to-nearest on the calibration inputs, and with
     true_sequential the first group of layer 0 equals a by-hand calibration of those three projections."""
     import copy
     import types
@@ -440,16 +440,16 @@ def test_layer_sequential_gptq_drivers(msq, family):
         prefix, fn = "model.decoder.layers", sequential.opt_sequential
     model.seqlen = 64
     g = torch.Generator().manual_seed(2)
-    data = [(torch.randint(0, 256, (1, 64), generator=g), None) for _ in range(6)]
-    test_ids = torch.randint(0, 256, (4, 64), generator=g).to(dev())
+    data = [(torch.randint(0, 256, (1, 64), generator=g), None) for _ in range(16)]
+    test_ids = torch.cat([b for b, _ in data[:8]]).to(dev())          # in-sample: what the layer-wise solver minimises
     ref = copy.deepcopy(model).to(dev())
     with torch.no_grad():
-        y_ref = ref(test_ids).logits
+        y_ref = ref(test_ids, output_hidden_states=True).hidden_states[1]      # output of decoder layer 0
     qcfg = dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[0], block_size=16)
     rtn = copy.deepcopy(model).to(dev())
     from msq.harness.evalppl import quantize_layers_nearest
     quantize_layers_nearest(layers_of(rtn), dev(), qcfg)
-    args = types.SimpleNamespace(nsamples=6, true_sequential=(family == "llama"), use_mx=True)
+    args = types.SimpleNamespace(nsamples=16, true_sequential=(family == "llama"), use_mx=True)
     cal = copy.deepcopy(model)
     quantizers = fn(cal, data, dev(), args=args, quant_cfg=qcfg, log=None)
     names = [n for n in find_layers(layers_of(cal)[0])]
@@ -465,8 +465,8 @@ def test_layer_sequential_gptq_drivers(msq, family):
                 msq.qlinear.pack_values(W)
     assert torch.equal(cal.lm_head.weight, ref.lm_head.weight)
     with torch.no_grad():
-        e_cal = float(((cal(test_ids).logits - y_ref) ** 2).mean())
-        e_rtn = float(((rtn(test_ids).logits - y_ref) ** 2).mean())
+        e_cal = float(((cal(test_ids, output_hidden_states=True).hidden_states[1] - y_ref) ** 2).mean())
+        e_rtn = float(((rtn(test_ids, output_hidden_states=True).hidden_states[1] - y_ref) ** 2).mean())
     assert e_cal < e_rtn, (e_cal, e_rtn)
     if family == "llama":
         # by hand: Hessians of q / k / v of layer 0 from hooks on the unquantised model, same solver
