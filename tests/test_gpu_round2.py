@@ -486,3 +486,33 @@ def test_layer_sequential_gptq_drivers(msq, family):
         for n in gp:
             gp[n].fasterquant(verbose=False)
             assert torch.equal(find_layers(l0)[n].weight.data, find_layers(cal.model.layers[0])[n].weight.data), n
+
+
+def test_bench_ppl_delta_hook_with_local_checkpoint(msq, tmp_path, monkeypatch):
+    """bench.py fills `ppl_delta` when MSQ_PPL_MODEL / MSQ_WIKITEXT2_DIR name a local checkpoint and dataset: here a tiny
+    random Llama saved with save_pretrained next to the fixture tokenizer, and the fixture text.  PPL of the CPU reference
+    arithmetic (oracle fake-quant, dense forward) vs the HIP quantiser + packed fused GEMM path: the weights are
+    bit-identical, so the delta is the bf16 activation rounding of the fused GEMM only."""
+    import shutil
+    import sys
+    from transformers import LlamaConfig, LlamaForCausalLM
+    G_ = os.path.join(ROOT, "tests", "golden")
+    mdir = tmp_path / "tiny_llama"
+    torch.manual_seed(0)
+    m = LlamaForCausalLM(LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                     num_key_value_heads=4, vocab_size=64, max_position_embeddings=128))
+    m.save_pretrained(mdir)
+    for f in os.listdir(os.path.join(G_, "tiny_tokenizer")):
+        shutil.copy(os.path.join(G_, "tiny_tokenizer", f), mdir / f)
+    monkeypatch.setenv("MSQ_PPL_MODEL", str(mdir))
+    monkeypatch.setenv("MSQ_WIKITEXT2_DIR", os.path.join(G_, "wikitext2_tiny"))
+    monkeypatch.setenv("MSQ_PPL_SEQLEN", "64")
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.ppl_delta_from_env(dev(), "fp4_e2m1", "fp8_e4m3", 32) is not None
+    r = bench.ppl_delta_from_env(dev(), "fp4_e2m1", "posit8_es1", 32)
+    assert r["windows"] == 880 // 64 and r["layers_kept_dense"] == 0
+    assert np.isfinite(r["ppl_cpu_reference"]) and np.isfinite(r["ppl_hip_packed_fused"])
+    assert abs(r["delta"]) / r["ppl_cpu_reference"] < 0.05 / 5.5, r               # BASELINE's 0.05 at PPL ~5.5, as a ratio
+    monkeypatch.delenv("MSQ_PPL_MODEL")
+    assert bench.ppl_delta_from_env(dev(), "fp4_e2m1", "fp8_e4m3", 32) is None

@@ -304,3 +304,28 @@ def test_gsm8k_scorer_kats(msq):
         ok, pred, pl, gold, gl = gsm8k.evaluate_pred_answer(k["pred_str"], k["ans_str"])
         assert (ok, pred, pl, gold, gl) == (k["is_pred_true"], k["pred"], k["pred_list"], k["gold"], k["gold_list"]), k
     assert gsm8k.accuracy(["The answer is 18.\nQuestion: what is 3?", "no idea"], ["#### 18", "#### 2"]) == 0.5
+
+
+def test_get_wikitext2_windowing_golden(msq):
+    """harness.data_utils.get_wikitext2 executed end to end on a local fixture (raw text + a tiny tokenizer on disk): the
+    calibration windows (seeded `random` draws, labels masked except the last position) and the tokenised test split
+    equal what the reference's utils/data_utils.py:36-56 returns for the same rows (tests/golden/make_golden_data.py)."""
+    import numpy as np
+    from msq.harness import data_utils
+    G = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(G, "wikitext2_loader.npz"))
+    for (ns, seed, seqlen) in ((5, 0, 16), (3, 7, 32)):
+        loader, testenc = data_utils.get_wikitext2(ns, seed, seqlen, os.path.join(G, "tiny_tokenizer"),
+                                                   data_dir=os.path.join(G, "wikitext2_tiny"))
+        assert len(loader) == ns
+        assert (np.stack([a.numpy()[0] for a, _ in loader]) == z[f"inp|{ns}|{seed}|{seqlen}"]).all()
+        assert (np.stack([b.numpy()[0] for _, b in loader]) == z[f"tar|{ns}|{seed}|{seqlen}"]).all()
+        assert (testenc.input_ids.numpy() == z["test_ids"]).all()
+    os.environ["MSQ_WIKITEXT2_DIR"] = os.path.join(G, "wikitext2_tiny")          # the environment variable is honoured too
+    try:
+        loader, _ = data_utils.get_loaders("wikitext2", nsamples=5, seed=0, seqlen=16, model=os.path.join(G, "tiny_tokenizer"))
+        assert (np.stack([a.numpy()[0] for a, _ in loader]) == z["inp|5|0|16"]).all()
+    finally:
+        del os.environ["MSQ_WIKITEXT2_DIR"]
+    with pytest.raises(ValueError):
+        data_utils.get_loaders("c4")
