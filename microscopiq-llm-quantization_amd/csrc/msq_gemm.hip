@@ -308,7 +308,19 @@ MSQ_D __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64_t bytes) {
     n = __builtin_amdgcn_readfirstlane(n);
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
 }
-MSQ_D uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// SGPR offsets of the buffer ops.  Every caller passes a value derived from blockIdx / the wave id (itself a readfirstlane)
+// and loop counters, which hipcc already proves wave-uniform: wrapping them in v_readfirstlane (as round 1 did) FORCES a
+// VGPR detour -- the index arithmetic (v_add, v_min, quarter-rate v_mul_lo_u32) moved to the VALU and every use paid a
+// readfirstlane + hazard nops: 238 vector instructions of the U8X kernel, ~80 per K-step.  No waterfall loop appears
+// without it (checked in the ISA: no s_and_saveexec in any GEMM kernel).  MSQ_UNI_RFL=1 restores the wrapper (A/B).
+#ifndef MSQ_UNI_RFL
+#define MSQ_UNI_RFL 0
+#endif
+MSQ_D uint32_t uni(uint32_t v) { return MSQ_UNI_RFL ? __builtin_amdgcn_readfirstlane(v) : v; }
+// ... instead the few BASE indices (tile row, first / last K-step, the K-step counter once per step) go through one
+// readfirstlane each: everything derived from them is then scalar arithmetic by construction, in every instantiation
+// (with no anchor at all hipcc's uniformity analysis gave up in 11 of the 72 GEMM kernels and emitted waterfall loops).
+MSQ_D int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <int IN_KIND, int OUT_KIND>
 MSQ_D void load_half_buf(HalfRegs<IN_KIND, OUT_KIND>& h, const PlaneRsrc& r, int lane16, uint32_t tile2kf) {
     constexpr int HS = HalfSlots<OUT_KIND>::n;
@@ -494,7 +506,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(pr.scl, scl_lane_off, uni(tile * scl_tile_bytes), 0));
         return u32x4_t{v[0], v[1], 0u, 0u};
     };
-    const uint32_t tile_row32 = (uint32_t)tile_row;
+    const uint32_t tile_row32 = (uint32_t)sgpr((int)tile_row);
 
     // A staging sources: piece = 4*wid + p, row = 8*piece + lane/8, swizzled source chunk
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, (int64_t)M * K * 2);
@@ -536,8 +548,8 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     u32x4_t wfA[4], wfB[4];
     u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0}, sc_nn = {0, 0, 0, 0};
 
-    const int kt_last = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);
-    const int kt0 = (kt_lo < KT) ? kt_lo : KT - 1;             // an empty split still runs a harmless prologue
+    const int kt_last = sgpr((kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1));
+    const int kt0 = sgpr((kt_lo < KT) ? kt_lo : KT - 1);       // an empty split still runs a harmless prologue
     const int kt1 = (kt0 + 1 <= kt_last) ? kt0 + 1 : kt_last;
     // activation tiles: three LDS buffers, staged TWO K-steps ahead (an L2 miss of the activation stream is as
     // long as a K-step; with one step of distance the wait before the barrier exposed it)
@@ -578,7 +590,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     int abuf = 0;
 #define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                       \
     {                                                                                                        \
-        const int kt_ = (KT_CUR);                                                                            \
+        const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf;                                                                                \
         const int buf2 = (abuf == 0) ? 2 : abuf - 1;             /* (abuf + 2) % 3 */                          \
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
@@ -704,7 +716,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     const __amdgpu_buffer_rsrc_t wsr = make_rsrc(Ws, wtiles * 256);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xc, (int64_t)M * K);
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(Xs, (int64_t)M * (K / 32));
-    const uint32_t tile_row32 = (uint32_t)((n0 / 64 + wn) * KT);
+    const uint32_t tile_row32 = (uint32_t)sgpr((n0 / 64 + wn) * KT);
     const int lane16 = lane * 16;
     // activation staging: piece = 4 wid + p covers rows 8 piece .. +7, 16-byte chunk (lane & 7) ^ ((row >> 1) & 7)
     // Two lane offsets only (pieces 0 and 1; piece p + 2 lies 16 rows = 16 K bytes further, the chunk swizzle repeats
@@ -759,8 +771,8 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     };
     constexpr int CBSZ = W8 ? 0 : 4;                             // A-operand format: e4m3 / e2m1
     constexpr int N_WAIT_MX = W8 ? 5 : (XBUFS == 4 ? 15 : 10);
-    const int kl = (kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1);   // an empty split runs a harmless prologue
-    const int kf0 = (kt_lo < KT) ? kt_lo : KT - 1, kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
+    const int kl = sgpr((kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1));   // an empty split runs a harmless prologue
+    const int kf0 = sgpr((kt_lo < KT) ? kt_lo : KT - 1), kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
     stage_A(kf0, 0);
     stage_A(kf1, 1);
     if (XBUFS == 4) stage_A((kf1 + 1 <= kl) ? kf1 + 1 : kl, 2);
@@ -771,7 +783,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 
 #define MSQ_MX_STEP(KT_CUR, WCUR, WLOAD)                                                                      \
     {                                                                                                        \
-        const int kt_ = (KT_CUR);                                                                            \
+        const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf, buf2 = (XBUFS == 4) ? ((abuf + 3) & 3) : ((abuf == 0) ? 2 : abuf - 1);         \
         abuf = (XBUFS == 4) ? ((abuf + 1) & 3) : ((abuf == 2) ? 0 : abuf + 1);                               \
         const char* abase = smem + buf * A_TILE;                                                             \

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Static check of the GEMM kernels' ISA (run after editing csrc/msq_gemm.hip): compiles the device code to assembly and
+reports, per kernel, waterfall loops (s_cbranch_execnz beyond the float epilogue's), scratch use, readfirstlane and
+quarter-rate v_mul_lo counts.  Exit code 1 if a bf16-output GEMM kernel has a waterfall loop or touches scratch."""
+import os, re, subprocess, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__))
+src = os.path.join(HERE, "..", "microscopiq-llm-quantization_amd", "csrc", "msq_gemm.hip")
+out = os.path.join(tempfile.gettempdir(), "msq_gemm_check.s")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+                       "--cuda-device-only", "-S", src, "-o", out] + sys.argv[1:], stderr=subprocess.DEVNULL)
+s = open(out).read()
+bad = 0
+for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm|qgemv|mxgemv)\S*):', s, re.M):
+    i = s.index('\n' + nm + ':'); j = s.index('s_endpgm', i)
+    body = s[i:j]
+    w, sc = body.count('s_cbranch_execnz'), body.count('scratch_')
+    line = "%-62s execnz %3d scratch %3d readfirstlane %3d v_mul_lo %3d valu %5d" % (nm[3:65], w, sc, body.count('readfirstlane'), body.count('v_mul_lo'), len(re.findall(r'\n\s+v_(?!mfma)', body)))
+    main = ('k_qgemm3' in nm or 'k_mxgemm' in nm)
+    flag = main and ((w and ('Et' in nm.split('Li')[2] if 'qgemm3' in nm else 'ItL' in nm)) or sc > 2)
+    if flag:
+        bad += 1
+    print(("!! " if flag else "   ") + line)
+sys.exit(1 if bad else 0)
