@@ -311,6 +311,8 @@ int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t 
  * All tensors f32, contiguous.  The exp inside gelu is the device's expf (torch uses Sleef's): results can differ from the
  * CPU reference by one unit of the rounded format on isolated elements (none observed on the fixtures).
  * ------------------------------------------------------------------------- */
+int msq_vec_round(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
+                  int force_codec, void* stream);   /* Q() alone; force_codec = 1 bypasses the bfloat fast path (tests) */
 int msq_vec_layernorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H,
                       float eps, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream);
 int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bits, int exp_bits, float max_norm,

@@ -30,6 +30,7 @@ _SIGS = {
     "msq_outlier_fakequant": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64,
                                         _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
     "msq_vec_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "msq_vec_round": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
     "msq_vec_gelu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_add": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_gptq_block_workspace_bytes": (_i64, [_i64, _i32]),

@@ -48,9 +48,11 @@ MSQ_D float kv_codec(float x, float mn, float scale) {
     return v * scale + mn;                               // :30 / :61 (two roundings: compiled with -ffp-contract=off)
 }
 
-// ---- groups along head.dim of one token.  LPG lanes per group (power of two <= 64); element i of group g of token
-// (b, s) is hd = g * gs + i -> address ((b * H + hd / D) * S + s) * D + hd % D.
-template <int DT>
+// ---- groups along head.dim of one token.  A lane owns V = 8 consecutive head.dim entries (16 bytes of a half-precision
+// cache: one dwordx4 access; two for f32), LPG lanes share a group (LPG = gs / 8 rounded up to a power of two, at most 64;
+// longer groups loop), groups packed 64 / LPG per wave.  hd = g * gs + i -> address ((b * H + hd / D) * S + s) * D + hd % D;
+// D % 8 == 0 and gs % 8 == 0 keep a lane's 8 entries inside one head (the launcher falls back to V = 1 otherwise).
+template <int DT, int V>
 __global__ void __launch_bounds__(256)
 k_kv_token(const typename KvIO<DT>::T* __restrict__ in, typename KvIO<DT>::T* __restrict__ out, int64_t B, int64_t H, int64_t S,
            int64_t D, int64_t gs, int lpg, float levels) {
@@ -64,23 +66,63 @@ k_kv_token(const typename KvIO<DT>::T* __restrict__ in, typename KvIO<DT>::T* __
     const bool live = grp < total;
     const int64_t g = live ? grp % ngrp : 0, bs = live ? grp / ngrp : 0;
     const int64_t s = bs % S, b = bs / S;
+    constexpr int MAXIT = 16;                                        // chunks of V per lane kept in registers (gs <= 64 * V * MAXIT = 8192)
+    float x[MAXIT][V];
     float mx = -__builtin_inff(), mn = __builtin_inff();
-    if (live)
-        for (int64_t i = li; i < gs; i += lpg) {
-            const int64_t hd = g * gs + i;
-            const float x = KvIO<DT>::ld(in, ((b * H + hd / D) * S + s) * D + hd % D);
-            mx = nmax(mx, x); mn = nmin(mn, x);
+    const int64_t nchunk = gs / V;                                   // V-element chunks of the group
+#pragma unroll
+    for (int nit = 0; nit < MAXIT; ++nit) {
+        const int64_t c = li + (int64_t)nit * lpg;
+        if (live && c < nchunk) {
+            const int64_t hd = g * gs + c * V;
+            const int64_t a = ((b * H + hd / D) * S + s) * D + hd % D;
+            if constexpr (V == 8 && DT != 0) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(in + a);
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (DT == 1) { x[nit][2 * k] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] & 0xFFFFu)); x[nit][2 * k + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] >> 16)); }
+                    else { x[nit][2 * k] = u2f(w[k] << 16); x[nit][2 * k + 1] = u2f(w[k] & 0xFFFF0000u); }
+                }
+            } else if constexpr (V == 8) {
+                const float4 r0 = *reinterpret_cast<const float4*>(in + a), r1 = *reinterpret_cast<const float4*>(in + a + 4);
+                x[nit][0] = r0.x; x[nit][1] = r0.y; x[nit][2] = r0.z; x[nit][3] = r0.w; x[nit][4] = r1.x; x[nit][5] = r1.y; x[nit][6] = r1.z; x[nit][7] = r1.w;
+            } else {
+                x[nit][0] = KvIO<DT>::ld(in, a);
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) { mx = nmax(mx, x[nit][k]); mn = nmin(mn, x[nit][k]); }
         }
+    }
     for (int o = 1; o < lpg; o <<= 1) {                            // butterfly inside the lpg-lane group
         mx = nmax(mx, __shfl_xor(mx, o, 64));
         mn = nmin(mn, __shfl_xor(mn, o, 64));
     }
     if (!live) return;
     const float scale = (mx - mn) / levels;                        // :26
-    for (int64_t i = li; i < gs; i += lpg) {
-        const int64_t hd = g * gs + i;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int64_t c = li + (int64_t)it * lpg;
+        if (c >= nchunk) break;
+        const int64_t hd = g * gs + c * V;
         const int64_t a = ((b * H + hd / D) * S + s) * D + hd % D;
-        KvIO<DT>::st(out, a, kv_codec(KvIO<DT>::ld(in, a), mn, scale));
+        float y[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) y[k] = kv_codec(x[it][k], mn, scale);
+        if constexpr (V == 8 && DT != 0) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (DT == 1) w[k] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)y[2 * k]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)y[2 * k + 1]) << 16);
+                else w[k] = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)y[2 * k]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)y[2 * k + 1]) << 16);
+            }
+            *reinterpret_cast<uint4*>(out + a) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else if constexpr (V == 8) {
+            *reinterpret_cast<float4*>(out + a) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(out + a + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+            KvIO<DT>::st(out, a, y[0]);
+        }
     }
 }
 
@@ -133,14 +175,22 @@ int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t 
     } else {
         // :15-17: "group_size should be a factor of the last dimension size"
         if ((H * D) % group_size) return kv_fail(MSQ_ERR_BAD_ARG, "group_size should be a factor of the last dimension size");
-        int lpg = 64;
-        while (lpg > 1 && lpg > group_size) lpg >>= 1;                // largest power of two <= min(64, group_size)
+        // V = 8 entries per lane (16-byte accesses) when the geometry and the alignment allow it, else one entry per lane;
+        // a lane keeps at most 16 chunks in registers: groups of more than 64 * V * 16 entries are not built
+        const bool v8 = (D % 8 == 0) && (group_size % 8 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+        const int V = v8 ? 8 : 1;
+        const int64_t chunks = group_size / V;
+        if (chunks > 64 * 16) return kv_fail(MSQ_ERR_UNSUPPORTED, "msq_kv_group_quant: group too long for the per-token kernel (max 8192 entries, 1024 unaligned)");
+        int lpg = 1;
+        while (lpg < 64 && lpg < chunks) lpg <<= 1;                   // lanes per group: power of two covering the chunks (<= 64)
         const int64_t groups = B * S * ((H * D) / group_size);
         const int64_t waves = (groups + (64 / lpg) - 1) / (64 / lpg);
         const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
-        if (dtype == 0) hipLaunchKernelGGL(k_kv_token<0>, grid, blk, 0, st, (const float*)in, (float*)out, B, H, S, D, group_size, lpg, levels);
-        else if (dtype == 1) hipLaunchKernelGGL(k_kv_token<1>, grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, B, H, S, D, group_size, lpg, levels);
-        else hipLaunchKernelGGL(k_kv_token<2>, grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, B, H, S, D, group_size, lpg, levels);
+#define MSQ_KVT(DTV, TY)                                                                                               \
+        do { if (v8) hipLaunchKernelGGL((k_kv_token<DTV, 8>), grid, blk, 0, st, (const TY*)in, (TY*)out, B, H, S, D, group_size, lpg, levels); \
+             else hipLaunchKernelGGL((k_kv_token<DTV, 1>), grid, blk, 0, st, (const TY*)in, (TY*)out, B, H, S, D, group_size, lpg, levels); } while (0)
+        if (dtype == 0) MSQ_KVT(0, float); else if (dtype == 1) MSQ_KVT(1, uint16_t); else MSQ_KVT(2, uint16_t);
+#undef MSQ_KVT
     }
     return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
 }

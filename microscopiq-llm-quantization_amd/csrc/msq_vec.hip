@@ -22,8 +22,22 @@ using namespace msq;
 namespace {
 
 struct VQ { int bits, ebits, rmode, dn; float max_norm; };
+// bfloatX (8 exponent bits, subnormals kept): the target shares fp32's exponent range, so rounding to `bits - 2` explicit
+// mantissa bits is integer arithmetic on the fp32 pattern, subnormals and the carry into the exponent (up to Inf: the
+// reference does not saturate here) included: nearest = half away from zero = add half a quantum to the magnitude and
+// truncate; even = add (half - 1 + kept lsb); floor = truncate.  Bit-identical to quant_bits for every finite input
+// (tests/test_gpu_round2.py::test_vector_rounding_fast_path_equals_codec); Inf / NaN pass through.
+MSQ_D float Qbf(float a, int drop, int rmode) {
+    const uint32_t u = f2u(a);
+    if ((u & 0x7F800000u) == 0x7F800000u) return a;
+    const uint32_t mag = u & 0x7FFFFFFFu, half = 1u << (drop - 1);
+    const uint32_t add = (rmode == 0) ? half : ((rmode == 2) ? (half - 1u + ((mag >> drop) & 1u)) : 0u);
+    return u2f((u & 0x80000000u) | ((mag + add) & ~((1u << drop) - 1u)));
+}
 MSQ_D float Q(float a, const VQ& q) {
-    return q.bits > 0 ? quant_bits(a, q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0) : a;
+    if (q.bits <= 0) return a;
+    if (q.ebits == 8 && q.dn && q.bits < 24) return Qbf(a, 25 - q.bits, q.rmode);
+    return quant_bits(a, q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0);
 }
 
 MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
@@ -40,7 +54,13 @@ MSQ_D float row_sum_inner8(F elem, int64_t n, int lane) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int64_t i = 0;
         while (i + step <= size_ilp) {
-            for (int64_t j = 0; j < step; ++j, ++i) acc[0] += elem(i * 32 + lane);
+            for (int64_t j = 0; j < step; j += 8, i += 8) {          // step is a multiple of 16: fetch 8, then add in order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = elem((i + u) * 32 + lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[0] += v[u];
+            }
             for (int j = 1; j < 4; ++j) {
                 acc[j] += acc[j - 1]; acc[j - 1] = 0.f;
                 if ((i & (lmask << (j * lp))) != 0) break;
@@ -128,7 +148,25 @@ static int vq_check(int bits, int exp_bits, int rmode) {
 }
 static int grid1(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g)); }
 
+namespace {
+__global__ void __launch_bounds__(256) k_vec_round(const float* __restrict__ x, float* __restrict__ out, int64_t n, VQ q, int force_codec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = force_codec ? quant_bits(x[i], q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0) : Q(x[i], q);
+}
+}  // namespace
+
 extern "C" {
+
+/* the rounding Q() of the vector ops on its own (force_codec = 1: always through the generic element codec) */
+int msq_vec_round(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
+                  int force_codec, void* stream) {
+    if (n <= 0) return MSQ_OK;
+    if (!x || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_round: null buffer");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    hipLaunchKernelGGL(k_vec_round, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, VQ{bits, exp_bits, rmode, allow_denorm, max_norm}, force_codec);
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_round: launch failed");
+}
 
 int msq_vec_layernorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H, float eps,
                       int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../microscopiq-llm-quantization_amd/csrc"
 OUT=../../scripts/experiments/abl; mkdir -p $OUT
 for v in "$@"; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DMSQ_ABL=$v $MSQ_ABL_EXTRA -c msq_gemm.hip -o $OUT/msq_gemm_a$v.o 2>/dev/null &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsq_hip_abl$v.so msq_quant.o msq_quant_lowp.o msq_quant_hw.o msq_pack_emit.o msq_pack_twopass.o msq_pack_unified.o msq_act.o msq_mx.o $OUT/msq_gemm_a$v.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsq_hip_abl$v.so msq_quant.o msq_quant_lowp.o msq_quant_hw.o msq_pack_emit.o msq_pack_twopass.o msq_pack_unified.o msq_act.o msq_mx.o msq_kv.o msq_vec.o msq_gptq.o $OUT/msq_gemm_a$v.o &&
     rm $OUT/msq_gemm_a$v.o && echo built $v ) &
 done
 wait

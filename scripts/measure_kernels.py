@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timings of every kernel on the hot path at the BASELINE sizes (run on the GPU box; HIP events on the
 launch stream, inputs resident in HBM).  Writes a text table to stdout; the committed copy lives in
-profiles/r01_kernel_timings.txt.  Usage: python scripts/measure_kernels.py [section ...]"""
+profiles/r02_kernel_timings.txt.  Usage: python scripts/measure_kernels.py [section ...]"""
 import os
 import sys
 
@@ -150,7 +150,73 @@ def sec_mx(w8=False):
         print(f"N{N:5d} K{K:5d} weight pack (offline): {tpw*1e3:6.0f} us {N*K*(4+P.bits_per_element/8)/tpw/1e6:5.0f} GB/s, {P.bits_per_element:.2f} bits/weight")
 
 
-SECTIONS = {"fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8, "mx": sec_mx, "mx8": lambda: sec_mx(True)}
+def sec_a12():
+    """the seven plug-in functions of the reference's native module (cpp/funcs.cpp:218-226), HBM-bound: bytes = read + written"""
+    from msq import funcs
+    print("# a12 native plug-in kernels, 67.1 M elements f32 (algorithmic bytes = 2 * numel * 4; reduce: numel * 4)")
+    A = synth(16384, 4096)
+    n = A.numel()
+    ms = t(lambda: funcs.quantize_elemwise_func_cuda(A, 9, 8, 3.3895313892515355e38, 0, False, True))
+    print(f"k_elemwise_f32 (bf16 rounding, quantize_elemwise_func_cuda): {ms*1e3:7.1f} us {2*n*4/ms/1e6:6.0f} GB/s (incl. the output allocation)")
+    ms = t(lambda: funcs.quantize_elemwise_func_cuda(A, 5, 4, 448.0, 0, True, True))
+    print(f"k_elemwise_f32 (fp8_e4m3, saturating)                      : {ms*1e3:7.1f} us {2*n*4/ms/1e6:6.0f} GB/s")
+    Ah = A.half()
+    ms = t(lambda: funcs.quantize_elemwise_func_cuda(Ah, 5, 4, 448.0, 0, True, True))
+    print(f"k_elemwise_16<half>                                         : {ms*1e3:7.1f} us {2*n*2/ms/1e6:6.0f} GB/s")
+    for axis, tile in ((1, 32), (0, 16), (0, 32)):
+        ms = t(lambda: funcs.quantize_mx_by_tile_func_cuda(A, 8, 2, 3, 6.0, tile, axis, False, 0))
+        print(f"k_mx_tile_{'inner' if axis == 1 else 'generic'} (quantize_mx_by_tile, fp4, axis {axis}, tile {tile:2d})    : {ms*1e3:7.1f} us {2*n*4/ms/1e6:6.0f} GB/s")
+    mv = A.abs().amax(dim=1, keepdim=True).contiguous()
+    ms = t(lambda: funcs.quantize_mx_func_cuda(A, 8, 2, 3, 6.0, mv, 1, False, 0))
+    print(f"k_mx_maxvals (quantize_mx_func_cuda, axis 1 whole rows)       : {ms*1e3:7.1f} us {2*n*4/ms/1e6:6.0f} GB/s")
+    for inner in (32, 1024, 4096):
+        B = A.reshape(-1, inner)
+        ms = t(lambda: funcs.reduce_sum_inner_dim(B))
+        m2 = t(lambda: funcs.reduce_max_inner_dim(B))
+        print(f"k_reduce_inner sum / max, inner {inner:5d}                       : {ms*1e3:7.1f} / {m2*1e3:7.1f} us {n*4/ms/1e6:6.0f} / {n*4/m2/1e6:6.0f} GB/s")
+
+
+def sec_lowp():
+    print("# msq_outlier_fakequant computed in the tensor dtype (MSQ_DTYPE_F16_NATIVE / BF16_NATIVE), W[16384,4096]; bytes = 2 * numel * 2")
+    A = synth(16384, 4096)
+    for dt in (torch.float16, torch.bfloat16):
+        Ah = A.to(dt)
+        for (axis, bs, fi, fo) in [(0, 16, "int2", "fp4"), (-1, 32, "fp4_e2m1", "fp8_e4m3")]:
+            keep = quant.CHECK_NAN; quant.CHECK_NAN = False
+            try:
+                ms = t(lambda: quant.outlier_fakequant(Ah, 8, 8, fi, fo, 2, axis, bs), 10, 5)
+            finally:
+                quant.CHECK_NAN = keep
+            print(f"{str(dt)[6:]:9s} axis {axis:2d} bs {bs} {fi}/{fo}: {ms*1e3:7.1f} us {2*A.numel()*2/ms/1e6:6.0f} GB/s, {A.numel()/ms/1e6:6.1f} G weights/s (Llama-2-7B: {6.5e9/(A.numel()/ms*1e3):.2f} s)")
+
+
+def sec_kv():
+    from msq import kvcache
+    print("# msq_kv_group_quant on a Llama-2-7B layer cache [1, 32, 4096, 128] (bytes = 2 * numel * sizeof)")
+    for dt in (torch.float16, torch.float32):
+        k = torch.randn(1, 32, 4096, 128, device=dev).to(dt)
+        for bits in (2, 4):
+            mc = t(lambda: kvcache.fake_groupwise_channel_asymmetric_quantization_new(k, bits, 32))
+            mt = t(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 32))
+            mw = t(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 4096))
+            b = 2 * k.numel() * k.element_size()
+            print(f"{str(dt)[6:]:8s} {bits} bit: per-channel g32 {mc*1e3:6.1f} us {b/mc/1e6:5.0f} GB/s | per-token g32 {mt*1e3:6.1f} us {b/mt/1e6:5.0f} GB/s | per-token g4096 {mw*1e3:6.1f} us {b/mw/1e6:5.0f} GB/s")
+        mk = t(lambda: kvcache.mx_quantize_keys(k, "fp8_e4m3", 32)); mv = t(lambda: kvcache.mx_quantize_values(k, "fp8_e4m3", 32))
+        print(f"{str(dt)[6:]:8s} MX-FP8: keys (blocks along tokens) {mk*1e3:6.1f} us | values (blocks along head_dim) {mv*1e3:6.1f} us")
+
+
+def sec_vec():
+    from msq import vector_ops
+    sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32, "bfloat": 16, "custom_cuda": True})
+    print("# bfloat-rounded vector ops, X[2048, 4096] f32 (bytes = 2 * numel * 4)")
+    X = torch.randn(2048, 4096, device=dev); w = torch.randn(4096, device=dev); b = torch.randn(4096, device=dev)
+    n = X.numel()
+    ms = t(lambda: vector_ops.layer_norm(X, w, b, 1e-12, sp)); print(f"msq_vec_layernorm: {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
+    ms = t(lambda: vector_ops.gelu(X, mx_specs=sp)); print(f"msq_vec_gelu     : {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
+    ms = t(lambda: vector_ops.simd_add(X, X, mx_specs=sp)); print(f"msq_vec_add      : {ms*1e3:6.1f} us {3*n*4/ms/1e6:5.0f} GB/s")
+
+
+SECTIONS = {"a12": sec_a12, "lowp": sec_lowp, "kv": sec_kv, "vec": sec_vec, "fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8, "mx": sec_mx, "mx8": lambda: sec_mx(True)}
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SECTIONS)
     print("device:", torch.cuda.get_device_name(0))

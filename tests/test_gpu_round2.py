@@ -516,3 +516,28 @@ def test_bench_ppl_delta_hook_with_local_checkpoint(msq, tmp_path, monkeypatch):
     assert abs(r["delta"]) / r["ppl_cpu_reference"] < 0.05 / 5.5, r               # BASELINE's 0.05 at PPL ~5.5, as a ratio
     monkeypatch.delenv("MSQ_PPL_MODEL")
     assert bench.ppl_delta_from_env(dev(), "fp4_e2m1", "fp8_e4m3", 32) is None
+
+
+def test_vector_rounding_fast_path_equals_codec(msq):
+    """The bfloat rounding inside the vector ops is integer arithmetic on the fp32 pattern; it must equal the generic
+    element codec (quantize_elemwise semantics) for every input class: 4 M random patterns over the whole exponent range,
+    all ties, subnormals, the largest finite values (overflow to Inf: the reference does not saturate here), Inf, NaN."""
+    L = msq._lib.lib()
+    g = torch.Generator(device=dev()).manual_seed(8)
+    bits = torch.randint(0, 2 ** 31 - 1, (4_000_000,), generator=g, device=dev(), dtype=torch.int64)
+    bits = (bits | (torch.randint(0, 2, bits.shape, generator=g, device=dev(), dtype=torch.int64) << 31)).to(torch.int32)
+    x = bits.view(torch.float32)
+    ties = (torch.arange(0, 1 << 16, device=dev(), dtype=torch.int64) << 16 | 0x8000).to(torch.int32).view(torch.float32)
+    special = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 3.3895e38, 3.40e38, -3.40e38, 1e-45, -1e-45,
+                            1.1754944e-38, 5.9e-39], device=dev())
+    x = torch.cat([x, ties, -ties, special])
+    for bfloat in (16, 12, 10, 20):
+        m = bfloat - 7
+        mn = 2.0 ** 127 * (2 ** (m - 1) - 1) / 2 ** (m - 2)
+        for rm in (0, 1, 2):
+            a = torch.empty_like(x); b = torch.empty_like(x)
+            for out, force in ((a, 0), (b, 1)):
+                msq._lib.check(L.msq_vec_round(msq._lib.ptr(x), msq._lib.ptr(out), x.numel(), m, 8, mn, rm, 1, force,
+                                               msq._lib.current_stream(dev())), "msq_vec_round")
+            same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            assert bool(same.all()), (bfloat, rm, int((~same).sum()))
