@@ -32,7 +32,8 @@ MSQ_D float Qbf(float a, int drop, int rmode) {
     if ((u & 0x7F800000u) == 0x7F800000u) return a;
     const uint32_t mag = u & 0x7FFFFFFFu, half = 1u << (drop - 1);
     const uint32_t add = (rmode == 0) ? half : ((rmode == 2) ? (half - 1u + ((mag >> drop) & 1u)) : 0u);
-    return u2f((u & 0x80000000u) | ((mag + add) & ~((1u << drop) - 1u)));
+    const uint32_t r = (mag + add) & ~((1u << drop) - 1u);
+    return r ? u2f((u & 0x80000000u) | r) : 0.0f;                  // zero is +0, as the codec returns it
 }
 MSQ_D float Q(float a, const VQ& q) {
     if (q.bits <= 0) return a;
