@@ -28,4 +28,12 @@ if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None:
 if g("TCC_HIT_sum") and g("TCC_MISS_sum") is not None:
     print("L2 hit rate                     %.3f" % (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
 if g("SQ_INSTS_VALU") and g("SQ_INSTS_MFMA"):
-    print("VALU / MFMA instructions        %.2f" % (g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA")))
+    # SQ_INSTS_VALU counts the MFMAs too (U8 kernel: 32 converts + 8 shifts per 64 MFMAs in the ISA = 0.6-0.9; the counter
+    # ratio reads 1.88): report both
+    print("VALU (incl. MFMA) / MFMA instr  %.2f" % (g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA")))
+    print("non-MFMA VALU / MFMA instr      %.2f" % (g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA") - 1.0))
+if g("GRBM_GUI_ACTIVE") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs carry the matrix pipes
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0
+    print("kernel cycles (per XCD)         %.4g" % cyc)
+    print("MFMA pipe busy fraction         %.3f  (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * cyc)))
