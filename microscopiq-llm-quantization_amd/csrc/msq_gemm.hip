@@ -41,6 +41,9 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MSQ_ABL
 #define MSQ_ABL 0
 #endif
+#ifndef MSQ_EXP_SKIPBAR
+#define MSQ_EXP_SKIPBAR 0   /* timing experiment only (results are WRONG): no wait / barrier after the first K-step of every pair */
+#endif
 #define TILE_N 64
 #define TILE_K 64
 
@@ -588,7 +591,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     constexpr int N_INFLIGHT = HalfLoads<IN_KIND, OUT_KIND>::n * (DEEP ? 2 : 1);
     constexpr int N_WAIT_ST = N_INFLIGHT + PPW;                // + the LDS-DMA ops of the tile staged in this K-step
     int abuf = 0;
-#define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                       \
+#define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2, BAR)                                                       \
     {                                                                                                        \
         const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf;                                                                                \
@@ -621,21 +624,21 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         /* the tile staged in THIS K-step (4 LDS-DMA ops, older than the packed loads and younger than the    \
            scale load thanks to the sched_barriers above) may stay in flight too: it is needed two barriers   \
            from now */                                                                                       \
-        __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT_ST & 15) | ((N_WAIT_ST >> 4) << 14));                    \
+        if (!(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT_ST & 15) | ((N_WAIT_ST >> 4) << 14)); \
         sc_cur = sc_nxt; if (DEEP) sc_nxt = sc_nn;                                                           \
-        __builtin_amdgcn_s_barrier();                                                                        \
+        if (!(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_barrier();                                  \
     }
 
     {
         int kt = kt_lo;
         if (DEEP) {
             for (; kt + 1 < kt_hi; kt += 2) {
-                MSQ_K_STEP(kt, pk1, pk0, pk2, pk1)
-                MSQ_K_STEP(kt + 1, pk3, pk2, pk0, pk3)
+                MSQ_K_STEP(kt, pk1, pk0, pk2, pk1, 0)
+                MSQ_K_STEP(kt + 1, pk3, pk2, pk0, pk3, 1)
             }
-            if (kt < kt_hi) MSQ_K_STEP(kt, pk1, pk0, pk2, pk1)
+            if (kt < kt_hi) MSQ_K_STEP(kt, pk1, pk0, pk2, pk1, 1)
         } else {
-            for (; kt < kt_hi; ++kt) MSQ_K_STEP(kt, pk1, pk0, pk0, pk1)
+            for (; kt < kt_hi; ++kt) MSQ_K_STEP(kt, pk1, pk0, pk0, pk1, 1)
         }
     }
 #undef MSQ_K_STEP
