@@ -116,6 +116,12 @@ int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_
 int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                             int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
+/* the same with the divisor of the reference's PYTHON path, `2**shared_exp + 1e-6` in fp32 (number_system/mx/mx_ops.py:444,
+ * taken when mx_specs["custom_cuda"] is False): ties of the scaled element round DOWN for every scale below 2^5.  The
+ * native kernel above (cpp/mx.cuh:132) and the upstream OCP-MX KATs divide by the scale itself. */
+int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                               int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                               float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
 
 /* replace reduce_sum_inner_dim / reduce_max_inner_dim (cpp/funcs.cpp:203-215, cpp/reduce.cu:19-93):
  * out[outer] = sum / max over the innermost `inner` elements. */

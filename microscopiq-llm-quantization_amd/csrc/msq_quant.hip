@@ -107,7 +107,9 @@ k_mx_maxvals(const float* __restrict__ in, float* __restrict__ out, const float*
 //             or is re-read (L2-resident) for larger tiles.
 //  post == 1: TS lanes of the wave share a tile (tile innermost, power of two <= 64):
 //             max biased exponent by a DPP/shuffle butterfly inside the wave.
-template <int TS>
+// EPS: the divisor of the reference's PYTHON path, `2**shared_exp + 1e-6` in fp32 (mx_ops.py:444; custom_cuda = False) --
+// the native path the entry replaces divides by the scale itself (cpp/mx.cuh:132).
+template <int TS, bool EPS = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t total, int scale_bits,
                 int ebits, int mbits, float max_norm, int flush, int rmode) {
@@ -122,10 +124,11 @@ k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t t
     }
     const bool fl = (se == 0) && flush;
     const float scale = mx_shared_scale(se, scale_bits, max_norm);
-    const float si = fl ? 0.f : v / scale;
+    const float si = fl ? 0.f : v / (EPS ? scale + 1e-6f : scale);
     if (i < total) out[i] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
 }
 
+template <bool EPS = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len,
                   int64_t post, int tile, int64_t ntiles, int scale_bits, int ebits, int mbits,
@@ -147,7 +150,7 @@ k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t
         const bool fl = (se == 0) && flush;
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         for (int64_t a = a0; a < a1; ++a) {
-            const float si = fl ? 0.f : in[base + a * post] / scale;
+            const float si = fl ? 0.f : in[base + a * post] / (EPS ? scale + 1e-6f : scale);
             out[base + a * post] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
         }
     }
@@ -402,6 +405,33 @@ static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, 
     return MSQ_OK;
 }
 
+template <bool EPS>
+static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                             int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
+    if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: negative size");
+    const int64_t total = pre * axis_len * post;
+    if (total == 0) return MSQ_OK;
+    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: null buffer");
+    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: bad rounding mode");
+    if (tile_size <= 0) tile_size = (int)axis_len;
+    hipStream_t st = (hipStream_t)stream;
+    const bool pow2 = (tile_size & (tile_size - 1)) == 0;
+    if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
+        const int g = grid_for(total, 256);
+#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, total, \
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
+        switch (tile_size) { MSQ_TI(1) MSQ_TI(2) MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
+#undef MSQ_TI
+    } else {
+        const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
+        hipLaunchKernelGGL(k_mx_tile_generic<EPS>, dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
+                           in, out, pre, axis_len, post, tile_size, ntiles, scale_bits, elem_ebits, elem_mbits,
+                           elem_max_norm, flush_fp32_subnorms, rmode);
+    }
+    return check_launch("msq_quantize_mx_by_tile");
+}
+
 extern "C" {
 
 int msq_version(void) { return 200; }
@@ -474,27 +504,15 @@ int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_
 int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                             int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
-    if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: negative size");
-    const int64_t total = pre * axis_len * post;
-    if (total == 0) return MSQ_OK;
-    if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: null buffer");
-    if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: bad rounding mode");
-    if (tile_size <= 0) tile_size = (int)axis_len;
-    hipStream_t st = (hipStream_t)stream;
-    const bool pow2 = (tile_size & (tile_size - 1)) == 0;
-    if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
-        const int g = grid_for(total, 256);
-#define MSQ_TI(TS) case TS: hipLaunchKernelGGL(k_mx_tile_inner<TS>, dim3(g), dim3(256), 0, st, in, out, total, \
-                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
-        switch (tile_size) { MSQ_TI(1) MSQ_TI(2) MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
-#undef MSQ_TI
-    } else {
-        const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
-        hipLaunchKernelGGL(k_mx_tile_generic, dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
-                           in, out, pre, axis_len, post, tile_size, ntiles, scale_bits, elem_ebits, elem_mbits,
-                           elem_max_norm, flush_fp32_subnorms, rmode);
-    }
-    return check_launch("msq_quantize_mx_by_tile");
+    return launch_mx_by_tile<false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                    elem_max_norm, flush_fp32_subnorms, rmode, stream);
+}
+
+int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                               int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                               float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
+    return launch_mx_by_tile<true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                   elem_max_norm, flush_fp32_subnorms, rmode, stream);
 }
 
 int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream) {

@@ -13,6 +13,28 @@ from .quant import VARIANT_MXOPS, outlier_fakequant
 from .specs import mx_assert_test
 
 
+# The reference's `_quantize_mx` has two arithmetic variants: its native kernel divides by the shared scale
+# (cpp/mx.cuh:132, custom_cuda=True), its Python path by `scale + 1e-6` (mx_ops.py:444, custom_cuda=False), which moves
+# every tie of the scaled element down (3 % of bfloat16-rounded activations in fp6).  The native variant is the default
+# here whatever the flag says (it is what the MX-native GEMM operands encode and what the upstream KATs pin);
+# `with reference_python_divisor():` selects the Python variant, bit for bit.
+_PY_DIVISOR = [False]
+
+
+class reference_python_divisor:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _PY_DIVISOR[0]
+        _PY_DIVISOR[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _PY_DIVISOR[0] = self.prev
+        return False
+
+
 def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None, block_size=0, round="nearest",
                  flush_fp32_subnorms=False, custom_cuda=False):
     """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile."""
@@ -32,7 +54,8 @@ def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None,
     tile = block_size if block_size > 0 else A.shape[axis]
     x = A.contiguous()
     y = funcs.quantize_mx_by_tile_func_cuda(x.float() if x.dtype != torch.float32 else x, scale_bits, ebits, mbits,
-                                            max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]))
+                                            max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]),
+                                            python_divisor=_PY_DIVISOR[0])
     return y if A.dtype == torch.float32 else y.to(A.dtype)
 
 

@@ -250,6 +250,47 @@ def test_vector_ops_golden_gpu(msq):
         msq.vector_ops.gelu(a.cpu(), mx_specs=specs)
 
 
+def test_mx_matmul_bmm_golden_gpu(msq, O):
+    """mx.matmul ('aa' / 'aw' + bias / 'wa') and mx.bmm against the reference's CPU outputs (vec_ops.npz), which come from
+    its PYTHON `_quantize_mx` (divisor `2**e + 1e-6`, mx_ops.py:444): selected with `reference_python_divisor()`; the
+    operand quantiser is bit-exact against the oracle in both variants, along the strided axis -2 too.  The fp32 product is hipBLASLt's instead of MKL's, so a sum may differ in its
+    last bits and the final vector rounding may land one unit of that format away: every element within one unit
+    (2^-7 relative for bfloat16, 2^-3 for bfloat12), and at least 99 % of them identical."""
+    z = np.load(os.path.join(G, "vec_ops.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    for sn, sp, ulp in (("fp6_bf16", {"bfloat": 16}, 2.0 ** -7), ("bf12_even", {"bfloat": 12, "round": "even"}, 2.0 ** -3)):
+        specs = msq.specs.finalize_mx_specs(dict({"w_elem_format": "fp4_e2m1", "a_elem_format": "fp6_e3m2", "scale_bits": 4,
+                                                  "block_size": 32, "custom_cuda": True}, **sp))
+        i1, i2, w2, b = (t(z[f"mm|{sn}|{k}"]) for k in ("in1", "in2", "w2", "bias"))
+        bf2 = msq.elemwise_ops.quantize_elemwise_op(i2, mx_specs=specs, round="nearest")
+        for py in (False, True):
+            with msq.mx_ops.reference_python_divisor(py):
+                q2 = msq.mx_ops.quantize_mx_op(bf2, specs, elem_format="fp6_e3m2", axes=[-2])
+            ref = O.quantize_mx(bf2.cpu().numpy(), 4, "fp6_e3m2", axis=2, block_size=32, plus_eps_defect=py)
+            assert (q2.cpu().numpy() == ref).all(), (sn, py)
+        with msq.mx_ops.reference_python_divisor():
+            outs = {"aa": msq.matmul(i1, i2, mx_specs=specs, mode_config="aa"),
+                    "aw_bias": msq.matmul(i1, w2, bias=b, mx_specs=specs, mode_config="aw"),
+                    "wa": msq.matmul(i1, w2, mx_specs=specs, mode_config="wa"),
+                    "bmm": msq.bmm(i1.reshape(6, 40, 64), i2.reshape(6, 64, 24), mx_specs=specs)}
+        native = msq.matmul(i1, i2, mx_specs=specs, mode_config="aa")
+        assert float((native != outs["aa"]).float().mean()) > 0.02        # the two variants are not the same function
+        for k, y in outs.items():
+            ref = z[f"mm|{sn}|{k}"]
+            y = y.cpu().numpy()
+            assert y.shape == ref.shape
+            same = y == ref
+            assert same.mean() >= 0.99, (sn, k, float(same.mean()))
+            assert (np.abs(y - ref) <= np.abs(ref) * ulp * 1.0001 + 1e-30).all(), (sn, k)
+        assert not torch.equal(outs["wa"], msq.matmul(i1, w2, mx_specs=specs, mode_config="aw"))     # the modes differ
+    a = torch.randn(3, 8, 8, device=dev())
+    assert torch.equal(msq.bmm(a, a), torch.bmm(a, a)) and torch.equal(msq.matmul(a, a), torch.matmul(a, a))
+    with pytest.raises(msq._lib.MsqError):
+        msq.matmul(a.cpu(), a.cpu(), mx_specs=specs)
+    with pytest.raises(AssertionError):
+        msq.matmul(a, a, mx_specs=specs, mode_config="ww")
+
+
 def test_scratch3_residual_mlp_golden(msq):
     """BASELINE config 1's module: the ResidualMLP of examples/scratch_3.py:13-51 (LayerNorm -> MXLinear -> gelu ->
     MXLinear -> simd_add, run_mx_fp6.sh spec: fp6_e3m2 both ways, scale_bits 4, block 32, bfloat 16) on randn(16, 128)
