@@ -122,12 +122,7 @@ MSQ_HD float quant_bits(float x, int bits, int ebits, float max_norm, int rmode,
     }
     if (q == 0) return 0.0f;
     // q * 2^(shift + e_true - 23): exact (q < 2^25 and the result is representable or overflows)
-    float mag = (float)q;
-    int sc = shift + e_true - 23;
-    // apply in two exact steps to stay inside pow2i's range
-    while (sc > 127) { mag *= pow2i(127); sc -= 127; }
-    while (sc < -126) { mag *= pow2i(-126); sc += 126; }
-    mag *= pow2i(sc);
+    float mag = __builtin_ldexpf((float)q, shift + e_true - 23);     // one v_ldexp_f32
     if (mag > max_norm) mag = (is_int || saturate) ? max_norm : u2f(0x7F800000u);
     return u2f(sign | f2u(mag));
 }

@@ -51,6 +51,22 @@ k_elemwise_f32(const float* __restrict__ in, float* __restrict__ out, int64_t n,
     if (t < n) out[t] = quant_bits(in[t], bits, ebits, max_norm, rmode, saturate, allow_denorm);
 }
 
+// 8 half / bfloat16 elements per lane per access (16 bytes), tail by the scalar kernel below
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_elemwise_16x8(const T* __restrict__ in, T* __restrict__ out, int64_t nvec, int bits, int ebits,
+                float max_norm, int rmode, int saturate, int allow_denorm) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        union { uint4 u; T e[8]; } v;
+        v.u = reinterpret_cast<const uint4*>(in)[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            IO<T>::st(v.e, k, quant_bits(IO<T>::ld(v.e, k), bits, ebits, max_norm, rmode, saturate, allow_denorm));
+        reinterpret_cast<uint4*>(out)[i] = v.u;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_elemwise_16(const T* __restrict__ in, T* __restrict__ out, int64_t n, int bits, int ebits,
@@ -156,6 +172,114 @@ k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t
     }
 }
 
+// 16-byte versions (HBM-bound: 4 elements per lane per access, like k_elemwise_f32).  The division by the power-of-two
+// scale is a multiplication by its exact reciprocal: both are the correctly rounded value of the same real number
+// (the reciprocal 2^-k, k in [-127, 127], is always a float, subnormal at k = 127), NaN scales stay NaN.
+MSQ_D float mx_scale_recip(float scale) {
+    const uint32_t u = f2u(scale);
+    const int e = (int)((u >> 23) & 0xFF);
+    if (e == 255) return scale;                                  // NaN scale (overflow of the scale format)
+    if (e == 0) return u2f(254u << 23);                          // 2^-127 -> 2^127
+    return e == 254 ? u2f(1u << 22) : u2f((uint32_t)(254 - e) << 23);
+}
+
+template <bool EPS>
+MSQ_D float mx_apply(float v, float scale, float rs, bool fl, int mbits, int ebits, float max_norm, int rmode) {
+    const float si = fl ? 0.f : (EPS ? v / (scale + 1e-6f) : v * rs);
+    return quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+}
+
+// tile innermost (post == 1), TS in {4, 8, 16, 32, 64}: TS / 4 neighbouring lanes share a tile
+template <int TS, bool EPS>
+__global__ void __launch_bounds__(256)
+k_mx_tile_inner4(const float* __restrict__ in, float* __restrict__ out, int64_t nvec, int scale_bits,
+                 int ebits, int mbits, float max_norm, int flush, int rmode) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < nvec; b += stride) {
+        const int64_t i = b + threadIdx.x;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) v = reinterpret_cast<const float4*>(in)[i];
+        const uint32_t m01 = max(f2u(v.x) & 0x7F800000u, f2u(v.y) & 0x7F800000u);
+        const uint32_t m23 = max(f2u(v.z) & 0x7F800000u, f2u(v.w) & 0x7F800000u);
+        int se = (int)(max(m01, m23) >> 23);
+#pragma unroll
+        for (int m = TS / 8; m > 0; m >>= 1) {
+            const int o = __shfl_xor(se, m, 64);
+            se = o > se ? o : se;
+        }
+        const bool fl = (se == 0) && flush;
+        const float scale = mx_shared_scale(se, scale_bits, max_norm);
+        const float rs = mx_scale_recip(scale);
+        v.x = mx_apply<EPS>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.y = mx_apply<EPS>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.z = mx_apply<EPS>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.w = mx_apply<EPS>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        if (i < nvec) reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+// tile along an outer axis (post % 4 == 0, tile <= TILE): one lane per (tile, 4 neighbouring columns); the TILE x 4
+// values stay in registers between the exponent scan and the quantisation, every access is a coalesced 16-byte one
+template <int TILE, bool EPS>
+__global__ void __launch_bounds__(256)
+k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len, int64_t post4,
+                int tile, int64_t ntiles, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode) {
+    const int64_t total = pre * ntiles * post4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = t % post4;
+    const int64_t ti = (t / post4) % ntiles;
+    const int64_t p = t / (post4 * ntiles);
+    const int64_t a0 = ti * tile;
+    int rows = (int)(axis_len - a0); rows = rows > tile ? tile : rows;
+    const float4* src = reinterpret_cast<const float4*>(in) + (p * axis_len + a0) * post4 + q;
+    float4* dst = reinterpret_cast<float4*>(out) + (p * axis_len + a0) * post4 + q;
+    float4 r[TILE];
+    uint32_t mx = 0, my = 0, mz = 0, mw = 0;
+#pragma unroll
+    for (int j = 0; j < TILE; ++j) {
+        r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < rows) r[j] = src[(int64_t)j * post4];
+        mx = max(mx, f2u(r[j].x) & 0x7F800000u); my = max(my, f2u(r[j].y) & 0x7F800000u);
+        mz = max(mz, f2u(r[j].z) & 0x7F800000u); mw = max(mw, f2u(r[j].w) & 0x7F800000u);
+    }
+    const int ex = (int)(mx >> 23), ey = (int)(my >> 23), ez = (int)(mz >> 23), ew = (int)(mw >> 23);
+    const float sx = mx_shared_scale(ex, scale_bits, max_norm), sy = mx_shared_scale(ey, scale_bits, max_norm);
+    const float sz = mx_shared_scale(ez, scale_bits, max_norm), sw = mx_shared_scale(ew, scale_bits, max_norm);
+    const float rx = mx_scale_recip(sx), ry = mx_scale_recip(sy), rz = mx_scale_recip(sz), rw = mx_scale_recip(sw);
+    const bool fx = (ex == 0) && flush, fy = (ey == 0) && flush, fz = (ez == 0) && flush, fw = (ew == 0) && flush;
+#pragma unroll
+    for (int j = 0; j < TILE; ++j) {
+        float4 o;
+        o.x = mx_apply<EPS>(r[j].x, sx, rx, fx, mbits, ebits, max_norm, rmode);
+        o.y = mx_apply<EPS>(r[j].y, sy, ry, fy, mbits, ebits, max_norm, rmode);
+        o.z = mx_apply<EPS>(r[j].z, sz, rz, fz, mbits, ebits, max_norm, rmode);
+        o.w = mx_apply<EPS>(r[j].w, sw, rw, fw, mbits, ebits, max_norm, rmode);
+        if (j < rows) dst[(int64_t)j * post4] = o;
+    }
+}
+
+// quantize_mx with precomputed max values, max over whole rows (post == 1, axis_len % 4 == 0): 16-byte accesses,
+// one row-index division per 4 elements
+__global__ void __launch_bounds__(256)
+k_mx_maxvals_rows4(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ maxv,
+                   int64_t nvec, int64_t row_vecs, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const int64_t p = (nvec >> 32) ? i / row_vecs : (int64_t)((uint32_t)i / (uint32_t)row_vecs);
+        const int se = (int)((f2u(maxv[p]) >> 23) & 0xFF);
+        const bool fl = (se == 0) && flush;
+        const float scale = mx_shared_scale(se, scale_bits, max_norm);
+        const float rs = mx_scale_recip(scale);
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x = mx_apply<false>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.y = mx_apply<false>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.z = mx_apply<false>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.w = mx_apply<false>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
 // ===========================================================================
 // inner-dim reductions (replace cpp/reduce.cuh:154-210): one wave per row,
 // 16-byte loads, wave64 shuffle tree; rows of any length >= 1.
@@ -188,6 +312,28 @@ k_reduce_inner(const float* __restrict__ in, float* __restrict__ out, int64_t ou
         acc = IS_MAX ? fmaxf(acc, o) : acc + o;
     }
     if (lane == 0) out[row] = acc;
+}
+
+// short rows (inner = 4 G, G a power of two <= 16, 16-byte aligned): G neighbouring lanes share a row, so a wave
+// covers 64 / G rows per access instead of one; the additions happen in the same order as in k_reduce_inner.
+template <bool IS_MAX, int G>
+__global__ void __launch_bounds__(256)
+k_reduce_inner_short(const float* __restrict__ in, float* __restrict__ out, int64_t nvec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < nvec; b += stride) {
+        const int64_t i = b + threadIdx.x;
+        float acc = IS_MAX ? -__builtin_inff() : 0.f;
+        if (i < nvec) {
+            const float4 x = reinterpret_cast<const float4*>(in)[i];
+            acc = IS_MAX ? fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)) : (x.x + x.y) + (x.z + x.w);
+        }
+#pragma unroll
+        for (int m = G / 2; m > 0; m >>= 1) {
+            const float o = __shfl_xor(acc, m, 64);
+            acc = IS_MAX ? fmaxf(acc, o) : acc + o;
+        }
+        if (i < nvec && (i & (G - 1)) == 0) out[i / G] = acc;
+    }
 }
 
 // variant 1 statistics (mx_ops.py:62-66,248): mean / unbiased std of the SIGNED values
@@ -405,6 +551,36 @@ static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, 
     return MSQ_OK;
 }
 
+template <bool IS_MAX>
+static bool launch_reduce_short(const float* in, float* out, int64_t outer, int64_t inner, hipStream_t st) {
+    if (inner < 4 || inner > 64 || (inner & (inner - 1)) || (reinterpret_cast<uintptr_t>(in) & 15)) return false;
+    const int64_t nvec = outer * (inner / 4);
+    const dim3 g(grid_for(nvec, 256, 2048 * 4)), b(256);
+    switch (inner / 4) {
+        case 1: hipLaunchKernelGGL((k_reduce_inner_short<IS_MAX, 1>), g, b, 0, st, in, out, nvec); break;
+        case 2: hipLaunchKernelGGL((k_reduce_inner_short<IS_MAX, 2>), g, b, 0, st, in, out, nvec); break;
+        case 4: hipLaunchKernelGGL((k_reduce_inner_short<IS_MAX, 4>), g, b, 0, st, in, out, nvec); break;
+        case 8: hipLaunchKernelGGL((k_reduce_inner_short<IS_MAX, 8>), g, b, 0, st, in, out, nvec); break;
+        default: hipLaunchKernelGGL((k_reduce_inner_short<IS_MAX, 16>), g, b, 0, st, in, out, nvec); break;
+    }
+    return true;
+}
+
+template <typename T>
+static void launch_elemwise_16(const void* in, void* out, int64_t n, int bits, int ebits, float max_norm, int rmode,
+                               int saturate, int allow_denorm, hipStream_t st) {
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 8) {
+        const int64_t nvec = n / 8;
+        hipLaunchKernelGGL(k_elemwise_16x8<T>, dim3(grid_for(nvec, 256, 2048 * 4)), dim3(256), 0, st, (const T*)in, (T*)out,
+                           nvec, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+        done = nvec * 8;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_elemwise_16<T>, dim3(grid_for(n - done, 256, 8192)), dim3(256), 0, st, (const T*)in + done,
+                           (T*)out + done, n - done, bits, ebits, max_norm, rmode, saturate, allow_denorm);
+}
+
 template <bool EPS>
 static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                              int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
@@ -417,7 +593,25 @@ static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t a
     if (tile_size <= 0) tile_size = (int)axis_len;
     hipStream_t st = (hipStream_t)stream;
     const bool pow2 = (tile_size & (tile_size - 1)) == 0;
-    if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
+    const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (post == 1 && pow2 && tile_size >= 4 && tile_size <= 64 && axis_len % tile_size == 0 && al16) {
+        const int64_t nvec = total / 4;
+        const int g = grid_for(nvec, 256, 2048 * 4);
+#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner4<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, nvec, \
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
+        switch (tile_size) { MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
+#undef MSQ_TI
+    } else if (post > 1 && post % 4 == 0 && tile_size <= 32 && al16 && pre * ((axis_len + tile_size - 1) / tile_size) * (post / 4) < (int64_t)0x7FFFFFFF * 256) {
+        const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
+        const int64_t nthreads = pre * ntiles * (post / 4);
+        const unsigned g = (unsigned)((nthreads + 255) / 256);
+        if (tile_size <= 16)
+            hipLaunchKernelGGL((k_mx_tile_cols4<16, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
+        else
+            hipLaunchKernelGGL((k_mx_tile_cols4<32, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
+    } else if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
         const int g = grid_for(total, 256);
 #define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, total, \
                         scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
@@ -465,13 +659,9 @@ int msq_quantize_elemwise(const void* in, void* out, int64_t n, int dtype, int b
         hipLaunchKernelGGL(k_elemwise_f32, dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, n, bits,
                            exp_bits, max_norm, rmode, saturate_normals, allow_denorm);
     } else if (dtype == 1) {
-        hipLaunchKernelGGL(k_elemwise_16<__half>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
-                           (const __half*)in, (__half*)out, n, bits, exp_bits, max_norm, rmode,
-                           saturate_normals, allow_denorm);
+        launch_elemwise_16<__half>(in, out, n, bits, exp_bits, max_norm, rmode, saturate_normals, allow_denorm, st);
     } else if (dtype == 2) {
-        hipLaunchKernelGGL(k_elemwise_16<__hip_bfloat16>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st,
-                           (const __hip_bfloat16*)in, (__hip_bfloat16*)out, n, bits, exp_bits, max_norm,
-                           rmode, saturate_normals, allow_denorm);
+        launch_elemwise_16<__hip_bfloat16>(in, out, n, bits, exp_bits, max_norm, rmode, saturate_normals, allow_denorm, st);
     } else return fail(MSQ_ERR_UNSUPPORTED, "msq_quantize_elemwise: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
     return check_launch("msq_quantize_elemwise");
 }
@@ -495,9 +685,14 @@ int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_
     if (total == 0) return MSQ_OK;
     if (!in || !out || !max_values) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx: null buffer");
     if (rmode < 0 || rmode > 2) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx: bad rounding mode");
-    hipLaunchKernelGGL(k_mx_maxvals, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, in,
-                       out, max_values, total, axis_len, post, scale_bits, elem_ebits, elem_mbits,
-                       elem_max_norm, flush_fp32_subnorms, rmode);
+    if (post == 1 && axis_len % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(k_mx_maxvals_rows4, dim3(grid_for(total / 4, 256, 2048 * 4)), dim3(256), 0, (hipStream_t)stream, in,
+                           out, max_values, total / 4, axis_len / 4, scale_bits, elem_ebits, elem_mbits,
+                           elem_max_norm, flush_fp32_subnorms, rmode);
+    else
+        hipLaunchKernelGGL(k_mx_maxvals, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, in,
+                           out, max_values, total, axis_len, post, scale_bits, elem_ebits, elem_mbits,
+                           elem_max_norm, flush_fp32_subnorms, rmode);
     return check_launch("msq_quantize_mx");
 }
 
@@ -519,8 +714,9 @@ int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inn
     if (outer < 0 || inner < 0) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_sum_inner: negative size");
     if (outer == 0) return MSQ_OK;
     if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_sum_inner: null buffer");
-    hipLaunchKernelGGL(k_reduce_inner<false>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
-                       out, outer, inner);
+    if (!launch_reduce_short<false>(in, out, outer, inner, (hipStream_t)stream))
+        hipLaunchKernelGGL(k_reduce_inner<false>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
+                           out, outer, inner);
     return check_launch("msq_reduce_sum_inner");
 }
 
@@ -528,8 +724,9 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
     if (outer < 0 || inner < 0) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_max_inner: negative size");
     if (outer == 0) return MSQ_OK;
     if (!in || !out) return fail(MSQ_ERR_BAD_ARG, "msq_reduce_max_inner: null buffer");
-    hipLaunchKernelGGL(k_reduce_inner<true>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
-                       out, outer, inner);
+    if (!launch_reduce_short<true>(in, out, outer, inner, (hipStream_t)stream))
+        hipLaunchKernelGGL(k_reduce_inner<true>, dim3(grid_for(outer, 4)), dim3(256), 0, (hipStream_t)stream, in,
+                           out, outer, inner);
     return check_launch("msq_reduce_max_inner");
 }
 
