@@ -22,6 +22,89 @@ MSQ_D uint32_t bf16_bits_exact(float v, int& status) {
     return u >> 16;
 }
 
+// Lean form of outlier_block_fast<BS, 0, false, 1> + the bf16 packing for the activation kernel, same results bit
+// for bit (tests: test_act_quant_*): about a quarter fewer vector instructions per block (the kernel is VALU-issue
+// bound: ~1300 instructions per 64 blocks measured with SQ_INSTS_VALU, profiles/r02_act_quant_pmc.txt).
+//  * the inlier / outlier maxima are integer maxima of the |a| bit patterns (v_max3_u32: one instruction per two
+//    elements and class); a NaN / Inf element shows up as a maximum >= 0x7F800000;
+//  * variant 0 recomputes the mask bit from (lo, hi) in the codec loop instead of building and unpacking a mask word;
+//  * two results are packed with one v_perm_b32; the "exact in bf16" proof ORs the dropped halves of the whole block.
+// Blocks with a NaN / Inf element, a flushed or NaN scale, or an exponent outside +-60 return false untouched and take
+// the general routine.
+// variant 1 bounds: lane_tab = true -> lane l of the wave holds (lo, hi) of block position l in (tlo, thi) (the 64
+// blocks of the wave share one table row: 3 instructions per wave + 2 v_readlane per position instead of 2 scalar
+// loads + 3 instructions per position); otherwise they are computed from the per-lane table rows vm / vs.
+template <int BS, int KI, int KO>
+MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const OutlierArgs& A, const float* vm, const float* vs,
+                          bool lane_tab, float tlo, float thi, int& status) {
+    float lo = 0.f, hi = 0.f;
+    const bool v1 = (A.variant != 0);
+    if (!v1) {
+        float ab[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(a[b]);
+        const float mean = sum_inner8<BS>(ab) / (float)BS;
+        const float ks = A.k * std_twopass_checked<BS>(ab, 0);
+        lo = mean - ks; hi = mean + ks;
+    }
+    uint32_t mkw[(BS + 31) / 32];
+#pragma unroll
+    for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
+    uint32_t ui = 0u, uo = 0u;
+#pragma unroll
+    for (int b = 0; b < BS; b += 2) {
+        bool m[2];
+        uint32_t ti[2], to[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (v1) {
+                if (lane_tab) {
+                    lo = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(tlo), b + j));
+                    hi = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(thi), b + j));
+                } else {
+                    const float ks = A.k * vs[b + j];
+                    lo = vm[b + j] - ks; hi = vm[b + j] + ks;
+                }
+            }
+            m[j] = (a[b + j] < lo) || (a[b + j] > hi);
+            if (v1) mkw[(b + j) >> 5] |= (m[j] ? 1u : 0u) << ((b + j) & 31);
+            const uint32_t t = f2u(a[b + j]) & 0x7FFFFFFFu;
+            ti[j] = m[j] ? 0u : t; to[j] = m[j] ? t : 0u;
+        }
+        ui = max(ui, max(ti[0], ti[1])); uo = max(uo, max(to[0], to[1]));
+    }
+    if (max(ui, uo) >= 0x7F800000u) return false;                      // NaN / Inf element (a NaN compares false: unmasked)
+    const float mx_in = u2f(ui), mx_o = u2f(uo);
+    float se_in = shared_exp_of_max(mx_in);
+    if (A.flush && !(se_in > -127.f)) return false;
+    se_in = clamp_scale_exp(se_in - (float)A.fi.emax, A.in_sb, A.variant);
+    if (!(se_in >= -60.f && se_in <= 60.f)) return false;               // also NaN
+    const float sc_in = exp2f_int(se_in);
+    const bool no_out = (uo == 0u);
+    float se_out = shared_exp_of_max(mx_o * sc_in);
+    se_out = clamp_scale_exp(se_out - (float)A.fo.emax, A.out_sb, A.variant);
+    if (!(no_out || (se_out >= -60.f && se_out <= 60.f))) return false;
+    const int ei = (int)se_in, eo = no_out ? 0 : (int)se_out - (int)se_in;
+    const float s_in = u2f((uint32_t)(ei + 127) << 23), s_eff = u2f((uint32_t)(eo + 127) << 23);
+    const float b_in = A.fi.max_norm * s_in, b_out = A.fo.max_norm * s_eff;
+    uint32_t dropped = 0u;
+#pragma unroll
+    for (int b = 0; b < BS; b += 2) {
+        const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);
+        float vi0, vi1, vo0, vo1;
+        hw_codec_pair(KI, x0, x1, s_in, b_in, vi0, vi1);
+        hw_codec_pair(KO, x0, x1, s_eff, b_out, vo0, vo1);
+        bool m0, m1;
+        if (v1) { m0 = (mkw[b >> 5] >> (b & 31)) & 1u; m1 = (mkw[(b + 1) >> 5] >> ((b + 1) & 31)) & 1u; }
+        else { m0 = (a[b] < lo) || (a[b] > hi); m1 = (a[b + 1] < lo) || (a[b + 1] > hi); }
+        const uint32_t r0 = f2u((m0 ? vo0 : vi0) + 0.0f), r1 = f2u((m1 ? vo1 : vi1) + 0.0f);
+        dropped |= r0 | r1;
+        h[b >> 1] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);           // (r0 >> 16) | (r1 & 0xFFFF0000)
+    }
+    if (dropped & 0xFFFFu) status |= MSQ_STATUS_INEXACT;                   // no NaN can reach this point
+    return true;
+}
+
 // A wave owns 64 consecutive blocks = one contiguous run of 64*BS floats: coalesced 16-byte loads,
 // transpose through LDS (row stride BS+4 words), one block per lane, and back the same way as bf16.
 template <int BS, int RM, int HW>
@@ -56,11 +139,13 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
 #pragma unroll
         for (int b = 0; b < BS; ++b) a[b] = (gidx < nblocks) ? X[gidx * BS + b] : 0.f;
     }
-    uint32_t mkw[(BS + 31) / 32];
-    float se_in = 0.f, se_out = 0.f;
+    uint32_t h[BS / 2];
     int status = 0;
     if (gidx < nblocks) {
-        if (A.vmean && full && (A.nblk % 64 == 0)) {
+        const bool uni_tab = A.vmean && full && (A.nblk % 64 == 0);
+        const float *vm = nullptr, *vs = nullptr;
+        float tlo = 0.f, thi = 0.f;
+        if (uni_tab) {
             // the 64 blocks of this wave lie in one row: the statistics tables are wave-uniform, read them
             // through scalar loads (the mean / std of position b are the same for every lane)
             const int64_t prow = g0 / A.nblk;
@@ -70,18 +155,30 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
                 return ((uint64_t)hi << 32) | (uint64_t)lo;
             };
-            const float* vm = (const float*)uni64(pm);
-            const float* vs = (const float*)uni64(ps);
-            status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
-        } else {
-            const float* vm = A.vmean ? A.vmean + (gidx / A.nblk) * BS : nullptr;
-            const float* vs = A.vstd ? A.vstd + (gidx / A.nblk) * BS : nullptr;
-            status = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+            vm = (const float*)uni64(pm); vs = (const float*)uni64(ps);
+            if (BS <= 64) {
+                const int l = lane < BS ? lane : 0;
+                const float ks = A.k * vs[l];
+                tlo = vm[l] - ks; thi = vm[l] + ks;
+            }
+        } else if (A.vmean) {
+            vm = A.vmean + (gidx / A.nblk) * BS; vs = A.vstd + (gidx / A.nblk) * BS;
+        }
+        bool done = false;
+        if (HW == 1 && RM == 0) {
+            const int ki = hw_codec_kind(A.fi), ko = hw_codec_kind(A.fo);          // wave-uniform
+            if (ki == 1 && ko == 1) done = act_block_lean<BS, 1, 1>(a, h, A, vm, vs, uni_tab, tlo, thi, status);
+            else if (ki == 3 && ko == 3) done = act_block_lean<BS, 3, 3>(a, h, A, vm, vs, uni_tab, tlo, thi, status);
+            else if (ki == 3 && ko == 1) done = act_block_lean<BS, 3, 1>(a, h, A, vm, vs, uni_tab, tlo, thi, status);
+        }
+        if (!done) {
+            uint32_t mkw[(BS + 31) / 32];
+            float se_in = 0.f, se_out = 0.f;
+            status |= outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+#pragma unroll
+            for (int b = 0; b < BS / 2; ++b) h[b] = bf16_bits_exact(a[2 * b], status) | (bf16_bits_exact(a[2 * b + 1], status) << 16);
         }
     }
-    uint32_t h[BS / 2];
-#pragma unroll
-    for (int b = 0; b < BS / 2; ++b) h[b] = bf16_bits_exact(a[2 * b], status) | (bf16_bits_exact(a[2 * b + 1], status) << 16);
     if (full) {
         // bf16 rows: BS/2 words per block, LDS row stride BS/2 + 4 words (16-byte aligned, conflict-free)
         constexpr int HS = BS / 2 + 4;

@@ -347,9 +347,13 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     // be scaled exactly round to zero on both routes.  Anything else takes the arithmetic codec below.
     if (RM == 0 && !EMIT && HW != 0) {
         const int in_hw = hw_codec_kind(A.fi), out_hw = hw_codec_kind(A.fo);
-        const bool safe = !nonfinite && !fl && status == 0 && se_in >= -60.f && se_in <= 60.f && se_out >= -60.f && se_out <= 60.f;
+        // a block without (non-zero) outliers never uses the outlier scale: every masked element is +-0 and comes
+        // out as +0 on either route, so its se_out (-127 with 8 scale bits in variant 1) must not force the slow path
+        const bool no_out = (mx_o == 0.f);
+        const bool safe = !nonfinite && !fl && status == 0 && se_in >= -60.f && se_in <= 60.f &&
+                          (no_out || (se_out >= -60.f && se_out <= 60.f));
         if (safe) {
-            const int ei = (int)se_in, eo = (int)se_out - (int)se_in;
+            const int ei = (int)se_in, eo = no_out ? 0 : (int)se_out - (int)se_in;
             const float s_in = u2f((uint32_t)(ei + 127) << 23), s_eff = u2f((uint32_t)(eo + 127) << 23);
             const float b_in = A.fi.max_norm * s_in, b_out = A.fo.max_norm * s_eff;   // exact (|exponent| <= 120)
             // the format kinds are wave-uniform run-time values: select a loop specialised on them once, outside
