@@ -41,6 +41,11 @@ MSQ_D float Q(float a, const VQ& q) {
     return quant_bits(a, q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0);
 }
 
+// FAST = 1: bfloat16, round to nearest (the run_mx_fp6.sh spec) with compile-time constants; 0: run-time parameters
+template <int FAST>
+MSQ_D float QT(float a, const VQ& q) { return FAST ? Qbf(a, 16, 0) : Q(a, q); }
+MSQ_D bool vq_is_fast(const VQ& q) { return q.bits == 9 && q.ebits == 8 && q.dn && q.rmode == 0; }
+
 MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
 
 // ATen's inner-dimension sum of row[0..n) (oracle sum_inner_v8): lane t < 32 owns the partial sum of elements
@@ -112,6 +117,121 @@ k_vec_layernorm(const float* __restrict__ x, const float* __restrict__ w, const 
     }
 }
 
+// Rows with H = 512 G, G <= 16 (one cascade level of ATen's sum): four waves per row.  Thread (k = tid / 32, t = tid % 32)
+// sums the 16-element groups g = k, k + 8 of interleave slot t sequentially from 0 (multi_row_sum's level 0), lane t of
+// wave 0 adds the G group sums in order (level 1), then the 32 slots are combined exactly as in row_sum_inner8.
+template <int FAST, typename F>
+MSQ_D float row_sum_inner8_par(F elem, int G, float* part /* [16][32] */, float* bcast, int tid) {
+    const int k = tid >> 5, t = tid & 31;
+    for (int g = k; g < G; g += 8) {
+        float s = 0.f;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = elem((g * 16 + j) * 32 + t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+        part[g * 32 + t] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float p = 0.f;
+        if (tid < 32) { for (int g = 0; g < G; ++g) p += part[g * 32 + tid]; p = 0.f + p; }
+        float p0 = p;
+        for (int kk = 1; kk < 4; ++kk) { const float o = __shfl(p, (tid & 7) + 8 * kk, 64); p0 += o; }
+        float fin = 0.f;
+        for (int l = 0; l < 8; ++l) fin += __shfl(p0, l, 64);
+        if (tid == 0) *bcast = fin;
+    }
+    __syncthreads();
+    return *bcast;
+}
+
+template <int FAST>
+__global__ void __launch_bounds__(256)
+k_vec_layernorm_par(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+                    int64_t rows, int H, float eps, VQ q) {
+    extern __shared__ float xs[];                       // H floats + 512 partials + 1
+    float* part = xs + H;
+    float* bc = part + 512;
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int G = H / 512;
+    const float4* xr = reinterpret_cast<const float4*>(x + r * H);
+    for (int i = tid; i < H / 4; i += 256) {
+        float4 v = xr[i];
+        v.x = QT<FAST>(v.x, q); v.y = QT<FAST>(v.y, q); v.z = QT<FAST>(v.z, q); v.w = QT<FAST>(v.w, q);
+        reinterpret_cast<float4*>(xs)[i] = v;
+    }
+    __syncthreads();
+    float mean = QT<FAST>(row_sum_inner8_par<FAST>([&](int i) { return xs[i]; }, G, part, bc, tid), q);
+    mean = QT<FAST>(mean / (float)H, q);
+    for (int i = tid; i < H / 4; i += 256) {
+        float4 v = reinterpret_cast<float4*>(xs)[i];
+        v.x = QT<FAST>(v.x - mean, q); v.y = QT<FAST>(v.y - mean, q); v.z = QT<FAST>(v.z - mean, q); v.w = QT<FAST>(v.w - mean, q);
+        reinterpret_cast<float4*>(xs)[i] = v;
+    }
+    __syncthreads();
+    float var = QT<FAST>(row_sum_inner8_par<FAST>([&](int i) { return QT<FAST>(xs[i] * xs[i], q); }, G, part, bc, tid), q);
+    var = QT<FAST>(var / (float)H, q);
+    const float vare = QT<FAST>(var + eps, q);
+    const float sd = QT<FAST>(__builtin_sqrtf(vare), q);
+    const float inv = QT<FAST>(1.0f / sd, q);
+    float4* orow = reinterpret_cast<float4*>(out + r * H);
+    for (int i = tid; i < H / 4; i += 256) {
+        const float4 v = reinterpret_cast<float4*>(xs)[i];
+        const float4 ww = reinterpret_cast<const float4*>(w)[i], bb = reinterpret_cast<const float4*>(b)[i];
+        float4 o;
+        o.x = QT<FAST>(QT<FAST>(QT<FAST>(ww.x, q) * QT<FAST>(v.x * inv, q), q) + QT<FAST>(bb.x, q), q);
+        o.y = QT<FAST>(QT<FAST>(QT<FAST>(ww.y, q) * QT<FAST>(v.y * inv, q), q) + QT<FAST>(bb.y, q), q);
+        o.z = QT<FAST>(QT<FAST>(QT<FAST>(ww.z, q) * QT<FAST>(v.z * inv, q), q) + QT<FAST>(bb.z, q), q);
+        o.w = QT<FAST>(QT<FAST>(QT<FAST>(ww.w, q) * QT<FAST>(v.w * inv, q), q) + QT<FAST>(bb.w, q), q);
+        orow[i] = o;
+    }
+}
+
+template <int FAST>
+MSQ_D float gelu_one(float x, int first_order, const VQ& q) {
+    const float qi = QT<FAST>(x, q);
+    float s;
+    if (first_order) s = QT<FAST>(1.703125f * qi, q);
+    else {
+        s = QT<FAST>(qi * qi, q); s = QT<FAST>(s * qi, q); s = QT<FAST>(0.044677734f * s, q);
+        s = QT<FAST>(s + qi, q); s = QT<FAST>(1.59375f * s, q);
+    }
+    float phi = QT<FAST>(expf(-s), q);                             // torch.exp (vec_use_exp2 off)
+    phi = QT<FAST>(phi + 1.0f, q);
+    phi = QT<FAST>(1.0f / phi, q);
+    return QT<FAST>(qi * phi, q);
+}
+
+// 16-byte accesses (n4 float4 vectors; the tail goes through k_vec_gelu)
+template <int FAST>
+__global__ void __launch_bounds__(256)
+k_vec_gelu4(const float* __restrict__ x, float* __restrict__ out, int64_t n4, int first_order, VQ q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = gelu_one<FAST>(v.x, first_order, q); v.y = gelu_one<FAST>(v.y, first_order, q);
+        v.z = gelu_one<FAST>(v.z, first_order, q); v.w = gelu_one<FAST>(v.w, first_order, q);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+template <int FAST>
+__global__ void __launch_bounds__(256)
+k_vec_add4(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n4, int b_is_scalar, float bs, VQ q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 va = reinterpret_cast<const float4*>(a)[i];
+        float4 vb = make_float4(bs, bs, bs, bs);
+        if (!b_is_scalar) { vb = reinterpret_cast<const float4*>(b)[i]; vb.x = QT<FAST>(vb.x, q); vb.y = QT<FAST>(vb.y, q); vb.z = QT<FAST>(vb.z, q); vb.w = QT<FAST>(vb.w, q); }
+        float4 o;
+        o.x = QT<FAST>(QT<FAST>(va.x, q) + vb.x, q); o.y = QT<FAST>(QT<FAST>(va.y, q) + vb.y, q);
+        o.z = QT<FAST>(QT<FAST>(va.z, q) + vb.z, q); o.w = QT<FAST>(QT<FAST>(va.w, q) + vb.w, q);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_vec_gelu(const float* __restrict__ x, float* __restrict__ out, int64_t n, int first_order, VQ q) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -176,6 +296,16 @@ int msq_vec_layernorm(const float* x, const float* weight, const float* bias, fl
     if (!x || !weight || !bias || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_layernorm: null buffer");
     if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
     if (H * 4 > 160 * 1024 - 1024) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_layernorm: a row must fit the CU's LDS (H <= 40704)");
+    const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
+    if (H % 512 == 0 && H <= 8192 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(weight) |
+                                       reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
+        const size_t l2 = (size_t)H * 4 + 513 * 4;
+        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+            hipLaunchKernelGGL(k_vec_layernorm_par<1>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
+        else
+            hipLaunchKernelGGL(k_vec_layernorm_par<0>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
+        return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_layernorm: launch failed");
+    }
     const size_t lds = (size_t)H * 4;
     if (lds > 65536) hipFuncSetAttribute((const void*)k_vec_layernorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_vec_layernorm, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, x, weight, bias, out, rows, H, eps,
@@ -189,8 +319,18 @@ int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bit
     if (n == 0) return MSQ_OK;
     if (!x || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_gelu: null buffer");
     if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
-    hipLaunchKernelGGL(k_vec_gelu, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, first_order,
-                       VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
+    const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 4) {
+        const int64_t n4 = n / 4;
+        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+            hipLaunchKernelGGL(k_vec_gelu4<1>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, x, out, n4, first_order, vq);
+        else
+            hipLaunchKernelGGL(k_vec_gelu4<0>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, x, out, n4, first_order, vq);
+        done = n4 * 4;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_vec_gelu, dim3(grid1(n - done)), dim3(256), 0, (hipStream_t)stream, x + done, out + done, n - done, first_order, vq);
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_gelu: launch failed");
 }
 
@@ -200,8 +340,18 @@ int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int6
     if (n == 0) return MSQ_OK;
     if (!a || !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_add: null buffer");
     if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
-    hipLaunchKernelGGL(k_vec_add, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, b ? 0 : 1, b_scalar,
-                       VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
+    const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 4) {
+        const int64_t n4 = n / 4;
+        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+            hipLaunchKernelGGL(k_vec_add4<1>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4, b ? 0 : 1, b_scalar, vq);
+        else
+            hipLaunchKernelGGL(k_vec_add4<0>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4, b ? 0 : 1, b_scalar, vq);
+        done = n4 * 4;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_vec_add, dim3(grid1(n - done)), dim3(256), 0, (hipStream_t)stream, a + done, b ? b + done : nullptr, out + done, n - done, b ? 0 : 1, b_scalar, vq);
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_add: launch failed");
 }
 

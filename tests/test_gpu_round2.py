@@ -250,6 +250,32 @@ def test_vector_ops_golden_gpu(msq):
         msq.vector_ops.gelu(a.cpu(), mx_specs=specs)
 
 
+def test_vector_ops_wide_rows_vs_oracle(msq, O):
+    """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
+    kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
+    (bfloat12, round to even); ragged element counts exercise the scalar tails."""
+    g = torch.Generator(device=dev()).manual_seed(21)
+    cfgs = (({"bfloat": 16}, dict(bits=9)), ({"bfloat": 12, "round": "even"}, dict(bits=5, round="even")))
+    for sp, okw in cfgs:
+        specs = msq.specs.finalize_mx_specs(dict({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4,
+                                                  "block_size": 32, "custom_cuda": True}, **sp))
+        mn = float(msq.formats._get_max_norm(8, okw["bits"]))
+        for H in (512, 1536, 4096, 8192, 8704):                                        # 8704 = 17 * 512: the one-wave kernel
+            x = torch.randn(24, H, generator=g, device=dev()) * 3 + 0.5
+            w = torch.randn(H, generator=g, device=dev()) * 0.5 + 1.0
+            b = torch.randn(H, generator=g, device=dev()) * 0.1
+            y = msq.vector_ops.layer_norm(x, w, b, 1e-12, specs)
+            ref = O.vec_layernorm(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), 1e-12, okw["bits"], 8, mn, okw.get("round", "nearest"))
+            assert (y.cpu().numpy() == ref).all(), (sp, H)
+        for n in (4096 * 33, 1027):
+            a = torch.randn(n, generator=g, device=dev()) * 3; c = torch.randn(n, generator=g, device=dev()) * 50
+            y = msq.vector_ops.simd_add(a, c, mx_specs=specs)
+            assert (y.cpu().numpy() == O.vec_add(a.cpu().numpy(), c.cpu().numpy(), okw["bits"], 8, mn, okw.get("round", "nearest"))).all()
+            y = msq.vector_ops.gelu(a, mx_specs=specs).cpu().numpy()
+            ref = O.vec_gelu(a.cpu().numpy(), False, okw["bits"], 8, mn, okw.get("round", "nearest"))
+            assert (y != ref).sum() <= max(2, n // 3000), (sp, n, int((y != ref).sum()))   # device expf vs libm: isolated one-unit cases
+
+
 def test_mx_matmul_bmm_golden_gpu(msq, O):
     """mx.matmul ('aa' / 'aw' + bias / 'wa') and mx.bmm against the reference's CPU outputs (vec_ops.npz), which come from
     its PYTHON `_quantize_mx` (divisor `2**e + 1e-6`, mx_ops.py:444): selected with `reference_python_divisor()`; the
