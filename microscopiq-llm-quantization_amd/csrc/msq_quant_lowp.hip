@@ -65,6 +65,21 @@ template <int DT> MSQ_D float floor_log2_lowp(float v) {
     }
     return (m > c) ? (float)u : (float)k;
 }
+// x / d for the divisors of this file, which are R(2^e): a normal fp32 power of two has an exact reciprocal and
+// x * (1 / d) is the same correctly rounded quotient (one v_mul instead of the ~11-instruction IEEE division); 0, Inf,
+// NaN, subnormal or non-power divisors (possible only through under- / overflow of R(2^e)) take the real division.
+struct Div { float d, r; bool fast; };
+MSQ_D Div make_div(float d) {
+    const uint32_t u = f2u(d);
+    const uint32_t e = (u >> 23) & 0xFFu;
+    Div v; v.d = d; v.fast = ((u & 0x807FFFFFu) == 0u) && e >= 1u && e <= 253u;
+    v.r = u2f((254u - e) << 23);
+    return v;
+}
+MSQ_D float divp(float x, const Div& v) {
+    if (__builtin_expect(v.fast, 1)) return x * v.r;
+    return x / v.d;
+}
 template <int DT> MSQ_D float pow2_lowp(float e) { return Rr<DT>(exp2f_int(e)); }     // R(powf(2, e))
 
 // elemwise_ops.py:47-78
@@ -92,12 +107,12 @@ template <int DT> MSQ_D float core_lowp(float a, const Fmt& f, int rmode) {
         pe = (pe == pe && pe < min_exp) ? min_exp : pe;
         p2 = pow2_lowp<DT>(pe);
     }
-    const float sh = pow2i(f.mbits - 2);
-    if (have_pe) out = Rr<DT>(Rr<DT>(out / p2) * sh);
+    const float sh = pow2i(f.mbits - 2), rsh = pow2i(2 - f.mbits);      // out / sh == out * rsh exactly
+    if (have_pe) out = Rr<DT>(Rr<DT>(divp(out, make_div(p2))) * sh);
     else out = Rr<DT>(out * sh);
     out = round_mantissa_lowp<DT>(out, rmode);
-    if (have_pe) out = Rr<DT>(Rr<DT>(out / sh) * p2);
-    else out = Rr<DT>(out / sh);
+    if (have_pe) out = Rr<DT>(Rr<DT>(out * rsh) * p2);
+    else out = Rr<DT>(out * rsh);
     const float mn = Rr<DT>(f.max_norm);
     if (out == out) { out = out < -mn ? -mn : out; out = out > mn ? mn : out; }
     if (__builtin_isinf(a)) out = a;
@@ -146,12 +161,13 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     se_in = Rr<DT>(se_in - (float)A.fi.emax);                           // :207
     se_in = clamp_scale_exp(se_in, A.in_sb, 0);                         // :208-211
     const float sc_in = pow2_lowp<DT>(se_in);
+    const Div d_in = make_div(sc_in);
     float mx_out = 0.f;
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         float v = inl[b];
         if (fl) v = v * 0.f;
-        v = Rr<DT>(v / sc_in);                                          // :214
+        v = Rr<DT>(divp(v, d_in));                                      // :214
         a[b] = Rr<DT>(a[b] * sc_in);                                    // :216
         v = core_lowp<DT>(v, A.fi, A.rmode);                            // :218-221
         v = Rr<DT>(v * sc_in);                                          // :224
@@ -166,12 +182,13 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     se_out = clamp_scale_exp(se_out, A.out_sb, 0);                      // :239-242
     if (se_out != se_out) status |= MSQ_STATUS_NAN;
     const float sc_out = pow2_lowp<DT>(se_out);
+    const Div d_out = make_div(sc_out);
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
-        float o = Rr<DT>(a[b] / sc_out);                                // :247
+        float o = Rr<DT>(divp(a[b], d_out));                            // :247
         if (o != o) status |= MSQ_STATUS_NAN;                           // :250
         o = core_lowp<DT>(o, A.fo, A.rmode);                            // :252-255
-        o = Rr<DT>(Rr<DT>(o * sc_out) / sc_in);                         // :258
+        o = Rr<DT>(divp(Rr<DT>(o * sc_out), d_in));                     // :258
         a[b] = Rr<DT>(inl[b] + o);                                      // :262
     }
     se_in_o = se_in; se_out_o = se_out;
@@ -192,9 +209,22 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     const int64_t a0 = nb * BS;
     const int64_t base = (p * A.axis_len + a0) * A.post + q;
     float a[BS];
+    // blocks along the contiguous axis: the lane's block is BS * 2 contiguous bytes -> 16-byte accesses
+    const bool vec = (BS % 8 == 0) && A.post == 1 && (A.axis_len % BS) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) {
 #pragma unroll
-    for (int b = 0; b < BS; ++b)
-        a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;     // zero padding, :563-583
+        for (int c = 0; c < BS / 8; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+            v.u = *reinterpret_cast<const uint4*>(in + base + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[c * 8 + j] = ld16<DT>(v.h, j);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+            a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;     // zero padding, :563-583
+    }
     int order = 1;                                           // reduced dim contiguous
     if (A.post > 1) {
         const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
@@ -203,11 +233,25 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     uint32_t mkw[(BS + 31) / 32];
     float se_in, se_out;
     const int status = outlier_block_lowp<BS, DT>(a, mkw, se_in, se_out, A, order);
+    if (vec) {
 #pragma unroll
-    for (int b = 0; b < BS; ++b) {
-        if (a0 + b < A.axis_len) {
-            st16<DT>(out, base + (int64_t)b * A.post, a[b]);
-            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        for (int c = 0; c < BS / 8; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, a[c * 8 + j]);
+            *reinterpret_cast<uint4*>(out + base + c * 8) = v.u;
+        }
+        if (A.mask) {
+#pragma unroll
+            for (int b = 0; b < BS; ++b) A.mask[base + b] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            if (a0 + b < A.axis_len) {
+                st16<DT>(out, base + (int64_t)b * A.post, a[b]);
+                if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+            }
         }
     }
     if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
