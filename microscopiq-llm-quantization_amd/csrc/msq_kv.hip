@@ -147,10 +147,182 @@ k_kv_channel(const typename KvIO<DT>::T* __restrict__ in, typename KvIO<DT>::T* 
         KvIO<DT>::st(out, base + i * D, kv_codec(KvIO<DT>::ld(in, base + i * D), mn, scale));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast forms for tensors of fewer than 2^31 16-byte chunks: 32-bit index arithmetic with host-computed multiply-shift
+// division (the 64-bit / and % of the general kernels cost more than the quantiser itself).
+// ---------------------------------------------------------------------------------------------------------------------
+struct FastDiv { uint32_t d, mul, shr; };                            // n / d for n < 2^31: d == 1 ? n : umulhi(n, mul) >> shr
+MSQ_D uint32_t fdiv(uint32_t n, const FastDiv& f) { return f.d == 1u ? n : (__umulhi(n, f.mul) >> f.shr); }
+
+template <int DT> struct Chunk;                                      // one 16-byte access: 8 half / bf16 values or 4 floats
+template <> struct Chunk<0> { static constexpr int N = 4; };
+template <> struct Chunk<1> { static constexpr int N = 8; };
+template <> struct Chunk<2> { static constexpr int N = 8; };
+template <int DT> MSQ_D void unpack16(const uint4& raw, float* x) {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    if (DT == 0) { x[0] = u2f(w[0]); x[1] = u2f(w[1]); x[2] = u2f(w[2]); x[3] = u2f(w[3]); return; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (DT == 1) { x[2 * k] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] & 0xFFFFu)); x[2 * k + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[k] >> 16)); }
+        else { x[2 * k] = u2f(w[k] << 16); x[2 * k + 1] = u2f(w[k] & 0xFFFF0000u); }
+    }
+}
+template <int DT> MSQ_D uint4 pack16(const float* y) {
+    if (DT == 0) return make_uint4(f2u(y[0]), f2u(y[1]), f2u(y[2]), f2u(y[3]));
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (DT == 1) w[k] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)y[2 * k]) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)y[2 * k + 1]) << 16);
+        else w[k] = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)y[2 * k]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)y[2 * k + 1]) << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// groups along head.dim of one token, LPG = group_size / Chunk::N lanes per group (power of two <= 64): every lane owns
+// one 16-byte chunk; chunk q -> row = q / CPR (b, s), cr = q % CPR -> head cr / DC, offset cr % DC (CPR = H D / N, DC = D / N)
+template <int DT, int LPG>
+__global__ void __launch_bounds__(256)
+k_kv_token_fast(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t nq, uint32_t H, uint32_t S, FastDiv cpr, FastDiv dc,
+                FastDiv sdiv, float levels) {
+    constexpr int N = Chunk<DT>::N;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t q0 = blockIdx.x * 256u; q0 < nq; q0 += stride) {
+        const uint32_t q = q0 + threadIdx.x;
+        const bool live = q < nq;
+        const uint32_t qq = live ? q : 0u;
+        const uint32_t row = fdiv(qq, cpr), cr = qq - row * cpr.d;
+        const uint32_t h = fdiv(cr, dc), dv = cr - h * dc.d;
+        const uint32_t b = fdiv(row, sdiv), s = row - b * sdiv.d;
+        const uint32_t a = ((b * H + h) * S + s) * dc.d + dv;          // in 16-byte chunks
+        float x[N];
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+        if (live) {
+            unpack16<DT>(in[a], x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) { mx = nmax(mx, x[k]); mn = nmin(mn, x[k]); }
+        }
+#pragma unroll
+        for (int o = 1; o < LPG; o <<= 1) {
+            mx = nmax(mx, __shfl_xor(mx, o, 64));
+            mn = nmin(mn, __shfl_xor(mn, o, 64));
+        }
+        if (live) {
+            const float scale = (mx - mn) / levels;                    // :26
+            float y[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn, scale);
+            out[a] = pack16<DT>(y);
+        }
+    }
+}
+
+// groups of gs <= 32 tokens of one channel: a lane owns one 16-byte chunk of channels over the gs tokens of its group, the
+// raw chunks stay in registers between the min / max scan and the quantisation.  t -> dv = t % DC, g = (t / DC) % ngrp, bh
+template <int DT>
+__global__ void __launch_bounds__(256)
+k_kv_channel_fast(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t total, uint32_t S, uint32_t gs, FastDiv dc,
+                  FastDiv ng, float levels) {
+    constexpr int N = Chunk<DT>::N;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t u = fdiv(t, dc), dv = t - u * dc.d;
+    const uint32_t bh = fdiv(u, ng), g = u - bh * ng.d;
+    const uint32_t base = (bh * S + g * gs) * dc.d + dv;
+    uint4 raw[32];
+    float mx[N], mn[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { mx[k] = -__builtin_inff(); mn[k] = __builtin_inff(); }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)i < gs) raw[i] = in[base + (uint32_t)i * dc.d];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if ((uint32_t)i < gs) {
+            float x[N];
+            unpack16<DT>(raw[i], x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], x[k]); mn[k] = nmin(mn[k], x[k]); }
+        }
+    }
+    float scale[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) scale[k] = (mx[k] - mn[k]) / levels;  // :57
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if ((uint32_t)i < gs) {
+            float x[N], y[N];
+            unpack16<DT>(raw[i], x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn[k], scale[k]);
+            out[base + (uint32_t)i * dc.d] = pack16<DT>(y);
+        }
+    }
+}
+
+// the same for gs = 8 LG tokens (LG a power of two <= 64): LG neighbouring lanes share a group, 8 tokens each -- four
+// times the waves of the one-lane form at gs = 32 (the [1, 32, 4096, 128] cache has only 1024 waves there) and groups of
+// up to 512 tokens.  t -> j = t % LG (token eighth), dv = (t / LG) % DC, g, bh
+template <int DT, int LG>
+__global__ void __launch_bounds__(256)
+k_kv_channel_fast8(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t total, uint32_t S, FastDiv dc, FastDiv ng, float levels) {
+    constexpr int N = Chunk<DT>::N;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool live = t < total;                                      // total is a multiple of LG: groups are never partial
+    const uint32_t tt = live ? t : 0u;
+    const uint32_t j = tt % LG, r = tt / LG;
+    const uint32_t u = fdiv(r, dc), dv = r - u * dc.d;
+    const uint32_t bh = fdiv(u, ng), g = u - bh * ng.d;
+    const uint32_t base = (bh * S + g * (8u * LG) + j * 8u) * dc.d + dv;
+    uint4 raw[8];
+    float mx[N], mn[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { mx[k] = -__builtin_inff(); mn[k] = __builtin_inff(); }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[i] = in[base + (uint32_t)i * dc.d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float x[N];
+            unpack16<DT>(raw[i], x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], x[k]); mn[k] = nmin(mn[k], x[k]); }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LG; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], __shfl_xor(mx[k], o, 64)); mn[k] = nmin(mn[k], __shfl_xor(mn[k], o, 64)); }
+    }
+    if (!live) return;
+    float scale[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) scale[k] = (mx[k] - mn[k]) / levels;  // :57
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x[N], y[N];
+        unpack16<DT>(raw[i], x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn[k], scale[k]);
+        out[base + (uint32_t)i * dc.d] = pack16<DT>(y);
+    }
+}
+
 }  // namespace
 
 extern "C" void msq_set_error_(const char* msg);      // msq_quant.hip: the message msq_last_error() returns
 static int kv_fail(int code, const char* msg) { msq_set_error_(msg); return code; }
+static FastDiv make_fastdiv(uint32_t d) {             // exact for n < 2^31 (Granlund-Montgomery round-up multiplier)
+    FastDiv f{d, 0u, 0u};
+    if (d <= 1u) return f;
+    uint32_t l = 0; while ((1ull << l) < d) ++l;      // ceil(log2 d)
+    const uint32_t p = 31u + l;
+    f.mul = (uint32_t)(((1ull << p) + d - 1ull) / d);
+    f.shr = p - 32u;
+    return f;
+}
 
 extern "C" {
 
@@ -167,6 +339,32 @@ int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t 
     if (along_tokens) {
         // compress_function.py:50-52: group_num = seq // group_size, then .view(batch, group_num, group_size, H * D)
         if (S % group_size) return kv_fail(MSQ_ERR_BAD_ARG, "msq_kv_group_quant: group_size must divide the sequence length (the reference's view() raises)");
+        const int cn = dtype == 0 ? 4 : 8;
+        const bool al = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+        const int64_t lg = group_size / 8;
+        if (al && D % cn == 0 && group_size % 8 == 0 && lg <= 64 && (lg & (lg - 1)) == 0 && B * H * S * D / cn < (int64_t)0x7FFFFFFF) {
+            const uint32_t DC = (uint32_t)(D / cn), ngrp = (uint32_t)(S / group_size);
+            const uint32_t tot = (uint32_t)(B * H) * ngrp * DC * (uint32_t)lg;
+            const dim3 grid((tot + 255u) / 256u), blk(256);
+            const FastDiv fdc = make_fastdiv(DC), fng = make_fastdiv(ngrp);
+#define MSQ_KC(DTV, L) hipLaunchKernelGGL((k_kv_channel_fast8<DTV, L>), grid, blk, 0, st, (const uint4*)in, (uint4*)out, tot, (uint32_t)S, fdc, fng, levels)
+#define MSQ_KCL(DTV) do { switch ((int)lg) { case 1: MSQ_KC(DTV, 1); break; case 2: MSQ_KC(DTV, 2); break; case 4: MSQ_KC(DTV, 4); break; \
+                       case 8: MSQ_KC(DTV, 8); break; case 16: MSQ_KC(DTV, 16); break; case 32: MSQ_KC(DTV, 32); break; default: MSQ_KC(DTV, 64); break; } } while (0)
+            if (dtype == 0) MSQ_KCL(0); else if (dtype == 1) MSQ_KCL(1); else MSQ_KCL(2);
+#undef MSQ_KCL
+#undef MSQ_KC
+            return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
+        }
+        if (al && D % cn == 0 && group_size <= 32 && B * H * S * D / cn < (int64_t)0x7FFFFFFF) {
+            const uint32_t DC = (uint32_t)(D / cn), ngrp = (uint32_t)(S / group_size);
+            const uint32_t tot = (uint32_t)(B * H) * ngrp * DC;
+            const dim3 grid((tot + 255u) / 256u), blk(256);
+            const FastDiv fdc = make_fastdiv(DC), fng = make_fastdiv(ngrp);
+            if (dtype == 0) hipLaunchKernelGGL(k_kv_channel_fast<0>, grid, blk, 0, st, (const uint4*)in, (uint4*)out, tot, (uint32_t)S, (uint32_t)group_size, fdc, fng, levels);
+            else if (dtype == 1) hipLaunchKernelGGL(k_kv_channel_fast<1>, grid, blk, 0, st, (const uint4*)in, (uint4*)out, tot, (uint32_t)S, (uint32_t)group_size, fdc, fng, levels);
+            else hipLaunchKernelGGL(k_kv_channel_fast<2>, grid, blk, 0, st, (const uint4*)in, (uint4*)out, tot, (uint32_t)S, (uint32_t)group_size, fdc, fng, levels);
+            return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
+        }
         const int64_t total = B * H * (S / group_size) * D;
         const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
         if (dtype == 0) hipLaunchKernelGGL(k_kv_channel<0>, grid, blk, 0, st, (const float*)in, (float*)out, B, H, S, D, group_size, levels);
@@ -177,6 +375,25 @@ int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t 
         if ((H * D) % group_size) return kv_fail(MSQ_ERR_BAD_ARG, "group_size should be a factor of the last dimension size");
         // V = 8 entries per lane (16-byte accesses) when the geometry and the alignment allow it, else one entry per lane;
         // a lane keeps at most 16 chunks in registers: groups of more than 64 * V * 16 entries are not built
+        {
+            const int cn = dtype == 0 ? 4 : 8;
+            const bool al = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+            const int64_t lp = group_size / cn;
+            if (al && D % cn == 0 && group_size % cn == 0 && lp >= 1 && lp <= 64 && (lp & (lp - 1)) == 0 &&
+                B * H * S * D / cn < (int64_t)0x7FFFFFFF) {
+                const uint32_t nq = (uint32_t)(B * H * S * D / cn);
+                const FastDiv fcpr = make_fastdiv((uint32_t)(H * D / cn)), fdc = make_fastdiv((uint32_t)(D / cn)), fs = make_fastdiv((uint32_t)S);
+                uint32_t gblocks = (nq + 255u) / 256u; if (gblocks > 256u * 16u) gblocks = 256u * 16u;
+                const dim3 grid(gblocks), blk(256);
+#define MSQ_KVF(DTV, L) hipLaunchKernelGGL((k_kv_token_fast<DTV, L>), grid, blk, 0, st, (const uint4*)in, (uint4*)out, nq, (uint32_t)H, (uint32_t)S, fcpr, fdc, fs, levels)
+#define MSQ_KVFL(DTV) do { switch ((int)lp) { case 1: MSQ_KVF(DTV, 1); break; case 2: MSQ_KVF(DTV, 2); break; case 4: MSQ_KVF(DTV, 4); break; \
+                        case 8: MSQ_KVF(DTV, 8); break; case 16: MSQ_KVF(DTV, 16); break; case 32: MSQ_KVF(DTV, 32); break; default: MSQ_KVF(DTV, 64); break; } } while (0)
+                if (dtype == 0) MSQ_KVFL(0); else if (dtype == 1) MSQ_KVFL(1); else MSQ_KVFL(2);
+#undef MSQ_KVFL
+#undef MSQ_KVF
+                return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
+            }
+        }
         const bool v8 = (D % 8 == 0) && (group_size % 8 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
         const int V = v8 ? 8 : 1;
         const int64_t chunks = group_size / V;
