@@ -1407,13 +1407,21 @@ static int pick_ksplit(int64_t M, int64_t N, int64_t K, int mf = 8) {
     const int64_t KT = K / BK;
     if (forced > 0) return forced < KT ? forced : (int)KT;
     if (blocks >= 192 || KT < 8) return 1;
-    // measured (scripts/experiments/ks_sweep.py, ks_sweep_graph.py): best is about one block per CU, power-of-two
-    // splits (even K chunks); the cost model below was tried here too and lost where pick_wm takes 256-row blocks
-    int64_t ks = 1;
-    while (ks * blocks < 256) ks *= 2;
-    if (ks > KT / 4) ks = KT / 4;
-    if (ks > 32) ks = 32;
-    return ks < 1 ? 1 : (int)ks;
+    // cost model fitted to HIP-graph replays of the four Llama-7B shapes at M = 65 ... 512 (scripts/experiments/
+    // ks_sweep_graph.py, round 2): a block spends ~0.62 us per K-step (the 128 x 256 tile is MFMA-bound per step
+    // whatever M is), 256 blocks run at a time, and the fp32 partial planes cost ~0.4 us per MB (written by the GEMM's
+    // epilogue, read back by k_splitk_reduce).  It picks the measured best split in all 16 sweep cells; the earlier
+    // "fill 256 blocks" rule over-split short K (4096 x 4096 M 65: 18.9 -> 17.1 us, M 256: 24.9 -> 23.1) and
+    // under-used one pass for wide N (11008 x 4096 M 512: 58.2 -> 50.2 us).
+    int best = 1;
+    double best_t = 1e30;
+    for (int ks = 1; ks <= 32 && ks * 2 <= KT; ks *= 2) {
+        const double rounds = (double)((blocks * ks + 255) / 256);
+        const double mb = (ks > 1) ? (double)ks * (double)M * (double)N * 4.0e-6 : 0.0;
+        const double t = 0.62 * (double)((KT + ks - 1) / ks) * rounds + 0.4 * mb;
+        if (t < best_t) { best_t = t; best = ks; }
+    }
+    return best;
 }
 
 // Decode kernel or (split-K) GEMM.  Measured from HIP graphs (scripts/experiments/mx_midm_check.py): with the LDS
