@@ -290,6 +290,24 @@ int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w
                         const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* MX-FP6 weights on the same path -- NEW: plain OCP-MX fp6_e3m2 / fp6_e2m3 weight codes (number_system/mx/formats.py:76-79,
+ * mx_ops.py:332-457 native semantics, block 32 along K) as a true 6-bit plane in the fp6 operand order of the scaled MFMA:
+ * lane (n % 16, kg) of slot nf holds k = 32 kg .. +31 of the 128-k tile as 32 six-bit codes (little endian) = 24 bytes, stored
+ * as a 16-byte and an 8-byte piece, 1.5 KiB per (tile, nf); one E8M0 scale byte per 32 weights: 6.25 bits per weight.
+ *   msq_mx_pack_w6: W [N,K] f32 -> codes [N*K*3/4] bytes + scales [N*K/32] bytes.  N % 64 == 0, K % 128 == 0;
+ *                   w_format MSQ_FMT_FP6_E3M2 or MSQ_FMT_FP6_E2M3.
+ *   msq_qlinear_mx_w6a8: as msq_qlinear_mx_w4a8 with that weight operand (same workspace size).  Activations whose codes
+ *                   hold fp6 values (every fp6 value is an e4m3 value) give the W6A6 product of the fp6 spec exactly. */
+int msq_mx_pack_w6(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K, int w_format,
+                   int flush_fp32_subnorms, void* stream);
+/* msq_mx_pack_a6: as msq_mx_pack_a8, but X is quantised to MX-FP6 (a_format, fp6 block scale) and the fp6 VALUES are
+ * stored as e4m3 codes with that scale (exact) for the fp8 activation operand. */
+int msq_mx_pack_a6(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K, int a_format,
+                   int flush_fp32_subnorms, void* stream);
+int msq_qlinear_mx_w6a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales,
+                        const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_format,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * KV-cache group quantisation at the GEAR hook (BASELINE config 4).  Replaces
  * kv_quant/GEARLM/Simulated/compress_function.py:8-38 fake_groupwise_token_asymmetric_quantization (along_tokens = 0:

@@ -28,6 +28,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 #ifndef MSQ_MX_PIN_READS
 #define MSQ_MX_PIN_READS 0   /* 1: sched_barrier between the LDS prefetch of group mf + 1 and the MFMAs of group mf (hipcc sinks the reads below them); same-box A/B 99.7 vs 99.5 us: the second wave of the SIMD already covers the wait */
@@ -505,7 +506,6 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     const uint32_t scl_tile_bytes = (uint32_t)scl_groups * (uint32_t)SCLB;
     auto load_scales = [&](uint32_t tile) -> u32x4_t {
         if (SCLB == 16) return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.scl, scl_lane_off, uni(tile * scl_tile_bytes), 0));
-        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(pr.scl, scl_lane_off, uni(tile * scl_tile_bytes), 0));
         return u32x4_t{v[0], v[1], 0u, 0u};
     };
@@ -685,12 +685,18 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // kernel sits at the register limit; hipcc used to park loop-invariant LDS addresses in scratch and a reload behind
 // the weight loads made every K-step wait for the loads it had just issued (in-order vmcnt): those addresses are
 // re-derived from the lane id inside the loop instead (no spills).
-template <typename YT, bool W8>
+// WF = weight operand format: 0 e2m1 (16 B per lane and 16 n), 1 e4m3 (32 B in two half-slots), 2 / 3 = fp6 e2m3 / e3m2
+// (the MFMA's own format codes; 24 B per lane: a 16-byte and an 8-byte piece, 1.5 KiB per fragment slot = 6 bits per
+// weight; lane (n % 16, kg) holds k = 32 kg .. +31, six bits each, little endian: scripts/experiments/mx_mfma_layout_fp6.hip).
+// The fp6 operand uses the two-deep ring and the register budget of the e4m3 operand.
+template <typename YT, int WF>
 __global__ void __launch_bounds__(256, 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool W8 = (WF != 0);                                // wide operand: two pieces per fragment, two-deep ring
+    constexpr bool W6 = (WF >= 2);
     constexpr int BMX = 128, KS = 128, A_TILE = BMX * KS;         // 16 KiB per activation buffer
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -715,7 +721,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     } else { bm = bid % MT; bn = bid / MT; }
     const int m0 = bm * BMX, n0 = bn * BN;
     const int64_t wtiles = (int64_t)(N / 64) * KT;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * (W8 ? 8192 : 4096));
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * (W6 ? 6144 : (W8 ? 8192 : 4096)));
     const __amdgpu_buffer_rsrc_t wsr = make_rsrc(Ws, wtiles * 256);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(Xc, (int64_t)M * K);
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(Xs, (int64_t)M * (K / 32));
@@ -768,11 +774,19 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-            for (int h = 0; h < WV; ++h)
-                ws.w[nf][h] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni((((tile_row32 + (uint32_t)kt) * 4u + nf) * WV + h) * 1024u), 0));
+            for (int h = 0; h < WV; ++h) {
+                if (W6 && h == 1) {
+                    const u32x2_t t2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(wr, lane * 8, uni(((tile_row32 + (uint32_t)kt) * 4u + nf) * 1536u + 1024u), 0));
+                    ws.w[nf][1] = u32x4_t{t2[0], t2[1], 0u, 0u};
+                } else if (W6) {
+                    ws.w[nf][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni(((tile_row32 + (uint32_t)kt) * 4u + nf) * 1536u), 0));
+                } else {
+                    ws.w[nf][h] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, lane16, uni((((tile_row32 + (uint32_t)kt) * 4u + nf) * WV + h) * 1024u), 0));
+                }
+            }
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
-    constexpr int CBSZ = W8 ? 0 : 4;                             // A-operand format: e4m3 / e2m1
+    constexpr int CBSZ = W6 ? WF : (W8 ? 0 : 4);                 // A-operand format: e2m3 / e3m2 / e4m3 / e2m1
     constexpr int N_WAIT_MX = W8 ? 5 : (XBUFS == 4 ? 15 : 10);
     const int kl = sgpr((kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1));   // an empty split runs a harmless prologue
     const int kf0 = sgpr((kt_lo < KT) ? kt_lo : KT - 1), kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
@@ -861,7 +875,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 // of K (nkb == 1, `direct`) wave 0 adds the bias and writes Y itself: one launch, no partial planes, no reduce kernel.
 // NFB = 16-column fragments per block: 4 (the whole 64-column strip) or 2 (half strips: twice the blocks for the
 // narrow projections, where 64 blocks leave three quarters of the CUs without work)
-template <bool W8, int MG, int WAVES, int NFB = 4>
+template <int WF, int MG, int WAVES, int NFB = 4>
 __global__ void __launch_bounds__(64 * WAVES)
 k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, float* __restrict__ partial, int M, int N, int K, int kc,
@@ -894,13 +908,23 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     for (int i = 0; i < NFB; ++i)
 #pragma unroll
         for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int WV = W8 ? 2 : 1, CBSZ = W8 ? 0 : 4;
+    constexpr bool W8 = (WF != 0), W6 = (WF >= 2);               // as k_mxgemm
+    constexpr int WV = W8 ? 2 : 1, CBSZ = W6 ? WF : (W8 ? 0 : 4);
     struct WT { u32x4_t w[NFB][WV]; uint32_t s; };
     auto load_w = [&](WT& t, int64_t tile) {
 #pragma unroll
         for (int nf = 0; nf < NFB; ++nf)
 #pragma unroll
-            for (int h = 0; h < WV; ++h) t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16);
+            for (int h = 0; h < WV; ++h) {
+                if (W6 && h == 1) {
+                    const u32x2_t t2 = *reinterpret_cast<const u32x2_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + 1024 + lane * 8);
+                    t.w[nf][1] = u32x4_t{t2[0], t2[1], 0u, 0u};
+                } else if (W6) {
+                    t.w[nf][0] = *reinterpret_cast<const u32x4_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + lane * 16);
+                } else {
+                    t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16);
+                }
+            }
         t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4) >> (8 * nf0);       // byte nf of the dword = fragment nf0 + nf
     };
     // tiles in flight ahead of the one being multiplied: 1 with four waves per block (~3000 waves in the grid), 2 with
@@ -1680,7 +1704,8 @@ int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int ks = pick_mx_ksplit(M, N, K);
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
-static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+// wf: weight operand format of k_mxgemm (0 e2m1, 1 e4m3, 2 fp6 e2m3, 3 fp6 e3m2)
+static int mx_linear(int wf, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
                      void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
                      void* stream) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: negative M");
@@ -1709,19 +1734,19 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
                      if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_done(once_); } \
                      hipLaunchKernelGGL((k_mxgemv<W8V, MGV, 16, 2>), dim3((unsigned)(N / 32)), dim3(1024), ldsh, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
                                         (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, 1, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
-                if (mg == 1) { if (w8) MSQ_MXH(true, 1); else MSQ_MXH(false, 1); }
-                else { if (w8) MSQ_MXH(true, 2); else MSQ_MXH(false, 2); }
+                if (mg == 1) { if (wf == 0) MSQ_MXH(0, 1); else if (wf == 1) MSQ_MXH(1, 1); else if (wf == 2) MSQ_MXH(2, 1); else MSQ_MXH(3, 1); }
+                else { if (wf == 0) MSQ_MXH(0, 2); else if (wf == 1) MSQ_MXH(1, 2); else if (wf == 2) MSQ_MXH(2, 2); else MSQ_MXH(3, 2); }
 #undef MSQ_MXH
                 return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, half strips)");
             }
             if (kcd) {
-                if (mg == 1) { if (w8) MSQ_MXV(true, 1, 16); else MSQ_MXV(false, 1, 16); }
-                else { if (w8) MSQ_MXV(true, 2, 16); else MSQ_MXV(false, 2, 16); }
+                if (mg == 1) { if (wf == 0) MSQ_MXV(0, 1, 16); else if (wf == 1) MSQ_MXV(1, 1, 16); else if (wf == 2) MSQ_MXV(2, 1, 16); else MSQ_MXV(3, 1, 16); }
+                else { if (wf == 0) MSQ_MXV(0, 2, 16); else if (wf == 1) MSQ_MXV(1, 2, 16); else if (wf == 2) MSQ_MXV(2, 2, 16); else MSQ_MXV(3, 2, 16); }
                 return check_launch2("msq_qlinear_mx_w4a8(decode, single launch)");
             }
-            if (mg == 1) { if (w8) MSQ_MXV(true, 1, 4); else MSQ_MXV(false, 1, 4); }
-            else if (mg == 2) { if (w8) MSQ_MXV(true, 2, 4); else MSQ_MXV(false, 2, 4); }
-            else { if (w8) MSQ_MXV(true, 4, 4); else MSQ_MXV(false, 4, 4); }
+            if (mg == 1) { if (wf == 0) MSQ_MXV(0, 1, 4); else if (wf == 1) MSQ_MXV(1, 1, 4); else if (wf == 2) MSQ_MXV(2, 1, 4); else MSQ_MXV(3, 1, 4); }
+            else if (mg == 2) { if (wf == 0) MSQ_MXV(0, 2, 4); else if (wf == 1) MSQ_MXV(1, 2, 4); else if (wf == 2) MSQ_MXV(2, 2, 4); else MSQ_MXV(3, 2, 4); }
+            else { if (wf == 0) MSQ_MXV(0, 4, 4); else if (wf == 1) MSQ_MXV(1, 4, 4); else if (wf == 2) MSQ_MXV(2, 4, 4); else MSQ_MXV(3, 4, 4); }
 #undef MSQ_MXV
             int rc0 = check_launch2("msq_qlinear_mx_w4a8(decode)");
             if (rc0) return rc0;
@@ -1736,15 +1761,15 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
     int ksplit = pick_mx_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
-    const size_t lds = (size_t)(w8 ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
+    const size_t lds = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
     float* partial = (float*)workspace;
 #define MSQ_MXL(YT, W8V)                                                                                              \
     do { static DevOnce once_;                                                                                 \
          if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
                             (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } while (0)
-    if (y_dtype == 0) { if (w8) MSQ_MXL(float, true); else MSQ_MXL(float, false); }
-    else { if (w8) MSQ_MXL(uint16_t, true); else MSQ_MXL(uint16_t, false); }
+    if (y_dtype == 0) { if (wf == 0) MSQ_MXL(float, 0); else if (wf == 1) MSQ_MXL(float, 1); else if (wf == 2) MSQ_MXL(float, 2); else MSQ_MXL(float, 3); }
+    else { if (wf == 0) MSQ_MXL(uint16_t, 0); else if (wf == 1) MSQ_MXL(uint16_t, 1); else if (wf == 2) MSQ_MXL(uint16_t, 2); else MSQ_MXL(uint16_t, 3); }
 #undef MSQ_MXL
     int rc = check_launch2("msq_qlinear_mx_w4a8");
     if (rc || ksplit == 1) return rc;
@@ -1757,12 +1782,20 @@ static int mx_linear(bool w8, const void* x_codes, const void* x_scales, const v
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
                         void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
                         void* stream) {
-    return mx_linear(false, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
+    return mx_linear(0, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
 }
 int msq_qlinear_mx_w8a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
                         void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
                         void* stream) {
-    return mx_linear(true, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
+    return mx_linear(1, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace, workspace_bytes, stream);
+}
+int msq_qlinear_mx_w6a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                        void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_format, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+    if (w_format != MSQ_FMT_FP6_E3M2 && w_format != MSQ_FMT_FP6_E2M3)
+        return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w6a8: w_format must be MSQ_FMT_FP6_E3M2 or MSQ_FMT_FP6_E2M3");
+    return mx_linear(w_format == MSQ_FMT_FP6_E3M2 ? 3 : 2, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace,
+                     workspace_bytes, stream);
 }
 
 }  // extern "C"

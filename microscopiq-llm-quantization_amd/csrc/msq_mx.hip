@@ -38,7 +38,9 @@ MSQ_D int mx_scale_byte(int max_biased_exp, int elem_emax, int& status) {
 // otherwise activations, e4m3 codes written back row-major through the same LDS tile.
 // MODE 0: activations (e4m3, row-major), 1: weights (e2m1, operand order), 2: exact values (e4m3, operand order)
 // XBF16: the source holds bfloat16 (activations of a bf16 model: every bf16 is an fp32 value, same results as casting first)
-template <int MODE, bool XBF16 = false>
+// AF6 (activations only): 3 / 2 = quantise to fp6_e3m2 / fp6_e2m3 VALUES with the fp6 block scale and store them as e4m3
+// codes (every fp6 value is an e4m3 normal: exact) -- the W6A6 product of the fp6 spec on the fp8 activation operand.
+template <int MODE, bool XBF16 = false, int AF6 = 0>
 __global__ void __launch_bounds__(256)
 k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t rows, int64_t K,
           int flush, int* status_flag) {
@@ -90,7 +92,7 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
 #pragma unroll
     for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
     const bool fl = (se == 0) && flush && !VAL;
-    int sb = mx_scale_byte(se, FP4 ? 2 : 8, status);
+    int sb = mx_scale_byte(se, FP4 ? 2 : (AF6 == 3 ? 4 : (AF6 == 2 ? 2 : 8)), status);
     if (VAL) {                                                   // MSQ-U1 rule: max |v| 2^-s in [256, 448] or (448, 512) -> s + 1
         float mx = 0.f;
 #pragma unroll
@@ -104,13 +106,18 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
         if (su > 127) { su = 127; status |= MSQ_STATUS_INEXACT; }
         sb = su + 127;
     }
-    const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
+    const float s_op = AF6 ? 1.0f : u2f((uint32_t)sb << 23);    // the converts read the exponent field only
     const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
     uint32_t cw[FP4 ? 4 : 8];
 #pragma unroll
     for (int p = 0; p < BS / 2; ++p) {
         typedef short v2s_t __attribute__((ext_vector_type(2)));
         float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | (VAL ? 0u : 1u)), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | (VAL ? 0u : 1u));
+        if (AF6) {                                               // fp6 value of a / 2^(sb - 127) (arithmetic codec), then an exact convert
+            const int sh = 127 - (sb == 255 ? 127 : sb);
+            x0 = fl ? 0.f : quant_bits(__builtin_ldexpf(a[2 * p], sh), AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
+            x1 = fl ? 0.f : quant_bits(__builtin_ldexpf(a[2 * p + 1], sh), AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
+        }
         if (FP4) {
             uint32_t w = (p & 3) ? cw[p >> 2] : 0u;
             if ((p & 3) == 0) w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, x0, x1, s_op, 0);
@@ -178,6 +185,76 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
     if (status && status_flag) atomicOr(status_flag, status);
 }
 
+// MX-FP6 weights (fp6_e3m2 / fp6_e2m3, formats.py:76-79) in the fp6 operand order of the scaled MFMA: lane (n % 16, kg) of
+// slot nf holds k = 32 kg .. +31 of the 128-k tile as 32 six-bit codes, little endian, in 24 bytes -- stored as a 16-byte
+// piece and an 8-byte piece, 1.5 KiB per (tile, nf) = exactly 6 bits per weight (+ the E8M0 scale byte per 32:
+// 6.25 bits per weight).  The codes are those of the arithmetic element codec (quant_bits, the routine
+// msq_quantize_mx_by_tile uses): decoded, they ARE the oracle's quantize_mx values.
+template <int EB> MSQ_D uint32_t fp6_code(float q) {
+    constexpr int MB = 5 - EB, BIAS = (1 << (EB - 1)) - 1;
+    const uint32_t u = f2u(q), s = (u >> 31) << 5, a = u & 0x7FFFFFFFu;
+    if (a == 0u) return s;
+    const int E = (int)(a >> 23) - 127;
+    if (E >= 1 - BIAS) return s | ((uint32_t)(E + BIAS) << MB) | ((a >> (23 - MB)) & ((1u << MB) - 1u));
+    return s | (uint32_t)__builtin_ldexpf(u2f(a), BIAS - 1 + MB);       // subnormal: m x 2^(1 - BIAS - MB), m = 1 .. 2^MB - 1
+}
+
+template <int EB>
+__global__ void __launch_bounds__(256)
+k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t rows, int64_t K,
+             int flush, int* status_flag) {
+    constexpr int BS = 32, LDS_STRIDE = BS + 4;
+    constexpr int EMAX = (EB == 3) ? 4 : 2, MBITS = (EB == 3) ? 4 : 5;
+    constexpr float MAXN = (EB == 3) ? 28.0f : 7.5f;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nblk = K / BS, nblocks = rows * nblk;            // rows % 64 == 0 and K % 128 == 0: every wave is full
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (g0 >= nblocks) return;
+    const int64_t g = g0 + lane;
+    float* tl = tile[wv];
+    float a[BS];
+    const float4* s4 = reinterpret_cast<const float4*>(src + g0 * BS);
+#pragma unroll
+    for (int t = 0; t < BS / 4; ++t) {
+        const int f = lane + 64 * t;
+        const int row = f / (BS / 4), c4 = f % (BS / 4);
+        *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = s4[f];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int c = 0; c < BS / 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
+        a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
+    }
+    int status = 0, se = 0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
+    const bool fl = (se == 0) && flush;
+    const int sb = mx_scale_byte(se, EMAX, status);
+    uint32_t w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (sb != 255) {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            const float si = fl ? 0.f : __builtin_ldexpf(a[b], 127 - sb);               // a / 2^(sb - 127), exact
+            const uint32_t cd = fp6_code<EB>(quant_bits(si, MBITS, EB, MAXN, 0, true, true));
+            const int bit = 6 * b;
+            w[bit >> 5] |= cd << (bit & 31);
+            if ((bit & 31) > 26) w[(bit >> 5) + 1] |= cd >> (32 - (bit & 31));
+        }
+    }
+    const int64_t r = g / nblk, kb = g % nblk;
+    const int64_t KT = K / 128;
+    const int64_t t = (r / 64) * KT + kb / 4;
+    const int nf = (int)((r % 64) / 16), ln = (int)((kb % 4) * 16 + (r % 16));
+    uint8_t* slot = codes + (t * 4 + nf) * 1536;
+    *reinterpret_cast<uint4*>(slot + ln * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint2*>(slot + 1024 + ln * 8) = make_uint2(w[4], w[5]);
+    scales[(t * 64 + ln) * 4 + nf] = (uint8_t)sb;
+    if (status && status_flag) atomicOr(status_flag, status);
+}
+
 }  // namespace
 
 extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
@@ -189,6 +266,24 @@ extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* st
     const int64_t nblocks = M * (K / 32);
     hipLaunchKernelGGL((k_mx_pack<0>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                        (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+extern "C" int msq_mx_pack_a6(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K, int a_format,
+                              int flush_fp32_subnorms, void* stream) {
+    if (M < 0 || K < 0) { msq_set_error_("msq_mx_pack_a6: negative size"); return MSQ_ERR_BAD_ARG; }
+    if (M == 0 || K == 0) return MSQ_OK;
+    if (K % 128) { msq_set_error_("msq_mx_pack_a6: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a6: null buffer"); return MSQ_ERR_BAD_ARG; }
+    if (a_format != MSQ_FMT_FP6_E3M2 && a_format != MSQ_FMT_FP6_E2M3) { msq_set_error_("msq_mx_pack_a6: a_format must be MSQ_FMT_FP6_E3M2 or MSQ_FMT_FP6_E2M3"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = M * (K / 32);
+    const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);
+    if (a_format == MSQ_FMT_FP6_E3M2)
+        hipLaunchKernelGGL((k_mx_pack<0, false, 3>), grid, blk, 0, (hipStream_t)stream, X, (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
+    else
+        hipLaunchKernelGGL((k_mx_pack<0, false, 2>), grid, blk, 0, (hipStream_t)stream, X, (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;
@@ -212,6 +307,22 @@ extern "C" int msq_mx_pack_w8(const float* Wq, void* codes, void* scales, int* s
     const int64_t nblocks = N * (K / 32);
     hipLaunchKernelGGL((k_mx_pack<2>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wq,
                        (uint8_t*)codes, (uint8_t*)scales, N, K, 0, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+extern "C" int msq_mx_pack_w6(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K, int w_format,
+                              int flush_fp32_subnorms, void* stream) {
+    if (N <= 0 || K <= 0 || (N % 64) || (K % 128)) { msq_set_error_("msq_mx_pack_w6: N must be a multiple of 64 and K of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!W || !codes || !scales) { msq_set_error_("msq_mx_pack_w6: null buffer"); return MSQ_ERR_BAD_ARG; }
+    if (w_format != MSQ_FMT_FP6_E3M2 && w_format != MSQ_FMT_FP6_E2M3) { msq_set_error_("msq_mx_pack_w6: w_format must be MSQ_FMT_FP6_E3M2 or MSQ_FMT_FP6_E2M3"); return MSQ_ERR_BAD_ARG; }
+    const int64_t nblocks = N * (K / 32);
+    const dim3 grid((unsigned)((nblocks + 255) / 256)), blk(256);
+    if (w_format == MSQ_FMT_FP6_E3M2)
+        hipLaunchKernelGGL((k_mx_pack_w6<3>), grid, blk, 0, (hipStream_t)stream, W, (uint8_t*)codes, (uint8_t*)scales, N, K, flush_fp32_subnorms, status_flag);
+    else
+        hipLaunchKernelGGL((k_mx_pack_w6<2>), grid, blk, 0, (hipStream_t)stream, W, (uint8_t*)codes, (uint8_t*)scales, N, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;

@@ -250,9 +250,22 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
 # ---------------------------------------------------------------------------------------------------------
 # MX-native W4A8 (BASELINE config 3): plain OCP-MX operands, no outlier split, multiplied by the scaled fp8 / fp4 MFMA
 # ---------------------------------------------------------------------------------------------------------
+_FP6_IDS = {"e3m2": 6, "e2m3": 7}                        # MSQ_FMT_FP6_E3M2 / MSQ_FMT_FP6_E2M3 (include/msq.h)
+_MX_FMT_ALIASES = {"fp4": "e2m1", "fp4_e2m1": "e2m1", "fp6_e3m2": "e3m2", "fp6_e2m3": "e2m3", "fp8_e4m3": "e4m3"}
+
+
+def _mx_fmt(name):
+    name = str(name).lower()
+    name = _MX_FMT_ALIASES.get(name, name)
+    if name not in ("e2m1", "e3m2", "e2m3", "e4m3"):
+        raise MsqError("MX operand format must be e2m1 / e3m2 / e2m3 / e4m3 (got %r)" % (name,))
+    return name
+
+
 class MXPackedWeight:
     """Codes in the operand order of the scaled MFMA + E8M0 block scales of one [N, K] weight: ``w_fmt`` "e2m1"
-    (plain MX-FP4, 4.25 bits per weight) or "e4m3" (exactly packed fake-quant values, 8.25 bits per weight)."""
+    (plain MX-FP4, 4.25 bits per weight), "e3m2" / "e2m3" (plain MX-FP6, a true 6-bit plane: 6.25 bits per weight)
+    or "e4m3" (exactly packed fake-quant values, 8.25 bits per weight)."""
 
     def __init__(self, codes, scales, N, K, w_fmt="e2m1"):
         self.codes, self.scales, self.N, self.K, self.w_fmt = codes, scales, N, K, w_fmt
@@ -271,19 +284,28 @@ def _mx_status(status, what):
         raise AssertionError("%s: a block holds Inf / NaN or its shared exponent overflows" % what)
 
 
-def mx_pack_weight(W, flush_fp32_subnorms=False):
-    """W [N, K] -> MX-FP4 (e2m1, block 32 along K, scale_bits 8, round nearest: mx_ops.py:332-457)."""
+def mx_pack_weight(W, flush_fp32_subnorms=False, w_fmt="e2m1"):
+    """W [N, K] -> plain OCP-MX codes (block 32 along K, scale_bits 8, round nearest: mx_ops.py:332-457): MX-FP4
+    (``w_fmt`` "e2m1", the default) or MX-FP6 ("e3m2" / "e2m3": six bits per code in HBM)."""
     if not W.is_cuda:
         raise MsqError("mx_pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
+    w_fmt = _mx_fmt(w_fmt)
+    if w_fmt == "e4m3":
+        raise MsqError("mx_pack_weight: e4m3 operands hold exact VALUES, use mx_pack_values")
     Wf = W.detach().contiguous().float()
     N, K = Wf.shape
-    codes = torch.empty(N * K // 2, dtype=torch.uint8, device=Wf.device)
     scales = torch.empty(N * K // 32, dtype=torch.uint8, device=Wf.device)
     status = torch.zeros(1, dtype=torch.int32, device=Wf.device)
-    check(lib().msq_mx_pack_w4(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, int(bool(flush_fp32_subnorms)),
-                               current_stream(Wf.device)), "msq_mx_pack_w4")
+    if w_fmt == "e2m1":
+        codes = torch.empty(N * K // 2, dtype=torch.uint8, device=Wf.device)
+        check(lib().msq_mx_pack_w4(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, int(bool(flush_fp32_subnorms)),
+                                   current_stream(Wf.device)), "msq_mx_pack_w4")
+    else:
+        codes = torch.empty(N * K * 3 // 4, dtype=torch.uint8, device=Wf.device)
+        check(lib().msq_mx_pack_w6(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, _FP6_IDS[w_fmt],
+                                   int(bool(flush_fp32_subnorms)), current_stream(Wf.device)), "msq_mx_pack_w6")
     _mx_status(status, "mx_pack_weight")
-    return MXPackedWeight(codes, scales, N, K)
+    return MXPackedWeight(codes, scales, N, K, w_fmt)
 
 
 def mx_pack_values(Wq, allow_inexact=False):
@@ -308,17 +330,27 @@ def mx_pack_values(Wq, allow_inexact=False):
     return MXPackedWeight(codes, scales, N, K, "e4m3")
 
 
-def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
-    """x [..., K] -> MX-FP8 (e4m3) codes [M, K] + scales [M, K / 32]."""
+def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False, a_fmt="e4m3"):
+    """x [..., K] -> MX-FP8 (e4m3) codes [M, K] + scales [M, K / 32].  ``a_fmt`` "e3m2" / "e2m3": the activations are
+    quantised to MX-FP6 and the fp6 values travel as e4m3 codes with the fp6 block scale (exact)."""
     if not x.is_cuda:
         raise MsqError("mx_pack_act needs a CUDA/HIP tensor (no CPU fallback)")
+    a_fmt = _mx_fmt(a_fmt)
+    if a_fmt == "e2m1":
+        raise MsqError("mx_pack_act: the activation operand is e4m3 (or fp6 values as e4m3)")
     K = x.shape[-1]
-    bf = x.dtype == torch.bfloat16                       # read as is (every bf16 is an fp32 value: same codes)
+    bf = x.dtype == torch.bfloat16 and a_fmt == "e4m3"   # read as is (every bf16 is an fp32 value: same codes)
     xf = x.reshape(-1, K).contiguous() if bf else x.reshape(-1, K).float().contiguous()
     M = xf.shape[0]
     codes = torch.empty(M, K, dtype=torch.uint8, device=x.device)
     scales = torch.empty(M, K // 32, dtype=torch.uint8, device=x.device)
     status = torch.zeros(1, dtype=torch.int32, device=x.device) if check_status else None
+    if a_fmt != "e4m3":
+        check(lib().msq_mx_pack_a6(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, _FP6_IDS[a_fmt],
+                                   int(bool(flush_fp32_subnorms)), current_stream(x.device)), "msq_mx_pack_a6")
+        if check_status:
+            _mx_status(status, "mx_pack_act")
+        return codes, scales
     fn = lib().msq_mx_pack_a8_bf16 if bf else lib().msq_mx_pack_a8
     check(fn(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, int(bool(flush_fp32_subnorms)),
              current_stream(x.device)), "msq_mx_pack_a8")
@@ -327,9 +359,10 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False):
     return codes, scales
 
 
-def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False, out=None):
-    """y = MXFP8(x) . MXFP4(W)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4: one pass packs the activations,
-    the GEMM consumes codes and scale bytes directly."""
+def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=False, out=None, a_fmt="e4m3"):
+    """y = MXFP8(x) . MX(W)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4: one pass packs the activations, the GEMM
+    consumes codes and scale bytes directly.  The weight operand is whatever ``P`` holds (MX-FP4, MX-FP6 or exact e4m3
+    values); ``a_fmt`` "e3m2" / "e2m3" quantises the activations to MX-FP6 instead of MX-FP8 (W6A6 of the fp6 spec)."""
     if isinstance(x, (tuple, list)):                     # activations already packed by mx_pack_act: q / k / v or
         xc, xs = x                                       # gate / up projections of one input share the pack
         K, lead, xdev = xc.shape[-1], tuple(xc.shape[:-1]), xc.device
@@ -339,7 +372,7 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
     if K != P.K:
         raise MsqError("qlinear_mx_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
     if not isinstance(x, (tuple, list)):
-        xc, xs = mx_pack_act(x, check_status=check_status)
+        xc, xs = mx_pack_act(x, check_status=check_status, a_fmt=a_fmt)
     M = xc.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
@@ -347,8 +380,13 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
     b = bias.detach().float().contiguous() if bias is not None else None
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=xdev) if wsb > 0 else None
+    yd = 0 if out_dtype == torch.float32 else 2
+    if P.w_fmt in _FP6_IDS:
+        check(lib().msq_qlinear_mx_w6a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), yd, M, P.N, K,
+                                        _FP6_IDS[P.w_fmt], ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w6a8")
+        return y.reshape(*lead, P.N)
     fn = lib().msq_qlinear_mx_w8a8 if P.w_fmt == "e4m3" else lib().msq_qlinear_mx_w4a8
-    check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), 0 if out_dtype == torch.float32 else 2,
+    check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), yd,
              M, P.N, K, ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w%sa8" % ("8" if P.w_fmt == "e4m3" else "4"))
     return y.reshape(*lead, P.N)
 
@@ -358,10 +396,11 @@ class MXLinearW4A8(nn.Module):
     to MX-FP8 and multiplies on the scaled MFMA (plain OCP-MX semantics: quantize_mx_op on both operands,
     number_system/mx/mx_ops.py:460-490, block 32 along in_features)."""
 
-    def __init__(self, in_features, out_features, bias=True, out_dtype=torch.bfloat16, device=None, w_fmt="e2m1"):
+    def __init__(self, in_features, out_features, bias=True, out_dtype=torch.bfloat16, device=None, w_fmt="e2m1", a_fmt="e4m3"):
         super().__init__()
-        self.in_features, self.out_features, self.out_dtype, self.w_fmt = in_features, out_features, out_dtype, w_fmt
-        nb = out_features * in_features // (2 if w_fmt == "e2m1" else 1)
+        w_fmt, a_fmt = _mx_fmt(w_fmt), _mx_fmt(a_fmt)
+        self.in_features, self.out_features, self.out_dtype, self.w_fmt, self.a_fmt = in_features, out_features, out_dtype, w_fmt, a_fmt
+        nb = out_features * in_features * {"e2m1": 4, "e3m2": 6, "e2m3": 6, "e4m3": 8}[w_fmt] // 8
         self.register_buffer("w_codes", torch.zeros(nb, dtype=torch.uint8, device=device))
         self.register_buffer("w_scales", torch.zeros(out_features * in_features // 32, dtype=torch.uint8, device=device))
         if bias:
@@ -370,9 +409,11 @@ class MXLinearW4A8(nn.Module):
             self.bias = None
 
     @classmethod
-    def from_linear(cls, linear, out_dtype=torch.bfloat16):
-        m = cls(linear.in_features, linear.out_features, linear.bias is not None, out_dtype, linear.weight.device)
-        P = mx_pack_weight(linear.weight.data)
+    def from_linear(cls, linear, out_dtype=torch.bfloat16, w_fmt="e2m1", a_fmt="e4m3"):
+        """``w_fmt`` "e3m2" / "e2m3": MX-FP6 weights as a 6-bit plane; ``a_fmt`` likewise quantises the activations to
+        MX-FP6 (run_mx_fp6.sh's formats with plain OCP-MX quantisers)."""
+        m = cls(linear.in_features, linear.out_features, linear.bias is not None, out_dtype, linear.weight.device, w_fmt, a_fmt)
+        P = mx_pack_weight(linear.weight.data, w_fmt=m.w_fmt)
         m.w_codes.copy_(P.codes); m.w_scales.copy_(P.scales)
         if m.bias is not None:
             m.bias.copy_(linear.bias.data.float())
@@ -394,7 +435,7 @@ class MXLinearW4A8(nn.Module):
         return MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features, self.w_fmt)
 
     def forward(self, x, out=None):
-        y = qlinear_mx_w4a8(x, self._packed(), self.bias, self.out_dtype, out=out)
+        y = qlinear_mx_w4a8(x, self._packed(), self.bias, self.out_dtype, out=out, a_fmt=getattr(self, "a_fmt", "e4m3"))
         # an fp16 / bf16 model gets its own dtype back (as QuantLinear.forward); pre-packed activations (a tuple of
         # codes and scales) carry no dtype: those callers take out_dtype
         if out is None and torch.is_tensor(x) and x.is_floating_point() and x.dtype != torch.float32 and y.dtype != x.dtype:

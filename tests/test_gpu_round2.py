@@ -250,6 +250,58 @@ def test_vector_ops_golden_gpu(msq):
         msq.vector_ops.gelu(a.cpu(), mx_specs=specs)
 
 
+@pytest.mark.parametrize("fmt", ["fp6_e3m2", "fp6_e2m3"])
+def test_mx_fp6_weight_plane(msq, O, fmt):
+    """MX-FP6 weights as a true 6-bit plane in the scaled MFMA's fp6 operand order (msq_mx_pack_w6 / msq_qlinear_mx_w6a8).
+    (1) the plane holds exactly the oracle's quantize_mx values: read back through the GEMM and through the decode kernels
+    with one-hot activations (every product has a single non-zero term: exact); (2) random activations against the fp64
+    product of the oracle's operands (tolerance of the MX path: 1e-4 max|y|); (3) fp6 activations (W6A6) likewise;
+    (4) the module form and its state_dict."""
+    from msq import qlinear
+    g = torch.Generator(device=dev()).manual_seed(31)
+    N, K = 512, 256
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.05
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.01] *= 12.0
+    W[5, 32:64] = 0.0                                                   # an all-zero block
+    W[7, 64:96] *= 1e-30                                                # tiny block
+    P = qlinear.mx_pack_weight(W, w_fmt=fmt)
+    assert P.codes.numel() == N * K * 3 // 4 and abs(P.bits_per_element - 6.25) < 1e-9
+    Wq = O.quantize_mx(W.cpu().numpy(), 8, fmt, axis=1, block_size=32)
+    assert 0 < (Wq != W.cpu().numpy()).mean()
+    eye = torch.eye(K, device=dev())
+    Y = qlinear.qlinear_mx_w4a8(eye, P, None, torch.float32)            # GEMM kernel (M = 256)
+    assert (Y.cpu().numpy() == Wq.T).all()
+    for m0, m1 in ((0, 1), (3, 19), (40, 88), (100, 164)):              # decode kernels (M = 1, 16, 48, 64)
+        Y = qlinear.qlinear_mx_w4a8(eye[m0:m1].contiguous(), P, None, torch.float32)
+        assert (Y.cpu().numpy() == Wq.T[m0:m1]).all(), (m0, m1)
+    N, K = 1024, 1024
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.03
+    bias = torch.randn(N, generator=g, device=dev())
+    P = qlinear.mx_pack_weight(W, w_fmt=fmt)
+    Wq = O.quantize_mx(W.cpu().numpy(), 8, fmt, axis=1, block_size=32).astype(np.float64)
+    for M in (8, 48, 200, 640):
+        X = torch.randn(M, K, generator=g, device=dev()) * 2
+        for a_fmt in ("fp8_e4m3", fmt):
+            Xq = O.quantize_mx(X.cpu().numpy(), 8, a_fmt, axis=1, block_size=32).astype(np.float64)
+            ref = Xq @ Wq.T + bias.double().cpu().numpy()
+            y = qlinear.qlinear_mx_w4a8(X, P, bias, torch.float32, a_fmt=a_fmt).double().cpu().numpy()
+            assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max(), (M, a_fmt, np.abs(y - ref).max(), np.abs(ref).max())
+    lin = torch.nn.Linear(K, N, bias=True).to(dev())
+    with torch.no_grad():
+        lin.weight.copy_(W); lin.bias.copy_(bias)
+    m = qlinear.MXLinearW4A8.from_linear(lin, torch.float32, w_fmt=fmt, a_fmt=fmt)
+    X = torch.randn(4, 33, K, generator=g, device=dev())
+    y = m(X)
+    m2 = qlinear.MXLinearW4A8(K, N, True, torch.float32, dev(), w_fmt=fmt, a_fmt=fmt)
+    m2.load_state_dict(m.state_dict())
+    assert y.shape == (4, 33, N) and torch.equal(m2(X), y)
+    Xq = O.quantize_mx(X.reshape(-1, K).cpu().numpy(), 8, fmt, axis=1, block_size=32).astype(np.float64)
+    ref = Xq @ Wq.T + bias.double().cpu().numpy()
+    assert np.abs(y.reshape(-1, N).double().cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    with pytest.raises(msq._lib.MsqError):
+        qlinear.mx_pack_weight(W, w_fmt="fp5")
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
