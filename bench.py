@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--outlier", default="posit8_es1")
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_mx_w6a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
     ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
                     help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
     ap.add_argument("--mx", action="store_true",
@@ -133,7 +133,8 @@ def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False, budget_s=10.0):
     Ws = (rng.randn(N, K) * 0.02).astype(np.float32)         # fake-quant sample: the whole [N, K] weight
     Ws[rng.rand(N, K) < 0.005] *= 16
     t0 = time.perf_counter()
-    r = {"out": O.quantize_mx(Ws, 8, "fp4_e2m1", axis=-1, block_size=bs)} if plain_mx else O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs)
+    r = ({"out": O.quantize_mx(Ws, 8, fi.split()[0], axis=-1, block_size=bs)} if plain_mx
+         else O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs))
     t_q = time.perf_counter() - t0
     Xs = rng.randn(M, K).astype(np.float32)
     # linear sample: probe, then as many of the N output columns as fit the time budget (all M rows)
@@ -289,7 +290,8 @@ def main(argv=None):
                 "X[%d,%d] x W[%d,%d]^T" % (args.outlier, M, K, N, K))
     W = synth_weight(N, K, dev, seed=rank)
     w4a8 = args.workload == "llama7b_w4a8"
-    mxw4a8 = args.workload == "llama7b_mx_w4a8"
+    mxw6 = args.workload == "llama7b_mx_w6a8"             # MX-FP6 weight plane (6.25 bits/weight) on the same path
+    mxw4a8 = args.workload == "llama7b_mx_w4a8" or mxw6
     msqmx = args.workload == "llama7b_msq_w4a8_mx" or (rowpar and args.mx)
     rp = None
     if rowpar:
@@ -329,7 +331,10 @@ def main(argv=None):
         name = ("Llama-2-7B W4A8 on the MX matrix path (MX-FP4 weights x MX-FP8 activations, scaled MFMA, no dequantisation), "
                 "act-pack + GEMM X[%d,%d] x W[%d,%d]^T" % (M, K, N, K))
         args.inlier, args.outlier = "fp4_e2m1 (plain MX)", "none"
-        P = qlinear.mx_pack_weight(W)
+        if mxw6:
+            name = name.replace("W4A8", "W6A8").replace("MX-FP4 weights", "MX-FP6 (e3m2) weights, 6-bit plane,")
+            args.inlier = "fp6_e3m2 (plain MX)"
+        P = qlinear.mx_pack_weight(W, w_fmt="e3m2" if mxw6 else "e2m1")
         X = torch.randn(M, K, device=dev)
     elif w4a8:
         # BASELINE config 3 = MXLinear(w=fp4_e2m1, a=fp8_e4m3, block 32) semantics (mx_ops variant, std_dev 5):
@@ -410,8 +415,8 @@ def main(argv=None):
     # scripts/profile_gpu.sh, scripts/summarize_profiles.py); they cannot be collected from inside this run.
     tag = {"posit8_es1": "posit", "fp8_e4m3": "fp8"}.get(args.outlier)
     if mxw4a8:
-        tag = "msq_w4a8_mx" if msqmx else "mx_w4a8"
-    if tag and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8", "llama7b_msq_w4a8_mx") and (M, H) == (2048, 4096):
+        tag = "msq_w4a8_mx" if msqmx else ("mx_w6a8" if mxw6 else "mx_w4a8")
+    if tag and args.workload in ("llama7b_w4_fused_gemm", "llama7b_mx_w4a8", "llama7b_mx_w6a8", "llama7b_msq_w4a8_mx") and (M, H) == (2048, 4096):
         for rt in (ROUND_TAG, "r01"):
             prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rt, tag))
             if not os.path.exists(prof):
