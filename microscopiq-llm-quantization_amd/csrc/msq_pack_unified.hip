@@ -20,28 +20,37 @@ extern "C" void msq_set_error_(const char* msg);
 // ===========================================================================
 // BS == 0: the input already holds fake-quant VALUES (any block direction, GPTQ output, ...): no quantiser runs,
 // the values are only encoded and checked (msq_pack_values).
+// A wave owns 64 n x KW k of a packed tile: KW = 32 (one 32-k half: its own code slots, scale dword and extension word, so
+// the two halves of a tile are independent work items) whenever the quantiser block fits (BS <= 32 or values only), else
+// the whole 64 x 64 tile.  The half tile needs 9.2 KB of LDS per wave instead of 17.4: four workgroups per CU instead of
+// two -- the kernel is latency-bound (one row per lane, LDS round trips between its phases), occupancy is what it lacks.
 template <int BS, bool EXT, int HW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (BS <= 32 ? 4 : 2))
 k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
               uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
-    // Lane r owns row r of the tile in LDS (68 words = 272 B per row) and works on it IN PLACE, one block /
-    // one 32-k half at a time, so that no 64-element register array is needed: the fake-quant values
-    // overwrite the inputs; the codes of half h then go to bytes 32 h .. 32 h + 31 of the row (already
-    // consumed), the two scale bytes to 64..65 and the extension bytes to 68..75 once both halves are encoded.
-    constexpr int ROW_W = 68;                                    // words per row
+    // Lane r owns row r of the tile in LDS (KW + 4 words per row) and works on it IN PLACE, one block / one 32-k half at
+    // a time, so that no 64-element register array is needed: the fake-quant values overwrite the inputs; the codes of
+    // half h then go to bytes 32 h .. 32 h + 31 of the row (already consumed), the scale bytes to word KW and the
+    // extension bytes to words KW + 1 .. once the halves are encoded.
+    constexpr int KW = (BS <= 32) ? 32 : 64;                     // k columns per wave
+    constexpr int NH = KW / 32;                                  // 32-k halves per wave
+    constexpr int ROW_W = KW + 4;                                // words per row
     constexpr int WAVE_LDS = 64 * ROW_W * 4;
     __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t KT = K / 64, NT = N / 64;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t tile = unit / (64 / KW);
+    const int kf0 = (int)(unit % (64 / KW)) * NH;                // first half of the tile this wave owns
     if (tile >= KT * NT) return;
     const int64_t nt = tile / KT, kt = tile % KT;
     float* ft = reinterpret_cast<float*>(lds + wv * WAVE_LDS);
     {
-        const float* src = W + (nt * 64) * K + kt * 64;
+        const float* src = W + (nt * 64) * K + kt * 64 + kf0 * 32;
+        constexpr int C4 = KW / 4, RPI = 64 / C4;                // float4 per row, rows per iteration
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = i * 4 + (lane >> 4), c4 = lane & 15;
+        for (int i = 0; i < 64 / RPI; ++i) {
+            const int row = i * RPI + lane / C4, c4 = lane % C4;
             *reinterpret_cast<float4*>(ft + row * ROW_W + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)row * K + c4 * 4);
         }
     }
@@ -53,7 +62,7 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
     if constexpr (BS > 0) {
         constexpr int B = BS > 0 ? BS : 64;
 #pragma nounroll
-        for (int j = 0; j < 64 / B; ++j) {
+        for (int j = 0; j < KW / B; ++j) {
             float a[B];
 #pragma unroll
             for (int c = 0; c < B / 4; ++c) {
@@ -69,9 +78,9 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
         }
     }
     // 2. one scale + 32 codes (+ 32 extension bits) per half
-    uint32_t sbytes = 0, eb_lo = 0, eb_hi = 0;
+    uint32_t sbytes = 0, eb_w[NH];
 #pragma nounroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         float v[32];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -123,36 +132,41 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             *reinterpret_cast<uint4*>(crow + c * 4) = make_uint4(cw[c * 4], cw[c * 4 + 1], cw[c * 4 + 2], cw[c * 4 + 3]);
-        if (h == 0) eb_lo = eb; else eb_hi = eb;
+        eb_w[h] = eb;
     }
-    reinterpret_cast<uint32_t*>(myrow)[16] = sbytes;             // bytes 64..65: the two scales
-    if (EXT) { reinterpret_cast<uint32_t*>(myrow)[17] = eb_lo; reinterpret_cast<uint32_t*>(myrow)[18] = eb_hi; }
+    reinterpret_cast<uint32_t*>(myrow)[KW] = sbytes;             // the scale byte(s)
+    if (EXT) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) reinterpret_cast<uint32_t*>(myrow)[KW + 1 + h] = eb_w[h];
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     // 3. fragment gather + slot stores
     const int c = lane & 15, g = lane >> 4;
     const uint32_t* rows = reinterpret_cast<const uint32_t*>(ft);
-    uint32_t sc[2] = {0, 0};
+    uint32_t sc[NH];
 #pragma unroll
-    for (int kf = 0; kf < 2; ++kf) {
+    for (int h = 0; h < NH; ++h) {
+        const int kf = kf0 + h;
         uint32_t ew = 0;
+        sc[h] = 0;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const int n = nf * 16 + c, k8 = kf * 4 + g;
+            const int n = nf * 16 + c, k8 = h * 4 + g;
             const uint32_t* r = rows + n * ROW_W;
-            sc[kf] |= ((r[16] >> (8 * kf)) & 0xFFu) << (8 * nf);
+            sc[h] |= ((r[KW] >> (8 * h)) & 0xFFu) << (8 * nf);
             const uint2 o = *reinterpret_cast<const uint2*>(r + k8 * 2);
             *reinterpret_cast<uint2*>(code_plane + ((tile * 4 + kf * 2 + (nf >> 1)) * 64 + lane) * 16 + (nf & 1) * 8) = o;
             if (EXT) {
-                const uint32_t eb = (r[17 + kf] >> (8 * g)) & 0xFFu;      // elements 8 g .. 8 g + 7 of half kf
+                const uint32_t eb = (r[KW + 1 + h] >> (8 * g)) & 0xFFu;    // elements 8 g .. 8 g + 7 of half kf
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     ew |= ((eb >> j) & 1u) << ((3 + 16 * (j & 1) + 4 * nf + (j >> 1)) & 31);
             }
         }
         if (EXT) *reinterpret_cast<uint32_t*>(ext_plane + ((tile * 2 + kf) * 64 + lane) * 4) = ew;
+        if (g == 0) *reinterpret_cast<uint32_t*>(scl_plane + (tile * 16 + c) * 8 + kf * 4) = sc[h];
     }
-    if (g == 0) *reinterpret_cast<uint2*>(scl_plane + (tile * 16 + c) * 8) = make_uint2(sc[0], sc[1]);
     if (status && A.status) atomicOr(A.status, status);
 }
 
@@ -160,7 +174,7 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
 extern "C" int msq_pack_unified_(const float* W, void* ext_plane, void* code_plane, void* scale_plane, const OutlierArgs* Ap,
                                  int64_t N, int64_t K, int block, int out_kind, int hw, void* stream) {
     const OutlierArgs A = *Ap;
-    const int64_t tiles = (N / 64) * (K / 64);
+    const int64_t tiles = (N / 64) * (K / 64) * (block <= 32 ? 2 : 1);     // work items: half tiles for blocks <= 32
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
 #define MSQ_PU(BS, EXTV, HWV) hipLaunchKernelGGL((k_pack_tile_u<BS, EXTV, HWV>), grid, blk, 0, st, W, (uint8_t*)ext_plane, \
@@ -181,7 +195,7 @@ extern "C" int msq_pack_values_u_(const float* W, void* ext_plane, void* code_pl
                                   int64_t N, int64_t K, int out_kind, void* stream) {
     OutlierArgs A = {};
     A.status = status;
-    const int64_t tiles = (N / 64) * (K / 64);
+    const int64_t tiles = (N / 64) * (K / 64) * 2;                        // half tiles
     const dim3 grid((unsigned)((tiles + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (out_kind == MSQ_PLANE_U8) hipLaunchKernelGGL((k_pack_tile_u<0, false, 0>), grid, blk, 0, st, W, (uint8_t*)ext_plane, (uint8_t*)code_plane, (uint8_t*)scale_plane, A, N, K);
