@@ -302,6 +302,40 @@ def test_mx_fp6_weight_plane(msq, O, fmt):
         qlinear.mx_pack_weight(W, w_fmt="fp5")
 
 
+def test_round2_kernels_run_to_run_identical(msq):
+    """The kernels of this round that exchange data between lanes or waves (LDS partial sums of the four-wave LayerNorm,
+    LDS tiles of the half-tile pack and of the fp6 pack, shuffle groups of the KV quantisers, the fp6 operand of the
+    GEMM with its split-K partials): 40 launches each must reproduce the first result bit for bit."""
+    from msq import qlinear
+    g = torch.Generator(device=dev()).manual_seed(5)
+    specs = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32,
+                                         "bfloat": 16, "custom_cuda": True})
+    X = torch.randn(300, 4096, generator=g, device=dev()); w = torch.randn(4096, generator=g, device=dev()); b = torch.randn(4096, generator=g, device=dev())
+    W = torch.randn(1024, 2048, generator=g, device=dev()) * 0.02
+    W[torch.rand(1024, 2048, generator=g, device=dev()) < 0.01] *= 16
+    kv = torch.randn(1, 8, 256, 128, generator=g, device=dev()).half()
+    P6 = qlinear.mx_pack_weight(W, w_fmt="e3m2")
+    Xa = torch.randn(130, 2048, generator=g, device=dev())
+
+    def pack_bytes():
+        P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified")
+        return torch.cat([P.out.flatten(), P.scl.flatten(), P.inl.flatten()])
+    cases = {
+        "layernorm": lambda: msq.vector_ops.layer_norm(X, w, b, 1e-12, specs),
+        "pack_u8x": pack_bytes,
+        "pack_fp6": lambda: qlinear.mx_pack_weight(W, w_fmt="e3m2").codes,
+        "kv_channel": lambda: msq.kvcache.fake_groupwise_channel_asymmetric_quantization_new(kv, 4, 32),
+        "kv_token": lambda: msq.kvcache.fake_groupwise_token_asymmetric_quantization(kv, 4, 32),
+        "gemm_fp6_splitk": lambda: qlinear.qlinear_mx_w4a8(Xa, P6, None, torch.float32),
+    }
+    for name, fn in cases.items():
+        y0 = fn()
+        y0 = y0.clone()
+        for _ in range(40):
+            y = fn()
+            assert torch.equal(y.view(torch.uint8) if y.dtype != torch.uint8 else y, y0.view(torch.uint8) if y0.dtype != torch.uint8 else y0), name
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
