@@ -397,8 +397,8 @@ MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
 // transposes its tile through its own 8 KiB LDS slice (XOR-swizzled 16-byte chunks, no block barrier
 // needed) and writes whole 128-byte (bf16) / 256-byte (f32) row segments with 16-byte stores.
 // ---------------------------------------------------------------------------
-template <typename YT>
-MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[8][4], char* wsm, YT* __restrict__ Y, int m_base, int n_base,
+template <typename YT, int NMF = 8>
+MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[NMF][4], char* wsm, YT* __restrict__ Y, int m_base, int n_base,
                                int M, int N, const float* __restrict__ bias, int lane) {
     const int c = lane & 15, g = lane >> 4;
     constexpr int ROW_B = 64 * (int)sizeof(YT);             // bytes per tile row: 128 (bf16) / 256 (f32)
@@ -411,7 +411,7 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[8][4], char* wsm, YT* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[nf][j] = bias ? bias[n_base + nf * 16 + g * 4 + j] : 0.f;
 #pragma unroll
-    for (int p = 0; p < 8 / MF_PER_PASS; ++p) {
+    for (int p = 0; p < NMF / MF_PER_PASS; ++p) {
 #pragma unroll
         for (int i = 0; i < MF_PER_PASS; ++i) {
             const int mf = p * MF_PER_PASS + i;
@@ -573,16 +573,19 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     // One half-step, hand-interleaved: group mf = { LDS read of A fragment mf+2, 4 MFMAs on fragment mf,
     // one quarter (2 dwords) of the NEXT half-step's weight fragments converted }, groups fenced with
     // sched_barrier so the compiler keeps the interleave.
+    constexpr int GPQ = (MF >= 8) ? MF / 8 : 1;                 // MFMA groups per converted quarter
+    constexpr int QPG = (MF >= 8) ? 1 : 8 / MF;                 // quarters converted per group (MF = 4: two)
 #define MSQ_HALF_STEP(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, RD)                                         \
     {                                                                                                        \
         bf16x8_t xf[3];                                                                                      \
         xf[0] = *reinterpret_cast<const bf16x8_t*>(abase + (RD));                                            \
-        xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                                     \
+        if (MF > 1) xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                         \
         _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                  \
             if (mf + 2 < MF && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
-            if (!(MSQ_ABL & 2) && (mf % (MF / 8)) == 0) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf / (MF / 8)); \
+            if (!(MSQ_ABL & 2) && (mf % GPQ) == 0) {                                                         \
+                _Pragma("unroll") for (int q_ = 0; q_ < QPG; ++q_) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, (mf / GPQ) * QPG + q_); } \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
@@ -649,14 +652,21 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     __builtin_amdgcn_s_barrier();
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
-#pragma unroll
-    for (int h = 0; h < MF / 8; ++h) {                          // 128 rows at a time through the wave's 8 KiB slice
-        const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
+    if constexpr (MF < 8) {                                    // 64-row wave tile: one pass (bf16) / two (f32)
         if (ksplit > 1)
-            store_wave_tile_lds<float>(acch, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N,
-                                       nullptr, lane);
+            store_wave_tile_lds<float, MF>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS, n0 + wn * 64, M, N, nullptr, lane);
         else
-            store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N, bias, lane);
+            store_wave_tile_lds<YT, MF>(acc, smem + wid * 8192, Y, m0 + wm * WROWS, n0 + wn * 64, M, N, bias, lane);
+    } else {
+#pragma unroll
+        for (int h = 0; h < MF / 8; ++h) {                      // 128 rows at a time through the wave's 8 KiB slice
+            const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
+            if (ksplit > 1)
+                store_wave_tile_lds<float>(acch, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N,
+                                           nullptr, lane);
+            else
+                store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N, bias, lane);
+        }
     }
 }
 
@@ -1588,6 +1598,28 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         else { if (y_dtype == 0) MSQ_LAUNCH8(MSQ_PLANE_U8X, float); else MSQ_LAUNCH8(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCH8
         return check_launch2("msq_qlinear_bf16(eight waves along n)");
+    }
+    // 64-row wave tiles (64 x 256 blocks instead of 128 x 256): for grids a little larger than the chip -- between one and
+    // two 128-row blocks per CU, e.g. 5120 x 5120 at M = 2048 (320 blocks) or M = 3072 on 4096 x 4096 (384) -- the second
+    // round is mostly empty; half-height blocks fill it: 113.7 -> 108.2 us posit / 99.0 -> 88.3 us fp8 at 320 blocks,
+    // 83.1 -> 78.8 us fp8 at 384 (scripts/experiments/shape_ab.py).  At exactly 256 blocks (Llama-2-7B's 4096 x 4096 and
+    // down_proj at M = 2048) they LOSE 5-14 %: a converted weight fragment then feeds 4 MFMAs instead of 8 and the loop is
+    // vector-issue bound, so the rule starts above 256.  MSQ_GEMM_MF=4 / 8 forces (tuning only).
+    static const int mf_forced = [] { const char* e = getenv("MSQ_GEMM_MF"); return e ? atoi(e) : 0; }();
+    const int64_t blocks128 = ((M + 127) / 128) * (N / BN);
+    const bool mf4 = unified && ksplit == 1 && wm_sel == 1 && mf_sel == 8 && (mf_forced == 4 || (mf_forced == 0 && blocks128 > 256 && blocks128 < 448));
+    if (mf4) {
+        const dim3 grid4((unsigned)(((M + 63) / 64) * (N / BN))), blk4(256);
+        const size_t lds4 = 4 * 8192;                               // max(3 x 8 KiB activation buffers, 4 x 8 KiB epilogue slices)
+#define MSQ_LAUNCH4(OK, YT)                                                                                            \
+        do { static DevOnce once_;                                                                                     \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
+             hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 4>), grid4, blk4, lds4, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial); } while (0)
+        if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH4(MSQ_PLANE_U8, float); else MSQ_LAUNCH4(MSQ_PLANE_U8, uint16_t); }
+        else { if (y_dtype == 0) MSQ_LAUNCH4(MSQ_PLANE_U8X, float); else MSQ_LAUNCH4(MSQ_PLANE_U8X, uint16_t); }
+#undef MSQ_LAUNCH4
+        return check_launch2("msq_qlinear_bf16(64-row wave tiles)");
     }
     if (mf_sel == 16) {
 #define MSQ_LAUNCH16(OK, YT)                                                                                           \

@@ -336,6 +336,29 @@ def test_round2_kernels_run_to_run_identical(msq):
             assert torch.equal(y.view(torch.uint8) if y.dtype != torch.uint8 else y, y0.view(torch.uint8) if y0.dtype != torch.uint8 else y0), name
 
 
+def test_fused_gemm_64_row_tiles(msq):
+    """The 64-row wave-tile form of the fused GEMM (taken for grids between one and two 128-row blocks per CU): M = 640 and a
+    ragged M = 600 on N = 16384 (320 / 5 x 64 blocks), both unified layouts, f32 and bf16 output, bias -- against the fp64
+    product of the unpacked weight (the packed values are exact, so only the fp32 accumulation order differs)."""
+    from msq import qlinear
+    g = torch.Generator(device=dev()).manual_seed(77)
+    N, K = 16384, 512
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    W[torch.rand(N, K, generator=g, device=dev()) < 0.005] *= 16
+    bias = torch.randn(N, generator=g, device=dev())
+    for fo in ("fp8_e4m3", "posit8_es1"):
+        P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+        Wd = qlinear.unpack_weight(P, torch.float32).double()
+        for M in (640, 600):
+            X = torch.randn(M, K, generator=g, device=dev()).to(torch.bfloat16)
+            ref = X.double() @ Wd.t() + bias.double()
+            y = qlinear.qlinear(X, P, bias, torch.float32)
+            assert y.shape == (M, N)
+            assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (fo, M)
+            yb = qlinear.qlinear(X, P, bias, torch.bfloat16)
+            assert torch.equal(yb, y.to(torch.bfloat16)), (fo, M)          # same accumulation, one rounding
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
