@@ -454,14 +454,22 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[NMF][4], char* wsm, YT* __re
 // converted weight fragment feeds 16 MFMAs instead of 8: half the converts, rotates and and-ors per MFMA).
 // WN = waves along n (4: block 256 columns; 8: one block of eight waves per CU covering 512 columns of ONE activation tile --
 // half the LDS-DMA issue per wave and half the activation bytes pulled from L2 per CU and K-step).
-template <int IN_KIND, int OUT_KIND, typename YT, int WM, int MF = 8, int WN = 4>
-__global__ void __launch_bounds__(64 * WN * WM, (MF == 16) ? 1 : (WN == 8 ? 1 : 2))
+// KG = k-groups per block (1, or 2 with WN = 4, WM = 1, MF = 8): two groups of four waves share the block's output tile, each
+// runs the unchanged K-loop over one half of the block's K range out of its own three activation buffers, and group 1 hands
+// its accumulators to group 0 through LDS at the end (fixed order: first half + second half).  For grids of at most one block
+// per CU this puts two waves on every SIMD -- the same occupancy two resident blocks give the large grids -- without any
+// partial plane in memory; under split-K it halves the K-steps per block at the same number of partial planes.
+template <int IN_KIND, int OUT_KIND, typename YT, int WM, int MF = 8, int WN = 4, int KG = 1>
+__global__ void __launch_bounds__(64 * WN * WM * KG, (MF == 16) ? 1 : ((WN == 8 || KG == 2) ? 1 : 2))
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int scl_groups, int ksplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR offsets below)
+    static_assert(KG == 1 || (KG == 2 && WN == 4 && WM == 1 && MF == 8), "k-groups: four-wave 128 x 256 blocks only");
+    const int wid_blk = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR offsets below)
+    const int kgid = (KG == 2) ? (wid_blk >> 2) : 0;            // k-group of this wave
+    const int wid = (KG == 2) ? (wid_blk & 3) : wid_blk;        // wave inside its group
     constexpr int WROWS = 16 * MF;                              // rows of a wave tile
     constexpr int BMT = WROWS * WM;                             // block rows: WM wave rows
     constexpr int PPW = BMT / 8 / (WN * WM);                     // 1 KiB staging pieces (8 rows) per wave and K-step
@@ -489,8 +497,13 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     const int KT = K / BK;
     // split-K: this block covers K-steps [kt_lo, kt_hi) and writes an fp32 partial tile
     const int kchunk = (KT + ksplit - 1) / ksplit;
-    const int kt_lo = ks * kchunk;
-    const int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
+    int kt_lo = ks * kchunk;
+    int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
+    if (KG == 2) {                                              // the launcher guarantees an even number of K-steps per block
+        const int half = (kt_hi - kt_lo) >> 1;
+        kt_lo += kgid * half; kt_hi = kt_lo + half;
+    }
+    char* const smem_g = smem + kgid * (3 * A_TILE);            // this group's activation buffers
     const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
 
     // packed planes and activations through buffer descriptors (SGPR slot / K-step offsets)
@@ -526,7 +539,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     auto stage_A = [&](int kt, int buf) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * PPW + p) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * PPW + p) * 1024),
                                                      16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
     };
     // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
@@ -600,7 +613,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         const int buf = abuf;                                                                                \
         const int buf2 = (abuf == 0) ? 2 : abuf - 1;             /* (abuf + 2) % 3 */                          \
         abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
-        const char* abase = smem + buf * A_TILE;                                                             \
+        const char* abase = smem_g + buf * A_TILE;                                                           \
         const int ktn = (kt_ + 1 <= kt_last) ? kt_ + 1 : kt_last;   /* branch-free tail: re-load the last tile */ \
         const int ktnn2 = (kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last;                                          \
         const int ktnn = DEEP ? ktnn2 : ktn;                                                                 \
@@ -652,6 +665,32 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     __builtin_amdgcn_s_barrier();
     if (MSQ_ABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     // all waves are past the last K-step barrier: the A buffers are dead, every wave owns 8 KiB
+    if constexpr (KG == 2) {
+        // group 1 -> LDS (32 KiB per wave, [fragment][lane] float4: conflict-free), group 0 adds: first half + second half
+        float4* red = reinterpret_cast<float4*>(smem) + wid * 2048;
+        if (kgid == 1) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[(i * 4 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (kgid == 0) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = red[(i * 4 + j) * 64 + lane];
+                    acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w;
+                }
+        }
+        // the epilogue slices (8 KiB per wave from the start of LDS) overlap the reduction area of wave 0: every wave of
+        // group 0 must have read its partner's data before any of them writes
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (kgid == 1) return;
+    }
     if constexpr (MF < 8) {                                    // 64-row wave tile: one pass (bf16) / two (f32)
         if (ksplit > 1)
             store_wave_tile_lds<float, MF>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS, n0 + wn * 64, M, N, nullptr, lane);
@@ -1620,6 +1659,35 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         else { if (y_dtype == 0) MSQ_LAUNCH4(MSQ_PLANE_U8X, float); else MSQ_LAUNCH4(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCH4
         return check_launch2("msq_qlinear_bf16(64-row wave tiles)");
+    }
+    // Two k-groups per block (eight waves, KG = 2) for single-pass grids of at most one block per CU (192 ... 256 blocks:
+    // Llama-2-7B's 4096 x 4096 projections and down_proj at M = 2048 are exactly 256): two waves per SIMD without partial
+    // planes.  Measured (scripts/experiments/shape_ab.py, posit / fp8): M2048 4096 x 4096 62.0 -> 58.0 / 55.8 -> 53.6 us,
+    // K = 11008 154.1 -> 147.5 / 138.2 -> 131.0, M1536 57.0 -> 51.0 / 49.8 -> 46.6, 8192 x 8192 M1024 116.0 -> 107.3 us.
+    // Under split-K it buys nothing (the groups share the CU's MFMA pipes: a full pass over K = 4096 takes 42.6 us instead
+    // of 47.4; more blocks on more CUs is what shortens it), so the rule is single-pass only.  MSQ_GEMM_KG=1 / 2 forces.
+    static const int kg_forced = [] { const char* e = getenv("MSQ_GEMM_KG"); return e ? atoi(e) : 0; }();
+    const int64_t KTq = K / BK;
+    const bool kg2 = unified && mf_sel == 8 && wm_sel == 1 && (KTq % (2 * ksplit)) == 0 && KTq / (2 * ksplit) >= 2 &&
+                     (kg_forced == 2 || (kg_forced == 0 && ksplit == 1 && blocks128 <= 256));
+    if (kg2) {
+        const dim3 blk2(512);
+        const size_t lds2 = 4 * 32768;                              // max(2 x 3 x 16 KiB activation buffers, 4 x 32 KiB accumulator hand-over)
+#define MSQ_LAUNCHKG(OK, YT)                                                                                           \
+        do { static DevOnce once_;                                                                                     \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done(once_); } \
+             hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 4, 2>), grid, blk2, lds2, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
+        if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCHKG(MSQ_PLANE_U8, float); else MSQ_LAUNCHKG(MSQ_PLANE_U8, uint16_t); }
+        else { if (y_dtype == 0) MSQ_LAUNCHKG(MSQ_PLANE_U8X, float); else MSQ_LAUNCHKG(MSQ_PLANE_U8X, uint16_t); }
+#undef MSQ_LAUNCHKG
+        rc = check_launch2("msq_qlinear_bf16(two k-groups per block)");
+        if (rc || ksplit == 1) return rc;
+        const int64_t MNk = M * N;
+        const dim3 rgk((unsigned)((MNk / 4 + 255) / 256));
+        if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgk, dim3(256), 0, st, partial, bias, (float*)Y, MNk, (int)N, ksplit);
+        else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgk, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MNk, (int)N, ksplit);
+        return check_launch2("msq_qlinear_bf16(split-K reduce)");
     }
     if (mf_sel == 16) {
 #define MSQ_LAUNCH16(OK, YT)                                                                                           \

@@ -336,7 +336,7 @@ def test_round2_kernels_run_to_run_identical(msq):
             assert torch.equal(y.view(torch.uint8) if y.dtype != torch.uint8 else y, y0.view(torch.uint8) if y0.dtype != torch.uint8 else y0), name
 
 
-def test_fused_gemm_64_row_tiles(msq):
+def test_fused_gemm_64_row_tiles_and_k_groups(msq):
     """The 64-row wave-tile form of the fused GEMM (taken for grids between one and two 128-row blocks per CU): M = 640 and a
     ragged M = 600 on N = 16384 (320 / 5 x 64 blocks), both unified layouts, f32 and bf16 output, bias -- against the fp64
     product of the unpacked weight (the packed values are exact, so only the fp32 accumulation order differs)."""
@@ -357,6 +357,18 @@ def test_fused_gemm_64_row_tiles(msq):
             assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (fo, M)
             yb = qlinear.qlinear(X, P, bias, torch.bfloat16)
             assert torch.equal(yb, y.to(torch.bfloat16)), (fo, M)          # same accumulation, one rounding
+        # two k-groups per block (single-pass grids of 192 ... 256 blocks): M = 384 / ragged 380 -> 3 x 64 = 192 blocks, the
+        # K range halved inside the block (K = 512: 4 + 4 K-steps; a K slice of 384: 3 + 3) and summed through LDS
+        for M, Kc in ((384, 512), (380, 384)):
+            Pc = qlinear.pack_weight(W[:, :Kc].contiguous(), 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+            Wc = qlinear.unpack_weight(Pc, torch.float32).double()
+            X = torch.randn(M, Kc, generator=g, device=dev()).to(torch.bfloat16)
+            ref = X.double() @ Wc.t() + bias.double()
+            y = qlinear.qlinear(X, Pc, bias, torch.float32)
+            assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (fo, M, Kc)
+            assert torch.equal(qlinear.qlinear(X, Pc, bias, torch.bfloat16), y.to(torch.bfloat16))
+            for _ in range(20):
+                assert torch.equal(qlinear.qlinear(X, Pc, bias, torch.float32), y), "run-to-run difference (k-group hand-over)"
 
 
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
