@@ -738,8 +738,9 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // (the MFMA's own format codes; 24 B per lane: a 16-byte and an 8-byte piece, 1.5 KiB per fragment slot = 6 bits per
 // weight; lane (n % 16, kg) holds k = 32 kg .. +31, six bits each, little endian: scripts/experiments/mx_mfma_layout_fp6.hip).
 // The fp6 operand uses the two-deep ring and the register budget of the e4m3 operand.
-template <typename YT, int WF>
-__global__ void __launch_bounds__(256, 2)
+// KG = 2: two k-groups of four waves per block, as k_qgemm3 (single-pass grids of at most one block per CU).
+template <typename YT, int WF, int KG = 1>
+__global__ void __launch_bounds__(256 * KG, KG == 2 ? 1 : 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
          int ksplit, float* __restrict__ partial) {
@@ -748,7 +749,9 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     constexpr bool W6 = (WF >= 2);
     constexpr int BMX = 128, KS = 128, A_TILE = BMX * KS;         // 16 KiB per activation buffer
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid_blk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kgid = (KG == 2) ? (wid_blk >> 2) : 0;            // k-group of this wave
+    const int wid = (KG == 2) ? (wid_blk & 3) : wid_blk;        // wave inside its group
     const int wn = wid;
     const int c = lane & 15, g = lane >> 4;
     const int MT = (M + BMX - 1) / BMX, NTB = N / BN;
@@ -756,8 +759,12 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     const int ks = (int)(blockIdx.x % (unsigned)ksplit);           // split-K (small M): K-steps [kt_lo, kt_hi), fp32 partial tile
     const int bid = (int)(blockIdx.x / (unsigned)ksplit);
     const int kchunk = (KT + ksplit - 1) / ksplit;
-    const int kt_lo = ks * kchunk;
-    const int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
+    int kt_lo = ks * kchunk;
+    int kt_hi = (kt_lo + kchunk < KT) ? kt_lo + kchunk : KT;
+    if (KG == 2) {                                              // the launcher guarantees an even number of K-steps per block
+        const int half = (kt_hi - kt_lo) >> 1;
+        kt_lo += kgid * half; kt_hi = kt_lo + half;
+    }
     int bm, bn;
     if ((NTB & 7) == 0 && ksplit == 1) {                           // XCD-aware order, as k_qgemm3
         const int xcd = bid & 7, i = bid >> 3;
@@ -793,15 +800,16 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     // activation buffers: 3 staged two K-steps ahead (MSQ_MX_XBUFS = 4: the fp4 kernel stages three ahead; no gain)
     constexpr int XBUFS = W8 ? 3 : MSQ_MX_XBUFS;
     constexpr int XS_BASE = XBUFS * A_TILE;
+    char* const smem_g = smem + kgid * (XBUFS * (A_TILE + 1024));   // this group's code and scale tiles
     int xs_goff = m0 + wid * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
     auto stage_A = [&](int kt, int buf) {
         int k16 = 16 * K;
         asm volatile("" : "+s"(k16));                             // keeps the two derived offsets out of registers across K-steps
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 4 + p) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * 4 + p) * 1024),
                                                      16, p < 2 ? aoff[p] : aoff[p - 2] + k16, uni((uint32_t)kt * KS), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem + XS_BASE + buf * 1024 + wid * 256),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem_g + XS_BASE + buf * 1024 + wid * 256),
                                                  4, xs_goff, uni((uint32_t)kt * 4u), 0, 0);
     };
     // LDS reads of one B fragment (row mf * 16 + c): chunks g and 4 + g (k = 16 g .. and 64 + 16 g ..)
@@ -852,7 +860,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf, buf2 = (XBUFS == 4) ? ((abuf + 3) & 3) : ((abuf == 0) ? 2 : abuf - 1);         \
         abuf = (XBUFS == 4) ? ((abuf + 1) & 3) : ((abuf == 2) ? 0 : abuf + 1);                               \
-        const char* abase = smem + buf * A_TILE;                                                             \
+        const char* abase = smem_g + buf * A_TILE;                                                           \
         const int k1 = (kt_ + 1 <= kl) ? kt_ + 1 : kl, k2 = (kt_ + 2 <= kl) ? kt_ + 2 : kl;   /* branch-free tail */ \
         if (!(MSQ_MXABL & 2)) load_w(WLOAD, W8 ? k1 : k2);   /* issue order (vmcnt is in-order): weights, then LDS-DMA */ \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -868,11 +876,11 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         u32x4_t xl[2], xh[2];                                                                                \
         xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl_); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh_);           \
         uint32_t xsc[2];                                                                                     \
-        xsc[0] = *reinterpret_cast<const uint8_t*>(smem + xs_rd_ + buf * 1024);                               \
+        xsc[0] = *reinterpret_cast<const uint8_t*>(smem_g + xs_rd_ + buf * 1024);                               \
         _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
             if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl_ + (mf + 1) * 2048);                 \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh_ + (mf + 1) * 2048);                 \
-                              xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem + xs_rd_ + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }  \
+                              xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem_g + xs_rd_ + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }  \
             if (!W8 && MSQ_MX_PIN_READS) __builtin_amdgcn_sched_barrier(0);   /* hipcc otherwise sinks these reads below the MFMAs of this group and waits for them at once (fp8 ring: the pin costs registers -> a scratch reload in the loop, slower) */ \
             const u32x4_t lo = xl[(MSQ_MXABL & 1) ? 0 : (mf & 1)], hi = xh[(MSQ_MXABL & 1) ? 0 : (mf & 1)];  \
             const v8i_t bfr = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; \
@@ -909,6 +917,29 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
     if (MSQ_MXABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    if constexpr (KG == 2) {                                    // group 1 -> LDS, group 0 adds (first half of K + second half), as k_qgemm3
+        float4* red = reinterpret_cast<float4*>(smem) + wid * 2048;
+        if (kgid == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[(i * 4 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (kgid == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = red[(i * 4 + j) * 64 + lane];
+                    acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w;
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                           // the epilogue slices overlap wave 0's hand-over area
+        if (kgid == 1) return;
+    }
     if (ksplit > 1) store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
     else store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
 }
@@ -1860,14 +1891,23 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     const int MT = (int)((M + 127) / 128), NTB = (int)(N / BN);
     int ksplit = pick_mx_ksplit(M, N, K);
     if (ksplit > 1 && (!workspace || workspace_bytes < (int64_t)ksplit * M * N * 4)) ksplit = 1;
-    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(256);
-    const size_t lds = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
+    // two k-groups per block for single-pass grids of at most one block per CU (rule and switch as msq_qlinear_bf16)
+    static const int kg_forced = [] { const char* e = getenv("MSQ_MX_KG"); return e ? atoi(e) : 0; }();
+    const int64_t KTm = K / 128;
+    const bool kg2 = ksplit == 1 && (KTm % 2) == 0 && KTm >= 4 && (kg_forced == 2 || (kg_forced == 0 && (int64_t)MT * NTB <= 256));
+    const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(kg2 ? 512 : 256);
+    size_t lds = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
+    if (kg2) { lds *= 2; if (lds < 4 * 32768) lds = 4 * 32768; }        // two groups; 4 x 32 KiB accumulator hand-over
     float* partial = (float*)workspace;
 #define MSQ_MXL(YT, W8V)                                                                                              \
-    do { static DevOnce once_;                                                                                 \
+    do { if (kg2) { static DevOnce once_;                                                                      \
+         if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
+         hipLaunchKernelGGL((k_mxgemm<YT, W8V, 2>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); }        \
+         else { static DevOnce once_;                                                                          \
          if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } while (0)
+                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } } while (0)
     if (y_dtype == 0) { if (wf == 0) MSQ_MXL(float, 0); else if (wf == 1) MSQ_MXL(float, 1); else if (wf == 2) MSQ_MXL(float, 2); else MSQ_MXL(float, 3); }
     else { if (wf == 0) MSQ_MXL(uint16_t, 0); else if (wf == 1) MSQ_MXL(uint16_t, 1); else if (wf == 2) MSQ_MXL(uint16_t, 2); else MSQ_MXL(uint16_t, 3); }
 #undef MSQ_MXL

@@ -371,6 +371,31 @@ def test_fused_gemm_64_row_tiles_and_k_groups(msq):
                 assert torch.equal(qlinear.qlinear(X, Pc, bias, torch.float32), y), "run-to-run difference (k-group hand-over)"
 
 
+def test_mx_gemm_k_groups(msq, O):
+    """The MX GEMM with two k-groups per block (single-pass grids of at most 256 blocks: M = 384 / ragged 380 on N = 16384 ->
+    192 blocks, K = 512 and 1024 -> 2 + 2 and 4 + 4 K-steps) for all three weight operand formats, against the fp64 product
+    of the oracle's operands (tolerance of the MX path) and run to run."""
+    from msq import qlinear, quant
+    g = torch.Generator(device=dev()).manual_seed(41)
+    N = 16384
+    for K in (512, 1024):
+        W = torch.randn(N, K, generator=g, device=dev()) * 0.03
+        bias = torch.randn(N, generator=g, device=dev())
+        ops = {"e2m1": (qlinear.mx_pack_weight(W), O.quantize_mx(W.cpu().numpy(), 8, "fp4_e2m1", axis=1, block_size=32)),
+               "e3m2": (qlinear.mx_pack_weight(W, w_fmt="e3m2"), O.quantize_mx(W.cpu().numpy(), 8, "fp6_e3m2", axis=1, block_size=32))}
+        Wq8 = quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+        ops["e4m3"] = (qlinear.mx_pack_values(Wq8), Wq8.cpu().numpy())
+        for M in (384, 380):
+            X = torch.randn(M, K, generator=g, device=dev()) * 2
+            Xq = O.quantize_mx(X.cpu().numpy(), 8, "fp8_e4m3", axis=1, block_size=32).astype(np.float64)
+            for name, (P, Wq) in ops.items():
+                ref = Xq @ Wq.astype(np.float64).T + bias.double().cpu().numpy()
+                y = qlinear.qlinear_mx_w4a8(X, P, bias, torch.float32)
+                assert np.abs(y.double().cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), (K, M, name)
+                for _ in range(10):
+                    assert torch.equal(qlinear.qlinear_mx_w4a8(X, P, bias, torch.float32), y), (K, M, name)
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
