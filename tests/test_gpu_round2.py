@@ -396,6 +396,27 @@ def test_mx_gemm_k_groups(msq, O):
                     assert torch.equal(qlinear.qlinear_mx_w4a8(X, P, bias, torch.float32), y), (K, M, name)
 
 
+def test_c_abi_error_codes_round2(msq):
+    """Return codes of the entry points added in round 2 (0 ok, -1 bad argument, -2 unsupported, message through
+    msq_last_error): nothing exits, nothing falls back."""
+    L = msq._lib.lib()
+    p = msq._lib.ptr
+    x = torch.zeros(64 * 128, device=dev()); b = torch.zeros(64 * 128, dtype=torch.uint8, device=dev())
+    assert L.msq_mx_pack_w6(p(x), p(b), p(b), None, 64, 128, 5, 0, None) == -1 and b"w_format" in L.msq_last_error()     # e4m3 id
+    assert L.msq_mx_pack_w6(p(x), p(b), p(b), None, 60, 128, 6, 0, None) == -2                                           # N % 64
+    assert L.msq_mx_pack_w6(p(x), None, p(b), None, 64, 128, 6, 0, None) == -1                                           # null plane
+    assert L.msq_mx_pack_a6(p(x), p(b), p(b), None, 64, 100, 6, 0, None) == -2                                           # K % 128
+    assert L.msq_mx_pack_a6(p(x), p(b), p(b), None, 0, 128, 6, 0, None) == 0                                             # empty
+    assert L.msq_qlinear_mx_w6a8(p(b), p(b), p(b), p(b), None, p(x), 0, 16, 256, 128, 8, None, 0, None) == -1            # fp4 id
+    assert L.msq_kv_group_quant(p(x), p(x), 0, 1, 2, 32, 128, 4, 48, 0, None) == -1 and b"factor" in L.msq_last_error()  # 48 does not divide 256
+    assert L.msq_kv_group_quant(p(x), p(x), 3, 1, 2, 32, 128, 4, 32, 0, None) == -2                                      # dtype
+    assert L.msq_kv_group_quant(p(x), p(x), 0, 1, 2, 32, 128, 0, 32, 0, None) == -1                                      # bits
+    assert L.msq_vec_layernorm(p(x), p(x), p(x), p(x), 2, 64 * 1024, 1e-5, 9, 8, 1.0, 0, 1, None) == -2                  # row larger than LDS
+    assert L.msq_vec_gelu(p(x), p(x), 64, 0, 40, 8, 1.0, 0, 1, None) == -1                                               # bits > 24
+    assert L.msq_quantize_mx_by_tile_py(p(x), p(x), 1, 64, 1, 32, 8, 2, 3, 6.0, 0, 7, None) == -1                        # rounding mode
+    assert L.msq_quantize_mx_by_tile_py(None, None, 0, 64, 1, 32, 8, 2, 3, 6.0, 0, 0, None) == 0
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
