@@ -1655,7 +1655,11 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     // one block per CU (M2048 N16384: 214 -> 206 us; N8192 K28672: 755 -> 719 us), -30 % with half-empty grids.
     // MSQ_GEMM_WN=4 (tuning only) keeps the four-wave blocks.
     static const int wn_forced = [] { const char* e = getenv("MSQ_GEMM_WN"); return e ? atoi(e) : 0; }();
-    const bool wn8 = wn_forced == 8 || (wn_forced == 0 && ((M + 127) / 128) * (N / 512) >= 256);
+    // ... and only when its last round of 256 blocks is at least 85 % full: a half-empty last round of eight-wave blocks
+    // leaves half of the CUs idle, while the four-wave blocks of the same tail run one per CU on all of them (fused QKV
+    // N = 12288 at M = 2048, 1.5 rounds: 181.7 -> 161.0 us posit, 163.4 -> 142.7 fp8; N = 10240: 181.6 -> 148.6 us).
+    const int64_t b8 = ((M + 127) / 128) * (N / 512);
+    const bool wn8 = wn_forced == 8 || (wn_forced == 0 && b8 >= 256 && b8 * 100 >= 85 * 256 * ((b8 + 255) / 256));
     if (wn8 && mf_sel == 8 && unified && (N % 512) == 0 && ksplit == 1) {
         const dim3 grid8((unsigned)(((M + 127) / 128) * (N / 512))), blk8(512);
         const size_t lds8 = 65536;                                  // max(3 x 16 KiB activation buffers, 8 x 8 KiB epilogue slices)
