@@ -44,7 +44,6 @@ MSQ_D float Q(float a, const VQ& q) {
 // FAST = 1: bfloat16, round to nearest (the run_mx_fp6.sh spec) with compile-time constants; 0: run-time parameters
 template <int FAST>
 MSQ_D float QT(float a, const VQ& q) { return FAST ? Qbf(a, 16, 0) : Q(a, q); }
-MSQ_D bool vq_is_fast(const VQ& q) { return q.bits == 9 && q.ebits == 8 && q.dn && q.rmode == 0; }
 
 MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
 
@@ -267,6 +266,7 @@ static int vq_check(int bits, int exp_bits, int rmode) {
     if (rmode < 0 || rmode > 2) return vfail(MSQ_ERR_BAD_ARG, "vector op: bad rounding mode");
     return MSQ_OK;
 }
+static bool vq_is_fast(int bits, int exp_bits, int rmode, int allow_denorm) { return bits == 9 && exp_bits == 8 && allow_denorm && rmode == 0; }
 static int grid1(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g)); }
 
 namespace {
@@ -300,7 +300,7 @@ int msq_vec_layernorm(const float* x, const float* weight, const float* bias, fl
     if (H % 512 == 0 && H <= 8192 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(weight) |
                                        reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
         const size_t l2 = (size_t)H * 4 + 513 * 4;
-        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+        if (vq_is_fast(bits, exp_bits, rmode, allow_denorm))
             hipLaunchKernelGGL(k_vec_layernorm_par<1>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
         else
             hipLaunchKernelGGL(k_vec_layernorm_par<0>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
@@ -323,7 +323,7 @@ int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bit
     int64_t done = 0;
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 4) {
         const int64_t n4 = n / 4;
-        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+        if (vq_is_fast(bits, exp_bits, rmode, allow_denorm))
             hipLaunchKernelGGL(k_vec_gelu4<1>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, x, out, n4, first_order, vq);
         else
             hipLaunchKernelGGL(k_vec_gelu4<0>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, x, out, n4, first_order, vq);
@@ -344,7 +344,7 @@ int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int6
     int64_t done = 0;
     if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 4) {
         const int64_t n4 = n / 4;
-        if (vq.bits == 9 && vq.ebits == 8 && vq.dn && vq.rmode == 0)
+        if (vq_is_fast(bits, exp_bits, rmode, allow_denorm))
             hipLaunchKernelGGL(k_vec_add4<1>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4, b ? 0 : 1, b_scalar, vq);
         else
             hipLaunchKernelGGL(k_vec_add4<0>, dim3(grid1(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4, b ? 0 : 1, b_scalar, vq);
