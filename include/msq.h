@@ -245,6 +245,11 @@ int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, void* workspa
                        int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt,
                        int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
                        int flush_fp32_subnorms, int variant, void* stream);
+/* the same with bfloat16 activations X (a bf16 model): no cast pass in front; the mx_ops variant needs block 32 or 64 */
+int msq_act_quant_bf16_x16(const void* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
+                       int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt,
+                       int inlier_scale_bits, int outlier_scale_bits, float std_dev, int rmode,
+                       int flush_fp32_subnorms, int variant, void* stream);
 int64_t msq_qlinear_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_block, int a_variant);
 int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block,
@@ -252,6 +257,12 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
                      int a_inlier_scale_bits, int a_outlier_scale_bits, float a_std_dev, int a_rmode,
                      int a_flush_fp32_subnorms, int a_variant, int* status_flag, void* workspace,
                      int64_t workspace_bytes, void* stream);
+int msq_qlinear_w4a8_x16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block,
+                     int in_kind, int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt,
+                     int a_inlier_scale_bits, int a_outlier_scale_bits, float a_std_dev, int a_rmode,
+                     int a_flush_fp32_subnorms, int a_variant, int* status_flag, void* workspace,
+                     int64_t workspace_bytes, void* stream);   /* bfloat16 X */
 
 /* ---------------------------------------------------------------------------
  * MX-native W4A8 Linear -- NEW (BASELINE config 3, "CDNA4 fp8 MFMA path"): plain OCP-MX operands (block 32 along K,

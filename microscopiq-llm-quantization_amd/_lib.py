@@ -51,6 +51,8 @@ _SIGS = {
     "msq_act_quant_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "msq_act_quant_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
                                      _i32, _i32, _vp]),
+    "msq_act_quant_bf16_x16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32,
+                                     _i32, _i32, _vp]),
     "msq_mx_pack_a8": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "msq_mx_pack_w4": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "msq_qlinear_mx_w4a8_workspace_bytes": (_i64, [_i64, _i64, _i64]),
@@ -63,6 +65,8 @@ _SIGS = {
     "msq_qlinear_mx_w8a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
     "msq_qlinear_w4a8_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
     "msq_qlinear_w4a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "msq_qlinear_w4a8_x16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
 }
 

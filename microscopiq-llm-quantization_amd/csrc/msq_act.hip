@@ -11,8 +11,8 @@
 #include "msq_outlier_core.h"
 
 extern "C" void msq_set_error_(const char* msg);
-extern "C" int msq_mxops_stats_(const float* in, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post,
-                                int block, int* status, void* stream);
+extern "C" int msq_mxops_stats_x_(const void* in, int x_bf16, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post,
+                                  int block, int* status, void* stream);
 
 namespace {
 
@@ -107,7 +107,8 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
 
 // A wave owns 64 consecutive blocks = one contiguous run of 64*BS floats: coalesced 16-byte loads,
 // transpose through LDS (row stride BS+4 words), one block per lane, and back the same way as bf16.
-template <int BS, int RM, int HW>
+// XBF16: X holds bfloat16 (the activations of a bf16 model: every bf16 is an fp32 value, same results as casting first)
+template <int BS, int RM, int HW, bool XBF16 = false>
 __global__ void __launch_bounds__(256)
 k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs A) {
     constexpr int LDS_STRIDE = BS + 4;
@@ -120,13 +121,26 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
     const int64_t gidx = g0 + lane;
     float* tl = tile[wv];
     float a[BS];
+    const uint16_t* Xh = reinterpret_cast<const uint16_t*>(X);
     if (full) {
-        const float4* src = reinterpret_cast<const float4*>(X + g0 * BS);
+        if (XBF16) {
+            const uint4* s8 = reinterpret_cast<const uint4*>(Xh + g0 * BS);          // 8 bf16 per 16-byte load
 #pragma unroll
-        for (int t = 0; t < BS / 4; ++t) {
-            const int f = lane + 64 * t;
-            const int row = f / (BS / 4), c4 = f % (BS / 4);
-            *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
+            for (int t = 0; t < BS / 8; ++t) {
+                const int f = lane + 64 * t;
+                const int row = f / (BS / 8), c8 = f % (BS / 8);
+                const uint4 v = s8[f];
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8) = make_float4(u2f(v.x << 16), u2f(v.x & 0xFFFF0000u), u2f(v.y << 16), u2f(v.y & 0xFFFF0000u));
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4) = make_float4(u2f(v.z << 16), u2f(v.z & 0xFFFF0000u), u2f(v.w << 16), u2f(v.w & 0xFFFF0000u));
+            }
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(X + g0 * BS);
+#pragma unroll
+            for (int t = 0; t < BS / 4; ++t) {
+                const int f = lane + 64 * t;
+                const int row = f / (BS / 4), c4 = f % (BS / 4);
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c4 * 4) = src[f];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -137,7 +151,7 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
         }
     } else {
 #pragma unroll
-        for (int b = 0; b < BS; ++b) a[b] = (gidx < nblocks) ? X[gidx * BS + b] : 0.f;
+        for (int b = 0; b < BS; ++b) a[b] = (gidx < nblocks) ? (XBF16 ? u2f((uint32_t)Xh[gidx * BS + b] << 16) : X[gidx * BS + b]) : 0.f;
     }
     uint32_t h[BS / 2];
     int status = 0;
@@ -209,10 +223,11 @@ extern "C" int64_t msq_act_quant_workspace_bytes(int64_t M, int64_t K, int block
     return 2 * (int64_t)sizeof(float) * M * block;
 }
 
-extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
-                                  int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
-                                  int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms, int variant,
-                                  void* stream) {
+static int act_quant_impl(const void* Xv, int x_bf16, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
+                          int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
+                          int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms, int variant,
+                          void* stream) {
+    const float* X = (const float*)Xv;
     if (M < 0 || K < 0) { msq_set_error_("msq_act_quant_bf16: negative size"); return MSQ_ERR_BAD_ARG; }
     if (M == 0 || K == 0) return MSQ_OK;
     if (!X || !Xq) { msq_set_error_("msq_act_quant_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
@@ -239,7 +254,8 @@ extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, vo
             msq_set_error_("msq_act_quant_bf16: workspace too small (msq_act_quant_workspace_bytes)"); return MSQ_ERR_BAD_ARG; }
         float* vmean = (float*)workspace;
         float* vstd = vmean + M * block;
-        const int rc = msq_mxops_stats_(X, vmean, vstd, M, K, 1, block, status_flag, stream);
+        if (x_bf16 && block == 16) { msq_set_error_("msq_act_quant_bf16_x16: the mx_ops variant on bfloat16 input needs block 32 or 64"); return MSQ_ERR_UNSUPPORTED; }
+        const int rc = msq_mxops_stats_x_(Xv, x_bf16, vmean, vstd, M, K, 1, block, status_flag, stream);
         if (rc) return rc;
         A.vmean = vmean; A.vstd = vstd;
     }
@@ -249,7 +265,10 @@ extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, vo
     // RM = 0: round-to-nearest (half away) specialised, through the hardware converts when both formats have
     // one (e4m3 / e5m2 / e2m1); -1: any rounding mode, arithmetic codec
     const bool hw = (rmode == 0) && hw_codec_kind(A.fi) && hw_codec_kind(A.fo);
-#define MSQ_AQ(BS) do { if (hw) hipLaunchKernelGGL((k_act_quant<BS, 0, 1>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+#define MSQ_AQ(BS) do { if (x_bf16) { if (hw) hipLaunchKernelGGL((k_act_quant<BS, 0, 1, true>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                                         else if (rmode == 0) hipLaunchKernelGGL((k_act_quant<BS, 0, 0, true>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                                         else hipLaunchKernelGGL((k_act_quant<BS, -1, 0, true>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } \
+                        else if (hw) hipLaunchKernelGGL((k_act_quant<BS, 0, 1>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
                         else if (rmode == 0) hipLaunchKernelGGL((k_act_quant<BS, 0, 0>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
                         else hipLaunchKernelGGL((k_act_quant<BS, -1, 0>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } while (0)
     switch (block) {
@@ -261,4 +280,21 @@ extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, vo
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;
+}
+
+extern "C" int msq_act_quant_bf16(const float* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
+                                  int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
+                                  int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms, int variant,
+                                  void* stream) {
+    return act_quant_impl(X, 0, Xq, status_flag, workspace, workspace_bytes, M, K, block, inlier_fmt, outlier_fmt, inlier_scale_bits,
+                          outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, variant, stream);
+}
+
+// the same with bfloat16 activations (no cast pass in front: 2 + 2 bytes per element instead of 2 + 4 + 4 + 2)
+extern "C" int msq_act_quant_bf16_x16(const void* X, void* Xq, int* status_flag, void* workspace, int64_t workspace_bytes,
+                                      int64_t M, int64_t K, int block, int inlier_fmt, int outlier_fmt, int inlier_scale_bits,
+                                      int outlier_scale_bits, float std_dev, int rmode, int flush_fp32_subnorms, int variant,
+                                      void* stream) {
+    return act_quant_impl(X, 1, Xq, status_flag, workspace, workspace_bytes, M, K, block, inlier_fmt, outlier_fmt, inlier_scale_bits,
+                          outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, variant, stream);
 }

@@ -1769,11 +1769,11 @@ int64_t msq_qlinear_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K, int a_
            msq_qlinear_workspace_bytes(M, N, K);
 }
 
-int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
-                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block, int in_kind,
-                     int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt, int a_inlier_scale_bits,
-                     int a_outlier_scale_bits, float a_std_dev, int a_rmode, int a_flush_fp32_subnorms, int a_variant,
-                     int* status_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+static int qlinear_w4a8_impl(const void* X, int x_bf16, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                             const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block, int in_kind,
+                             int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt, int a_inlier_scale_bits,
+                             int a_outlier_scale_bits, float a_std_dev, int a_rmode, int a_flush_fp32_subnorms, int a_variant,
+                             int* status_flag, void* workspace, int64_t workspace_bytes, void* stream) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_w4a8: negative M");
     if (!workspace || workspace_bytes < msq_qlinear_w4a8_workspace_bytes(M, N, K, a_block, a_variant))
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_w4a8: workspace too small (msq_qlinear_w4a8_workspace_bytes)");
@@ -1781,12 +1781,33 @@ int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plan
     char* aws = xq + align256(M * K * 2);
     const int64_t aws_bytes = align256(msq_act_quant_workspace_bytes(M, K, a_block, a_variant));
     char* gws = aws + aws_bytes;
-    int rc = msq_act_quant_bf16(X, xq, status_flag, aws, aws_bytes, M, K, a_block, a_inlier_fmt, a_outlier_fmt,
-                                a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode, a_flush_fp32_subnorms,
-                                a_variant, stream);
+    int rc = x_bf16 ? msq_act_quant_bf16_x16(X, xq, status_flag, aws, aws_bytes, M, K, a_block, a_inlier_fmt, a_outlier_fmt,
+                                             a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode, a_flush_fp32_subnorms,
+                                             a_variant, stream)
+                    : msq_act_quant_bf16((const float*)X, xq, status_flag, aws, aws_bytes, M, K, a_block, a_inlier_fmt, a_outlier_fmt,
+                                         a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode, a_flush_fp32_subnorms,
+                                         a_variant, stream);
     if (rc) return rc;
     return msq_qlinear_bf16(xq, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, w_block, in_kind, out_kind,
                             gws, workspace_bytes - (gws - (char*)workspace), stream);
+}
+int msq_qlinear_w4a8(const float* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block, int in_kind,
+                     int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt, int a_inlier_scale_bits,
+                     int a_outlier_scale_bits, float a_std_dev, int a_rmode, int a_flush_fp32_subnorms, int a_variant,
+                     int* status_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+    return qlinear_w4a8_impl(X, 0, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, w_block, in_kind, out_kind, a_block,
+                             a_inlier_fmt, a_outlier_fmt, a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode,
+                             a_flush_fp32_subnorms, a_variant, status_flag, workspace, workspace_bytes, stream);
+}
+int msq_qlinear_w4a8_x16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                         const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int w_block, int in_kind,
+                         int out_kind, int a_block, int a_inlier_fmt, int a_outlier_fmt, int a_inlier_scale_bits,
+                         int a_outlier_scale_bits, float a_std_dev, int a_rmode, int a_flush_fp32_subnorms, int a_variant,
+                         int* status_flag, void* workspace, int64_t workspace_bytes, void* stream) {
+    return qlinear_w4a8_impl(X, 1, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, w_block, in_kind, out_kind, a_block,
+                             a_inlier_fmt, a_outlier_fmt, a_inlier_scale_bits, a_outlier_scale_bits, a_std_dev, a_rmode,
+                             a_flush_fp32_subnorms, a_variant, status_flag, workspace, workspace_bytes, stream);
 }
 
 // MX-native W4A8 GEMM on pre-packed operands (msq_mx_pack_a8 / msq_mx_pack_w4).  Few row tiles (small M): K is

@@ -406,9 +406,10 @@ k_mxops_stats(const float* __restrict__ in, float* __restrict__ vmean, float* __
 // rounded to float only when it is provably on the same side of the rounding boundary as torch's sequential
 // Welford result (both are within a few hundred double ulps of the exact value), else the column is redone
 // sequentially (about one column in 500 000).  Reads each row twice (second time from L2), coalesced.
-template <int BS>
+// XT = float, or uint16_t for bfloat16 rows (every bf16 is an fp32 value: the same statistics as after a cast pass)
+template <int BS, typename XT = float>
 __global__ void __launch_bounds__(256)
-k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, float* __restrict__ vstd,
+k_mxops_stats_rows(const XT* __restrict__ in, float* __restrict__ vmean, float* __restrict__ vstd,
                    int64_t axis_len, int64_t nblk, int* status) {
     constexpr int R = 256 / BS;                 // threads per column
     constexpr int MAXRUNS = 64;                 // nblk <= 1024
@@ -416,14 +417,15 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
     __shared__ double part_s[R][BS], part_q[R][BS], part_d[R][BS];
     const int b = threadIdx.x % BS, r = threadIdx.x / BS;
     const int64_t p = blockIdx.x;
-    const float* row = in + p * axis_len;
+    const XT* rowp = in + p * axis_len;
+    auto row = [&](int64_t i) -> float { if constexpr (sizeof(XT) == 4) return (float)rowp[i]; else return u2f((uint32_t)rowp[i] << 16); };
     const int nruns = (int)(nblk / 16), tail = (int)(nblk % 16);
     const bool has_tail = (r == (nruns % R));
     double ds = 0.0;
     for (int j = r; j < nruns; j += R) {
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = row[(int64_t)(j * 16 + i) * BS + b];
+        for (int i = 0; i < 16; ++i) v[i] = row((int64_t)(j * 16 + i) * BS + b);
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc += v[i]; ds += (double)v[i]; }
@@ -431,7 +433,7 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
     }
     if (has_tail) {                              // the tail run (may be empty)
         float acc = 0.f;
-        for (int i = 0; i < tail; ++i) { const float v = row[(int64_t)(nruns * 16 + i) * BS + b]; acc += v; ds += (double)v; }
+        for (int i = 0; i < tail; ++i) { const float v = row((int64_t)(nruns * 16 + i) * BS + b); acc += v; ds += (double)v; }
         run_sum[MAXRUNS][b] = acc;
     }
     part_s[r][b] = ds;
@@ -445,12 +447,12 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
     for (int j = r; j < nruns; j += R) {
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = row[(int64_t)(j * 16 + i) * BS + b];
+        for (int i = 0; i < 16; ++i) v[i] = row((int64_t)(j * 16 + i) * BS + b);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { const double d = (double)v[i] - dmean; dq = __builtin_fma(d, d, dq); dd += d; }
     }
     if (has_tail)
-        for (int i = 0; i < tail; ++i) { const double d = (double)row[(int64_t)(nruns * 16 + i) * BS + b] - dmean; dq = __builtin_fma(d, d, dq); dd += d; }
+        for (int i = 0; i < tail; ++i) { const double d = (double)row((int64_t)(nruns * 16 + i) * BS + b) - dmean; dq = __builtin_fma(d, d, dq); dd += d; }
     part_q[r][b] = dq; part_d[r][b] = dd;
     __syncthreads();
     if (r != 0) return;
@@ -481,7 +483,7 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
         for (; i + 16 <= nblk; i += 16) {                    // loads in batches, the recurrence stays sequential
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = row[(i + u) * BS + b];
+            for (int u = 0; u < 16; ++u) v[u] = row((i + u) * BS + b);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const double d = (double)v[u];
@@ -491,7 +493,7 @@ k_mxops_stats_rows(const float* __restrict__ in, float* __restrict__ vmean, floa
             }
         }
         for (; i < nblk; ++i) {
-            const double d = (double)row[i * BS + b];
+            const double d = (double)row(i * BS + b);
             const double delta = d - mean;
             mean = mean + delta / (double)(i + 1);
             m2 = m2 + delta * (d - mean);
@@ -731,17 +733,33 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
 }
 
 // internal (msq_outlier_pack / msq_act_quant_bf16 with variant 1)
+int msq_mxops_stats_x_(const void* in, int x_bf16, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post, int block,
+                       int* status, void* stream);
 int msq_mxops_stats_(const float* in, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post, int block,
                      int* status, void* stream) {
+    return msq_mxops_stats_x_(in, 0, vmean, vstd, pre, axis_len, post, block, status, stream);
+}
+// x_bf16: the rows hold bfloat16 (contiguous blocks only: post == 1, block 32 / 64 / 128 dividing the axis)
+int msq_mxops_stats_x_(const void* inv, int x_bf16, float* vmean, float* vstd, int64_t pre, int64_t axis_len, int64_t post, int block,
+                       int* status, void* stream) {
+    const float* in = (const float*)inv;
     const int64_t nblk = (axis_len + block - 1) / block;
     hipStream_t st = (hipStream_t)stream;
     if (post == 1 && axis_len % block == 0 && nblk <= 1024 && nblk >= 2 && pre < (1ll << 31) &&
         (block == 32 || block == 64 || block == 128)) {
         const dim3 grid((unsigned)pre), blk(256);
+        if (x_bf16) {
+            const uint16_t* ih = (const uint16_t*)inv;
+            if (block == 32) hipLaunchKernelGGL((k_mxops_stats_rows<32, uint16_t>), grid, blk, 0, st, ih, vmean, vstd, axis_len, nblk, status);
+            else if (block == 64) hipLaunchKernelGGL((k_mxops_stats_rows<64, uint16_t>), grid, blk, 0, st, ih, vmean, vstd, axis_len, nblk, status);
+            else hipLaunchKernelGGL((k_mxops_stats_rows<128, uint16_t>), grid, blk, 0, st, ih, vmean, vstd, axis_len, nblk, status);
+            return check_launch("mx_ops statistics");
+        }
         if (block == 32) hipLaunchKernelGGL(k_mxops_stats_rows<32>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
         else if (block == 64) hipLaunchKernelGGL(k_mxops_stats_rows<64>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
         else hipLaunchKernelGGL(k_mxops_stats_rows<128>, grid, blk, 0, st, in, vmean, vstd, axis_len, nblk, status);
     } else {
+        if (x_bf16) return fail(MSQ_ERR_UNSUPPORTED, "mx_ops statistics: bfloat16 rows need contiguous blocks of 32 / 64 / 128 and 2 ... 1024 blocks per row");
         hipLaunchKernelGGL(k_mxops_stats, dim3(grid_for(pre * block * post, 256)), dim3(256), 0, st,
                            in, vmean, vstd, pre, axis_len, post, block, nblk, status);
     }

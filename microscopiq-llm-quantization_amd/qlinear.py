@@ -198,17 +198,19 @@ def act_quant(x, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="
     if not x.is_cuda:
         raise MsqError("act_quant needs a CUDA/HIP tensor (no CPU fallback)")
     K = x.shape[-1]
-    xf = x.reshape(-1, K).float().contiguous()
+    x16 = x.dtype == torch.bfloat16 and (int(variant) == 0 or block_size in (32, 64))   # read as is: no cast pass
+    xf = x.reshape(-1, K).contiguous() if x16 else x.reshape(-1, K).float().contiguous()
     M = xf.shape[0]
     xq = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
     wsb = lib().msq_act_quant_workspace_bytes(M, K, block_size, int(variant))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     status = torch.zeros(1, dtype=torch.int32, device=x.device)
-    check(lib().msq_act_quant_bf16(ptr(xf), ptr(xq), ptr(status), ptr(ws), wsb, M, K, block_size,
-                                   format_id(inlier_elem_format), format_id(outlier_elem_format),
-                                   int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
-                                   int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), int(variant),
-                                   current_stream(x.device)), "msq_act_quant_bf16")
+    fn = lib().msq_act_quant_bf16_x16 if x16 else lib().msq_act_quant_bf16
+    check(fn(ptr(xf), ptr(xq), ptr(status), ptr(ws), wsb, M, K, block_size,
+             format_id(inlier_elem_format), format_id(outlier_elem_format),
+             int(inlier_scale_bits), int(outlier_scale_bits), float(std_dev),
+             int(RoundingMode[round]), int(bool(flush_fp32_subnorms)), int(variant),
+             current_stream(x.device)), "msq_act_quant_bf16")
     return xq.reshape(x.shape), status
 
 
@@ -222,7 +224,8 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     K = x.shape[-1]
     if K != P.K:
         raise MsqError("qlinear_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
-    xf = x.reshape(-1, K).float().contiguous()
+    x16 = x.dtype == torch.bfloat16 and (int(a_variant) == 0 or a_block_size in (32, 64))   # read as is: no cast pass
+    xf = x.reshape(-1, K).contiguous() if x16 else x.reshape(-1, K).float().contiguous()
     M = xf.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_w4a8: out_dtype must be float32 or bfloat16")
@@ -232,12 +235,13 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
     status = torch.zeros(1, dtype=torch.int32, device=x.device)
     fo = a_outlier_elem_format or a_elem_format
-    check(lib().msq_qlinear_w4a8(ptr(xf), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
-                                 0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
-                                 a_block_size, format_id(a_elem_format), format_id(fo), int(a_scale_bits),
-                                 int(a_scale_bits), float(a_std_dev), int(RoundingMode[a_round]),
-                                 int(bool(a_flush_fp32_subnorms)), int(a_variant), ptr(status), ptr(ws), wsb,
-                                 current_stream(x.device)), "msq_qlinear_w4a8")
+    fn = lib().msq_qlinear_w4a8_x16 if x16 else lib().msq_qlinear_w4a8
+    check(fn(ptr(xf), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
+             0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
+             a_block_size, format_id(a_elem_format), format_id(fo), int(a_scale_bits),
+             int(a_scale_bits), float(a_std_dev), int(RoundingMode[a_round]),
+             int(bool(a_flush_fp32_subnorms)), int(a_variant), ptr(status), ptr(ws), wsb,
+             current_stream(x.device)), "msq_qlinear_w4a8")
     if check_status:
         st = int(status.item())
         if st & 1:

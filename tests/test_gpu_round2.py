@@ -417,6 +417,32 @@ def test_c_abi_error_codes_round2(msq):
     assert L.msq_quantize_mx_by_tile_py(None, None, 0, 64, 1, 32, 8, 2, 3, 6.0, 0, 0, None) == 0
 
 
+def test_act_quant_bf16_input_equals_cast_path(msq):
+    """bfloat16 activations are read as they are (msq_act_quant_bf16_x16 / msq_qlinear_w4a8_x16: no cast pass in front): the
+    results equal those of the fp32 route on x.float(), bit for bit -- both quantiser variants, the block sizes each takes,
+    full and ragged wave tiles, and the fused W4A8 Linear."""
+    from msq import qlinear
+    g = torch.Generator(device=dev()).manual_seed(13)
+    for M, K in ((64, 4096), (37, 256), (2048, 1024)):
+        x = (torch.randn(M, K, generator=g, device=dev()) * 3).to(torch.bfloat16)
+        x[0, :32] = 0
+        for variant, sd, blocks in ((0, 2, (16, 32, 64)), (1, 5, (32, 64))):
+            for bs in blocks:
+                if variant == 1 and K // bs < 2:
+                    continue
+                a, sa = qlinear.act_quant(x, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, bs, "nearest", False, variant)
+                b, sb = qlinear.act_quant(x.float(), 8, 8, "fp8_e4m3", "fp8_e4m3", sd, bs, "nearest", False, variant)
+                assert torch.equal(a, b) and int(sa.item()) == int(sb.item()), (M, K, variant, bs)
+    N, K = 512, 1024
+    W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+    P = qlinear.pack_values(msq.mx_ops._quantize_mx_outlier_v1(W, 8, 8, "fp4_e2m1", "fp4_e2m1", "max", 5, [1], 32))
+    x = torch.randn(200, K, generator=g, device=dev()).to(torch.bfloat16)
+    for variant, sd in ((0, 2), (1, 5)):
+        ya = qlinear.qlinear_w4a8(x, P, None, torch.float32, a_std_dev=sd, a_variant=variant)
+        yb = qlinear.qlinear_w4a8(x.float(), P, None, torch.float32, a_std_dev=sd, a_variant=variant)
+        assert torch.equal(ya, yb), variant
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
