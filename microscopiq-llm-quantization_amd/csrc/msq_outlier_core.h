@@ -284,7 +284,9 @@ MSQ_D void hw_codec_pair(int kind, float x0, float x1, float s, float bound, flo
 template <int BS, int RM, bool EMIT = false, int HW = 0>
 MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
                              const OutlierArgs& A, int order, const float* vmean, const float* vstd, int64_t vstride,
-                             uint32_t* codes = nullptr, int in_kind = 0, int out_kind = 0) {
+                             uint32_t* codes = nullptr, int in_kind = 0, int out_kind = 0, float* lds_row = nullptr) {
+    // lds_row (HW == 2 only): the lane's own copy of the block's ORIGINAL values in LDS (BS consecutive floats); it lets the
+    // posit outliers be rounded one per loop trip instead of for every element (see below) and is clobbered.
     int status = 0;
     float lo = 0.f, hi = 0.f;
     if (A.variant == 0) {
@@ -374,7 +376,43 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
                 a[b] = (m0 ? vo0 : vi0) + 0.0f;                                                               \
                 a[b + 1] = (m1 ? vo1 : vi1) + 0.0f;                                                           \
             }
-            if (combo == 3 * 4 + 1) { MSQ_HW_LOOP(3, 1) }        // e2m1 inliers, e4m3 outliers
+            if (HW == 2 && combo == 3 * 4 + 0 && lds_row != nullptr) {
+                // e2m1 inliers + posit outliers, sparse form: the posit rounding (~18 instructions) is worth running only
+                // where the mask is set -- about one element in twenty.  Every element first takes the inlier convert; then
+                // each lane walks its mask bits, one outlier per trip (the wave makes as many trips as its fullest lane has
+                // outliers, typically 4-6 of 32), fetching the original value by its run-time position from the lane's LDS
+                // row -- a register array cannot be indexed like that -- and leaving the result there; one last pass merges.
+#pragma unroll
+                for (int b = 0; b < BS; b += 2) {
+                    const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);
+                    float vi0, vi1;
+                    hw_codec_pair(3, x0, x1, s_in, b_in, vi0, vi1);
+                    a[b] = vi0 + 0.0f; a[b + 1] = vi1 + 0.0f;
+                }
+#pragma unroll
+                for (int w = 0; w < (BS + 31) / 32; ++w) {
+                    uint32_t m = mkw[w];
+                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                        if (m != 0u) {
+                            const int b = w * 32 + __builtin_ctz(m);
+                            m &= m - 1u;
+                            const float x = lds_row[b];
+                            lds_row[b] = ((posit_round_fast((x * sc_in) * rc_out, A.fo.mbits, A.fo.ebits) * sc_out) * rc_in) + 0.0f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < BS / 4; ++c) {
+                    const float4 r = *reinterpret_cast<const float4*>(lds_row + c * 4);
+                    const float rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int b = c * 4 + j;
+                        a[b] = ((mkw[b >> 5] >> (b & 31)) & 1u) ? rv[j] : a[b];
+                    }
+                }
+            }
+            else if (combo == 3 * 4 + 1) { MSQ_HW_LOOP(3, 1) }   // e2m1 inliers, e4m3 outliers
             else if (combo == 3 * 4 + 0) { MSQ_HW_LOOP(3, 0) }   // e2m1 inliers, posit outliers (HW == 2)
             else if (combo == 1 * 4 + 1) { MSQ_HW_LOOP(1, 1) }   // e4m3 / e4m3 (activations)
             else if (combo == 3 * 4 + 2) { MSQ_HW_LOOP(3, 2) }   // e2m1 / e5m2

@@ -138,7 +138,8 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
         if (FAST == 1) status = outlier_block_fast<BS, 0>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
         else if (FAST == 2) status = outlier_block_fast<BS, -1>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
         else if (FAST == 3) status = outlier_block_fast<BS, 0, false, 1>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
-        else if (FAST == 4) status = outlier_block_fast<BS, 0, false, 2>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
+        else if (FAST == 4) status = outlier_block_fast<BS, 0, false, 2>(a, mkw, se_in, se_out, A, 1, vm, vs, 1, nullptr, 0, 0,
+                                                                         fast ? tl + lane * LDS_STRIDE : nullptr);
         else status = outlier_block<BS>(a, mkw, se_in, se_out, A, 1, vm, vs, 1);
     }
     if (fast) {

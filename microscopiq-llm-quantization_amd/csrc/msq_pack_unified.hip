@@ -71,7 +71,8 @@ k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint
             }
             uint32_t mkw[(B + 31) / 32];
             float se_in, se_out;
-            status |= outlier_block_fast<B, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1);
+            status |= outlier_block_fast<B, 0, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, nullptr, nullptr, 1, nullptr, 0, 0,
+                                                          (HW == 2) ? myrow + j * B : nullptr);
 #pragma unroll
             for (int c = 0; c < B / 4; ++c)
                 *reinterpret_cast<float4*>(myrow + j * B + c * 4) = make_float4(a[c * 4 + 0], a[c * 4 + 1], a[c * 4 + 2], a[c * 4 + 3]);
