@@ -13,7 +13,14 @@ bad = 0
 for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm|qgemv|mxgemv)\S*):', s, re.M):
     i = s.index('\n' + nm + ':'); j = s.index('s_endpgm', i)
     body = s[i:j]
-    w, sc = body.count('s_cbranch_execnz'), body.count('scratch_')
+    # waterfall loops are BACKWARD s_cbranch_execnz branches (the label is defined before the branch); forward ones are plain
+    # control flow (e.g. the block-order selection in the prologue)
+    w = 0
+    for mm in re.finditer(r's_cbranch_execnz (\S+)', body):
+        lab = body.find('\n' + mm.group(1) + ':')
+        if lab != -1 and lab < mm.start():
+            w += 1
+    sc = body.count('scratch_')
     line = "%-62s execnz %3d scratch %3d readfirstlane %3d v_mul_lo %3d valu %5d" % (nm[3:65], w, sc, body.count('readfirstlane'), body.count('v_mul_lo'), len(re.findall(r'\n\s+v_(?!mfma)', body)))
     main = ('k_qgemm3' in nm or 'k_mxgemm' in nm)
     flag = main and ((w and ('Et' in nm.split('Li')[2] if 'qgemm3' in nm else 'ItL' in nm)) or sc > 2)
