@@ -357,6 +357,13 @@ def test_fused_gemm_64_row_tiles_and_k_groups(msq):
             assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (fo, M)
             yb = qlinear.qlinear(X, P, bias, torch.bfloat16)
             assert torch.equal(yb, y.to(torch.bfloat16)), (fo, M)          # same accumulation, one rounding
+        # the half-chip window of the 64-row tiles (112 ... 128 blocks of 128 rows, short K): M = 1000 on N = 4096 in one pass
+        Ps = qlinear.pack_weight(W[:4096, :512].contiguous(), 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+        Wsd = qlinear.unpack_weight(Ps, torch.float32).double()
+        X = torch.randn(1000, 512, generator=g, device=dev()).to(torch.bfloat16)
+        ref = X.double() @ Wsd.t() + bias[:4096].double()
+        y = qlinear.qlinear(X, Ps, bias[:4096].contiguous(), torch.float32)
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, (fo, "half-chip window")
         # two k-groups per block (single-pass grids of 192 ... 256 blocks): M = 384 / ragged 380 -> 3 x 64 = 192 blocks, the
         # K range halved inside the block (K = 512: 4 + 4 K-steps; a K slice of 384: 3 + 3) and summed through LDS
         for M, Kc in ((384, 512), (380, 384)):
