@@ -739,7 +739,9 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // weight; lane (n % 16, kg) holds k = 32 kg .. +31, six bits each, little endian: scripts/experiments/mx_mfma_layout_fp6.hip).
 // The fp6 operand uses the two-deep ring and the register budget of the e4m3 operand.
 // KG = 2: two k-groups of four waves per block, as k_qgemm3 (single-pass grids of at most one block per CU).
-template <typename YT, int WF, int KG = 1>
+// MFM = 16-row fragments per wave along m: 8 (block 128 x 256) or 4 (block 64 x 256: grids between one and two 128-row blocks
+// per CU and half-chip grids with a short K, as k_qgemm3's 64-row tiles).
+template <typename YT, int WF, int KG = 1, int MFM = 8>
 __global__ void __launch_bounds__(256 * KG, KG == 2 ? 1 : 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
@@ -747,7 +749,9 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool W8 = (WF != 0);                                // wide operand: two pieces per fragment, two-deep ring
     constexpr bool W6 = (WF >= 2);
-    constexpr int BMX = 128, KS = 128, A_TILE = BMX * KS;         // 16 KiB per activation buffer
+    static_assert(MFM == 8 || (MFM == 4 && KG == 1), "64-row blocks: single k-group");
+    constexpr int BMX = 16 * MFM, KS = 128, A_TILE = BMX * KS;    // 16 / 8 KiB per activation buffer
+    constexpr int PPW = BMX / 32;                                 // 1 KiB staging pieces (8 rows) per wave and K-step: 4 / 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid_blk = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kgid = (KG == 2) ? (wid_blk >> 2) : 0;            // k-group of this wave
@@ -790,7 +794,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     int aoff[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int row = (wid * 4 + p) * 8 + (lane >> 3);
+        const int row = (wid * PPW + p) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         aoff[p] = (int)((int64_t)(m0 + row) * K + chunk * 16);
     }
@@ -801,15 +805,17 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     constexpr int XBUFS = W8 ? 3 : MSQ_MX_XBUFS;
     constexpr int XS_BASE = XBUFS * A_TILE;
     char* const smem_g = smem + kgid * (XBUFS * (A_TILE + 1024));   // this group's code and scale tiles
-    int xs_goff = m0 + wid * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
+    // (64-row blocks: waves 2 and 3 repeat the copies of waves 0 and 1 -- same bytes to the same place)
+    constexpr int XSW = (MFM == 8) ? 3 : 1;                      // wave -> 32-row scale group: wid & XSW
+    int xs_goff = m0 + (wid & XSW) * 32 + (lane & 31); xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
     auto stage_A = [&](int kt, int buf) {
         int k16 = 16 * K;
         asm volatile("" : "+s"(k16));                             // keeps the two derived offsets out of registers across K-steps
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * 4 + p) * 1024),
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * PPW + p) * 1024),
                                                      16, p < 2 ? aoff[p] : aoff[p - 2] + k16, uni((uint32_t)kt * KS), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem_g + XS_BASE + buf * 1024 + wid * 256),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem_g + XS_BASE + buf * 1024 + (wid & XSW) * 256),
                                                  4, xs_goff, uni((uint32_t)kt * 4u), 0, 0);
     };
     // LDS reads of one B fragment (row mf * 16 + c): chunks g and 4 + g (k = 16 g .. and 64 + 16 g ..)
@@ -818,9 +824,9 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     // scale byte of (row mf * 16 + c, block g): row r lives at wave r / 32, slot r % 32: + (mf / 2) * 256 + (mf % 2) * 64
     const int xs_rd = XS_BASE + c * 4 + g;
 
-    f32x4_t acc[8][4];
+    f32x4_t acc[MFM][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MFM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -844,7 +850,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         ws.s = __builtin_amdgcn_raw_buffer_load_b32(wsr, lane * 4, uni((tile_row32 + (uint32_t)kt) * 256u), 0);
     };
     constexpr int CBSZ = W6 ? WF : (W8 ? 0 : 4);                 // A-operand format: e2m3 / e3m2 / e4m3 / e2m1
-    constexpr int N_WAIT_MX = W8 ? 5 : (XBUFS == 4 ? 15 : 10);
+    constexpr int N_WAIT_MX = (W8 ? 0 : 5) + (PPW + 1) * (XBUFS == 4 ? 2 : 1);   // 128-row blocks: 5 / 10 (15 with four buffers)
     const int kl = sgpr((kt_hi > kt_lo) ? kt_hi - 1 : ((kt_lo < KT) ? kt_lo : KT - 1));   // an empty split runs a harmless prologue
     const int kf0 = sgpr((kt_lo < KT) ? kt_lo : KT - 1), kf1 = (kf0 + 1 <= kl) ? kf0 + 1 : kl;
     stage_A(kf0, 0);
@@ -877,8 +883,8 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         xl[0] = *reinterpret_cast<const u32x4_t*>(abase + rdl_); xh[0] = *reinterpret_cast<const u32x4_t*>(abase + rdh_);           \
         uint32_t xsc[2];                                                                                     \
         xsc[0] = *reinterpret_cast<const uint8_t*>(smem_g + xs_rd_ + buf * 1024);                               \
-        _Pragma("unroll") for (int mf = 0; mf < 8; ++mf) {                                                   \
-            if (mf + 1 < 8 && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl_ + (mf + 1) * 2048);                 \
+        _Pragma("unroll") for (int mf = 0; mf < MFM; ++mf) {                                                 \
+            if (mf + 1 < MFM && !(MSQ_MXABL & 1)) { xl[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdl_ + (mf + 1) * 2048);                 \
                               xh[(mf + 1) & 1] = *reinterpret_cast<const u32x4_t*>(abase + rdh_ + (mf + 1) * 2048);                 \
                               xsc[(mf + 1) & 1] = *reinterpret_cast<const uint8_t*>(smem_g + xs_rd_ + buf * 1024 + ((mf + 1) >> 1) * 256 + ((mf + 1) & 1) * 64); }  \
             if (!W8 && MSQ_MX_PIN_READS) __builtin_amdgcn_sched_barrier(0);   /* hipcc otherwise sinks these reads below the MFMAs of this group and waits for them at once (fp8 ring: the pin costs registers -> a scratch reload in the loop, slower) */ \
@@ -916,12 +922,12 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #undef MSQ_MX_STEP
     __builtin_amdgcn_s_waitcnt(0x0070);                        // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
-    if (MSQ_MXABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    if (MSQ_MXABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MFM; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     if constexpr (KG == 2) {                                    // group 1 -> LDS, group 0 adds (first half of K + second half), as k_qgemm3
         float4* red = reinterpret_cast<float4*>(smem) + wid * 2048;
         if (kgid == 1) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < MFM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) red[(i * 4 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
@@ -929,7 +935,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         __builtin_amdgcn_s_barrier();
         if (kgid == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < MFM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 t = red[(i * 4 + j) * 64 + lane];
@@ -940,8 +946,8 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         __builtin_amdgcn_s_barrier();                           // the epilogue slices overlap wave 0's hand-over area
         if (kgid == 1) return;
     }
-    if (ksplit > 1) store_wave_tile_lds<float>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
-    else store_wave_tile_lds<YT>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
+    if (ksplit > 1) store_wave_tile_lds<float, MFM>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
+    else store_wave_tile_lds<YT, MFM>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1926,7 +1932,33 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     // two k-groups per block for single-pass grids of at most one block per CU (rule and switch as msq_qlinear_bf16)
     static const int kg_forced = [] { const char* e = getenv("MSQ_MX_KG"); return e ? atoi(e) : 0; }();
     const int64_t KTm = K / 128;
-    const bool kg2 = ksplit == 1 && (KTm % 2) == 0 && KTm >= 4 && (kg_forced == 2 || (kg_forced == 0 && (int64_t)MT * NTB <= 256));
+    const bool kg2 = ksplit == 1 && (KTm % 2) == 0 && KTm >= 4 && (kg_forced == 2 || (kg_forced == 0 && (int64_t)MT * NTB <= 256));   // (ksplit == 1 here means >= 192 blocks: disjoint from the 64-row windows below)
+    // 64-row blocks for grids between one and two 128-row blocks per CU, and in ONE pass for half-chip grids with a short K
+    // (windows as msq_qlinear_bf16; MSQ_MX_MF=4 / 8 forces, tuning only)
+    static const int mf_forced = [] { const char* e = getenv("MSQ_MX_MF"); return e ? atoi(e) : 0; }();
+    static const int ks_forced = [] { const char* e = getenv("MSQ_MX_GEMM_KS"); return e ? atoi(e) : 0; }();
+    const int64_t blocks128 = (int64_t)MT * NTB;
+    if (mf_forced == 0 && ks_forced == 0 && blocks128 >= 112 && blocks128 <= 128 && KTm <= 32) ksplit = 1;
+    // measured (scripts/experiments/mx_kg_ab.py): half-chip window, M1024 4096 x 4096: fp4 30.4 -> 21.4 us, fp6 31.9 -> 26.1,
+    // e4m3 31.1 -> 25.7; M512 N8192: 29.4 -> 19.0 / 32.6 -> 25.4 / 36.3 -> 25.7.  Between one and two blocks per CU only the
+    // fp4 operand gains (5120 x 5120 54.1 -> 51.2 us); the 24- and 32-byte operands lose up to 20 % there (half as many MFMAs
+    // per weight load), so that window is fp4 only.
+    const bool mf4 = ksplit == 1 && (mf_forced == 4 || (mf_forced == 0 && ((wf == 0 && blocks128 > 256 && blocks128 < 448) ||
+                                                                            (blocks128 >= 112 && blocks128 <= 128 && KTm <= 32))));
+    if (mf4) {
+        const dim3 grid4((unsigned)(((M + 63) / 64) * NTB)), blk4(256);
+        size_t lds4 = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (64 * 128 + 1024);
+        if (lds4 < 4 * 8192) lds4 = 4 * 8192;                          // the epilogue stages 8 KiB per wave
+#define MSQ_MXL4(YT, W8V)                                                                                             \
+        do { static DevOnce once_;                                                                                    \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
+             hipLaunchKernelGGL((k_mxgemm<YT, W8V, 1, 4>), grid4, blk4, lds4, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); } while (0)
+        if (y_dtype == 0) { if (wf == 0) MSQ_MXL4(float, 0); else if (wf == 1) MSQ_MXL4(float, 1); else if (wf == 2) MSQ_MXL4(float, 2); else MSQ_MXL4(float, 3); }
+        else { if (wf == 0) MSQ_MXL4(uint16_t, 0); else if (wf == 1) MSQ_MXL4(uint16_t, 1); else if (wf == 2) MSQ_MXL4(uint16_t, 2); else MSQ_MXL4(uint16_t, 3); }
+#undef MSQ_MXL4
+        return check_launch2("msq_qlinear_mx_w4a8(64-row blocks)");
+    }
     const dim3 grid((unsigned)(MT * NTB * ksplit)), blk(kg2 ? 512 : 256);
     size_t lds = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (128 * 128 + 1024);   // code tiles + scale tiles
     if (kg2) { lds *= 2; if (lds < 4 * 32768) lds = 4 * 32768; }        // two groups; 4 x 32 KiB accumulator hand-over

@@ -15,7 +15,7 @@ def t(fn, n=50, warm=120):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
 out = []
-for (M, N, K) in [(2048, 4096, 4096), (2048, 4096, 11008), (1536, 4096, 4096), (1024, 8192, 8192), (2048, 16384, 4096), (2048, 11008, 4096)]:
+for (M, N, K) in [tuple(int(v) for v in a.split(",")) for a in (os.environ.get("SHAPES") or "2048,4096,4096 2048,4096,11008 1536,4096,4096 1024,8192,8192 2048,16384,4096 2048,11008,4096").split()]:
     W = torch.randn(N, K, device=dev) * 0.02
     X = torch.randn(M, K, device=dev)
     xc, xs = qlinear.mx_pack_act(X)
@@ -28,7 +28,7 @@ for (M, N, K) in [(2048, 4096, 4096), (2048, 4096, 11008), (1536, 4096, 4096), (
     out.append("M%d N%d K%d: %s" % (M, N, K, " | ".join(r)))
 print("RESULT " + " ;; ".join(out))
 '''
-for label, env_add in (("auto (k-groups for <= 256 blocks)", {}), ("kg1", {"MSQ_MX_KG": "1"})):
+for label, env_add in (("auto", {}), ("kg1 mf8", {"MSQ_MX_KG": "1", "MSQ_MX_MF": "8"})):
     env = dict(os.environ); env.update(env_add)
     out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]

@@ -392,7 +392,9 @@ def test_mx_gemm_k_groups(msq, O):
                "e3m2": (qlinear.mx_pack_weight(W, w_fmt="e3m2"), O.quantize_mx(W.cpu().numpy(), 8, "fp6_e3m2", axis=1, block_size=32))}
         Wq8 = quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
         ops["e4m3"] = (qlinear.mx_pack_values(Wq8), Wq8.cpu().numpy())
-        for M in (384, 380):
+        # 384 / 380 rows: 192 blocks (k-groups); 640 rows: 320 blocks (64-row blocks, fp4 operand); the half-chip window of
+        # the 64-row blocks (112 ... 128 blocks, K <= 4096) is covered on a 4096-column slice below
+        for M in (384, 380, 640):
             X = torch.randn(M, K, generator=g, device=dev()) * 2
             Xq = O.quantize_mx(X.cpu().numpy(), 8, "fp8_e4m3", axis=1, block_size=32).astype(np.float64)
             for name, (P, Wq) in ops.items():
@@ -401,6 +403,17 @@ def test_mx_gemm_k_groups(msq, O):
                 assert np.abs(y.double().cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), (K, M, name)
                 for _ in range(10):
                     assert torch.equal(qlinear.qlinear_mx_w4a8(X, P, bias, torch.float32), y), (K, M, name)
+        Ws = W[:4096].contiguous()
+        ops_s = {"e2m1": (qlinear.mx_pack_weight(Ws), O.quantize_mx(Ws.cpu().numpy(), 8, "fp4_e2m1", axis=1, block_size=32)),
+                 "e3m2": (qlinear.mx_pack_weight(Ws, w_fmt="e3m2"), O.quantize_mx(Ws.cpu().numpy(), 8, "fp6_e3m2", axis=1, block_size=32)),
+                 "e4m3": (qlinear.mx_pack_values(Wq8[:4096].contiguous()), Wq8[:4096].cpu().numpy())}
+        X = torch.randn(1000, K, generator=g, device=dev()) * 2                      # 8 x 16 = 128 blocks of 128 rows
+        Xq = O.quantize_mx(X.cpu().numpy(), 8, "fp8_e4m3", axis=1, block_size=32).astype(np.float64)
+        for name, (P, Wq) in ops_s.items():
+            ref = Xq @ Wq.astype(np.float64).T + bias[:4096].double().cpu().numpy()
+            y = qlinear.qlinear_mx_w4a8(X, P, bias[:4096].contiguous(), torch.float32)
+            assert np.abs(y.double().cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), (K, "half-chip", name)
+            assert torch.equal(qlinear.qlinear_mx_w4a8(X, P, bias[:4096].contiguous(), torch.bfloat16), y.to(torch.bfloat16))
 
 
 def test_c_abi_error_codes_round2(msq):
