@@ -1933,18 +1933,21 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     static const int kg_forced = [] { const char* e = getenv("MSQ_MX_KG"); return e ? atoi(e) : 0; }();
     const int64_t KTm = K / 128;
     const bool kg2 = ksplit == 1 && (KTm % 2) == 0 && KTm >= 4 && (kg_forced == 2 || (kg_forced == 0 && (int64_t)MT * NTB <= 256));   // (ksplit == 1 here means >= 192 blocks: disjoint from the 64-row windows below)
-    // 64-row blocks for grids between one and two 128-row blocks per CU, and in ONE pass for half-chip grids with a short K
-    // (windows as msq_qlinear_bf16; MSQ_MX_MF=4 / 8 forces, tuning only)
+    // 64-row blocks (MSQ_MX_MF=4 / 8 forces, tuning only).  Measured from HIP graphs (scripts/experiments/mx_mf4_graph.py):
+    //  * ONE pass of 64-row blocks instead of a split-K launch whenever they fit the chip (<= 256 blocks): the fp4 kernel then
+    //    takes a flat 17.4-19.5 us for K = 4096 at any M (512 x 4096 x 4096: 23.2 -> 17.9 us, 768: 26.4 -> 18.6, M384 N8192:
+    //    26.7 -> 18.6, M1024: 30.4 -> 21.4 from Python); with K = 11008 only from 192 blocks on (M768: 44.5 -> 41.3 us, M1024:
+    //    54.1 -> 42.8).  The 24- / 32-byte operands take ~25 us for the pass: a gain from 192 blocks on (768 x 4096 x 4096:
+    //    29.2 -> 25.1 us, M384 N8192: 31.2 -> 25.3), a loss below.
+    //  * between one and two 128-row blocks per CU only the fp4 operand gains (5120 x 5120 54.1 -> 51.2 us); the wider operands
+    //    lose up to 20 % there (half as many MFMAs per weight load).
     static const int mf_forced = [] { const char* e = getenv("MSQ_MX_MF"); return e ? atoi(e) : 0; }();
     static const int ks_forced = [] { const char* e = getenv("MSQ_MX_GEMM_KS"); return e ? atoi(e) : 0; }();
-    const int64_t blocks128 = (int64_t)MT * NTB;
-    if (mf_forced == 0 && ks_forced == 0 && blocks128 >= 112 && blocks128 <= 128 && KTm <= 32) ksplit = 1;
-    // measured (scripts/experiments/mx_kg_ab.py): half-chip window, M1024 4096 x 4096: fp4 30.4 -> 21.4 us, fp6 31.9 -> 26.1,
-    // e4m3 31.1 -> 25.7; M512 N8192: 29.4 -> 19.0 / 32.6 -> 25.4 / 36.3 -> 25.7.  Between one and two blocks per CU only the
-    // fp4 operand gains (5120 x 5120 54.1 -> 51.2 us); the 24- and 32-byte operands lose up to 20 % there (half as many MFMAs
-    // per weight load), so that window is fp4 only.
-    const bool mf4 = ksplit == 1 && (mf_forced == 4 || (mf_forced == 0 && ((wf == 0 && blocks128 > 256 && blocks128 < 448) ||
-                                                                            (blocks128 >= 112 && blocks128 <= 128 && KTm <= 32))));
+    const int64_t blocks128 = (int64_t)MT * NTB, blocks64 = ((M + 63) / 64) * NTB;
+    const bool one_pass64 = blocks64 <= 256 && M > 64 &&
+                            (KTm <= 32 ? (wf == 0 || blocks64 >= 192) : (wf == 0 && blocks64 >= 192));
+    if (mf_forced == 0 && ks_forced == 0 && one_pass64) ksplit = 1;
+    const bool mf4 = ksplit == 1 && (mf_forced == 4 || (mf_forced == 0 && ((wf == 0 && blocks128 > 256 && blocks128 < 448) || one_pass64)));
     if (mf4) {
         const dim3 grid4((unsigned)(((M + 63) / 64) * NTB)), blk4(256);
         size_t lds4 = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (64 * 128 + 1024);

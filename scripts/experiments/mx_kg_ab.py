@@ -28,7 +28,8 @@ for (M, N, K) in [tuple(int(v) for v in a.split(",")) for a in (os.environ.get("
     out.append("M%d N%d K%d: %s" % (M, N, K, " | ".join(r)))
 print("RESULT " + " ;; ".join(out))
 '''
-for label, env_add in (("auto", {}), ("kg1 mf8", {"MSQ_MX_KG": "1", "MSQ_MX_MF": "8"})):
+ARMS = {"auto": {}, "kg1 mf8": {"MSQ_MX_KG": "1", "MSQ_MX_MF": "8"}, "mf4 ks1": {"MSQ_MX_MF": "4", "MSQ_MX_GEMM_KS": "1"}}
+for label, env_add in [(a, ARMS[a]) for a in (os.environ.get("ARMS") or "auto,kg1 mf8").split(",")]:
     env = dict(os.environ); env.update(env_add)
     out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
