@@ -749,7 +749,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool W8 = (WF != 0);                                // wide operand: two pieces per fragment, two-deep ring
     constexpr bool W6 = (WF >= 2);
-    static_assert(MFM == 8 || (MFM == 4 && KG == 1), "64-row blocks: single k-group");
+    static_assert(MFM == 8 || MFM == 4, "block height");
     constexpr int BMX = 16 * MFM, KS = 128, A_TILE = BMX * KS;    // 16 / 8 KiB per activation buffer
     constexpr int PPW = BMX / 32;                                 // 1 KiB staging pieces (8 rows) per wave and K-step: 4 / 2
     const int tid = threadIdx.x, lane = tid & 63;
@@ -924,7 +924,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     __builtin_amdgcn_s_barrier();
     if (MSQ_MXABL & 16) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MFM; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
     if constexpr (KG == 2) {                                    // group 1 -> LDS, group 0 adds (first half of K + second half), as k_qgemm3
-        float4* red = reinterpret_cast<float4*>(smem) + wid * 2048;
+        float4* red = reinterpret_cast<float4*>(smem) + wid * (MFM * 4 * 64);
         if (kgid == 1) {
 #pragma unroll
             for (int i = 0; i < MFM; ++i)
@@ -1952,11 +1952,20 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
         const dim3 grid4((unsigned)(((M + 63) / 64) * NTB)), blk4(256);
         size_t lds4 = (size_t)(wf ? 3 : MSQ_MX_XBUFS) * (64 * 128 + 1024);
         if (lds4 < 4 * 8192) lds4 = 4 * 8192;                          // the epilogue stages 8 KiB per wave
+        // ... with two k-groups when the blocks leave every CU at most one (the K-step of a 64-row block is latency, not MFMA:
+        // 0.45 us for 16 MFMAs per wave): MSQ_MX_KG=1 keeps one group
+        const bool kg4 = (KTm % 2) == 0 && KTm >= 4 && blocks64 <= 256 && kg_forced != 1;
+        if (kg4) { lds4 *= 2; if (lds4 < 4 * 16384) lds4 = 4 * 16384; }   // two groups; 4 x 16 KiB accumulator hand-over
+        const dim3 blk4k(kg4 ? 512 : 256);
 #define MSQ_MXL4(YT, W8V)                                                                                             \
-        do { static DevOnce once_;                                                                                    \
+        do { if (kg4) { static DevOnce once_;                                                                         \
+             if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
+             hipLaunchKernelGGL((k_mxgemm<YT, W8V, 2, 4>), grid4, blk4k, lds4, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); }         \
+             else { static DevOnce once_;                                                                             \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
              hipLaunchKernelGGL((k_mxgemm<YT, W8V, 1, 4>), grid4, blk4, lds4, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); } while (0)
+                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); } } while (0)
         if (y_dtype == 0) { if (wf == 0) MSQ_MXL4(float, 0); else if (wf == 1) MSQ_MXL4(float, 1); else if (wf == 2) MSQ_MXL4(float, 2); else MSQ_MXL4(float, 3); }
         else { if (wf == 0) MSQ_MXL4(uint16_t, 0); else if (wf == 1) MSQ_MXL4(uint16_t, 1); else if (wf == 2) MSQ_MXL4(uint16_t, 2); else MSQ_MXL4(uint16_t, 3); }
 #undef MSQ_MXL4
