@@ -861,7 +861,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
-#define MSQ_MX_STEP(KT_CUR, WCUR, WLOAD)                                                                      \
+#define MSQ_MX_STEP(KT_CUR, WCUR, WLOAD, NWAIT)                                                               \
     {                                                                                                        \
         const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf, buf2 = (XBUFS == 4) ? ((abuf + 3) & 3) : ((abuf == 0) ? 2 : abuf - 1);         \
@@ -903,20 +903,25 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         }                                                                                                    \
         /* this K-step's 5 weight loads and 5 LDS-DMA ops (all for K-step kt + 2) stay in flight; everything \
            issued in the previous K-step -- the tile and the weights of K-step kt + 1 -- has landed */       \
-        __builtin_amdgcn_s_waitcnt(0x0070 | N_WAIT_MX);                                                      \
+        __builtin_amdgcn_s_waitcnt(0x0070 | (NWAIT));                                                        \
         if (!(MSQ_MXABL & 8)) __builtin_amdgcn_s_barrier();                                                  \
     }
 
     int abuf = 0;
     {
         int kt = kt_lo;
+        // The steps after the loop load weights nobody will use: hipcc deletes those loads, so such a step issues only its
+        // LDS-DMA ops and the loop's wait count (which lets a whole step's loads stay in flight) would no longer cover the
+        // tile staged one step earlier -- the next tail step would read it unawaited (seen as run-to-run differences with
+        // the short K-steps of the 64-row blocks).  Tail steps therefore let only their own LDS-DMA ops stay in flight.
+        constexpr int N_WAIT_TAIL = (PPW + 1) * (XBUFS == 4 ? 2 : 1);
         if constexpr (W8) {
-            for (; kt + 1 < kt_hi; kt += 2) { MSQ_MX_STEP(kt, w0, w1) MSQ_MX_STEP(kt + 1, w1, w0) }
-            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w1) ++kt; }
+            for (; kt + 1 < kt_hi; kt += 2) { MSQ_MX_STEP(kt, w0, w1, N_WAIT_MX) MSQ_MX_STEP(kt + 1, w1, w0, N_WAIT_MX) }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w1, N_WAIT_TAIL) ++kt; }
         } else {
-            for (; kt + 2 < kt_hi; kt += 3) { MSQ_MX_STEP(kt, w0, w2) MSQ_MX_STEP(kt + 1, w1, w0) MSQ_MX_STEP(kt + 2, w2, w1) }
-            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w2) ++kt; }
-            if (kt < kt_hi) { MSQ_MX_STEP(kt, w1, w0) ++kt; }
+            for (; kt + 2 < kt_hi; kt += 3) { MSQ_MX_STEP(kt, w0, w2, N_WAIT_MX) MSQ_MX_STEP(kt + 1, w1, w0, N_WAIT_MX) MSQ_MX_STEP(kt + 2, w2, w1, N_WAIT_MX) }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w0, w2, N_WAIT_TAIL) ++kt; }
+            if (kt < kt_hi) { MSQ_MX_STEP(kt, w1, w0, N_WAIT_TAIL) ++kt; }
         }
     }
 #undef MSQ_MX_STEP

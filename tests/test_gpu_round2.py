@@ -463,6 +463,24 @@ def test_act_quant_bf16_input_equals_cast_path(msq):
         assert torch.equal(ya, yb), variant
 
 
+def test_mx_gemm_tail_steps_run_to_run(msq):
+    """Regression: the steps after the fp4 kernel's three-step loop issue no weight loads (hipcc deletes the dead ones), so
+    the loop's wait count no longer covered the activation tile staged one step earlier and the last K-step could read it
+    before it had landed -- a handful of differing launches per 600 with the short K-steps of the 64-row blocks (K-step
+    counts with remainder 2 modulo 3: K = 4096, 1024).  Tail steps now wait for everything but their own LDS-DMA."""
+    from msq import qlinear
+    g = torch.Generator(device=dev()).manual_seed(3)
+    for (M, N, K) in ((640, 16384, 4096), (2048, 5120, 1024), (2048, 16384, 4096)):
+        W = torch.randn(N, K, generator=g, device=dev()) * 0.02
+        P = qlinear.mx_pack_weight(W)
+        xp = qlinear.mx_pack_act(torch.randn(M, K, generator=g, device=dev()))
+        y0 = qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32)
+        d = torch.zeros((), dtype=torch.int64, device=dev())
+        for _ in range(400):
+            d += (qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32) != y0).any().to(torch.int64)
+        assert int(d.item()) == 0, (M, N, K, int(d.item()))
+
+
 def test_vector_ops_wide_rows_vs_oracle(msq, O):
     """The four-waves-per-row LayerNorm (H = 512 G, G <= 16: one cascade level of ATen's sum) and the 16-byte gelu / add
     kernels against the oracle at model widths, in the bfloat16-nearest fast path and in a run-time rounding config
