@@ -27,4 +27,26 @@ for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm|qgemv|mxgemv)\S*):', s, re.M):
     if flag:
         bad += 1
     print(("!! " if flag else "   ") + line)
+# vmcnt accounting of the K-loops (k_qgemm3, k_mxgemm): between two barriers a step issues L vector-memory loads and ends with
+# s_waitcnt vmcnt(N); N > L lets loads of an EARLIER step stay in flight across the barrier -- only harmless when the next
+# step multiplies nothing (the drain before the epilogue).  (hipcc deletes dead loads of tail steps: see DESIGN.md 5.0.)
+for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm)\S*):', s, re.M):
+    i = s.index('\n' + nm + ':'); j = s.index('s_endpgm', i)
+    segs, cur = [], {"loads": 0, "wait": None, "mfma": 0}
+    for l in s[i:j].split('\n'):
+        l = l.strip()
+        if l.startswith('buffer_load') or l.startswith('global_load'):
+            cur["loads"] += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l:
+            cur["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
+        elif l.startswith('v_mfma'):
+            cur["mfma"] += 1
+        elif l.startswith('s_barrier'):
+            segs.append(cur); cur = {"loads": 0, "wait": None, "mfma": 0}
+    segs.append(cur)
+    for k in range(1, len(segs) - 1):
+        a, b = segs[k], segs[k + 1]
+        if a["wait"] is not None and a["wait"] > a["loads"] and b["mfma"] > 0 and a["mfma"] > 0:
+            print("!! %-62s K-step segment %d: %d loads issued but vmcnt(%d) before the barrier, and the next segment multiplies" % (nm[3:65], k, a["loads"], a["wait"]))
+            bad += 1
 sys.exit(1 if bad else 0)
