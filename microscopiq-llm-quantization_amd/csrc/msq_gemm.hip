@@ -1695,11 +1695,11 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     // ... and for grids of about half a chip of 128-row blocks with a short K (112 ... 128 blocks, K <= 4096: M = 1024 on a
     // 4096 x 4096 projection, M = 512 on N = 8192): the cost model would split K in two and pay 33 MB of partial planes;
     // half-height blocks fill the chip in ONE pass instead (fp8 outliers 39.3 -> 33.9 / 41.0 -> 33.6 us, posit 42.7 -> 41.5 /
-    // 43.7 -> 40.6 us).  Longer K (11008), smaller grids and larger ones (144+ blocks: more than 256 half-height blocks, 50 -> 60 us) lose, so the window is narrow.
+    // 43.7 -> 40.6 us; with fp8 outliers also from 96 blocks: M = 768 35.8 -> 31.6 us).  Longer K (11008), smaller grids and larger ones (144+ blocks: more than 256 half-height blocks, 50 -> 60 us) lose, so the window is narrow.
     static const int ks_forced = [] { const char* e = getenv("MSQ_GEMM_KS"); return e ? atoi(e) : 0; }();
-    if (unified && wm_sel == 1 && mf_sel == 8 && mf_forced == 0 && ks_forced == 0 && blocks128 >= 112 && blocks128 <= 128 && K / BK <= 64) ksplit = 1;
+    if (unified && wm_sel == 1 && mf_sel == 8 && mf_forced == 0 && ks_forced == 0 && blocks128 >= (out_kind == MSQ_PLANE_U8 ? 96 : 112) && blocks128 <= 128 && K / BK <= 64) ksplit = 1;
     const bool mf4 = unified && ksplit == 1 && wm_sel == 1 && mf_sel == 8 &&
-                     (mf_forced == 4 || (mf_forced == 0 && ((blocks128 > 256 && blocks128 < 448) || (blocks128 >= 112 && blocks128 <= 128 && K / BK <= 64))));
+                     (mf_forced == 4 || (mf_forced == 0 && ((blocks128 > 256 && blocks128 < 448) || (blocks128 >= (out_kind == MSQ_PLANE_U8 ? 96 : 112) && blocks128 <= 128 && K / BK <= 64))));
     if (mf4) {
         const dim3 grid4((unsigned)(((M + 63) / 64) * (N / BN))), blk4(256);
         const size_t lds4 = 4 * 8192;                               // max(3 x 8 KiB activation buffers, 4 x 8 KiB epilogue slices)
