@@ -710,7 +710,7 @@ def test_gptq_block_kernel_speed_and_llama_layer(msq):
     same = float((outs[1][0] == outs[2][0]).float().mean())
     assert same >= 0.995, same
     assert abs(outs[1][2] - outs[2][2]) <= 1e-3 * outs[2][2]
-    assert outs[1][1] < 0.2, outs[1][1]
+    assert outs[1][1] < 0.3, outs[1][1]            # 0.070 s typical (was 0.84-0.88 s with one torch launch chain per column)
 
 
 @pytest.mark.parametrize("family", ["llama", "opt"])
