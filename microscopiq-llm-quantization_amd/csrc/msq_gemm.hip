@@ -41,9 +41,17 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #endif
 #ifndef MSQ_ABL
 #define MSQ_ABL 0
+/* k_qgemm3 timing experiments (results are wrong by construction): 1 no LDS fragment reads, 2 no converts, 4 no packed loads,
+   8 no activation staging, 16 no output stores.  Bits 32 ... 1024 emulate the instruction mix of 256-row block shapes inside the
+   128-row kernel: 32 convert only fragments nf 0 / 1 (the MFMAs of nf 2 / 3 reuse them), 64 read every activation fragment
+   twice, 128 issue every LDS-DMA piece twice (1024: the same bytes again instead of the neighbouring half tile), 256 load one
+   packed slot per half-step instead of two, 512 four ds_write_b128 + twelve ds_read_b128 of "shared weight fragments" per K-step */
 #endif
 #ifndef MSQ_EXP_SKIPBAR
 #define MSQ_EXP_SKIPBAR 0   /* timing experiment only (results are WRONG): no wait / barrier after the first K-step of every pair */
+#endif
+#ifndef MSQ_STAGGER
+#define MSQ_STAGGER 1       /* eight-wave blocks, extension-bit layout: waves 4-7 run half a K-step behind waves 0-3 (k_qgemm3); 0 = off, 2 = also for MSQ-U1 without extension bits */
 #endif
 #define TILE_N 64
 #define TILE_K 64
@@ -288,7 +296,7 @@ k_unpack(const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_
 template <int OUT_KIND> struct HalfSlots { static constexpr int n = (OUT_KIND == MSQ_PLANE_BF16) ? 4 : 2; };
 // vector-memory loads one half-step issues for the packed operand (vmcnt bookkeeping)
 template <int IN_KIND, int OUT_KIND> struct HalfLoads {
-    static constexpr int n = (IN_KIND != MSQ_PLANE_NONE ? 1 : 0) + HalfSlots<OUT_KIND>::n + (OUT_KIND == MSQ_PLANE_U8X ? 1 : 0);
+    static constexpr int n = (IN_KIND != MSQ_PLANE_NONE ? 1 : 0) + (((MSQ_ABL & 256) && IsUnified<OUT_KIND>::v) ? 1 : HalfSlots<OUT_KIND>::n) + (OUT_KIND == MSQ_PLANE_U8X ? 1 : 0);
 };
 
 template <int IN_KIND, int OUT_KIND>
@@ -331,8 +339,10 @@ MSQ_D void load_half_buf(HalfRegs<IN_KIND, OUT_KIND>& h, const PlaneRsrc& r, int
     if (IN_KIND != MSQ_PLANE_NONE)
         h.inl = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r.inl, lane16, uni(tile2kf * 1024u), 0));
 #pragma unroll
-    for (int s = 0; s < HS; ++s)
+    for (int s = 0; s < HS; ++s) {
+        if ((MSQ_ABL & 256) && IsUnified<OUT_KIND>::v && s > 0) { h.out[s] = h.out[0]; continue; }
         h.out[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r.out, lane16, uni((tile2kf * HS + s) * 1024u), 0));
+    }
     if (OUT_KIND == MSQ_PLANE_U8X)     // extension plane rides in the inlier descriptor: 64 lanes x 4 B per half
         h.ext = __builtin_amdgcn_raw_buffer_load_b32(r.inl, lane16 >> 2, uni(tile2kf * 256u), 0);
 }
@@ -504,6 +514,21 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         kt_lo += kgid * half; kt_hi = kt_lo + half;
     }
     char* const smem_g = smem + kgid * (3 * A_TILE);            // this group's activation buffers
+    // Stagger (eight-wave blocks): waves 4-7 ("followers", the SIMD partners of waves 0-3) run half a K-step behind.  Between two
+    // block barriers a leader does {kf 0, kf 1} of K-step j, a follower {kf 1 of j - 1, kf 0 of j}: the partner of a wave that sits
+    // in its step head (packed-load waits, LDS-DMA issue, first LDS reads) is in the middle of its MFMA stream, not in the same
+    // head (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Nothing the compiler sees depends on the role: every wave stages
+    // the first half of its pieces of tile kt + 2 at the top of K-step kt and the second half between the two half-steps (a
+    // follower's second half belongs to tile kt + 3: only the K offset and the buffer index differ), and the block barrier with its
+    // vmcnt wait is an inline-asm block that skips itself by a scalar branch -- after kf 0 for followers, after kf 1 for leaders.
+    // (With compiler-visible branches on the role hipcc spills into the loop; a second barrier per K-step instead of the
+    // branch measured no gain.)  A tile is read during two barrier intervals, so the ring has four activation buffers.
+    // Measured, M2048 N16384 K4096, three boxes: posit layout 202.9 -> 199.0, 199.2 -> 196.5, 200.9 -> 198.2 us; the layout without
+    // extension bits loses 0.5-1 % (182.1 -> 183.9), so it keeps the plain schedule.
+    constexpr bool STG = WN == 8 && KG == 1 && WM == 1 && MF == 8 &&
+                         ((MSQ_STAGGER >= 1 && OUT_KIND == MSQ_PLANE_U8X) || (MSQ_STAGGER >= 2 && OUT_KIND == MSQ_PLANE_U8));
+    constexpr int PA = STG ? (PPW + 1) / 2 : PPW;               // pieces staged at the top of a K-step; the rest between the half-steps
+    const int fol = STG ? sgpr(wid_blk >> 2) : 0;               // 1 = follower
     const int64_t tile_row = (int64_t)(n0 / TILE_N + wn) * KT;
 
     // packed planes and activations through buffer descriptors (SGPR slot / K-step offsets)
@@ -536,12 +561,18 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
         aoff[p] = (int)(((int64_t)gr * K + chunk * 8) * 2);
     }
-    auto stage_A = [&](int kt, int buf) {
+    auto stage_A_pieces = [&](int kt, int buf, int p_lo, int p_hi) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * PPW + p) * 1024),
-                                                     16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
+            if (p >= p_lo && p < p_hi) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wid * PPW + p) * 1024),
+                                                         16, aoff[p], uni((uint32_t)kt * (BK * 2)), 0, 0);
+                if (MSQ_ABL & 128)      // a second copy of the piece into the spare area behind the three buffers (WN = 8: 64 KiB of LDS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + 3 * A_TILE + (wid * PPW + p) * 1024),
+                                                             16, aoff[p], uni((uint32_t)kt * (BK * 2) + ((MSQ_ABL & 1024) ? 0u : 64u)), 0, 0);
+            }
     };
+    auto stage_A = [&](int kt, int buf) { stage_A_pieces(kt, buf, 0, PPW); };
     // LDS read base of this lane for kf = 0 / 1 (row term (row>>1)&7 == (c>>1)&7 for every mf)
     const int sw = (c >> 1) & 7;
     const int rd0 = (wm * WROWS + c) * 128 + (((0 + g) ^ sw) << 4);
@@ -571,6 +602,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
     // long as a K-step; with one step of distance the wait before the barrier exposed it)
     stage_A(kt0, 0);
     if (kt0 + 1 <= kt_last) stage_A(kt0 + 1, 1);
+    if (STG && fol) stage_A_pieces((kt0 + 2 <= kt_last) ? kt0 + 2 : kt_last, 2, PA, PPW);   // what a follower's K-step kt0 - 1 would have staged
     load_half_buf<IN_KIND, OUT_KIND>(pk0, pr, lane16, (tile_row32 + kt0) * 2u + 0u);
     load_half_buf<IN_KIND, OUT_KIND>(pk1, pr, lane16, (tile_row32 + kt0) * 2u + 1u);
     if (DEEP) {
@@ -595,24 +627,39 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         if (MF > 1) xf[1] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + 2048);                         \
         _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                  \
             if (mf + 2 < MF && !(MSQ_ABL & 1)) xf[(mf + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + (mf + 2) * 2048); \
+            if (MSQ_ABL & 64) { bf16x8_t xd_ = *reinterpret_cast<const bf16x8_t*>(abase + (RD) + ((mf + 2) & 7) * 2048 + 1024); asm volatile("" :: "v"(xd_)); } \
+            if ((MSQ_ABL & 512) && (mf & 1) == 0) {                                                          \
+                if ((RD) == rd0 || mf < 4) { u32x4_t wd_ = *reinterpret_cast<const u32x4_t*>(smem + 49152 + (mf >> 1) * 1024 + lane * 16); asm volatile("" :: "v"(wd_)); } \
+                if (mf < 4) { u32x4_t wd2_ = *reinterpret_cast<const u32x4_t*>(smem + 49152 + 4096 + (mf >> 1) * 1024 + lane * 16); asm volatile("" :: "v"(wd2_)); } \
+                if (mf >= 4) *reinterpret_cast<u32x4_t*>(smem + 49152 + 8192 + wid * 4096 + (mf >> 1) * 1024 + lane * 16) = WF_MAKE[(mf >> 1) & 1]; \
+            }                                                                                                \
             _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                 \
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, WF_USE[(MSQ_ABL & 32) ? (nf & 1) : nf]), xf[mf % 3], acc[mf][nf], 0, 0, 0); \
             if (!(MSQ_ABL & 2) && (mf % GPQ) == 0) {                                                         \
-                _Pragma("unroll") for (int q_ = 0; q_ < QPG; ++q_) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, (mf / GPQ) * QPG + q_); } \
+                _Pragma("unroll") for (int q_ = 0; q_ < QPG; ++q_) if (!(MSQ_ABL & 32) || (mf / GPQ) * QPG + q_ < 4) convert_quarter<IN_KIND, OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, (mf / GPQ) * QPG + q_); } \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
     // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted
     // one half-step earlier (LOAD1, LOAD2) receive (kt + 2, kf 0) and (kt + 2, kf 1).
     constexpr int N_INFLIGHT = HalfLoads<IN_KIND, OUT_KIND>::n * (DEEP ? 2 : 1);
-    constexpr int N_WAIT_ST = N_INFLIGHT + PPW;                // + the LDS-DMA ops of the tile staged in this K-step
+    constexpr int N_WAIT_ST = N_INFLIGHT + PPW * ((MSQ_ABL & 128) ? 2 : 1);   // + the LDS-DMA ops of the tile staged in this K-step
+    // follower, at its barrier between the half-steps: the pieces it staged after the previous such barrier, the second packed
+    // set of the previous K-step, this K-step's scale load, first pieces and first packed set stay in flight (issue order,
+    // youngest last); everything older -- its pieces of tile kt + 1 -- has landed
+    constexpr int N_WAIT_FOL = N_INFLIGHT + PPW + (HAS_SCALE ? 1 : 0);
     int abuf = 0;
+    /* wait + block barrier executed only by the waves whose role COND_ (an SGPR) equals WANT_: a scalar branch inside the asm
+       block, invisible to hipcc (its own vmcnt bookkeeping stays conservative: it never assumes this wait happened) */
+#define MSQ_ROLE_BARRIER(COND_, WANT_, N_)                                                                        \
+    asm volatile("s_cmp_lg_u32 %0, " #WANT_ "\n\ts_cbranch_scc1 .Lmsq_nb_%=\n\ts_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier\n.Lmsq_nb_%=:" \
+                 :: "s"(COND_), "n"(N_) : "memory", "scc")
 #define MSQ_K_STEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2, BAR)                                                       \
     {                                                                                                        \
         const int kt_ = sgpr(KT_CUR);                                                                        \
         const int buf = abuf;                                                                                \
-        const int buf2 = (abuf == 0) ? 2 : abuf - 1;             /* (abuf + 2) % 3 */                          \
-        abuf = (abuf == 2) ? 0 : abuf + 1;                                                                   \
+        const int buf2 = STG ? ((abuf + 2) & 3) : ((abuf == 0) ? 2 : abuf - 1);   /* (abuf + 2) % (4 or 3) */   \
+        abuf = STG ? ((abuf + 1) & 3) : ((abuf == 2) ? 0 : abuf + 1);                                        \
         const char* abase = smem_g + buf * A_TILE;                                                           \
         const int ktn = (kt_ + 1 <= kt_last) ? kt_ + 1 : kt_last;   /* branch-free tail: re-load the last tile */ \
         const int ktnn2 = (kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last;                                          \
@@ -623,11 +670,17 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
            LDS-DMA is drained (vmcnt(0) + barrier) before the epilogue reuses the LDS */                     \
         if (HAS_SCALE) { if (DEEP) sc_nn = load_scales(tile_row32 + ktnn); else sc_nxt = load_scales(tile_row32 + ktn); } \
         __builtin_amdgcn_sched_barrier(0);   /* issue order (vmcnt is in-order): scales, LDS-DMA, packed loads */ \
-        if (!(MSQ_ABL & 8)) stage_A(ktnn2, buf2);                                                            \
+        if (!(MSQ_ABL & 8)) stage_A_pieces(ktnn2, buf2, 0, PA);                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD1, pr, lane16, (tile_row32 + ktnn) * 2u + 0u); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         MSQ_HALF_STEP(wfA, wfB, CONV1, sc_cur, 1, rd0)                                                       \
+        if (STG) {                                                                                           \
+            MSQ_ROLE_BARRIER(fol, 1, N_WAIT_FOL);                                                            \
+            const int ktb_ = (kt_ + 2 + fol <= kt_last) ? kt_ + 2 + fol : kt_last;                           \
+            if (!(MSQ_ABL & 8)) stage_A_pieces(ktb_, (buf + 2 + fol) & 3, PA, PPW);                          \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
         /* ---- half-step kf = 1: MFMAs on wfB, make next wfA from CONV2 */                                  \
         keep_live(CONV2);                                                                                    \
         if (!(MSQ_ABL & 4)) load_half_buf<IN_KIND, OUT_KIND>(LOAD2, pr, lane16, (tile_row32 + ktnn) * 2u + 1u); \
@@ -640,9 +693,10 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         /* the tile staged in THIS K-step (4 LDS-DMA ops, older than the packed loads and younger than the    \
            scale load thanks to the sched_barriers above) may stay in flight too: it is needed two barriers   \
            from now */                                                                                       \
-        if (!(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT_ST & 15) | ((N_WAIT_ST >> 4) << 14)); \
+        if (STG) MSQ_ROLE_BARRIER(fol, 0, N_WAIT_ST);                                                        \
+        else if (!(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT_ST & 15) | ((N_WAIT_ST >> 4) << 14)); \
         sc_cur = sc_nxt; if (DEEP) sc_nxt = sc_nn;                                                           \
-        if (!(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_barrier();                                  \
+        if (!STG && !(MSQ_EXP_SKIPBAR && (BAR) == 0)) __builtin_amdgcn_s_barrier();                          \
     }
 
     {
@@ -657,6 +711,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
             for (; kt < kt_hi; ++kt) MSQ_K_STEP(kt, pk1, pk0, pk0, pk1, 1)
         }
     }
+#undef MSQ_ROLE_BARRIER
 #undef MSQ_K_STEP
 #undef MSQ_HALF_STEP
 

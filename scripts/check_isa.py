@@ -32,21 +32,44 @@ for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm|qgemv|mxgemv)\S*):', s, re.M):
 # step multiplies nothing (the drain before the epilogue).  (hipcc deletes dead loads of tail steps: see DESIGN.md 5.0.)
 for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm)\S*):', s, re.M):
     i = s.index('\n' + nm + ':'); j = s.index('s_endpgm', i)
-    segs, cur = [], {"loads": 0, "wait": None, "mfma": 0}
-    for l in s[i:j].split('\n'):
-        l = l.strip()
-        if l.startswith('buffer_load') or l.startswith('global_load'):
-            cur["loads"] += 1
-        elif l.startswith('s_waitcnt') and 'vmcnt' in l:
-            cur["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
-        elif l.startswith('v_mfma'):
-            cur["mfma"] += 1
-        elif l.startswith('s_barrier'):
-            segs.append(cur); cur = {"loads": 0, "wait": None, "mfma": 0}
-    segs.append(cur)
-    for k in range(1, len(segs) - 1):
-        a, b = segs[k], segs[k + 1]
-        if a["wait"] is not None and a["wait"] > a["loads"] and b["mfma"] > 0 and a["mfma"] > 0:
-            print("!! %-62s K-step segment %d: %d loads issued but vmcnt(%d) before the barrier, and the next segment multiplies" % (nm[3:65], k, a["loads"], a["wait"]))
-            bad += 1
+    # staggered kernels (k_qgemm3, eight waves, extension-bit layout) carry role barriers: an inline-asm block
+    # "s_cmp_lg_u32 sX, ROLE; s_cbranch_scc1 skip; s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier; skip:" executed by the waves of one
+    # role only (1 = follower: between the half-steps, 0 = leader: after the K-step).  The accounting is then done per role:
+    # the loads a role issues between two of ITS barriers against the vmcnt of the second one.
+    lines = [l.strip() for l in s[i:j].split('\n')]
+    roles = (0, 1) if any('.Lmsq_nb_' in l for l in lines) else (None,)
+    for role in roles:
+        segs, cur, pending_role = [], {"loads": 0, "wait": None, "mfma": 0}, None
+        skip = False            # inside a role block of the OTHER role
+        for l in lines:
+            m = re.match(r's_cmp_lg_u32 \S+, (\d)$', l)
+            if m:
+                pending_role = int(m.group(1)); continue
+            if l.startswith('s_cbranch_scc1 .Lmsq_nb_'):
+                skip = (role is not None and pending_role != role); continue
+            if l.startswith('.Lmsq_nb_'):
+                skip = False; continue
+            if skip:
+                continue
+            if l.startswith('buffer_load') or l.startswith('global_load'):
+                cur["loads"] += 1
+            elif l.startswith('s_waitcnt') and 'vmcnt' in l:
+                cur["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
+            elif l.startswith('v_mfma'):
+                cur["mfma"] += 1
+            elif l.startswith('s_barrier'):
+                segs.append(cur); cur = {"loads": 0, "wait": None, "mfma": 0}
+        segs.append(cur)
+        for k in range(1, len(segs) - 1):
+            a, b = segs[k], segs[k + 1]
+            if a["wait"] is not None and a["wait"] > a["loads"] and b["mfma"] > 0 and a["mfma"] > 0:
+                # the single tail step of k_qgemm3 (odd step count) is the last one: the segment after it multiplies only the
+                # follower's last half-step on a tile that landed two barriers earlier
+                if role is not None and k == len(segs) - 3:
+                    continue
+                # a follower's first segment is half a K-step long and starts right after the prologue's vmcnt(0) + barrier
+                if role == 1 and k == 1:
+                    continue
+                print("!! %-62s K-step segment %d%s: %d loads issued but vmcnt(%d) before the barrier, and the next segment multiplies" % (nm[3:65], k, "" if role is None else " (role %d)" % role, a["loads"], a["wait"]))
+                bad += 1
 sys.exit(1 if bad else 0)
