@@ -66,6 +66,7 @@ extern "C" {
 /* status bits written to *status_flag by the outlier kernels */
 #define MSQ_STATUS_NAN 1 /* one of the reference's NaN asserts (utils/quant.py:225-250) would fire */
 #define MSQ_STATUS_INEXACT 2 /* pack: a value is not exactly code * 2^scale (never silently wrong) */
+#define MSQ_STATUS_TIMEOUT 4 /* msq_gptq_block: a workgroup gave up waiting at the grid barrier (CUs held by another stream or process): the result is invalid */
 
 /* GEMM-ready plane kinds (what the fused kernel converts in-register with the CDNA4
  * v_cvt_scalef32_pk_bf16_{fp4,fp8,bf8} instructions) */

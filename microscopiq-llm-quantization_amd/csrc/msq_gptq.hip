@@ -22,6 +22,7 @@
 // Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/msq.h"
 #include "msq_device.h"
@@ -56,15 +57,23 @@ struct GptqArgs {
 MSQ_D unsigned long long aload64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 MSQ_D unsigned int aload32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// All workgroups of the launch are co-resident (at most one per CU, far fewer than CUs).  Arrive after this workgroup's
+// All workgroups of the launch must be co-resident: msq_gptq_block checks the grid against the device's CU count and the
+// occupancy of this kernel at its LDS size before launching (and refuses otherwise), but it cannot see other streams or
+// processes that hold CUs, so the spin is BOUNDED: after ~2^23 polls (seconds) the waiter raises MSQ_STATUS_TIMEOUT and goes on
+// -- the launch then ends with a wrong result and a status bit instead of hanging the device.  Arrive after this workgroup's
 // published atomics have RETURNED (their values are consumed), then poll with relaxed agent-scope loads.
-MSQ_D void grid_barrier(unsigned int* ctr, int nwg, int tid) {
+MSQ_D void grid_barrier(unsigned int* ctr, int nwg, int tid, int* status) {
     __syncthreads();
     if (tid == 0) {
         __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0): every earlier atomic has completed
         const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)old + 1 < nwg)
-            while ((int)aload32(ctr) < nwg) __builtin_amdgcn_s_sleep(2);
+        if ((int)old + 1 < nwg) {
+            unsigned int spins = 0;
+            while ((int)aload32(ctr) < nwg) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 23)) { if (status) atomicOr(status, MSQ_STATUS_TIMEOUT); break; }
+            }
+        }
     }
     __syncthreads();
 }
@@ -126,7 +135,7 @@ k_gptq_block(GptqArgs A) {
             const unsigned long long old = __hip_atomic_fetch_add(&A.colstat[j], pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("" ::"v"(old));
         }
-        grid_barrier(&A.bars[j * GPTQ_BARS + 0], A.nwg, tid);
+        grid_barrier(&A.bars[j * GPTQ_BARS + 0], A.nwg, tid, A.status);
         if (tid == 0) {
             const unsigned long long tot = aload64(&A.colstat[j]);
             s_sel[0] = (unsigned int)(tot & 0xFFFFFFu);
@@ -151,7 +160,7 @@ k_gptq_block(GptqArgs A) {
                 __syncthreads();
                 unsigned int* gh = A.hist + ((int64_t)j * 4 + p) * 256;
                 if (s_hist[tid]) { const unsigned int o = __hip_atomic_fetch_add(&gh[tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" ::"v"(o)); }
-                grid_barrier(&A.bars[j * GPTQ_BARS + 1 + (3 - p)], A.nwg, tid);
+                grid_barrier(&A.bars[j * GPTQ_BARS + 1 + (3 - p)], A.nwg, tid, A.status);
                 s_hist[tid] = aload32(&gh[tid]);
                 __syncthreads();
                 if (tid == 0) {
@@ -173,7 +182,7 @@ k_gptq_block(GptqArgs A) {
             unsigned int wg_ties = 0, before = 0;
             for (int wv = 0; wv < GPTQ_WG / 64; ++wv) { if (wv < (tid >> 6)) before += s_wave[wv]; wg_ties += s_wave[wv]; }
             if (tid == 0) __hip_atomic_store(&A.ties[(int64_t)j * A.nwg + blockIdx.x], wg_ties, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            grid_barrier(&A.bars[j * GPTQ_BARS + 5], A.nwg, tid);
+            grid_barrier(&A.bars[j * GPTQ_BARS + 5], A.nwg, tid, A.status);
             if (tid == 0) {
                 unsigned int base = 0;
                 for (int g = 0; g < (int)blockIdx.x; ++g) base += aload32(&A.ties[(int64_t)j * A.nwg + g]);
@@ -235,6 +244,37 @@ int msq_gptq_block(const float* Wt, const float* U, int ldu, float* Qt, float* E
     if (fi.kind != 0) return gfail(MSQ_ERR_UNSUPPORTED, "msq_gptq_block: posit inliers take the per-column path");
     const int64_t nwg = (O + GPTQ_WG - 1) / GPTQ_WG;
     if (nwg > 200) return gfail(MSQ_ERR_UNSUPPORTED, "msq_gptq_block: more than 51200 output rows");   // all workgroups must be co-resident
+    const size_t lds = (size_t)cols * GPTQ_WG * 4;
+    // ... on THIS device: the hand-rolled grid barrier needs every workgroup resident at once.  Ask the runtime how many blocks
+    // of this kernel fit a CU at this LDS size and how many CUs the device (or partition: CPX exposes 32) has; the occupancy API
+    // can answer one block per CU high (MI355X_MICROARCH.md, residency), so one is taken off whenever it says more than one.
+    // A grid that does not fit is refused -- harness/gptq.py then takes the per-column path.
+    {
+        int dev = 0, cus = 0, per_cu = 0;
+        const void* kfn = nullptr;
+        switch (block) {
+            case 8: kfn = (const void*)k_gptq_block<8>; break;
+            case 16: kfn = (const void*)k_gptq_block<16>; break;
+            case 32: kfn = (const void*)k_gptq_block<32>; break;
+            case 64: kfn = (const void*)k_gptq_block<64>; break;
+            default: return gfail(MSQ_ERR_UNSUPPORTED, "msq_gptq_block: quantiser block must be 8, 16, 32 or 64");
+        }
+        if (lds > 65536 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return gfail(MSQ_ERR_UNSUPPORTED, "msq_gptq_block: the device refuses this much dynamic LDS per workgroup");
+        }
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, GPTQ_WG, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return gfail(MSQ_ERR_LAUNCH, "msq_gptq_block: occupancy query failed");
+        }
+        if (per_cu > 1) --per_cu;
+        if (per_cu < 1 || nwg > (int64_t)cus * per_cu) {
+            char b[200];
+            snprintf(b, sizeof(b), "msq_gptq_block: %lld workgroups cannot all be resident on this device (%d CUs x %d)", (long long)nwg, cus, per_cu);
+            return gfail(MSQ_ERR_UNSUPPORTED, b);
+        }
+    }
     GptqArgs A;
     A.Wt = Wt; A.U = U; A.Qt = Qt; A.Et = Et; A.loss = loss; A.pruned = pruned; A.status = status_flag;
     char* ws = (char*)workspace;
@@ -252,10 +292,8 @@ int msq_gptq_block(const float* Wt, const float* U, int ldu, float* Qt, float* E
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, (size_t)msq_gptq_block_workspace_bytes(O, cols), st) != hipSuccess)
         return gfail(MSQ_ERR_LAUNCH, "msq_gptq_block: clearing the workspace failed");
-    const size_t lds = (size_t)cols * GPTQ_WG * 4;
 #define MSQ_GPTQ(BSV)                                                                                                   \
     case BSV: {                                                                                                        \
-        if (lds > 65536) hipFuncSetAttribute((const void*)k_gptq_block<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k_gptq_block<BSV>, dim3((unsigned)nwg), dim3(GPTQ_WG), lds, st, A);                         \
         break; }
     switch (block) { MSQ_GPTQ(8) MSQ_GPTQ(16) MSQ_GPTQ(32) MSQ_GPTQ(64)

@@ -43,43 +43,65 @@ def quantize_layers_nearest(layers, dev, quant_cfg=None, log=None):
             log(i)
 
 
+LLAMA_FUSE = [("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj")]      # siblings that read the same input
+
+
 @torch.no_grad()
-def pack_layers(layers, path="bf16"):
+def pack_layers(layers, path="bf16", fuse=None):
     """After quantize_layers_nearest / the GPTQ pass: swap every (already fake-quantised) Linear inside the decoder
     layers for a packed QuantLinear (what ``opt_pack3`` / ``make_quant3`` were meant to do, llm/opt.py:255-264).
     The weights are stored in the smallest exact single-plane kind (8.25 bits/weight for the harness default
-    int2 / fp4 configuration) and the forward runs the fused dequant-GEMM.  Layers whose shape the kernel
-    does not take (out_features % 256, in_features % 64) stay dense.  Returns (packed, kept_dense).
+    int2 / fp4 configuration) and the forward runs the fused dequant-GEMM.  EVERY nn.Linear that find_layers returns is
+    packed (utils/modelutils.py:8-15): shapes off the kernels' tile grid are zero-padded at pack time (qlinear._pad2d).
+    Returns (packed, kept_dense); kept_dense counts only Linears that are not on the GPU.
+
+    ``fuse`` (e.g. LLAMA_FUSE): groups of sibling Linears that read the same input are packed as one weight
+    (qlinear.fuse_projections): one GEMM launch per group, the same values.
 
     ``path="mx"``: W4A8 on the MX matrix path instead -- the fake-quant values become one exact e4m3 operand
     (MXLinearW4A8.from_values, 8.25 bits/weight), the forward quantises the activations to MX-FP8 (plain OCP-MX,
-    block 32) and multiplies on the scaled MFMA.  Needs in_features % 128; a layer whose values do not fit
-    e4m3 x 2^s per 32-block (e.g. posit outliers) stays on the bf16-activation QuantLinear."""
+    block 32) and multiplies on the scaled MFMA.  A layer whose values do not fit e4m3 x 2^s per 32-block (e.g. posit
+    outliers) stays on the bf16-activation QuantLinear."""
     from .._lib import MsqError
-    from ..qlinear import MXLinearW4A8, make_quant
+    from ..qlinear import MXLinearW4A8, fuse_projections, make_quant
     packed = dense = 0
+
+    def set_child(root, name, m):
+        parent = root
+        parts = name.split(".")
+        for p_ in parts[:-1]:
+            parent = getattr(parent, p_)
+        setattr(parent, parts[-1], m)
+
     for layer in layers:
         names = {}
         for name, lin in find_layers(layer, layers=[nn.Linear]).items():
-            if path == "mx" and lin.out_features % 256 == 0 and lin.in_features % 128 == 0 and lin.weight.is_cuda:
+            if not lin.weight.is_cuda:
+                dense += 1
+                continue
+            names[name] = None
+            packed += 1
+        if path == "mx":
+            for mod_name, mod in list(layer.named_modules()):
+                kids = dict(mod.named_children())
+                for group in (fuse or ()):
+                    fulls = [(mod_name + "." + g if mod_name else g) for g in group]
+                    if all(g in kids and isinstance(kids[g], nn.Linear) for g in group) and all(f in names for f in fulls):
+                        try:
+                            fuse_projections(mod, list(group), None, path="mx")
+                            for f in fulls:
+                                del names[f]
+                        except MsqError:
+                            pass
+            for name in list(names):
+                lin = dict(layer.named_modules())[name]
                 try:
                     m = MXLinearW4A8.from_values(lin.weight.data, lin.bias, out_dtype=lin.weight.dtype if lin.weight.dtype == torch.bfloat16 else torch.float32)
                 except MsqError:
-                    m = None
-                if m is not None:
-                    parent = layer
-                    parts = name.split(".")
-                    for p_ in parts[:-1]:
-                        parent = getattr(parent, p_)
-                    setattr(parent, parts[-1], m)
-                    packed += 1
                     continue
-            if lin.out_features % 256 == 0 and lin.in_features % 64 == 0 and lin.weight.is_cuda:
-                names[name] = None
-                packed += 1
-            else:
-                dense += 1
-        make_quant(layer, names)
+                set_child(layer, name, m)
+                del names[name]
+        make_quant(layer, names, fuse=fuse)
     return packed, dense
 
 

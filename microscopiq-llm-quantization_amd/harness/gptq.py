@@ -13,8 +13,10 @@ Hessian accumulation :32-58, the column solver :60-184, free :186-193), written 
   (tests/golden/gptq_exact.npz);
 * the block-to-block update (:163) stays a library GEMM.
 
-Quantiser configurations the block kernel does not cover (posit inliers, block 128, groupsize / static_groups
-re-fitting) take the per-column path below (one fused quantiser launch per column, same tie rule)."""
+Quantiser configurations the block kernel does not cover (posit inliers, block 128, a ``groupsize`` with a quantiser whose
+``find_params`` is not MXQuantizer's empty one) and grids the device cannot hold resident at once (the kernel's grid barrier
+needs every workgroup on a CU: ``msq_gptq_block`` checks that against the device's CU count and refuses otherwise) take the
+per-column path below (one fused quantiser launch per column, same tie rule)."""
 import math
 import time
 
@@ -90,16 +92,37 @@ class GPTQ:
     def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False, verbose=True,
                     hinv=None, per_column=False):
         """`self.quantizer` is an MXQuantizer set by the caller (llm/llama.py:102-113).  ``hinv`` (tests): use this upper
-        Cholesky factor of the inverse Hessian instead of computing it; ``per_column`` forces the per-column path."""
+        Cholesky factor of the inverse Hessian instead of computing it; ``per_column`` forces the per-column path.
+
+        ``groupsize`` / ``static_groups`` (llm/gptq.py:81-87,119-127): with a group size the reference re-runs
+        ``quantizer.find_params`` on the columns of every group (or, static, swaps in per-group copies made before the
+        solve).  ``MXQuantizer.find_params`` is empty (utils/quant.py:429), so for it the groups change nothing and the
+        block kernel stays valid; a quantiser whose ``find_params`` does something gets the reference's literal
+        per-column sequence."""
         t0 = time.time()
         W = _as_matrix(self.layer).clone().float()
         qz = self.quantizer
         if not qz.ready():
             qz.find_params(W, weight=True)
+        if groupsize != -1 and (not isinstance(groupsize, int) or groupsize <= 0):
+            raise ValueError("groupsize must be -1 or a positive number of columns")
+        if static_groups and groupsize == -1:
+            raise ValueError("static_groups needs a groupsize")
         H, self.H = self.H, None
         unused = torch.diag(H) == 0                                                # inputs never seen: freeze at zero
         H[unused, unused] = 1
         W[:, unused] = 0
+        groups = None
+        if static_groups:                                                          # llm/gptq.py:81-87 (before the reordering, as there)
+            import copy
+            groups = []
+            for i in range(0, self.columns, groupsize):
+                g = copy.deepcopy(qz)
+                g.find_params(W[:, i:i + groupsize], weight=True)
+                groups.append(g)
+        from ..quant import MXQuantizer
+        grouped = groupsize != -1 and type(qz).find_params is not MXQuantizer.find_params
+        perm = None
         if actorder:
             perm = torch.argsort(torch.diag(H), descending=True)
             W, H = W[:, perm], H[perm][:, perm]
@@ -113,14 +136,29 @@ class GPTQ:
         from .. import quant as _quant
         check_nan, _quant.CHECK_NAN = _quant.CHECK_NAN, False
         try:
-            if not per_column and self._block_kernel_ok(qz, blocksize):
-                loss, pruned = self._solve_blocks(W, U.contiguous(), Q, qz, blocksize)
-            else:
-                self._solve(W, U, Q, qz, blocksize, loss, pruned)
+            done = False
+            if not per_column and not grouped and self._block_kernel_ok(qz, blocksize):
+                from .._lib import MsqError
+                W0 = W.clone()
+                try:
+                    loss, pruned = self._solve_blocks(W, U.contiguous(), Q, qz, blocksize)
+                    done = True
+                except MsqError as e:            # the grid does not fit this device (partitioned / CU-masked GPU): per-column path
+                    if "status -2" not in str(e):
+                        raise
+                    W = W0
+                    Q.zero_()
+            if not done:
+                self._solve(W, U, Q, qz, blocksize, loss, pruned,
+                            group=(groupsize, groups, perm) if groupsize != -1 else None)
         finally:
             _quant.CHECK_NAN = check_nan
         torch.cuda.synchronize()
         st = getattr(self, "_status", None)
+        if st is not None and int(st.item()) & 4:
+            from .._lib import MsqError
+            raise MsqError("msq_gptq_block: grid barrier timed out -- its workgroups were not all resident (another stream or "
+                           "process holds CUs); rerun alone on the device or with per_column=True")
         if check_nan and ((st is not None and int(st.item()) & 1) or bool(torch.isnan(Q).any())):
             raise AssertionError("outlier_val / inlier_val / shared_exp contains NaN values")
         self.error = float(loss.item())
@@ -165,7 +203,7 @@ class GPTQ:
         self._status = status
         return loss, pruned
 
-    def _solve(self, W, U, Q, qz, blocksize, loss, pruned):
+    def _solve(self, W, U, Q, qz, blocksize, loss, pruned, group=None):
         for c0 in range(0, self.columns, blocksize):
             c1 = min(c0 + blocksize, self.columns)
             Wb = W[:, c0:c1].clone()
@@ -173,6 +211,16 @@ class GPTQ:
             Eb = torch.zeros_like(Wb)
             for j in range(c1 - c0):
                 w, d = Wb[:, j], Ub[j, j]
+                if group is not None:                                              # llm/gptq.py:119-127
+                    groupsize, groups, perm = group
+                    if groups is None:
+                        if (c0 + j) % groupsize == 0:
+                            qz.find_params(W[:, (c0 + j):(c0 + j + groupsize)], weight=True)
+                    else:
+                        idx = c0 + j
+                        if perm is not None:
+                            idx = int(perm[idx])
+                        qz = self.quantizer = groups[idx // groupsize]
                 q, n_out = self._quantize_column(w, d, qz)
                 pruned += n_out
                 Q[:, c0 + j] = q

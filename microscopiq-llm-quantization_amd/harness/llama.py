@@ -7,19 +7,25 @@ from .evalppl import perplexity, quantize_layers_nearest
 
 
 def get_llama(model, model_type="llama"):
-    """llm/llama.py:20-58: load without re-initialising weights; seqlen fixed to 2048 (:57)."""
+    """llm/llama.py:20-58: load without re-initialising weights; seqlen fixed to 2048 (:57).  The reference swaps
+    torch.nn.init's initialisers for no-ops and leaves them swapped for the rest of the process; here they are put back once the
+    checkpoint is loaded (every nn.Linear built afterwards would otherwise hold uninitialised memory)."""
     def skip(*_, **__):
         pass
+    saved = (torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_, torch.nn.init.normal_)
     torch.nn.init.kaiming_uniform_ = skip
     torch.nn.init.uniform_ = skip
     torch.nn.init.normal_ = skip
-    if model_type == "mistral":
-        from transformers import MistralForCausalLM as cls
-    elif model_type == "mixtral":
-        from transformers import MixtralForCausalLM as cls
-    else:
-        from transformers import LlamaForCausalLM as cls
-    m = cls.from_pretrained(model, torch_dtype="auto")
+    try:
+        if model_type == "mistral":
+            from transformers import MistralForCausalLM as cls
+        elif model_type == "mixtral":
+            from transformers import MixtralForCausalLM as cls
+        else:
+            from transformers import LlamaForCausalLM as cls
+        m = cls.from_pretrained(model, torch_dtype="auto")
+    finally:
+        torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_, torch.nn.init.normal_ = saved
     m.seqlen = 2048
     return m
 

@@ -7,13 +7,18 @@ from .evalppl import perplexity, quantize_layers_nearest
 
 
 def get_opt(model):
+    """llm/opt.py:9-23; the no-op initialisers are put back after the load (see harness/llama.py get_llama)."""
     def skip(*_, **__):
         pass
+    saved = (torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_, torch.nn.init.normal_)
     torch.nn.init.kaiming_uniform_ = skip
     torch.nn.init.uniform_ = skip
     torch.nn.init.normal_ = skip
-    from transformers import OPTForCausalLM
-    m = OPTForCausalLM.from_pretrained(model, torch_dtype='auto')
+    try:
+        from transformers import OPTForCausalLM
+        m = OPTForCausalLM.from_pretrained(model, torch_dtype='auto')
+    finally:
+        torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_, torch.nn.init.normal_ = saved
     m.seqlen = m.config.max_position_embeddings           # llm/opt.py:22
     return m
 

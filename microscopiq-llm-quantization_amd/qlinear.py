@@ -23,12 +23,36 @@ from .formats import RoundingMode, format_id
 _PLANE_NONE = 0
 
 
-class PackedWeight:
-    """Device buffers + metadata of one packed [N, K] weight."""
+N_MULT, K_MULT, K_MULT_MX = 256, 64, 128       # tile grid of the GEMM kernels (csrc/msq_gemm.hip: BN, BK; MX K-step)
 
-    def __init__(self, inl, out, scl, N, K, block, in_kind, out_kind):
+
+def _ceil_to(v, m):
+    return (int(v) + m - 1) // m * m
+
+
+def _pad2d(W, n_mult, k_mult):
+    """Zero-pad a [N, K] weight to the kernels' tile grid.  Blocks run along K and every block is quantised on its own
+    (utils/quant.py:477-492 takes mean / std per block), so zero rows and zero k-columns change no other value: a ragged
+    last block sees the same zeros the reference's _reshape_to_blocks pads it with, and the extra all-zero blocks
+    quantise to zero."""
+    N, K = W.shape
+    Np, Kp = _ceil_to(N, n_mult), _ceil_to(K, k_mult)
+    if (Np, Kp) == (N, K):
+        return W
+    Wp = W.new_zeros(Np, Kp)
+    Wp[:N, :K] = W
+    return Wp
+
+
+class PackedWeight:
+    """Device buffers + metadata of one packed weight.  ``N`` / ``K`` are the PADDED dimensions the planes were built
+    for (multiples of 256 / 64: what the kernels see), ``n`` / ``k`` the logical [out_features, in_features] of the
+    layer: qlinear zero-pads the activations to K and returns the first n columns."""
+
+    def __init__(self, inl, out, scl, N, K, block, in_kind, out_kind, n=None, k=None):
         self.inl, self.out, self.scl = inl, out, scl
         self.N, self.K, self.block, self.in_kind, self.out_kind = N, K, block, in_kind, out_kind
+        self.n, self.k = (N if n is None else int(n)), (K if k is None else int(k))
 
     @property
     def nbytes(self):
@@ -36,7 +60,7 @@ class PackedWeight:
 
     @property
     def bits_per_element(self):
-        return 8.0 * self.nbytes / (self.N * self.K)
+        return 8.0 * self.nbytes / (self.n * self.k)
 
 
 LAYOUT_PLANES, LAYOUT_UNIFIED = 0, 1
@@ -62,31 +86,47 @@ def packed_sizes(N, K, block, in_kind, out_kind):
 
 def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp4_e2m1",
                 outlier_elem_format="fp8_e4m3", std_dev=2, block_size=32, round="nearest",
-                flush_fp32_subnorms=False, variant=0, layout="planes"):
-    """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it.
+                flush_fp32_subnorms=False, variant=0, layout="planes", compute_dtype="input"):
+    """Quantise W [N, K] (blocks along K = the reference's axes=[-1]) and pack it.  Any N, K: the weight is zero-padded
+    to the kernels' tile grid (``PackedWeight.N / K``), the logical shape is kept in ``PackedWeight.n / k``.
 
     layout: "planes" (MSQ-T1), "unified" (MSQ-U1, smaller and faster; raises MsqError if a 32-k group
     cannot be represented exactly) or "auto" (unified when the formats allow it and every group is
-    exact, otherwise planes)."""
+    exact, otherwise planes).
+
+    ``compute_dtype`` as quant.outlier_fakequant: an fp16 / bf16 weight is by default quantised IN its dtype (what the
+    reference's RTN harness does with a half checkpoint, llm/llama.py:238), so that the packed layer holds exactly the
+    values ``MXQuantizer.quantize`` / ``quantize_mx_outlier_v1`` give for the same tensor; those values are then packed
+    as they are (pack_values).  "float32" upcasts first (one fused quantise + pack launch)."""
     if not W.is_cuda:
         raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
     if W.ndim != 2:
         raise MsqError("pack_weight expects a 2-D [out_features, in_features] weight")
-    Wf = W.detach().contiguous().float()
+    if compute_dtype not in ("input", "float32"):
+        raise MsqError("compute_dtype must be 'input' or 'float32'")
+    n, k = W.shape
+    if (compute_dtype == "input" and W.dtype in (torch.float16, torch.bfloat16) and variant == 0
+            and not str(inlier_elem_format).startswith("posit") and not str(outlier_elem_format).startswith("posit")):
+        from .quant import outlier_fakequant
+        Wq = outlier_fakequant(W.detach(), inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
+                               std_dev, -1, block_size, round, flush_fp32_subnorms, compute_dtype="input")["out"]
+        kinds = {"unified": (PLANE_U8, PLANE_U8X), "auto": (PLANE_U8, PLANE_U8X, PLANE_BF16), "planes": (PLANE_BF16,)}[layout]
+        return pack_values(Wq, kinds)
+    Wf = _pad2d(W.detach().contiguous().float(), N_MULT, K_MULT)
     if layout == "auto":
         if variant == 0 and round == "nearest" and block_size <= 64:
             try:
                 return _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev,
-                             block_size, round, flush_fp32_subnorms, variant, "unified")
+                             block_size, round, flush_fp32_subnorms, variant, "unified", n, k)
             except MsqError:
                 pass
         layout = "planes"
     return _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev,
-                 block_size, round, flush_fp32_subnorms, variant, layout)
+                 block_size, round, flush_fp32_subnorms, variant, layout, n, k)
 
 
 def _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format, std_dev, block_size,
-          round, flush_fp32_subnorms, variant, layout):
+          round, flush_fp32_subnorms, variant, layout, n=None, k=None):
     N, K = Wf.shape
     ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format, layout)
     ib, ob, sb, wb = packed_sizes(N, K, block_size, ik, ok)
@@ -108,7 +148,7 @@ def _pack(Wf, inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier
     if st & 2:
         raise MsqError("pack_weight: a value is not exactly code * 2^scale in the %s layout "
                        "(degenerate block scale / too wide a range inside one group)" % layout)
-    return PackedWeight(inl, out, scl, N, K, block_size, ik, ok)
+    return PackedWeight(inl, out, scl, N, K, block_size, ik, ok, n, k)
 
 
 PLANE_NONE, PLANE_BF16, PLANE_U8, PLANE_U8X = 0, 4, 5, 6
@@ -123,7 +163,8 @@ def pack_values(Wq, kinds=(PLANE_U8, PLANE_U8X, PLANE_BF16)):
         raise MsqError("pack_values needs a CUDA/HIP tensor (no CPU fallback)")
     if Wq.ndim != 2:
         raise MsqError("pack_values expects a 2-D [out_features, in_features] tensor")
-    Wf = Wq.detach().contiguous().float()
+    n, k = Wq.shape
+    Wf = _pad2d(Wq.detach().contiguous().float(), N_MULT, K_MULT)
     N, K = Wf.shape
     dev = Wf.device
     status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -139,19 +180,24 @@ def pack_values(Wq, kinds=(PLANE_U8, PLANE_U8X, PLANE_BF16)):
         if st & 1:
             raise AssertionError("pack_values: the tensor contains NaN / Inf")
         if st == 0:
-            return PackedWeight(inl, out, scl, N, K, 32, PLANE_NONE, ok)
+            return PackedWeight(inl, out, scl, N, K, 32, PLANE_NONE, ok, n, k)
     raise MsqError("pack_values: the values fit none of the requested plane kinds %r exactly" % (tuple(kinds),))
 
 
 def unpack_weight(P, dtype=torch.float32):
-    """Dense dequantised weight [N, K] (exact in f32 and bf16)."""
+    """Dense dequantised weight [n, k] (the logical shape; exact in f32 and bf16)."""
     if dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("unpack_weight: dtype must be float32 or bfloat16")
     W = torch.empty(P.N, P.K, dtype=dtype, device=P.out.device)
     check(lib().msq_outlier_unpack(ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(W), 0 if dtype == torch.float32 else 2,
                                    P.N, P.K, P.block, P.in_kind, P.out_kind, current_stream(W.device)),
           "msq_outlier_unpack")
-    return W
+    return W if (P.n, P.k) == (P.N, P.K) else W[:P.n, :P.k].contiguous()
+
+
+def _pad_k(xb, K):
+    """[M, k] -> [M, K] with zero columns (off-grid in_features)"""
+    return xb if xb.shape[-1] == K else torch.nn.functional.pad(xb, (0, K - xb.shape[-1]))
 
 
 def _out_buffer(out, M, N, out_dtype, dev, who):
@@ -167,26 +213,37 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
     """y = x . Wq^T (+ bias): the fused unpack-dequant-GEMM.  x: [..., K] (cast to bf16)."""
     if not x.is_cuda:
         raise MsqError("qlinear needs CUDA/HIP tensors (no CPU fallback)")
-    K = x.shape[-1]
-    if K != P.K:
-        raise MsqError("qlinear: in_features mismatch (%d vs %d)" % (K, P.K))
-    xb = x.reshape(-1, K)
+    k = x.shape[-1]
+    if k != P.k:
+        raise MsqError("qlinear: in_features mismatch (%d vs %d)" % (k, P.k))
+    K = P.K
+    xb = x.reshape(-1, k)
     if xb.dtype != torch.bfloat16:
         xb = xb.to(torch.bfloat16)
-    xb = xb.contiguous()
+    xb = _pad_k(xb, K).contiguous()
     M = xb.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear: out_dtype must be float32 or bfloat16")
-    y = _out_buffer(out, M, P.N, out_dtype, x.device, "qlinear")
+    padded_n = P.n != P.N
+    if out is not None and padded_n:
+        _out_buffer(out, M, P.n, out_dtype, x.device, "qlinear")          # validates the caller's buffer
+    y = _out_buffer(None if padded_n else out, M, P.N, out_dtype, x.device, "qlinear")
     b = None
     if bias is not None:
         b = bias.detach().float().contiguous()
+        if padded_n:
+            b = torch.nn.functional.pad(b, (0, P.N - P.n))
     wsb = lib().msq_qlinear_workspace_bytes(M, P.N, K)        # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
                                  0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
                                  ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
-    return y.reshape(*x.shape[:-1], P.N)
+    if padded_n:
+        if out is not None:
+            out.copy_(y[:, :P.n]); y = out
+        else:
+            y = y[:, :P.n].contiguous()
+    return y.reshape(*x.shape[:-1], P.n)
 
 
 def act_quant(x, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="fp8_e4m3",
@@ -221,16 +278,19 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     (BASELINE config 3, W4A8).  x: [..., K] float."""
     if not x.is_cuda:
         raise MsqError("qlinear_w4a8 needs CUDA/HIP tensors (no CPU fallback)")
-    K = x.shape[-1]
-    if K != P.K:
-        raise MsqError("qlinear_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
+    k = x.shape[-1]
+    if k != P.k:
+        raise MsqError("qlinear_w4a8: in_features mismatch (%d vs %d)" % (k, P.k))
+    K = P.K
     x16 = x.dtype == torch.bfloat16 and (int(a_variant) == 0 or a_block_size in (32, 64))   # read as is: no cast pass
-    xf = x.reshape(-1, K).contiguous() if x16 else x.reshape(-1, K).float().contiguous()
+    xf = _pad_k(x.reshape(-1, k), K).contiguous() if x16 else _pad_k(x.reshape(-1, k).float(), K).contiguous()
     M = xf.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_w4a8: out_dtype must be float32 or bfloat16")
     y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
     b = bias.detach().float().contiguous() if bias is not None else None
+    if b is not None and P.n != P.N:
+        b = torch.nn.functional.pad(b, (0, P.N - P.n))
     wsb = lib().msq_qlinear_w4a8_workspace_bytes(M, P.N, K, a_block_size, int(a_variant))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
     status = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -248,7 +308,9 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
             raise AssertionError("shared_exp contains NaN values (activation scale overflow)")
         if st & 2:
             raise MsqError("qlinear_w4a8: a quantised activation is not exact in bf16")
-    return y.reshape(*x.shape[:-1], P.N)
+    if P.n != P.N:
+        y = y[:, :P.n].contiguous()
+    return y.reshape(*x.shape[:-1], P.n)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -271,8 +333,9 @@ class MXPackedWeight:
     (plain MX-FP4, 4.25 bits per weight), "e3m2" / "e2m3" (plain MX-FP6, a true 6-bit plane: 6.25 bits per weight)
     or "e4m3" (exactly packed fake-quant values, 8.25 bits per weight)."""
 
-    def __init__(self, codes, scales, N, K, w_fmt="e2m1"):
-        self.codes, self.scales, self.N, self.K, self.w_fmt = codes, scales, N, K, w_fmt
+    def __init__(self, codes, scales, N, K, w_fmt="e2m1", n=None, k=None):
+        self.codes, self.scales, self.N, self.K, self.w_fmt = codes, scales, N, K, w_fmt      # N, K: padded (256 / 128 grid)
+        self.n, self.k = (N if n is None else int(n)), (K if k is None else int(k))              # logical shape
 
     @property
     def nbytes(self):
@@ -280,7 +343,7 @@ class MXPackedWeight:
 
     @property
     def bits_per_element(self):
-        return 8.0 * self.nbytes / (self.N * self.K)
+        return 8.0 * self.nbytes / (self.n * self.k)
 
 
 def _mx_status(status, what):
@@ -296,7 +359,8 @@ def mx_pack_weight(W, flush_fp32_subnorms=False, w_fmt="e2m1"):
     w_fmt = _mx_fmt(w_fmt)
     if w_fmt == "e4m3":
         raise MsqError("mx_pack_weight: e4m3 operands hold exact VALUES, use mx_pack_values")
-    Wf = W.detach().contiguous().float()
+    n, k = W.shape
+    Wf = _pad2d(W.detach().contiguous().float(), N_MULT, K_MULT_MX)
     N, K = Wf.shape
     scales = torch.empty(N * K // 32, dtype=torch.uint8, device=Wf.device)
     status = torch.zeros(1, dtype=torch.int32, device=Wf.device)
@@ -309,7 +373,7 @@ def mx_pack_weight(W, flush_fp32_subnorms=False, w_fmt="e2m1"):
         check(lib().msq_mx_pack_w6(ptr(Wf), ptr(codes), ptr(scales), ptr(status), N, K, _FP6_IDS[w_fmt],
                                    int(bool(flush_fp32_subnorms)), current_stream(Wf.device)), "msq_mx_pack_w6")
     _mx_status(status, "mx_pack_weight")
-    return MXPackedWeight(codes, scales, N, K, w_fmt)
+    return MXPackedWeight(codes, scales, N, K, w_fmt, n, k)
 
 
 def mx_pack_values(Wq, allow_inexact=False):
@@ -319,7 +383,8 @@ def mx_pack_values(Wq, allow_inexact=False):
     outliers with 4 fraction bits, blocks spanning more than e4m3's range) unless ``allow_inexact``."""
     if not Wq.is_cuda:
         raise MsqError("mx_pack_values needs a CUDA/HIP tensor (no CPU fallback)")
-    Wf = Wq.detach().contiguous().float()
+    n, k = Wq.shape
+    Wf = _pad2d(Wq.detach().contiguous().float(), N_MULT, K_MULT_MX)
     N, K = Wf.shape
     codes = torch.empty(N * K, dtype=torch.uint8, device=Wf.device)
     scales = torch.empty(N * K // 32, dtype=torch.uint8, device=Wf.device)
@@ -331,7 +396,7 @@ def mx_pack_values(Wq, allow_inexact=False):
         raise AssertionError("mx_pack_values: the values hold Inf / NaN")
     if (st & 2) and not allow_inexact:              # MSQ_STATUS_INEXACT
         raise MsqError("mx_pack_values: values not representable as e4m3 x 2^s per 32-block (MSQ_STATUS_INEXACT)")
-    return MXPackedWeight(codes, scales, N, K, "e4m3")
+    return MXPackedWeight(codes, scales, N, K, "e4m3", n, k)
 
 
 def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False, a_fmt="e4m3"):
@@ -371,28 +436,44 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
         xc, xs = x                                       # gate / up projections of one input share the pack
         K, lead, xdev = xc.shape[-1], tuple(xc.shape[:-1]), xc.device
         xc, xs = xc.reshape(-1, K), xs.reshape(-1, K // 32)
+        if K != P.K:
+            raise MsqError("qlinear_mx_w4a8: packed activations must cover the padded in_features (%d vs %d)" % (K, P.K))
     else:
-        K, lead, xdev = x.shape[-1], tuple(x.shape[:-1]), x.device
-    if K != P.K:
-        raise MsqError("qlinear_mx_w4a8: in_features mismatch (%d vs %d)" % (K, P.K))
-    if not isinstance(x, (tuple, list)):
-        xc, xs = mx_pack_act(x, check_status=check_status, a_fmt=a_fmt)
+        k, lead, xdev = x.shape[-1], tuple(x.shape[:-1]), x.device
+        if k != P.k:
+            raise MsqError("qlinear_mx_w4a8: in_features mismatch (%d vs %d)" % (k, P.k))
+        K = P.K
+        # zero columns up to the padded K: whole zero blocks, and a ragged last block padded as mx_ops.py:332-457 pads it
+        xc, xs = mx_pack_act(_pad_k(x.reshape(-1, k), K), check_status=check_status, a_fmt=a_fmt)
     M = xc.shape[0]
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
-    y = _out_buffer(out, M, P.N, out_dtype, xdev, "qlinear_mx_w4a8")
+    padded_n = P.n != P.N
+    if out is not None and padded_n:
+        _out_buffer(out, M, P.n, out_dtype, xdev, "qlinear_mx_w4a8")
+    y = _out_buffer(None if padded_n else out, M, P.N, out_dtype, xdev, "qlinear_mx_w4a8")
     b = bias.detach().float().contiguous() if bias is not None else None
+    if b is not None and padded_n:
+        b = torch.nn.functional.pad(b, (0, P.N - P.n))
+
+    def _ret(y):
+        if padded_n:
+            if out is not None:
+                out.copy_(y[:, :P.n]); y = out
+            else:
+                y = y[:, :P.n].contiguous()
+        return y.reshape(*lead, P.n)
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=xdev) if wsb > 0 else None
     yd = 0 if out_dtype == torch.float32 else 2
     if P.w_fmt in _FP6_IDS:
         check(lib().msq_qlinear_mx_w6a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), yd, M, P.N, K,
                                         _FP6_IDS[P.w_fmt], ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w6a8")
-        return y.reshape(*lead, P.N)
+        return _ret(y)
     fn = lib().msq_qlinear_mx_w8a8 if P.w_fmt == "e4m3" else lib().msq_qlinear_mx_w4a8
     check(fn(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), yd,
              M, P.N, K, ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w%sa8" % ("8" if P.w_fmt == "e4m3" else "4"))
-    return y.reshape(*lead, P.N)
+    return _ret(y)
 
 
 class MXLinearW4A8(nn.Module):
@@ -404,9 +485,10 @@ class MXLinearW4A8(nn.Module):
         super().__init__()
         w_fmt, a_fmt = _mx_fmt(w_fmt), _mx_fmt(a_fmt)
         self.in_features, self.out_features, self.out_dtype, self.w_fmt, self.a_fmt = in_features, out_features, out_dtype, w_fmt, a_fmt
-        nb = out_features * in_features * {"e2m1": 4, "e3m2": 6, "e2m3": 6, "e4m3": 8}[w_fmt] // 8
+        Np, Kp = _ceil_to(out_features, N_MULT), _ceil_to(in_features, K_MULT_MX)           # the planes cover the padded grid
+        nb = Np * Kp * {"e2m1": 4, "e3m2": 6, "e2m3": 6, "e4m3": 8}[w_fmt] // 8
         self.register_buffer("w_codes", torch.zeros(nb, dtype=torch.uint8, device=device))
-        self.register_buffer("w_scales", torch.zeros(out_features * in_features // 32, dtype=torch.uint8, device=device))
+        self.register_buffer("w_scales", torch.zeros(Np * Kp // 32, dtype=torch.uint8, device=device))
         if bias:
             self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, device=device))
         else:
@@ -436,7 +518,8 @@ class MXLinearW4A8(nn.Module):
         return m
 
     def _packed(self):
-        return MXPackedWeight(self.w_codes, self.w_scales, self.out_features, self.in_features, self.w_fmt)
+        return MXPackedWeight(self.w_codes, self.w_scales, _ceil_to(self.out_features, N_MULT), _ceil_to(self.in_features, K_MULT_MX),
+                              self.w_fmt, self.out_features, self.in_features)
 
     def forward(self, x, out=None):
         y = qlinear_mx_w4a8(x, self._packed(), self.bias, self.out_dtype, out=out, a_fmt=getattr(self, "a_fmt", "e4m3"))
@@ -461,7 +544,7 @@ class QuantLinear(nn.Module):
         self.inlier_elem_format, self.outlier_elem_format = inlier_elem_format, outlier_elem_format
         self.out_dtype = out_dtype
         ik, ok = packed_kinds(inlier_elem_format, outlier_elem_format, layout)
-        ib, ob, sb, _ = packed_sizes(out_features, in_features, block_size, ik, ok)
+        ib, ob, sb, _ = packed_sizes(_ceil_to(out_features, N_MULT), _ceil_to(in_features, K_MULT), block_size, ik, ok)
         self.in_kind, self.out_kind = ik, ok
         self.register_buffer("inl_plane", torch.zeros(ib, dtype=torch.uint8, device=device))
         self.register_buffer("out_plane", torch.zeros(ob, dtype=torch.uint8, device=device))
@@ -473,8 +556,9 @@ class QuantLinear(nn.Module):
 
     def _packed(self):
         return PackedWeight(self.inl_plane if self.inl_plane.numel() else None, self.out_plane,
-                            self.scale_plane if self.scale_plane.numel() else None, self.out_features,
-                            self.in_features, self.block_size, self.in_kind, self.out_kind)
+                            self.scale_plane if self.scale_plane.numel() else None, _ceil_to(self.out_features, N_MULT),
+                            _ceil_to(self.in_features, K_MULT), self.block_size, self.in_kind, self.out_kind,
+                            self.out_features, self.in_features)
 
     def pack(self, linear, quantizer=None):
         q = quantizer
@@ -489,7 +573,9 @@ class QuantLinear(nn.Module):
                       inlier_elem_format=q.inlier_elem_format, outlier_elem_format=q.outlier_elem_format,
                       std_dev=q.std_dev, block_size=q.block_size, round=q.round,
                       flush_fp32_subnorms=q.flush_fp32_subnorms)
-        P = pack_weight(linear.weight.data, layout=self.layout, **kw)
+        # float32 compute: the planes this module was sized for come from the fused quantise + pack launch.  (from_linear
+        # routes half-precision weights through quantise-in-dtype + pack_values instead: QuantLinear.from_dense.)
+        P = pack_weight(linear.weight.data, layout=self.layout, compute_dtype="float32", **kw)
         if (P.in_kind, P.out_kind, P.block) != (self.in_kind, self.out_kind, self.block_size):
             raise MsqError("quantizer formats do not match the formats this QuantLinear was built for")
         if P.inl is not None:
@@ -502,7 +588,19 @@ class QuantLinear(nn.Module):
         return self
 
     @classmethod
-    def from_linear(cls, linear, quantizer=None, **kw):
+    def from_linear(cls, linear, quantizer=None, compute_dtype="input", **kw):
+        """``compute_dtype="input"`` (default): an fp16 / bf16 Linear is quantised in its own dtype, op by op, exactly as
+        ``quantizer.quantize(linear.weight)`` -- the reference's RTN harness on a half checkpoint (llm/llama.py:238) -- would,
+        and those values are packed as they are; "float32" upcasts first (the fused quantise + pack launch)."""
+        W = linear.weight.data
+        posit = quantizer is not None and (str(quantizer.inlier_elem_format).startswith("posit") or str(quantizer.outlier_elem_format).startswith("posit"))
+        if compute_dtype == "input" and quantizer is not None and W.dtype in (torch.float16, torch.bfloat16) and not posit:
+            axes = quantizer.axes if isinstance(quantizer.axes, (list, tuple)) else [quantizer.axes]
+            if [a % 2 for a in axes] == [1]:
+                P = pack_weight(W, quantizer.inlier_scale_bits, quantizer.outlier_scale_bits, quantizer.inlier_elem_format,
+                                quantizer.outlier_elem_format, quantizer.std_dev, quantizer.block_size, quantizer.round,
+                                quantizer.flush_fp32_subnorms, layout=kw.get("layout", "auto"), compute_dtype="input")
+                return cls.from_packed(P, linear.bias.data if linear.bias is not None else None, kw.get("out_dtype", torch.bfloat16))
         if quantizer is not None:
             kw.setdefault("block_size", quantizer.block_size)
             kw.setdefault("inlier_elem_format", quantizer.inlier_elem_format)
@@ -529,7 +627,7 @@ class QuantLinear(nn.Module):
         m.out_dtype = out_dtype
         m.layout = {PLANE_U8: "unified", PLANE_U8X: "unified", PLANE_BF16: "planes"}[out_kind]
         m.in_kind, m.out_kind = PLANE_NONE, out_kind
-        ib, ob, sb, _ = packed_sizes(out_features, in_features, 32, PLANE_NONE, out_kind)
+        ib, ob, sb, _ = packed_sizes(_ceil_to(out_features, N_MULT), _ceil_to(in_features, K_MULT), 32, PLANE_NONE, out_kind)
         m.register_buffer("inl_plane", torch.zeros(ib, dtype=torch.uint8, device=device))
         m.register_buffer("out_plane", torch.zeros(ob, dtype=torch.uint8, device=device))
         m.register_buffer("scale_plane", torch.zeros(sb, dtype=torch.uint8, device=device))
@@ -566,8 +664,9 @@ class QuantLinear(nn.Module):
         """Module around an existing PackedWeight (the planes are adopted, not copied)."""
         m = cls.__new__(cls)
         nn.Module.__init__(m)
-        m.in_features, m.out_features, m.block_size = P.K, P.N, P.block
-        m.inlier_elem_format = m.outlier_elem_format = "packed"
+        m.in_features, m.out_features, m.block_size = P.k, P.n, P.block
+        # single-plane kinds are what pack_values / empty_single_plane produce: a checkpoint reloads them as such
+        m.inlier_elem_format = m.outlier_elem_format = "values" if (P.in_kind == PLANE_NONE and P.block == 32) else "packed"
         m.out_dtype = out_dtype
         m.layout = "unified" if P.out_kind in (PLANE_U8, PLANE_U8X) else "planes"
         m.in_kind, m.out_kind = P.in_kind, P.out_kind
@@ -589,11 +688,116 @@ class QuantLinear(nn.Module):
         return y if out is not None else y.to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
 
 
-def make_quant(module, quantizers, name='', layout="auto"):
+class FusedProjections(nn.Module):
+    """Several Linears of ONE input (q / k / v, gate / up) as a single packed GEMM: their weights are concatenated along
+    out_features before packing.  Blocks run along in_features, so every row is quantised exactly as it would be alone: the
+    values do not change, only the launch count (and at decode sizes the weight stream is read by one kernel instead of
+    three).  The children of the model stay callable one by one (`ProjectionSlice`): the first call with a given input
+    tensor runs the fused GEMM, the others return their column slice of the same result."""
+
+    def __init__(self, qlinear_module, splits):
+        super().__init__()
+        self.proj = qlinear_module                        # QuantLinear or MXLinearW4A8 with out_features = sum(splits)
+        self.splits = [int(v) for v in splits]
+        self.offsets = [sum(self.splits[:i]) for i in range(len(self.splits) + 1)]
+        self._x = self._y = None
+        self._ver = -1
+        self._left = 0
+
+    def slice(self, i, x):
+        # the cached result is valid for this very tensor object only (holding the reference keeps its storage from being
+        # reused by another tensor) at the same version counter, and for one read per sibling
+        if self._x is not x or self._ver != x._version or self._left <= 0:
+            self._y = self.proj(x)
+            self._x, self._ver, self._left = x, x._version, len(self.splits)
+        y = self._y[..., self.offsets[i]:self.offsets[i + 1]]
+        self._left -= 1
+        if self._left == 0:
+            self._x = self._y = None
+        return y
+
+
+class ProjectionSlice(nn.Module):
+    """Stand-in for one of the fused Linears (same in_features / out_features): forward(x) = columns of the fused result.
+    The first slice owns the shared module as a submodule (its planes appear once in the state_dict, under
+    ``<first child>.fused.proj.*``); the others reference it."""
+
+    def __init__(self, fused, index, owner):
+        super().__init__()
+        if owner:
+            self.fused = fused
+        else:
+            object.__setattr__(self, "_fused_ref", fused)
+        self.index = index
+        self.in_features = fused.proj.in_features
+        self.out_features = fused.splits[index]
+
+    def shared(self):
+        return self.fused if "fused" in self._modules else self._fused_ref
+
+    def forward(self, x):
+        return self.shared().slice(self.index, x)
+
+
+def fuse_projections(parent, names, quantizer=None, layout="auto", path="bf16"):
+    """Replace the nn.Linear children ``names`` of ``parent`` (same in_features, same bias-ness) by ProjectionSlices of one
+    packed module.  ``quantizer`` None = the weights already hold fake-quant values (pack_values / from_values)."""
+    lins = [getattr(parent, n) for n in names]
+    if not all(isinstance(l, nn.Linear) for l in lins):
+        raise MsqError("fuse_projections: %r are not all nn.Linear" % (names,))
+    if len({l.in_features for l in lins}) != 1 or len({l.bias is None for l in lins}) != 1 or len({l.weight.dtype for l in lins}) != 1:
+        raise MsqError("fuse_projections: %r differ in in_features / bias / dtype" % (names,))
+    W = torch.cat([l.weight.data for l in lins], 0)
+    cat = nn.Linear(lins[0].in_features, W.shape[0], bias=lins[0].bias is not None, device="meta")
+    cat.weight = nn.Parameter(W, requires_grad=False)
+    if lins[0].bias is not None:
+        cat.bias = nn.Parameter(torch.cat([l.bias.data for l in lins], 0), requires_grad=False)
+    if path == "mx":
+        od = W.dtype if W.dtype == torch.bfloat16 else torch.float32
+        proj = MXLinearW4A8.from_values(W, cat.bias.data if cat.bias is not None else None, out_dtype=od) if quantizer is None \
+            else MXLinearW4A8.from_linear(cat, out_dtype=od)
+    else:
+        proj = QuantLinear.from_dense(cat) if quantizer is None else QuantLinear.from_linear(cat, quantizer, layout=layout)
+    fused = FusedProjections(proj, [l.out_features for l in lins])
+    for i, n in enumerate(names):
+        setattr(parent, n, ProjectionSlice(fused, i, owner=(i == 0)))
+    return fused
+
+
+def make_quant(module, quantizers, name='', layout="auto", fuse=None):
     """Swap every nn.Linear whose qualified name is in `quantizers` (name -> MXQuantizer) for a
     packed QuantLinear (the make_quant3 contract of llm/opt.py:258-264).  A value of None means "the weight
-    already holds fake-quant values" (RTN along any axis / GPTQ): it is packed as it is (from_dense)."""
-    for attr in list(dict(module.named_children()).keys()):
+    already holds fake-quant values" (RTN along any axis / GPTQ): it is packed as it is (from_dense).
+
+    ``fuse``: groups of sibling names, e.g. ``[("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj")]``: wherever a
+    module has all the Linears of a group as children (all listed in `quantizers`, with equal quantiser settings and blocks
+    along in_features, or all None) they are packed as ONE weight (fuse_projections): one GEMM launch instead of two or
+    three, the same values."""
+    children = dict(module.named_children())
+    for group in (fuse or ()):
+        if not all(g in children and isinstance(children[g], nn.Linear) for g in group):
+            continue
+        fulls = [(name + '.' + g if name != '' else g) for g in group]
+        if not all(f in quantizers for f in fulls):
+            continue
+        qs = [quantizers[f] for f in fulls]
+        if any(q is None for q in qs):
+            if not all(q is None for q in qs):
+                continue
+            q0 = None
+        else:
+            q0 = qs[0]
+            keys = ("inlier_scale_bits", "outlier_scale_bits", "inlier_elem_format", "outlier_elem_format", "std_dev",
+                    "block_size", "round", "flush_fp32_subnorms")
+            axes = q0.axes if isinstance(q0.axes, (list, tuple)) else [q0.axes]
+            if [a % 2 for a in axes] != [1] or any(getattr(q, k_) != getattr(q0, k_) for q in qs for k_ in keys):
+                continue
+        try:
+            fuse_projections(module, list(group), q0, layout)
+        except MsqError:
+            continue
+        children = dict(module.named_children())
+    for attr in list(children.keys()):
         child = getattr(module, attr)
         full = name + '.' + attr if name != '' else attr
         if isinstance(child, nn.Linear) and full in quantizers:
@@ -601,8 +805,8 @@ def make_quant(module, quantizers, name='', layout="auto"):
                 setattr(module, attr, QuantLinear.from_dense(child))
             else:
                 setattr(module, attr, QuantLinear.from_linear(child, quantizers[full], layout=layout))
-        else:
-            make_quant(child, quantizers, full, layout)
+        elif not isinstance(child, (ProjectionSlice, QuantLinear, MXLinearW4A8)):
+            make_quant(child, quantizers, full, layout, fuse)
     return module
 
 

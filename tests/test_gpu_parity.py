@@ -337,7 +337,7 @@ def _mx_unpack_w8(P):
                 k0 = 64 * half + 16 * kg
                 sc = scales[:, :, (k0 // 32) * 16 + r, nf].astype(np.float64)
                 W[:, nf * 16 + r, :, k0:k0 + 16] = _e4m3_decode(codes[:, :, nf, half, ln, :]) * np.exp2(sc - 127.0)[..., None]
-    return W.reshape(P.N, P.K)
+    return W.reshape(P.N, P.K)[:P.n, :P.k]          # the planes cover the padded 256 x 128 grid (qlinear._pad2d)
 
 
 @pytest.mark.parametrize("fo", ["fp8_e4m3", "fp4_e2m1", "posit8_es1"])
@@ -865,10 +865,10 @@ def test_mx_operand_pack_edge_cases(msq, O):
     Wn = W.clone(); Wn[5, 5] = float("inf")
     with pytest.raises(AssertionError):
         msq.qlinear.mx_pack_values(Wn)
-    with pytest.raises(msq._lib.MsqError):
-        msq.qlinear.mx_pack_values(torch.zeros(60, 128, device=dev()))     # N % 64
-    with pytest.raises(msq._lib.MsqError):
-        msq.qlinear.mx_pack_values(torch.zeros(64, 96, device=dev()))      # K % 128
+    assert L.msq_mx_pack_w8(msq._lib.ptr(Wn), msq._lib.ptr(Wn), msq._lib.ptr(Wn), None, 60, 128, None) == -2     # the raw ABI: N % 64
+    assert L.msq_mx_pack_w8(msq._lib.ptr(Wn), msq._lib.ptr(Wn), msq._lib.ptr(Wn), None, 64, 96, None) == -2      # K % 128
+    Pp = msq.qlinear.mx_pack_values(torch.zeros(60, 96, device=dev()))  # the Python layer pads to the 256 x 128 grid (round 3)
+    assert (Pp.n, Pp.k, Pp.N, Pp.K) == (60, 96, 256, 128)
     Pw = msq.qlinear.mx_pack_values(torch.randn(256, 128, device=dev()).to(torch.bfloat16).float().mul(0).add(1.0))
     y = msq.qlinear.qlinear_mx_w4a8(torch.zeros(0, 128, device=dev()), Pw, None, torch.float32)
     assert y.shape == (0, 256)
@@ -946,8 +946,11 @@ def test_c_abi_error_codes(msq):
     assert L.msq_outlier_fakequant(msq._lib.ptr(x), msq._lib.ptr(x), None, None, None, None, None, None, 0, 0, 1, 64, 1,
                                    16, 77, 5, 8, 8, 2.0, 0, 0, 0, None) == -1           # unknown format
     assert L.msq_quantize_elemwise(None, None, 0, 0, 5, 4, 448.0, 0, 1, 1, None) == 0       # empty input is fine
-    with pytest.raises(msq._lib.MsqError):
-        msq.qlinear.pack_weight(torch.zeros(100, 64, device=dev()))                         # N not a multiple of 64
+    import ctypes as C
+    sz = [C.c_int64() for _ in range(4)]
+    assert L.msq_packed_sizes(100, 64, 32, 0, 5, *[C.byref(v) for v in sz]) == -2              # the raw ABI takes the tile grid only
+    P = msq.qlinear.pack_weight(torch.zeros(100, 64, device=dev()))                            # ... the Python layer pads (round 3)
+    assert (P.n, P.k, P.N, P.K) == (100, 64, 256, 64)
 
 
 # ---------------------------------------------------------------- a14 harness (tiny models, reference-made fixtures)

@@ -1,0 +1,327 @@
+"""Round-3 GPU tests: the staggered eight-wave GEMM schedule, shapes off the kernels' tile grid, half-precision packing that
+matches the RTN harness, fused q / k / v and gate / up projections, HIP-graph capture of a packed decode step, GPTQ options."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def msq():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import msq as m
+    m._lib.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _weights(N, K, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(N, K, generator=g) * 0.02
+    W[torch.rand(N, K, generator=g) < 0.01] *= 16
+    return W
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# staggered schedule of k_qgemm3 (waves 4-7 half a K-step behind): K-step counts around the prologue / tail special cases
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [64, 128, 192, 320, 1088])
+@pytest.mark.parametrize("fo", ["posit8_es1", "fp8_e4m3"])
+def test_staggered_gemm_short_and_odd_k(msq, fo, K):
+    """The eight-wave blocks need (M / 128) (N / 512) >= 256: M 2048 x N 8192.  The posit layout runs the staggered schedule
+    (role barriers, four activation buffers), the fp8 layout the plain one: both must equal the dense product of the
+    unpacked weight (fp32 accumulation: 2e-5 max|y|) for 1, 2, 3, 5 and 17 K-steps, with ragged M, and repeat bit for bit."""
+    M, N = 2048 - 37, 8192 + 8192
+    W = _weights(N, K, 1).to(dev())
+    X = torch.randn(M, K, generator=torch.Generator().manual_seed(2)).to(dev()).to(torch.bfloat16)
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+    ref = X.float() @ msq.qlinear.unpack_weight(P).t()
+    y0 = msq.qlinear.qlinear(X, P, None, torch.float32)
+    assert (y0 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+    for _ in range(20):
+        assert torch.equal(msq.qlinear.qlinear(X, P, None, torch.float32), y0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# shapes off the tile grid: padded at pack time, sliced on the way out (utils/modelutils.py:8-15: every Linear is quantised)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K", [(1000, 520), (300, 96), (257, 4100)])
+def test_offgrid_pack_matches_oracle(msq, O, N, K):
+    W = _weights(N, K, 3)
+    X = torch.randn(70, K, generator=torch.Generator().manual_seed(4))
+    xb = X.to(dev()).to(torch.bfloat16)
+    for fo, layout in (("fp8_e4m3", "unified"), ("posit8_es1", "unified"), ("fp8_e4m3", "planes")):
+        o = O.outlier_fakequant(W.numpy(), 8, 8, "fp4_e2m1", fo, 2, -1, 32)["out"]
+        P = msq.qlinear.pack_weight(W.to(dev()), 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
+        assert (P.n, P.k) == (N, K) and P.N % 256 == 0 and P.K % 64 == 0
+        Wq = msq.qlinear.unpack_weight(P).cpu().numpy()
+        assert Wq.shape == (N, K) and (Wq == o).all(), (fo, layout)
+        for rows in (70, 5):
+            y = msq.qlinear.qlinear(xb[:rows], P, None, torch.float32).cpu().numpy()
+            yr = O.linear(xb[:rows].float().cpu().numpy(), o)
+            assert y.shape == (rows, N) and np.abs(y - yr).max() <= 2e-5 * np.abs(yr).max() + 1e-6
+    # values packed as they are, with a bias and a caller-provided output buffer
+    o = O.outlier_fakequant(W.numpy(), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    Pv = msq.qlinear.pack_values(torch.from_numpy(o).to(dev()))
+    b = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev())
+    out = torch.empty(70, N, dtype=torch.float32, device=dev())
+    y = msq.qlinear.qlinear(xb, Pv, b, torch.float32, out=out)
+    assert y.data_ptr() == out.data_ptr()
+    yr = O.linear(xb.float().cpu().numpy(), o, b.cpu().numpy())
+    assert np.abs(y.cpu().numpy() - yr).max() <= 2e-5 * np.abs(yr).max() + 1e-6
+    # MX matrix path: plain MX-FP4 weights x MX-FP8 activations on the padded grid == the oracle's quantisers on the logical shape
+    Wm = O.quantize_mx(W.numpy(), 8, "fp4_e2m1", axis=-1, block_size=32)
+    Xm = O.quantize_mx(X.numpy(), 8, "fp8_e4m3", axis=-1, block_size=32)
+    Pm = msq.qlinear.mx_pack_weight(W.to(dev()))
+    assert (Pm.n, Pm.k) == (N, K) and Pm.K % 128 == 0
+    ym = msq.qlinear.qlinear_mx_w4a8(X.to(dev()), Pm, None, torch.float32).cpu().numpy()
+    yr = O.linear(Xm, Wm)
+    assert ym.shape == (70, N) and np.abs(ym - yr).max() <= 1e-4 * np.abs(yr).max() + 1e-6
+
+
+def test_offgrid_model_is_fully_packed(msq, tmp_path):
+    """A model whose Linears fit no tile (hidden 200, intermediate 520): pack_layers leaves nothing dense, on both paths, the
+    packed model reproduces the fake-quantised one, and the checkpoint of the padded planes round-trips."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from msq.harness.data_utils import _Enc
+    from msq.harness.evalppl import pack_layers, perplexity, quantize_layers_nearest
+    from msq import checkpoint as ckpt
+    cfg = LlamaConfig(hidden_size=200, intermediate_size=520, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    tokens = _Enc(torch.randint(0, 512, (1, 64 * 4), generator=torch.Generator().manual_seed(1)))
+    for path in ("bf16", "mx"):
+        torch.manual_seed(0)
+        m = LlamaForCausalLM(cfg).eval().to(dev())
+        quantize_layers_nearest(m.model.layers, dev(), dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3",
+                                                            axes=[-1], block_size=32))
+        Wq = m.model.layers[1].mlp.down_proj.weight.data.clone()
+        ppl_dense = perplexity(m, tokens, dev(), 64)
+        packed, dense = pack_layers(m.model.layers, path=path)
+        assert (packed, dense) == (14, 0)
+        assert not any(isinstance(l, torch.nn.Linear) for layer in m.model.layers for l in layer.modules())
+        dp = m.model.layers[1].mlp.down_proj
+        assert (dp.in_features, dp.out_features) == (520, 200)
+        if path == "bf16":
+            assert torch.equal(dp.dequantize(), Wq)
+        ppl = perplexity(m, tokens, dev(), 64)
+        assert abs(ppl - ppl_dense) / ppl_dense < (0.02 if path == "bf16" else 0.05), (path, ppl, ppl_dense)
+        f = str(tmp_path / ("offgrid_%s.safetensors" % path))
+        ckpt.save_packed(m, f)
+        torch.manual_seed(0)
+        m2 = LlamaForCausalLM(cfg).eval().to(dev())
+        ckpt.load_packed(m2, f)
+        x = torch.randint(0, 512, (1, 16), device=dev())
+        assert torch.equal(m(x).logits, m2(x).logits)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# half-precision checkpoints: the packed layer holds exactly what the RTN harness writes into the weight (advisor, round 2)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_from_linear_on_half_weight_equals_rtn_values(msq, dtype):
+    g = torch.Generator().manual_seed(7)
+    lin = torch.nn.Linear(512, 768, bias=True)
+    lin.weight.data = torch.randn(768, 512, generator=g) * 0.03      # explicit: get_llama / get_opt swap torch's initialisers out
+    lin.weight.data[torch.rand(768, 512, generator=g) < 0.01] *= 12
+    lin.bias.data = torch.randn(768, generator=g) * 0.1
+    lin = lin.to(dev()).to(dtype)
+    q = msq.quant.MXQuantizer()
+    q.configure(8, 8, inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[-1], block_size=32)
+    rtn = q.quantize(lin.weight.data)                       # what llm/llama.py:238 stores (computed in `dtype`, op by op)
+    ql = msq.qlinear.QuantLinear.from_linear(lin, q)
+    assert torch.equal(ql.dequantize(), rtn.float())
+    # ... and differs from the upcast route on a few weights (that is the point of threading compute_dtype through)
+    ql32 = msq.qlinear.QuantLinear.from_linear(lin, q, compute_dtype="float32")
+    assert ql32.dequantize().shape == rtn.shape
+    x = torch.randn(9, 512, device=dev(), dtype=dtype)
+    y = ql(x)
+    assert y.dtype == dtype
+    ref = torch.nn.functional.linear(x.to(torch.bfloat16).float(), rtn.float(), lin.bias.float())
+    assert (y.float() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused q / k / v and gate / up projections (make_quant(fuse=...)) + HIP-graph capture of a decode step
+# ----------------------------------------------------------------------------------------------------------------------
+def _tiny_llama(dtype=torch.float32, hidden=256, inter=512, layers=2):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).eval().to(dtype).to(dev())
+
+
+@pytest.mark.parametrize("path", ["bf16", "mx"])
+def test_fused_projections_same_values_fewer_launches(msq, tmp_path, path):
+    from msq.harness import find_layers
+    from msq.harness.evalppl import LLAMA_FUSE, pack_layers, quantize_layers_nearest
+    from msq import checkpoint as ckpt
+    qc = dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[-1], block_size=32)
+    a, b = _tiny_llama(), _tiny_llama()
+    for m in (a, b):
+        quantize_layers_nearest(m.model.layers, dev(), qc)
+    assert pack_layers(a.model.layers, path=path) == (14, 0)
+    assert pack_layers(b.model.layers, path=path, fuse=LLAMA_FUSE) == (14, 0)
+    att = b.model.layers[0].self_attn
+    assert all(isinstance(p, msq.qlinear.ProjectionSlice) for p in (att.q_proj, att.k_proj, att.v_proj))
+    fused = att.q_proj.shared()
+    assert att.k_proj.shared() is fused and fused.proj.out_features == 768 and fused.splits == [256, 256, 256]
+    if path == "bf16":      # the values are those of the three separate weights
+        Wf = fused.proj.dequantize()
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            assert torch.equal(Wf[256 * i:256 * (i + 1)], getattr(a.model.layers[0].self_attn, n).dequantize())
+    # launches: one packed module per group
+    n_packed = lambda m: sum(isinstance(l, (msq.qlinear.QuantLinear, msq.qlinear.MXLinearW4A8)) for l in m.modules())
+    assert n_packed(a) == 14 and n_packed(b) == 8
+    x = torch.randint(0, 512, (2, 24), device=dev())
+    ya, yb = a(x).logits, b(x).logits
+    assert (ya - yb).abs().max().item() <= 2e-2 * ya.abs().max().item()       # same weights; the fused GEMM sums in another order
+    # the slices fall back to one GEMM per call when they are fed different tensors
+    h = torch.randn(3, 256, device=dev())
+    q1 = att.q_proj(h)
+    k1 = att.k_proj(h.clone())
+    assert q1.shape == (3, 256) and k1.shape == (3, 256)
+    assert torch.equal(att.v_proj(h), fused.proj(h)[..., 512:768])
+    # checkpoint round trip keeps the fusion
+    f = str(tmp_path / "fused.safetensors")
+    hdr = ckpt.save_packed(b, f)
+    assert any("fused" in d for d in hdr["layers"].values())
+    c = _tiny_llama()
+    ckpt.load_packed(c, f)
+    assert isinstance(c.model.layers[1].mlp.up_proj, msq.qlinear.ProjectionSlice)
+    assert torch.equal(c(x).logits, yb)
+
+
+@pytest.mark.parametrize("path", ["bf16", "mx"])
+def test_packed_decode_step_is_graph_capturable(msq, path):
+    """One decode step (M = 1) of a packed tiny Llama -- fused projections, QuantLinear / MXLinearW4A8 forwards through the
+    public modules -- captured into a HIP graph and replayed: no host synchronisation, no allocation-dependent pointers;
+    the replays equal the eager result bit for bit, also after the input buffer has been rewritten."""
+    from msq.harness.evalppl import LLAMA_FUSE, pack_layers, quantize_layers_nearest
+    m = _tiny_llama(torch.bfloat16)
+    quantize_layers_nearest(m.model.layers, dev(), dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3",
+                                                        axes=[-1], block_size=32))
+    assert pack_layers(m.model.layers, path=path, fuse=LLAMA_FUSE) == (14, 0)
+    layers = m.model.layers
+    rot = m.model.rotary_emb
+    h_in = torch.randn(1, 1, 256, device=dev(), dtype=torch.bfloat16)
+    pos = torch.zeros(1, 1, dtype=torch.long, device=dev())
+
+    def step(h):
+        pe = rot(h, pos)
+        for layer in layers:
+            out = layer(h, position_embeddings=pe, attention_mask=None)
+            h = out[0] if isinstance(out, tuple) else out
+        return h
+
+    with torch.no_grad():
+        eager = step(h_in).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                step(h_in)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = step(h_in)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager)
+        h2 = torch.randn(1, 1, 256, device=dev(), dtype=torch.bfloat16)
+        eager2 = step(h2).clone()
+        h_in.copy_(h2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, eager2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GPTQ options (llm/gptq.py:81-87,119-127) and the block kernel's residency check
+# ----------------------------------------------------------------------------------------------------------------------
+def test_gptq_groupsize_and_static_groups_are_honoured(msq):
+    from msq.harness.gptq import GPTQ
+    torch.manual_seed(11)
+    qc = dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[0], block_size=16)
+
+    def run(quantizer_cls=None, **kw):
+        gen = torch.Generator().manual_seed(11)
+        lin = torch.nn.Linear(256, 192, bias=False)
+        lin.weight.data = torch.randn(192, 256, generator=gen) * 0.05
+        lin = lin.to(dev())
+        g = GPTQ(lin)
+        X = torch.randn(4, 64, 256, generator=gen).to(dev())
+        g.add_batch(X, lin(X))
+        q = (quantizer_cls or msq.quant.MXQuantizer)()
+        q.configure(8, 8, **qc)
+        g.quantizer = q
+        g.fasterquant(blocksize=128, percdamp=0.01, verbose=False, **kw)
+        return lin.weight.data.clone(), g
+
+    base, _ = run()
+    # MXQuantizer.find_params is empty (utils/quant.py:429): groups change nothing, the block kernel stays in use
+    for kw in (dict(groupsize=64), dict(groupsize=64, static_groups=True), dict(groupsize=32, static_groups=True, actorder=True)):
+        w, _ = run(**kw)
+        if "actorder" not in kw:
+            assert torch.equal(w, base), kw
+    # a quantiser whose find_params does something is re-fitted per group, column by column
+    calls = []
+
+    class Counting(msq.quant.MXQuantizer):
+        def find_params(self, x, weight=False):
+            calls.append(tuple(x.shape))
+
+    w, _ = run(Counting, groupsize=64)
+    assert calls.count((192, 64)) == 4 and torch.equal(w, base)       # one re-fit per 64-column group, same values
+    calls.clear()
+    w, _ = run(Counting, groupsize=128, static_groups=True)
+    assert calls.count((192, 128)) == 2 and torch.equal(w, base)
+    with pytest.raises(ValueError):
+        run(static_groups=True)
+    with pytest.raises(ValueError):
+        run(groupsize=0)
+
+
+def test_gptq_block_kernel_checks_residency(msq):
+    """msq_gptq_block sizes its grid against the device (CUs x resident blocks at its LDS size) and refuses what cannot be
+    co-resident; on a whole MI355X every legal grid (<= 200 workgroups) fits, and the status word carries no time-out bit."""
+    from msq._lib import check, current_stream, lib, ptr
+    from msq.formats import format_id
+    L = lib()
+    O_, cols = 51200, 128
+    torch.manual_seed(2)
+    Wt = torch.randn(cols, O_, device=dev()) * 0.02
+    U = torch.eye(cols, device=dev()) + torch.triu(torch.randn(cols, cols, device=dev()) * 0.01, 1)
+    Qt, Et = torch.empty_like(Wt), torch.empty_like(Wt)
+    loss = torch.zeros((), dtype=torch.float64, device=dev())
+    pruned = torch.zeros((), dtype=torch.int64, device=dev())
+    status = torch.zeros(1, dtype=torch.int32, device=dev())
+    wsb = L.msq_gptq_block_workspace_bytes(O_, cols)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    check(L.msq_gptq_block(ptr(Wt), ptr(U), cols, ptr(Qt), ptr(Et), ptr(loss), ptr(pruned), ptr(status), ptr(ws), wsb, O_, cols, 16,
+                           format_id("fp4_e2m1"), format_id("fp8_e4m3"), 8, 8, 2.0, 0, 0, current_stream(dev())), "msq_gptq_block")
+    torch.cuda.synchronize()
+    assert int(status.item()) & 4 == 0 and torch.isfinite(Qt).all()
+    wsb2 = L.msq_gptq_block_workspace_bytes(51200 + 256, cols)          # 201 workgroups: refused before anything is launched
+    ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev())
+    rc = L.msq_gptq_block(ptr(Wt), ptr(U), cols, ptr(Qt), ptr(Et), ptr(loss), ptr(pruned), ptr(status), ptr(ws2), wsb2, 51200 + 256, cols, 16,
+                          format_id("fp4_e2m1"), format_id("fp8_e4m3"), 8, 8, 2.0, 0, 0, current_stream(dev()))
+    assert rc == -2
