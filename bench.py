@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
-ROUND_TAG = "r02"
+ROUND_TAG = "r03"
 
 
 def parse_args(argv=None):
@@ -48,7 +48,15 @@ def parse_args(argv=None):
     ap.add_argument("--outlier", default="posit8_es1")
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--workload", default="llama7b_w4_fused_gemm",
-                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_mx_w6a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel"])
+                    choices=["llama7b_w4_fused_gemm", "llama7b_w4a8", "llama7b_mx_w4a8", "llama7b_mx_w6a8", "llama7b_msq_w4a8_mx", "llama70b_rowparallel",
+                             "llama7b_e2e"])
+    ap.add_argument("--layers", type=int, default=32, help="llama7b_e2e: decoder layers of the Llama-2-7B-shaped model (tests use a slice)")
+    ap.add_argument("--seqlen", type=int, default=2048, help="llama7b_e2e: prefill / perplexity window")
+    ap.add_argument("--path", default="bf16", choices=["bf16", "mx"], help="llama7b_e2e: packed path (bf16 activations or the MX matrix path)")
+    ap.add_argument("--decode-tokens", type=int, default=64, help="llama7b_e2e: tokens of the per-token latency loop (llm/opt.py:332-376)")
+    ap.add_argument("--model-dtype", default="fp16", choices=["fp16", "bf16"],
+                    help="llama7b_e2e: dtype of the model (Llama-2 checkpoints load as fp16, llm/llama.py:33; bf16 needs no activation cast in front of the bf16 MFMA)")
+    ap.add_argument("--timeout", type=float, default=1800.0, help="--gpus N started by hand: overall time limit of the rank processes in seconds")
     ap.add_argument("--layout", default="auto", choices=["planes", "unified", "auto"],
                     help="packed layout: planes = MSQ-T1 (fp4 plane + outlier plane), unified = MSQ-U1 (one e4m3 code per weight)")
     ap.add_argument("--mx", action="store_true",
@@ -80,14 +88,53 @@ def spawn_ranks(args, argv):
                    MSQ_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE, stderr=None, text=True))
+    # Poll all ranks: when one dies (HIP / RCCL start-up failure, out of memory, a bad shape raising on one rank) the others
+    # sit in init_process_group or a barrier for ever -- terminate them and return the first failure, as torchrun does.  An
+    # overall time limit covers a hang of all of them.  Rank stdout is drained by reader threads (a full pipe would block).
+    import threading
+    outs = [[] for _ in procs]
+
+    def drain(i, p):
+        for ln in p.stdout:
+            outs[i].append(ln.rstrip("\n"))
+
+    readers = [threading.Thread(target=drain, args=(i, p), daemon=True) for i, p in enumerate(procs)]
+    for t in readers:
+        t.start()
+    deadline = time.time() + float(args.timeout)
     worst = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and worst == 0:
+                worst = rc
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
+        if live and (worst != 0 or time.time() > deadline):
+            if worst == 0:
+                worst = 124
+                sys.stderr.write("bench.py: ranks %s still running after %.0f s; stopping them\n" % (sorted(live), float(args.timeout)))
+            for r in live:
+                procs[r].terminate()
+            t_kill = time.time() + 10.0
+            while any(procs[r].poll() is None for r in live) and time.time() < t_kill:
+                time.sleep(0.1)
+            for r in live:
+                if procs[r].poll() is None:
+                    procs[r].kill()
+            for r in live:
+                procs[r].wait()
+            live.clear()
+        elif live:
+            time.sleep(0.05)
+    for t in readers:
+        t.join(timeout=5.0)
     lines = []
-    for r, p in enumerate(procs):
-        out, _ = p.communicate()
-        rc = p.returncode
-        if rc != 0:
-            worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
-        for ln in (out or "").splitlines():
+    for r in range(n):
+        for ln in outs[r]:
             if r == 0 and ln.startswith("{"):
                 lines.append(ln)
             else:
@@ -95,8 +142,8 @@ def spawn_ranks(args, argv):
     if worst == 0 and len(lines) != 1:
         sys.stderr.write("bench.py: rank 0 printed %d JSON lines (expected 1)\n" % len(lines))
         worst = 1
-    for ln in lines[-1:]:
-        print(ln)
+    if worst == 0:
+        print(lines[-1])
     sys.stdout.flush()
     return worst
 
@@ -236,15 +283,206 @@ def ppl_delta_from_env(dev, fi, fo, bs):
     del ref
     model.to(dev)
     q = msq.quant.MXQuantizer(); q.configure(8, 8, **qc)
-    kept = 0
+    kept = 0                                             # shapes off the tile grid are padded at pack time: nothing stays dense
     for layer in model.model.layers:
-        names = {n: q for n, l in find_layers(layer).items() if l.out_features % 256 == 0 and l.in_features % 64 == 0}
-        kept += len(find_layers(layer)) - len(names)
-        msq.qlinear.make_quant(layer, names)
+        msq.qlinear.make_quant(layer, {n: q for n in find_layers(layer)})
+        kept += sum(isinstance(l, torch.nn.Linear) for l in layer.modules())
     ppl_ours = perplexity(model, tokens, dev, seqlen)
     return {"ppl_cpu_reference": ppl_ref, "ppl_hip_packed_fused": ppl_ours, "delta": ppl_ours - ppl_ref,
             "windows": int(ids.numel() // seqlen), "seqlen": seqlen, "layers_kept_dense": kept,
             "model": os.path.basename(os.path.normpath(model_dir))}
+
+
+def e2e_main(args, dev):
+    """--workload llama7b_e2e: whole-model evidence at Llama-2-7B's true shapes with random weights (no checkpoint in the image;
+    side workload, the default line is untouched).  What the reference's harness does with a checkpoint, end to end:
+      (i)   RTN-quantise every decoder Linear through llama_eval's path (llm/llama.py:226-253)            -> rtn_quantise_s
+      (ii)  swap the fake-quantised Linears for packed modules (llm/opt.py:255-264, q/k/v and gate/up fused) -> packed_GB, kept_dense
+      (iii) prefill tokens/s at `seqlen` and per-token decode latency as llm/opt.py:332-376 `benchmark` measures it (median),
+            packed fused kernels against the fake-quantised fp16 model on hipBLASLt; the Linear stack of one decode step
+            replayed from a HIP graph (kernel time without the Python / eager launch overhead)
+      (iv)  perplexity of both models on synthetic tokens with the reference's formula (llm/llama.py:264-282) + the largest
+            logit difference                                                                                 -> ppl_proxy_7b"""
+    import copy
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import msq
+    from msq import qlinear
+    from msq.harness import find_layers
+    from msq.harness.data_utils import _Enc
+    from msq.harness.evalppl import LLAMA_FUSE, pack_layers, perplexity, quantize_layers_nearest
+    cfg = LlamaConfig(hidden_size=args.H, intermediate_size=11008 if args.H == 4096 else int(args.H * 8 / 3) // 256 * 256,
+                      num_hidden_layers=args.layers, num_attention_heads=max(1, args.H // 128), num_key_value_heads=max(1, args.H // 128),
+                      vocab_size=32000, max_position_embeddings=max(4096, args.seqlen))
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    mdt = torch.float16 if args.model_dtype == "fp16" else torch.bfloat16
+    torch.set_default_dtype(mdt)
+    try:
+        with torch.device(dev):
+            model = LlamaForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    model.eval()
+    model.config.use_cache = False
+    g = torch.Generator(device=dev).manual_seed(1)
+    n_lin = n_w = 0
+    for layer in model.model.layers:                      # the heavy tail of synth_weight: 0.5 % of the entries x 16
+        for lin in find_layers(layer).values():
+            w = lin.weight.data
+            w[torch.rand(w.shape, generator=g, device=dev) < 0.005] *= 16.0
+            n_lin += 1
+            n_w += w.numel()
+    fp16_bytes = 2 * n_w
+    qc = dict(inlier_elem_format=args.inlier, outlier_elem_format=args.outlier, axes=[-1], block_size=args.block)
+    # (i) RTN through the harness path
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    quantize_layers_nearest(model.model.layers, dev, qc)
+    torch.cuda.synchronize()
+    t_rtn = time.perf_counter() - t0
+    # the same arithmetic on the host cores (oracle, all cores) on ONE 4096 x 4096 layer, scaled to the model
+    cpu_rtn = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        threads = O.set_threads(physical_cores())
+        rng = np.random.RandomState(0)
+        Ws = (rng.randn(args.H, args.H) * 0.02).astype(np.float32)
+        t0 = time.perf_counter()
+        O.outlier_fakequant(Ws, 8, 8, args.inlier, args.outlier, 2, -1, args.block)
+        t1 = time.perf_counter() - t0
+        cpu_rtn = {"seconds_estimate": t1 * n_w / Ws.size, "threads": threads,
+                   "sample": "oracle fake-quant of one [%d x %d] weight in %.2f s, scaled to the %d decoder Linears" % (args.H, args.H, t1, n_lin)}
+    # (ii) pack
+    dense = model
+    packed = copy.deepcopy(model)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_packed, kept = pack_layers(packed.model.layers, path=args.path, fuse=LLAMA_FUSE)
+    torch.cuda.synchronize()
+    t_pack = time.perf_counter() - t0
+    mods = [m for m in packed.modules() if isinstance(m, (qlinear.QuantLinear, qlinear.MXLinearW4A8))]
+    packed_bytes = sum(b.numel() * b.element_size() for m in mods for n_, b in m.named_buffers(recurse=False) if n_ != "bias")
+    kinds = {}
+    for m in mods:
+        k_ = ("mx-" + m.w_fmt) if isinstance(m, qlinear.MXLinearW4A8) else {4: "bf16 plane", 5: "unified", 6: "unified+ext"}.get(m.out_kind, "planes")
+        kinds[k_] = kinds.get(k_, 0) + 1
+    # (iii) prefill and decode
+    S = args.seqlen
+    ids = torch.randint(0, 32000, (1, S), generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def prefill(m, n=5):
+        with torch.no_grad():
+            for _ in range(2):
+                m(ids)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                m(ids)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    def decode(m, T):
+        times = []
+        with torch.no_grad():
+            past = None
+            for i in range(T):
+                torch.cuda.synchronize()
+                tick = time.perf_counter()
+                out = m(ids[:, i:i + 1], past_key_values=past, use_cache=True)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - tick)
+                past = out.past_key_values
+        return float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
+
+    def linear_stack_graph(m, rows=1):
+        """the seven Linears of every decoder layer at M = rows (through the public modules, fused slices included), one HIP graph"""
+        h = torch.randn(rows, args.H, device=dev, dtype=mdt)
+        hi = torch.randn(rows, cfg.intermediate_size, device=dev, dtype=mdt)
+
+        def run():
+            acc = None
+            for layer in m.model.layers:
+                a, p = layer.self_attn, layer.mlp
+                q, k, v = a.q_proj(h), a.k_proj(h), a.v_proj(h)
+                o = a.o_proj(h)
+                gt, up = p.gate_proj(h), p.up_proj(h)
+                d = p.down_proj(hi)
+                acc = (q, k, v, o, gt, up, d)
+            return acc
+        with torch.no_grad():
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                for _ in range(3):
+                    run()
+            torch.cuda.current_stream().wait_stream(s_)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                run()
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20
+
+    res = {}
+    for tag, m in (("packed_fused", packed), ("fakequant_dense_fp16", dense)):
+        m.config.use_cache = False
+        tp = prefill(m)
+        m.config.use_cache = True
+        td = decode(m, args.decode_tokens)
+        m.config.use_cache = False
+        tg = linear_stack_graph(m)
+        tgp = linear_stack_graph(m, S)
+        res[tag if tag != "fakequant_dense_fp16" else "fakequant_dense_" + args.model_dtype] = {"prefill_s": tp, "prefill_tokens_per_s": S / tp, "decode_ms_per_token_eager": td * 1e3,
+                    "decode_linears_ms_per_token_hip_graph": tg, "prefill_linears_ms_hip_graph": tgp,
+                    "prefill_linears_tflops": 2.0 * S * n_w / (tgp * 1e-3) / 1e12}
+    # (iv) perplexity on synthetic tokens + logit error
+    nwin = max(1, min(4, 8192 // S))
+    toks = _Enc(torch.randint(0, 32000, (1, nwin * S), generator=torch.Generator().manual_seed(3)))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        ppl_d = perplexity(dense, toks, dev, S, fp32_loss=True)       # fp32 cross entropy: the reference's fp16 loss moves in 0.8 % steps here
+        ppl_p = perplexity(packed, toks, dev, S, fp32_loss=True)
+        ppl_d16 = perplexity(dense, toks, dev, S)
+        ppl_p16 = perplexity(packed, toks, dev, S)
+    with torch.no_grad():
+        ld = dense(ids).logits.float()
+        lp = packed(ids).logits.float()
+    lerr = (ld - lp).abs().max().item()
+    lmax = ld.abs().max().item()
+    out = {
+        "metric": "llama7b_e2e: prefill tokens/s of the packed model (side workload of bench.py; the headline metric is the default line)",
+        "value": S / res["packed_fused"]["prefill_s"], "unit": "tokens/s", "n_gpus": 1, "steps": 5, "warmup": 2,
+        "ms_per_step": res["packed_fused"]["prefill_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("bf16 MFMA inside an %s model" if args.path == "bf16" else "mxfp8 x e4m3 codes inside an %s model") % args.model_dtype, "data": "synthetic",
+        "config": {"workload": "Llama-2-7B-shaped decoder (hidden %d, intermediate %d, %d layers, %d heads, vocab 32000), random %s weights with a "
+                               "heavy tail, %s inliers + %s outliers, block %d along in_features; prefill / perplexity window %d tokens, batch 1"
+                               % (args.H, cfg.intermediate_size, args.layers, cfg.num_attention_heads, args.model_dtype, args.inlier, args.outlier, args.block, S),
+                   "path": args.path, "fused_groups": [list(gp) for gp in LLAMA_FUSE]},
+        "rtn_quantise_s": t_rtn, "rtn_linears": n_lin, "rtn_weights": n_w, "rtn_cpu_oracle": cpu_rtn,
+        "pack_s": t_pack, "packed_linears": n_packed, "kept_dense": kept, "packed_modules": len(mods), "packed_kinds": kinds,
+        "packed_GB": packed_bytes / 1e9, "dense_16bit_GB": fp16_bytes / 1e9, "packed_bits_per_weight": 8.0 * packed_bytes / n_w,
+        "speed": res,
+        "prefill_speedup_vs_fakequant_dense": res["fakequant_dense_" + args.model_dtype]["prefill_s"] / res["packed_fused"]["prefill_s"],
+        "decode_linears_speedup_hip_graph": res["fakequant_dense_" + args.model_dtype]["decode_linears_ms_per_token_hip_graph"] / res["packed_fused"]["decode_linears_ms_per_token_hip_graph"],
+        "prefill_linears_speedup_hip_graph": res["fakequant_dense_" + args.model_dtype]["prefill_linears_ms_hip_graph"] / res["packed_fused"]["prefill_linears_ms_hip_graph"],
+        "ppl_proxy_7b": {"ppl_fakequant_dense": ppl_d, "ppl_packed_fused": ppl_p, "relative_delta": abs(ppl_p - ppl_d) / ppl_d,
+                         "equivalent_delta_at_ppl_5.5": 5.5 * abs(ppl_p - ppl_d) / ppl_d, "windows": nwin, "seqlen": S,
+                         "loss": "fp32 cross entropy of the model's logits", "ppl_fakequant_dense_reference_formula": ppl_d16,
+                         "ppl_packed_fused_reference_formula": ppl_p16,
+                         "max_logit_abs_err": lerr, "max_abs_logit": lmax, "tokens": "uniform random ids (no dataset in the image)"},
+    }
+    print(json.dumps(out))
+    sys.stdout.flush()
 
 
 def main(argv=None):
@@ -274,6 +512,10 @@ def main(argv=None):
 
     from msq import qlinear
 
+    if args.workload == "llama7b_e2e":
+        if world > 1:
+            raise SystemExit("llama7b_e2e is a single-GPU workload")
+        return e2e_main(args, dev)
     M = args.M
     rowpar = args.workload == "llama70b_rowparallel"
     if rowpar:

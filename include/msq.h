@@ -219,7 +219,7 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
                        void* stream);
 
 /* fused unpack-dequant-GEMM: Y[M,N] = X[M,K] (bf16) . W^T (+ bias f32 [N] or NULL), fp32 accumulate on
- * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 2 = bf16.  Replaces the dense F.linear the reference
+ * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 1 = fp16, 2 = bf16 (the 16-bit kinds share one kernel: the epilogue converts either way).  Replaces the dense F.linear the reference
  * runs on the fake-quantised weight (number_system/mx/linear.py:91, llm/llama.py:255-256).
  * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0.  M <= 32 (<= 64 for the 4096 x 4096 class) takes the decode
  * kernel: one wave per (64 columns, k-chunk), k-chunks summed in LDS; for the unified layouts with N >= 8192 and
@@ -274,7 +274,7 @@ int msq_qlinear_w4a8_x16(const void* X, const void* inl_plane, const void* out_p
  *   msq_mx_pack_w4: W [N,K] f32 -> codes [N*K/2] bytes in MFMA operand order (tile 64 n x 128 k, slot nf = 16 n,
  *                   lane (n % 16, (k % 128) / 32) holds 32 k = 16 B) + scales [N*K/32] bytes ([tile][lane][nf]).
  *                   N % 64 == 0 (N % 256 == 0 for the GEMM), K % 128 == 0.  4.25 bits per weight.
- *   msq_qlinear_mx_w4a8: Y [M,N] = dq(X) . dq(W)^T + bias, y_dtype 0 = f32 / 2 = bf16.  The MFMA sums the 128
+ *   msq_qlinear_mx_w4a8: Y [M,N] = dq(X) . dq(W)^T + bias, y_dtype 0 = f32 / 1 = fp16 / 2 = bf16.  The MFMA sums the 128
  *                   products of one instruction with ~15 bits relative to the largest term: tolerance 1e-4 max|y|.
  * status_flag receives MSQ_STATUS_NAN when a block holds Inf / NaN or its scale overflows.
  * ------------------------------------------------------------------------- */

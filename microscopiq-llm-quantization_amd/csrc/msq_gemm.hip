@@ -407,9 +407,12 @@ MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
 // transposes its tile through its own 8 KiB LDS slice (XOR-swizzled 16-byte chunks, no block barrier
 // needed) and writes whole 128-byte (bf16) / 256-byte (f32) row segments with 16-byte stores.
 // ---------------------------------------------------------------------------
+// y16 (16-bit YT only): 0 = bf16, 1 = fp16 (IEEE half, round to nearest even) -- a wave-uniform run-time switch, not a third
+// instantiation of every GEMM kernel: an fp16 model gets its dtype back without a cast pass over the output.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <typename YT, int NMF = 8>
 MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[NMF][4], char* wsm, YT* __restrict__ Y, int m_base, int n_base,
-                               int M, int N, const float* __restrict__ bias, int lane) {
+                               int M, int N, const float* __restrict__ bias, int lane, int y16 = 0) {
     const int c = lane & 15, g = lane >> 4;
     constexpr int ROW_B = 64 * (int)sizeof(YT);             // bytes per tile row: 128 (bf16) / 256 (f32)
     constexpr int RP = 8192 / ROW_B;                         // rows per pass: 64 / 32
@@ -434,11 +437,18 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[NMF][4], char* wsm, YT* __re
                     const int chunk = (nf * 4 + g) ^ (row & (CHUNKS - 1));
                     *reinterpret_cast<float4*>(wsm + row * ROW_B + chunk * 16) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    bf16x2_t lo, hi;
-                    lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                    uint32_t plo, phi;
+                    if (y16) {
+                        f16x2_t lo, hi;
+                        lo[0] = (_Float16)v[0]; lo[1] = (_Float16)v[1]; hi[0] = (_Float16)v[2]; hi[1] = (_Float16)v[3];
+                        plo = __builtin_bit_cast(uint32_t, lo); phi = __builtin_bit_cast(uint32_t, hi);
+                    } else {
+                        bf16x2_t lo, hi;
+                        lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                        plo = __builtin_bit_cast(uint32_t, lo); phi = __builtin_bit_cast(uint32_t, hi);
+                    }
                     const int chunk = (nf * 2 + (g >> 1)) ^ (row & (CHUNKS - 1));
-                    *reinterpret_cast<uint2*>(wsm + row * ROW_B + chunk * 16 + (g & 1) * 8) =
-                        make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+                    *reinterpret_cast<uint2*>(wsm + row * ROW_B + chunk * 16 + (g & 1) * 8) = make_uint2(plo, phi);
                 }
             }
         }
@@ -473,7 +483,7 @@ template <int IN_KIND, int OUT_KIND, typename YT, int WM, int MF = 8, int WN = 4
 __global__ void __launch_bounds__(64 * WN * WM * KG, (MF == 16) ? 1 : ((WN == 8 || KG == 2) ? 1 : 2))
 k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
          const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-         int scl_groups, int ksplit, float* __restrict__ partial) {
+         int scl_groups, int ksplit, float* __restrict__ partial, int y16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     static_assert(KG == 1 || (KG == 2 && WN == 4 && WM == 1 && MF == 8), "k-groups: four-wave 128 x 256 blocks only");
@@ -750,7 +760,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
         if (ksplit > 1)
             store_wave_tile_lds<float, MF>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS, n0 + wn * 64, M, N, nullptr, lane);
         else
-            store_wave_tile_lds<YT, MF>(acc, smem + wid * 8192, Y, m0 + wm * WROWS, n0 + wn * 64, M, N, bias, lane);
+            store_wave_tile_lds<YT, MF>(acc, smem + wid * 8192, Y, m0 + wm * WROWS, n0 + wn * 64, M, N, bias, lane, y16);
     } else {
 #pragma unroll
         for (int h = 0; h < MF / 8; ++h) {                      // 128 rows at a time through the wave's 8 KiB slice
@@ -759,7 +769,7 @@ k_qgemm3(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, 
                 store_wave_tile_lds<float>(acch, smem + wid * 8192, partial + (int64_t)ks * M * N, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N,
                                            nullptr, lane);
             else
-                store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N, bias, lane);
+                store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + wm * WROWS + h * 128, n0 + wn * 64, M, N, bias, lane, y16);
         }
     }
 }
@@ -800,7 +810,7 @@ template <typename YT, int WF, int KG = 1, int MFM = 8>
 __global__ void __launch_bounds__(256 * KG, KG == 2 ? 1 : 2)
 k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc,
          const uint8_t* __restrict__ Ws, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
-         int ksplit, float* __restrict__ partial) {
+         int ksplit, float* __restrict__ partial, int y16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool W8 = (WF != 0);                                // wide operand: two pieces per fragment, two-deep ring
     constexpr bool W6 = (WF >= 2);
@@ -1007,7 +1017,7 @@ k_mxgemm(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
         if (kgid == 1) return;
     }
     if (ksplit > 1) store_wave_tile_lds<float, MFM>(acc, smem + wid * 8192, partial + (int64_t)ks * M * N, m0, n0 + wn * 64, M, N, nullptr, lane);
-    else store_wave_tile_lds<YT, MFM>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane);
+    else store_wave_tile_lds<YT, MFM>(acc, smem + wid * 8192, Y, m0, n0 + wn * 64, M, N, bias, lane, y16);
 }
 
 // ---------------------------------------------------------------------------
@@ -1139,7 +1149,11 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
             const int n = n0 + nf * 16;
             if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
             if (!y_bf16) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
+            else if (y_bf16 == 2) {
+                f16x2_t lo, hi;
+                lo[0] = (_Float16)v[0]; lo[1] = (_Float16)v[1]; hi[0] = (_Float16)v[2]; hi[1] = (_Float16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            } else {
                 bf16x2_t lo, hi;
                 lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
@@ -1244,7 +1258,11 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
             if (!direct) { *reinterpret_cast<float4*>(pbase + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]); continue; }
             if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
             if (!y_bf16) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + (int64_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
+            else if (y_bf16 == 2) {
+                f16x2_t lo, hi;
+                lo[0] = (_Float16)v[0]; lo[1] = (_Float16)v[1]; hi[0] = (_Float16)v[2]; hi[1] = (_Float16)v[3];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            } else {
                 bf16x2_t lo, hi;
                 lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + (int64_t)m * N + n) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
@@ -1259,7 +1277,7 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 template <typename YT>
 __global__ void __launch_bounds__(256)
 k_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bias, YT* __restrict__ Y, int64_t MN, int N,
-                int ksplit) {
+                int ksplit, int y16) {
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= MN) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1281,7 +1299,11 @@ k_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bia
     }
     if (bias) { const int n = (int)(i4 % N); s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
     if (sizeof(YT) == 4) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Y) + i4) = s;
-    else {
+    else if (y16) {
+        f16x2_t lo, hi;
+        lo[0] = (_Float16)s.x; lo[1] = (_Float16)s.y; hi[0] = (_Float16)s.z; hi[1] = (_Float16)s.w;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + i4) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+    } else {
         bf16x2_t lo, hi;
         lo[0] = (__bf16)s.x; lo[1] = (__bf16)s.y; hi[0] = (__bf16)s.z; hi[1] = (__bf16)s.w;
         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Y) + i4) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
@@ -1641,7 +1663,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     const bool unified = (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X);
     if (unified && (!scale_plane || (out_kind == MSQ_PLANE_U8X && !inl_plane)))
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: null buffer");
-    if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32) or 2 (bf16)");
+    if (y_dtype != 0 && y_dtype != 1 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: y_dtype must be 0 (f32), 1 (fp16) or 2 (bf16)");
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: dimension too large");
     {   // activations and packed planes are addressed with 32-bit buffer offsets (make_rsrc clamps num_records)
         int64_t ib = 0, ob = 0, sb = 0;
@@ -1650,6 +1672,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_bf16: activations (M*K*2 bytes) and every packed plane must stay below 4 GiB; split M (or N) on the host");
     }
     hipStream_t st0 = (hipStream_t)stream;
+    const int y16 = (y_dtype == 1) ? 1 : 0;                       // fp16 output: the 16-bit kernels with the half conversion
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     if (use_gemv(M, N, K)) {
         const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
@@ -1663,7 +1686,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             do { static DevOnce once_;                                                                         \
                  if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv<IK, OK, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_done(once_); } \
                  hipLaunchKernelGGL((k_qgemv<IK, OK, MGV, WV>), vgrid, dim3(64 * WV), ldsv, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, \
-                                    (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+                                    (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
 #define MSQ_GV(IK, OK) do { if (mg == 1) MSQ_GV1(IK, OK, 1, 4); else if (mg == 2) MSQ_GV1(IK, OK, 2, 4); else MSQ_GV1(IK, OK, 4, 4); } while (0)
             if (kcd) {
                 if (out_kind == MSQ_PLANE_U8) { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 2, 16); }
@@ -1683,8 +1706,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             if (rc) return rc;
             const int64_t MN0 = M * N;
             const dim3 rg((unsigned)((MN0 / 4 + 255) / 256));
-            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks);
-            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks);
+            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
+            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st0, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
             return check_launch2("msq_qlinear_bf16(gemv reduce)");
         }
     }
@@ -1703,7 +1726,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     do { static DevOnce once_;                                                                                 \
          if (attr_needed(once_)) { hipFuncSetAttribute((const void*)KERN<IK, OK, YT, WMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((KERN<IK, OK, YT, WMV>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane,  \
-                (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
+                (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial, y16); } while (0)
 #define MSQ_LAUNCH(KERN, IK, OK)                                                                                       \
     do { if (y_dtype == 0) { if (wm_sel == 2) MSQ_LAUNCH1(KERN, IK, OK, float, 2); else MSQ_LAUNCH1(KERN, IK, OK, float, 1); } \
          else { if (wm_sel == 2) MSQ_LAUNCH1(KERN, IK, OK, uint16_t, 2); else MSQ_LAUNCH1(KERN, IK, OK, uint16_t, 1); } } while (0)
@@ -1733,7 +1756,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         do { static DevOnce once_;                                                                                     \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); attr_done(once_); } \
              hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 8>), grid8, blk8, lds8, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial); } while (0)
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial, y16); } while (0)
         if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH8(MSQ_PLANE_U8, float); else MSQ_LAUNCH8(MSQ_PLANE_U8, uint16_t); }
         else { if (y_dtype == 0) MSQ_LAUNCH8(MSQ_PLANE_U8X, float); else MSQ_LAUNCH8(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCH8
@@ -1762,7 +1785,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         do { static DevOnce once_;                                                                                     \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
              hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 4>), grid4, blk4, lds4, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial); } while (0)
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, 1, partial, y16); } while (0)
         if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH4(MSQ_PLANE_U8, float); else MSQ_LAUNCH4(MSQ_PLANE_U8, uint16_t); }
         else { if (y_dtype == 0) MSQ_LAUNCH4(MSQ_PLANE_U8X, float); else MSQ_LAUNCH4(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCH4
@@ -1785,7 +1808,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         do { static DevOnce once_;                                                                                     \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done(once_); } \
              hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 8, 4, 2>), grid, blk2, lds2, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial, y16); } while (0)
         if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCHKG(MSQ_PLANE_U8, float); else MSQ_LAUNCHKG(MSQ_PLANE_U8, uint16_t); }
         else { if (y_dtype == 0) MSQ_LAUNCHKG(MSQ_PLANE_U8X, float); else MSQ_LAUNCHKG(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCHKG
@@ -1793,8 +1816,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         if (rc || ksplit == 1) return rc;
         const int64_t MNk = M * N;
         const dim3 rgk((unsigned)((MNk / 4 + 255) / 256));
-        if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgk, dim3(256), 0, st, partial, bias, (float*)Y, MNk, (int)N, ksplit);
-        else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgk, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MNk, (int)N, ksplit);
+        if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgk, dim3(256), 0, st, partial, bias, (float*)Y, MNk, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
+        else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgk, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MNk, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
         return check_launch2("msq_qlinear_bf16(split-K reduce)");
     }
     if (mf_sel == 16) {
@@ -1802,7 +1825,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
         do { static DevOnce once_;                                                                                     \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
              hipLaunchKernelGGL((k_qgemm3<MSQ_PLANE_NONE, OK, YT, 1, 16>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)inl_plane, \
-                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial); } while (0)
+                    (const uint8_t*)out_plane, (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, groups, ksplit, partial, y16); } while (0)
         if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) MSQ_LAUNCH16(MSQ_PLANE_U8, float); else MSQ_LAUNCH16(MSQ_PLANE_U8, uint16_t); }
         else { if (y_dtype == 0) MSQ_LAUNCH16(MSQ_PLANE_U8X, float); else MSQ_LAUNCH16(MSQ_PLANE_U8X, uint16_t); }
 #undef MSQ_LAUNCH16
@@ -1816,8 +1839,8 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (rc || ksplit == 1) return rc;
     const int64_t MN = M * N;
     const dim3 rgrid((unsigned)((MN / 4 + 255) / 256));
-    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
-    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
+    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
+    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
     return check_launch2("msq_qlinear_bf16(split-K reduce)");
 }
 
@@ -1940,7 +1963,8 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: negative M");
     if (N <= 0 || K <= 0 || (N % BN) || (K % 128)) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: N must be a multiple of 256 and K of 128");
     if (!x_codes || !x_scales || !w_codes || !w_scales || !Y) return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w4a8: null buffer");
-    if (y_dtype != 0 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32) or 2 (bf16)");
+    if (y_dtype != 0 && y_dtype != 1 && y_dtype != 2) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: y_dtype must be 0 (f32), 1 (fp16) or 2 (bf16)");
+    const int y16 = (y_dtype == 1) ? 1 : 0;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || M * K > 0xFFFFFFFFll) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_mx_w4a8: dimension too large");
     hipStream_t st = (hipStream_t)stream;
     if (use_mx_gemv(M, N, K)) {
@@ -1955,14 +1979,14 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
             do { static DevOnce once_;                                                                         \
                  if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_done(once_); } \
                  hipLaunchKernelGGL((k_mxgemv<W8V, MGV, WV>), dim3((unsigned)((N / 64) * nks)), dim3(64 * WV), ldsv, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
-                                    (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+                                    (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
             if (kcd && N < 8192) {                                       // half strips: N / 32 blocks
                 const size_t ldsh = (size_t)15 * 8 * mg * 64 * 4;
 #define MSQ_MXH(W8V, MGV)                                                                                               \
                 do { static DevOnce once_;                                                                     \
                      if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, MGV, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8 * MGV * 64 * 4); attr_done(once_); } \
                      hipLaunchKernelGGL((k_mxgemv<W8V, MGV, 16, 2>), dim3((unsigned)(N / 32)), dim3(1024), ldsh, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
-                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, 1, bias, Y, y_dtype == 2 ? 1 : 0); } while (0)
+                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc, 1, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
                 if (mg == 1) { if (wf == 0) MSQ_MXH(0, 1); else if (wf == 1) MSQ_MXH(1, 1); else if (wf == 2) MSQ_MXH(2, 1); else MSQ_MXH(3, 1); }
                 else { if (wf == 0) MSQ_MXH(0, 2); else if (wf == 1) MSQ_MXH(1, 2); else if (wf == 2) MSQ_MXH(2, 2); else MSQ_MXH(3, 2); }
 #undef MSQ_MXH
@@ -1981,8 +2005,8 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
             if (rc0) return rc0;
             const int64_t MN0 = M * N;
             const dim3 rg((unsigned)((MN0 / 4 + 255) / 256));
-            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks);
-            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks);
+            if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
+            else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
             return check_launch2("msq_qlinear_mx_w4a8(decode reduce)");
         }
     }
@@ -2021,11 +2045,11 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
         do { if (kg4) { static DevOnce once_;                                                                         \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
              hipLaunchKernelGGL((k_mxgemm<YT, W8V, 2, 4>), grid4, blk4k, lds4, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); }         \
+                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr, y16); }         \
              else { static DevOnce once_;                                                                             \
              if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr_done(once_); } \
              hipLaunchKernelGGL((k_mxgemm<YT, W8V, 1, 4>), grid4, blk4, lds4, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr); } } while (0)
+                                (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, 1, (float*)nullptr, y16); } } while (0)
         if (y_dtype == 0) { if (wf == 0) MSQ_MXL4(float, 0); else if (wf == 1) MSQ_MXL4(float, 1); else if (wf == 2) MSQ_MXL4(float, 2); else MSQ_MXL4(float, 3); }
         else { if (wf == 0) MSQ_MXL4(uint16_t, 0); else if (wf == 1) MSQ_MXL4(uint16_t, 1); else if (wf == 2) MSQ_MXL4(uint16_t, 2); else MSQ_MXL4(uint16_t, 3); }
 #undef MSQ_MXL4
@@ -2039,11 +2063,11 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     do { if (kg2) { static DevOnce once_;                                                                      \
          if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((k_mxgemm<YT, W8V, 2>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); }        \
+                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial, y16); }        \
          else { static DevOnce once_;                                                                          \
          if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemm<YT, W8V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done(once_); } \
          hipLaunchKernelGGL((k_mxgemm<YT, W8V>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
-                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial); } } while (0)
+                            (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, ksplit, partial, y16); } } while (0)
     if (y_dtype == 0) { if (wf == 0) MSQ_MXL(float, 0); else if (wf == 1) MSQ_MXL(float, 1); else if (wf == 2) MSQ_MXL(float, 2); else MSQ_MXL(float, 3); }
     else { if (wf == 0) MSQ_MXL(uint16_t, 0); else if (wf == 1) MSQ_MXL(uint16_t, 1); else if (wf == 2) MSQ_MXL(uint16_t, 2); else MSQ_MXL(uint16_t, 3); }
 #undef MSQ_MXL
@@ -2051,8 +2075,8 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     if (rc || ksplit == 1) return rc;
     const int64_t MN = M * N;
     const dim3 rgrid((unsigned)((MN / 4 + 255) / 256));
-    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit);
-    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit);
+    if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
+    else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
     return check_launch2("msq_qlinear_mx_w4a8(split-K reduce)");
 }
 int msq_qlinear_mx_w4a8(const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,

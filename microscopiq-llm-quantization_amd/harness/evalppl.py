@@ -106,7 +106,10 @@ def pack_layers(layers, path="bf16", fuse=None):
 
 
 @torch.no_grad()
-def perplexity(model, testenc, dev, seqlen):
+def perplexity(model, testenc, dev, seqlen, fp32_loss=False):
+    """llm/llama.py:264-282.  On an fp16 model the reference's cross entropy is an fp16 number (spacing 2^-7 around ln 72000 = 11.2:
+    the perplexity then moves in steps of 0.8 %); ``fp32_loss`` upcasts the logits first -- NOT the reference's arithmetic, for
+    comparisons finer than that step (bench.py llama7b_e2e)."""
     ids = testenc.input_ids if hasattr(testenc, "input_ids") else testenc
     nsamples = ids.numel() // seqlen
     model.to(dev)
@@ -115,6 +118,8 @@ def perplexity(model, testenc, dev, seqlen):
     for i in range(nsamples):
         batch = ids[:, (i * seqlen):((i + 1) * seqlen)].to(dev)
         lm_logits = model(batch).logits
+        if fp32_loss:
+            lm_logits = lm_logits.float()
         shift_logits = lm_logits[:, :-1, :].contiguous()
         shift_labels = batch[:, 1:]
         loss = loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.reshape(-1))

@@ -195,6 +195,9 @@ def unpack_weight(P, dtype=torch.float32):
     return W if (P.n, P.k) == (P.N, P.K) else W[:P.n, :P.k].contiguous()
 
 
+_YD = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}     # y_dtype codes of include/msq.h
+
+
 def _pad_k(xb, K):
     """[M, k] -> [M, K] with zero columns (off-grid in_features)"""
     return xb if xb.shape[-1] == K else torch.nn.functional.pad(xb, (0, K - xb.shape[-1]))
@@ -222,8 +225,8 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
         xb = xb.to(torch.bfloat16)
     xb = _pad_k(xb, K).contiguous()
     M = xb.shape[0]
-    if out_dtype not in (torch.float32, torch.bfloat16):
-        raise MsqError("qlinear: out_dtype must be float32 or bfloat16")
+    if out_dtype not in _YD:
+        raise MsqError("qlinear: out_dtype must be float32, float16 or bfloat16")
     padded_n = P.n != P.N
     if out is not None and padded_n:
         _out_buffer(out, M, P.n, out_dtype, x.device, "qlinear")          # validates the caller's buffer
@@ -236,7 +239,7 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
     wsb = lib().msq_qlinear_workspace_bytes(M, P.N, K)        # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
     check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
-                                 0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
+                                 _YD[out_dtype], M, P.N, K, P.block, P.in_kind, P.out_kind,
                                  ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
     if padded_n:
         if out is not None:
@@ -285,8 +288,8 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     x16 = x.dtype == torch.bfloat16 and (int(a_variant) == 0 or a_block_size in (32, 64))   # read as is: no cast pass
     xf = _pad_k(x.reshape(-1, k), K).contiguous() if x16 else _pad_k(x.reshape(-1, k).float(), K).contiguous()
     M = xf.shape[0]
-    if out_dtype not in (torch.float32, torch.bfloat16):
-        raise MsqError("qlinear_w4a8: out_dtype must be float32 or bfloat16")
+    if out_dtype not in _YD:
+        raise MsqError("qlinear_w4a8: out_dtype must be float32, float16 or bfloat16")
     y = torch.empty(M, P.N, dtype=out_dtype, device=x.device)
     b = bias.detach().float().contiguous() if bias is not None else None
     if b is not None and P.n != P.N:
@@ -297,7 +300,7 @@ def qlinear_w4a8(x, P, bias=None, out_dtype=torch.float32, a_elem_format="fp8_e4
     fo = a_outlier_elem_format or a_elem_format
     fn = lib().msq_qlinear_w4a8_x16 if x16 else lib().msq_qlinear_w4a8
     check(fn(ptr(xf), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
-             0 if out_dtype == torch.float32 else 2, M, P.N, K, P.block, P.in_kind, P.out_kind,
+             _YD[out_dtype], M, P.N, K, P.block, P.in_kind, P.out_kind,
              a_block_size, format_id(a_elem_format), format_id(fo), int(a_scale_bits),
              int(a_scale_bits), float(a_std_dev), int(RoundingMode[a_round]),
              int(bool(a_flush_fp32_subnorms)), int(a_variant), ptr(status), ptr(ws), wsb,
@@ -446,8 +449,8 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
         # zero columns up to the padded K: whole zero blocks, and a ragged last block padded as mx_ops.py:332-457 pads it
         xc, xs = mx_pack_act(_pad_k(x.reshape(-1, k), K), check_status=check_status, a_fmt=a_fmt)
     M = xc.shape[0]
-    if out_dtype not in (torch.float32, torch.bfloat16):
-        raise MsqError("qlinear_mx_w4a8: out_dtype must be float32 or bfloat16")
+    if out_dtype not in _YD:
+        raise MsqError("qlinear_mx_w4a8: out_dtype must be float32, float16 or bfloat16")
     padded_n = P.n != P.N
     if out is not None and padded_n:
         _out_buffer(out, M, P.n, out_dtype, xdev, "qlinear_mx_w4a8")
@@ -465,7 +468,7 @@ def qlinear_mx_w4a8(x, P, bias=None, out_dtype=torch.bfloat16, check_status=Fals
         return y.reshape(*lead, P.n)
     wsb = lib().msq_qlinear_mx_w4a8_workspace_bytes(M, P.N, K)     # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=xdev) if wsb > 0 else None
-    yd = 0 if out_dtype == torch.float32 else 2
+    yd = _YD[out_dtype]
     if P.w_fmt in _FP6_IDS:
         check(lib().msq_qlinear_mx_w6a8(ptr(xc), ptr(xs), ptr(P.codes), ptr(P.scales), ptr(b), ptr(y), yd, M, P.N, K,
                                         _FP6_IDS[P.w_fmt], ptr(ws), wsb, current_stream(xdev)), "msq_qlinear_mx_w6a8")
@@ -522,12 +525,12 @@ class MXLinearW4A8(nn.Module):
                               self.w_fmt, self.out_features, self.in_features)
 
     def forward(self, x, out=None):
-        y = qlinear_mx_w4a8(x, self._packed(), self.bias, self.out_dtype, out=out, a_fmt=getattr(self, "a_fmt", "e4m3"))
-        # an fp16 / bf16 model gets its own dtype back (as QuantLinear.forward); pre-packed activations (a tuple of
-        # codes and scales) carry no dtype: those callers take out_dtype
-        if out is None and torch.is_tensor(x) and x.is_floating_point() and x.dtype != torch.float32 and y.dtype != x.dtype:
-            y = y.to(x.dtype)
-        return y
+        # an fp16 / bf16 model gets its own dtype back, written by the kernel's epilogue (no cast pass); pre-packed activations
+        # (a tuple of codes and scales) carry no dtype: those callers take out_dtype
+        od = self.out_dtype
+        if out is None and torch.is_tensor(x) and x.dtype in (torch.float16, torch.bfloat16):
+            od = x.dtype
+        return qlinear_mx_w4a8(x, self._packed(), self.bias, od, out=out, a_fmt=getattr(self, "a_fmt", "e4m3"))
 
 
 class QuantLinear(nn.Module):
@@ -684,8 +687,9 @@ class QuantLinear(nn.Module):
         return unpack_weight(self._packed(), dtype)
 
     def forward(self, x, out=None):
-        y = qlinear(x, self._packed(), self.bias, self.out_dtype, out=out)
-        return y if out is not None else y.to(x.dtype if x.dtype != torch.float32 else self.out_dtype)
+        # half-precision models get their own dtype from the kernel's epilogue (fp16 included: no cast pass over the output)
+        od = self.out_dtype if (out is not None or x.dtype == torch.float32) else x.dtype
+        return qlinear(x, self._packed(), self.bias, od, out=out)
 
 
 class FusedProjections(nn.Module):

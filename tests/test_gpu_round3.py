@@ -325,3 +325,58 @@ def test_gptq_block_kernel_checks_residency(msq):
     rc = L.msq_gptq_block(ptr(Wt), ptr(U), cols, ptr(Qt), ptr(Et), ptr(loss), ptr(pruned), ptr(status), ptr(ws2), wsb2, 51200 + 256, cols, 16,
                           format_id("fp4_e2m1"), format_id("fp8_e4m3"), 8, 8, 2.0, 0, 0, current_stream(dev()))
     assert rc == -2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp16 output straight from the kernels' epilogues (y_dtype 1): an fp16 model needs no cast pass over the result
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [1, 20, 48, 130, 300, 2048])
+def test_fp16_output_equals_rounded_fp32_output(msq, M):
+    """Every launch shape (decode kernels with and without the reduce kernel, split-K, 64-row tiles, k-groups, eight-wave blocks;
+    bf16-activation and MX paths): the fp16 result is the fp32 result of the same launch rounded once to half."""
+    N, K = (8192, 1024) if M == 2048 else (4096, 1024)
+    W = _weights(N, K, 6).to(dev())
+    b = torch.randn(N, generator=torch.Generator().manual_seed(8)).to(dev())
+    X = torch.randn(M, K, generator=torch.Generator().manual_seed(7)).to(dev())
+    for fo in ("posit8_es1", "fp8_e4m3"):
+        P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+        y32 = msq.qlinear.qlinear(X, P, b, torch.float32)
+        y16 = msq.qlinear.qlinear(X, P, b, torch.float16)
+        assert y16.dtype == torch.float16 and torch.equal(y16, y32.to(torch.float16)), (fo, M)
+        assert torch.equal(msq.qlinear.qlinear(X, P, b, torch.bfloat16), y32.to(torch.bfloat16))
+    for Pm in (msq.qlinear.mx_pack_weight(W), msq.qlinear.mx_pack_weight(W, w_fmt="e3m2"),
+               msq.qlinear.mx_pack_values(msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"])):
+        y32 = msq.qlinear.qlinear_mx_w4a8(X, Pm, b, torch.float32)
+        assert torch.equal(msq.qlinear.qlinear_mx_w4a8(X, Pm, b, torch.float16), y32.to(torch.float16)), (Pm.w_fmt, M)
+    # the modules hand an fp16 model its dtype without a cast
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data, lin.bias.data = W.cpu(), b.cpu()
+    q = msq.quant.MXQuantizer(); q.configure(8, 8, inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[-1], block_size=32)
+    ql = msq.qlinear.QuantLinear.from_linear(lin.to(dev()), q)
+    assert ql(X.half()).dtype == torch.float16 and ql(X.bfloat16()).dtype == torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.py --workload llama7b_e2e on a 4-layer slice of the Llama-2-7B-shaped model
+# ----------------------------------------------------------------------------------------------------------------------
+def test_bench_llama7b_e2e_slice(msq):
+    """Whole-model evidence (llm/llama.py:176-284, llm/opt.py:332-376 at Llama-2-7B's true layer shapes, random weights): every key
+    is there, nothing stays dense, the packed model is 9.25 bits per weight, and the perplexity of the packed model is within
+    0.9 % of the fake-quantised dense one (= 0.05 at PPL 5.5, the north-star bound)."""
+    import json, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "llama7b_e2e", "--layers", "4", "--seqlen", "1024",
+                          "--decode-tokens", "10", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["kept_dense"] == 0 and d["packed_linears"] == 28 and d["packed_modules"] == 16
+    assert abs(d["packed_bits_per_weight"] - 9.25) < 1e-6 and d["packed_GB"] < 0.6 * d["dense_16bit_GB"]
+    assert d["rtn_quantise_s"] > 0 and d["pack_s"] > 0
+    for k in ("packed_fused", "fakequant_dense_fp16"):
+        r = d["speed"][k]
+        assert r["prefill_tokens_per_s"] > 0 and r["decode_ms_per_token_eager"] > 0 and r["decode_linears_ms_per_token_hip_graph"] > 0
+    assert d["decode_linears_speedup_hip_graph"] > 1.0          # the packed weight stream is 9.25 bits against 16
+    p = d["ppl_proxy_7b"]
+    assert p["relative_delta"] <= 0.009, p
+    assert p["max_logit_abs_err"] <= 0.05 * p["max_abs_logit"], p
