@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--comm", default="rs_ag", choices=["rs_ag", "all_reduce"],
                     help="llama70b_rowparallel: how the partial outputs are summed")
     ap.add_argument("--chunks", type=int, default=0, help="llama70b_rowparallel: row chunks overlapped with the collective (0 = auto)")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="llama70b_rowparallel on ONE GPU: still create the RCCL group (world size 1) and run the reduce-scatter / all-gather, "
+                         "so that the communication code path and its evidence keys can be checked without an 8-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stub", action="store_true",
                     help="CPU-only plumbing check (tests): gloo backend, the step is a no-op; exercises rank start-up, "
@@ -481,8 +484,7 @@ def e2e_main(args, dev):
                          "ppl_packed_fused_reference_formula": ppl_p16,
                          "max_logit_abs_err": lerr, "max_abs_logit": lmax, "tokens": "uniform random ids (no dataset in the image)"},
     }
-    print(json.dumps(out))
-    sys.stdout.flush()
+    _emit_json(json.dumps(out))
 
 
 def main(argv=None):
@@ -492,14 +494,36 @@ def main(argv=None):
         # launcher: start the ranks before anything here touches torch / HIP
         sys.exit(spawn_ranks(args, argv))
 
+    # Everything but the ONE JSON line goes to stderr -- at the file-descriptor level, because RCCL prints its version banner
+    # ("RCCL version : ...", "Librccl path ...") to the C stdout of every process that created a communicator.
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(_real_stdout, (line + "\n").encode())
+    globals()["_emit_json"] = emit
+    fail_hook = os.environ.get("MSQ_BENCH_FAIL_RANK")       # tests only: a child rank that dies / hangs before the rendezvous
+    if fail_hook and os.environ.get("MSQ_BENCH_CHILD") == "1":
+        if fail_hook == "hang":
+            time.sleep(3600)
+        if fail_hook == os.environ.get("RANK"):
+            sys.exit(7)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    src = bool(args.single_rank_collectives) and world == 1 and args.workload == "llama70b_rowparallel"
+    if world > 1 or src:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if src:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
         if not args.stub:
             torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if args.stub else "nccl", rank=rank, world_size=world)
@@ -554,7 +578,7 @@ def main(argv=None):
             shard = qlinear.QuantLinear.from_packed(P, None, out_dtype=torch.bfloat16)
             X = torch.randn(M, K, device=dev).to(torch.bfloat16)
         rp = qlinear.RowParallelQuantLinear(shard, world, rank, None, comm=args.comm, chunks=args.chunks,
-                                            reduce_dtype=torch.bfloat16)
+                                            reduce_dtype=torch.bfloat16, single_rank_collectives=src)
     elif msqmx:
         # BASELINE config 3 with the MicroScopiQ weight itself on the MX matrix path: the fake-quant values (MX-FP4
         # inliers + fp8_e4m3 outliers, utils/quant.py:147-266) packed exactly as one e4m3 code per weight + E8M0 scale
@@ -631,6 +655,54 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # who took part, and where the row-parallel step's time goes: GEMM chunks (events on the compute stream) against the whole
+    # step, and the collectives alone on the same buffers -- so that the line itself shows how much communication is exposed
+    ranks_seen, rowpar_times = None, None
+    group_on = world > 1 or src
+    if group_on:
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+              "world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl": rccl, "pid": os.getpid()}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+    if rp is not None:
+        nt = 20
+        evs = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if group_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nt):
+            rp(X, gemm_events=evs)
+        e1.record()
+        torch.cuda.synchronize()
+        step_ms = e0.elapsed_time(e1) / nt
+        gemm_ms = sum(a.elapsed_time(b) for a, b in evs) / nt
+        comm_ms = None
+        if group_on:
+            for _ in range(3):
+                rp.comm_only(M, torch.bfloat16, dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(nt):
+                rp.comm_only(M, torch.bfloat16, dev)
+            e1.record()
+            torch.cuda.synchronize()
+            comm_ms = e0.elapsed_time(e1) / nt
+        rowpar_times = {"step_ms": step_ms, "gemm_ms": gemm_ms, "comm_ms": comm_ms, "exposed_comm_ms": max(0.0, step_ms - gemm_ms),
+                        "chunks": rp.chunks_for(M), "comm": args.comm, "wire_dtype": "bf16",
+                        "note": "gemm_ms: the shard's GEMM chunks (events on the compute stream); comm_ms: the same collectives alone "
+                                "(includes the zero fill of the buffer); exposed = step - gemm"}
+        if world > 1:
+            t = torch.tensor([step_ms, gemm_ms, comm_ms or 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rowpar_times["max_over_ranks"] = {"step_ms": float(t[0]), "gemm_ms": float(t[1]), "comm_ms": float(t[2])}
+
     flops_step = 2.0 * M * N * K                            # algorithmic: dequant flops not counted
     total_flops = flops_step * args.steps * world
     value = total_flops / wall / 1e12
@@ -639,7 +711,9 @@ def main(argv=None):
     out = {
         "metric": "fused dequant-GEMM TFLOPS (% MFMA peak) + PPL delta, Llama-7B W4 1xMI355X",
         "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        # the 7B workloads are replicas (fixed work per GPU: weak); the 70B layer is ONE layer of fixed size cut over the ranks
+        "scaling": "strong" if rowpar else "weak",
         "vs_baseline": None, "dtype": ("mxfp8 x e4m3 codes (fp32 accumulate)" if msqmx else "mxfp8 x mxfp4 (fp32 accumulate)") if mxw4a8 else "bf16", "data": "synthetic",
         "config": {"workload": name, "M": M, "N": N, "K": K, "block": args.block, "inlier": args.inlier,
                    "outlier": args.outlier, "packed_bits_per_weight": P.bits_per_element, "clock_ramp_launches": RAMP,
@@ -671,6 +745,10 @@ def main(argv=None):
                 break
             except Exception:
                 pass
+    if ranks_seen is not None:
+        out["config"]["ranks_seen"] = ranks_seen
+    if rowpar_times is not None:
+        out["rowparallel"] = rowpar_times
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "llama7b_w4_fused_gemm":
         import contextlib
         try:
@@ -689,9 +767,8 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier, plain_mx=(mxw4a8 and not msqmx))
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if world > 1:
+        _emit_json(json.dumps(out))
+    if world > 1 or src:
         dist.destroy_process_group()
 
 
@@ -706,6 +783,7 @@ def stub_main(args, rank, world):
         dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"]), os.getpid()))
     else:
         seen = [(0, 0, 1, os.getpid())]
+    rowpar = args.workload == "llama70b_rowparallel"
     x = torch.zeros(1)
     for _ in range(args.warmup):
         x += 1
@@ -722,11 +800,12 @@ def stub_main(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "stub (no GPU work)", "value": 0.0, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        _emit_json(json.dumps({"metric": "stub (no GPU work)", "value": 0.0, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
-                          "config": {"workload": "stub", "ranks_seen": seen}}))
-        sys.stdout.flush()
+                          "scaling": "strong" if rowpar else "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "stub", "ranks_seen": seen},
+                          "rowparallel": ({"step_ms": 0.0, "gemm_ms": 0.0, "comm_ms": 0.0, "exposed_comm_ms": 0.0, "chunks": args.chunks,
+                                           "comm": args.comm, "wire_dtype": "none"} if rowpar else None)}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -894,8 +894,30 @@ class RowParallelQuantLinear(nn.Module):
         rows = (((M + nch - 1) // nch) + 127) // 128 * 128
         return [(r0, min(M, r0 + rows)) for r0 in range(0, M, rows)]
 
-    def forward(self, x_local):
-        """x_local: [..., K/G] (this rank's slice of the activations) -> the full sum [..., N] in ``reduce_dtype``."""
+    def comm_only(self, M, dtype=None, device=None):
+        """The collectives of one forward on an [M, N] buffer, without the GEMMs (bench.py: what the wire alone costs)."""
+        import torch.distributed as dist
+        N, G, pg = self.shard.out_features, self.world_size, self.process_group
+        dev = device if device is not None else next(self.shard.buffers()).device
+        y = torch.zeros(M, N, dtype=dtype or self.reduce_dtype, device=dev)
+        use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
+        pending = []
+        for r0, r1 in self.chunk_bounds(M):
+            yc = y[r0:r1]
+            if use_rs and (r1 - r0) % G == 0:
+                part = torch.empty((r1 - r0) // G, N, dtype=y.dtype, device=dev)
+                pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
+                pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
+            else:
+                pending.append(dist.all_reduce(yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
+        for h in pending:
+            h.wait()
+        return y
+
+    def forward(self, x_local, gemm_events=None):
+        """x_local: [..., K/G] (this rank's slice of the activations) -> the full sum [..., N] in ``reduce_dtype``.
+        ``gemm_events``: a list that receives one (start, end) event pair per GEMM chunk, recorded on the compute stream
+        (bench.py: GEMM time against the step time = the communication that is NOT hidden)."""
         import torch.distributed as dist
         lead = tuple(x_local.shape[:-1])
         x2 = x_local.reshape(-1, x_local.shape[-1])
@@ -904,10 +926,16 @@ class RowParallelQuantLinear(nn.Module):
         direct = isinstance(self.shard, (QuantLinear, MXLinearW4A8)) and getattr(self.shard, "out_dtype", None) == self.reduce_dtype
 
         def partial(r0, r1):                     # the shard's GEMM on rows [r0, r1), written into y[r0:r1]
+            if gemm_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             if direct:
                 self.shard(x2[r0:r1], out=y[r0:r1])
             else:
                 y[r0:r1].copy_(self.shard(x2[r0:r1]))
+            if gemm_events is not None:
+                e1.record()
+                gemm_events.append((e0, e1))
 
         if G == 1 and not self.single_rank_collectives:
             partial(0, M)

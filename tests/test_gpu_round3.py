@@ -380,3 +380,21 @@ def test_bench_llama7b_e2e_slice(msq):
     p = d["ppl_proxy_7b"]
     assert p["relative_delta"] <= 0.009, p
     assert p["max_logit_abs_err"] <= 0.05 * p["max_abs_logit"], p
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the 70B row-parallel bench line on ONE GPU with a real (world-size-1) RCCL group: the evidence keys of the multi-GPU run
+# ----------------------------------------------------------------------------------------------------------------------
+def test_bench_rowparallel_evidence_on_single_rank_rccl_group(msq):
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "llama70b_rowparallel", "--single-rank-collectives",
+                          "--steps", "10", "--warmup", "2", "--chunks", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    seen = d["config"]["ranks_seen"]
+    assert len(seen) == 1 and seen[0]["rank"] == 0 and seen[0]["world_size"] == 1 and seen[0]["backend"] == "nccl" and seen[0]["rccl"]
+    r = d["rowparallel"]
+    assert r["chunks"] == 2 and r["comm"] == "rs_ag" and r["gemm_ms"] > 0 and r["comm_ms"] > 0 and r["step_ms"] >= r["gemm_ms"] * 0.98
+    assert abs(r["exposed_comm_ms"] - (r["step_ms"] - r["gemm_ms"])) < 1e-6 or r["exposed_comm_ms"] == 0.0

@@ -221,6 +221,44 @@ def test_bench_gpus_flag_spawns_ranks(tmp_path):
     assert "import torch" not in body
 
 
+def test_bench_rowparallel_evidence_keys_and_strong_scaling(tmp_path):
+    """The 70B row-parallel line is self-evidencing: "scaling" is strong (one layer of fixed size cut over the ranks),
+    `config.ranks_seen` lists every rank, and a `rowparallel` object carries step / GEMM / communication times with the
+    chunk count and collective used (--stub: gloo, no GPU; the real path fills the same keys from HIP events)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub",
+                        "--workload", "llama70b_rowparallel", "--chunks", "2", "--comm", "rs_ag"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and len(j["config"]["ranks_seen"]) == 2
+    rpk = j["rowparallel"]
+    assert set(("step_ms", "gemm_ms", "comm_ms", "exposed_comm_ms", "chunks", "comm")) <= set(rpk) and rpk["chunks"] == 2 and rpk["comm"] == "rs_ag"
+    # the default (replica) workloads stay weak
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])["scaling"] == "weak"
+
+
+def test_bench_launcher_stops_siblings_when_a_rank_dies(tmp_path):
+    """`python bench.py --gpus 2`: a rank that fails at start-up must not leave the parent blocked on the surviving rank (which
+    would sit in the rendezvous for ever): the launcher polls all children, terminates the others and returns the failure."""
+    import time as _t
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MSQ_BENCH_FAIL_RANK"] = "1"                       # test hook: that rank exits with code 7 before the rendezvous
+    t0 = _t.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode == 7, (p.returncode, p.stderr[-1500:])
+    assert _t.time() - t0 < 120 and "stopping the other ranks" in p.stderr and p.stdout.strip() == ""
+    # ... and an overall time limit covers ranks that all hang
+    env["MSQ_BENCH_FAIL_RANK"] = "hang"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub", "--timeout", "5"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode == 124 and "still running" in p.stderr
+
+
 def test_bench_torchrun_env_is_honoured(tmp_path):
     """Started the driver's way (RANK / WORLD_SIZE already in the environment) bench.py must NOT spawn again."""
     import json
