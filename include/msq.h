@@ -124,6 +124,16 @@ int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t
                                int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                                float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
 
+/* `_quantize_mx` (number_system/mx/mx_ops.py:332-457) on a HALF-PRECISION tensor, as the reference executes it: its native kernel
+ * takes float32 only (cpp/mx.cu:124-125), so a Half / BFloat16 tensor runs the Python path op by op in the tensor dtype (ATen:
+ * each op in fp32, result rounded to the dtype): floor(log2) rounds values just under a power of two up, `2**e + 1e-6` (:444) is
+ * rounded to the dtype, 2**e can leave the fp16 range.  1-11 % of the elements differ from "upcast, fp32, round once".  in / out:
+ * [pre, axis_len, post] tensors of dtype 1 = fp16 / 2 = bf16, blocks of `block` (8 ... 128) along the axis, last block zero
+ * padded; elem_fmt = a float / int MSQ_FMT_* id; status_flag (device int, may be NULL) receives MSQ_STATUS_NAN when a shared
+ * exponent exceeds the scale range (the reference stores NaN).  One pass, no casts: the KV-cache MX variant (config 4). */
+int msq_quantize_mx_lowp(const void* in, void* out, int dtype, int64_t pre, int64_t axis_len, int64_t post, int block,
+                         int scale_bits, int elem_fmt, int rmode, int flush_fp32_subnorms, int* status_flag, void* stream);
+
 /* replace reduce_sum_inner_dim / reduce_max_inner_dim (cpp/funcs.cpp:203-215, cpp/reduce.cu:19-93):
  * out[outer] = sum / max over the innermost `inner` elements. */
 int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream);

@@ -28,7 +28,16 @@
 using namespace msq;
 
 template <int DT> MSQ_D float Rr(float x) {
-    if (DT == 1) return (float)(_Float16)x;          // v_cvt_f16_f32: RNE, fp16 subnormals kept, overflow -> Inf
+    if (DT == 1) {
+        // v_cvt_f16_f32: RNE, fp16 subnormals kept, overflow -> Inf.  Through asm: written as (float)(_Float16)(a * b) hipcc fuses the
+        // product and the conversion into v_fma_mixlo_f16 a, b, +0 -- and (-1)(+0) + (+0) = +0 loses the sign of a zero product
+        // (the reference keeps -0 where a negative value rounds to zero: sign * floor(...), elemwise_ops.py:64-70).
+        uint32_t h;
+        float r;
+        asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(x));
+        asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(h));
+        return r;
+    }
     return (float)(__bf16)x;                         // RNE on the upper 16 bits
 }
 template <int DT> MSQ_D float ld16(const uint16_t* p, int64_t i) {
@@ -257,6 +266,169 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
     if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
     if (status && A.status) atomicOr(A.status, status);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// `_quantize_mx` (number_system/mx/mx_ops.py:332-457, Python path) on a half-precision tensor, op by op as ATen's CPU half
+// kernels evaluate it (oracle: msq_oracle_quantize_mx_lowp; fixtures tests/golden/quantize_mx_lowp.npz).  Same thread <->
+// block map and access pattern as k_outlier_lowp: one lane per block of BS values along the axis.
+// ---------------------------------------------------------------------------------------------------------------
+// floor(R(log2f(t))) for a finite T value t > 0, integer form of floor_log2_lowp: the exact exponent E, plus one when the
+// significand sits within dmax T-ulps below 2.0 (d = 2^(p-1) - fraction <= dmax), dmax = what c[jb + 1] of floor_log2_lowp
+// allows for the binade of |E + 1| (checked against the reference-made fixtures through k_mx_lowp).
+template <int DT> MSQ_D int floor_log2_fast(float t) {
+    const uint32_t u = f2u(t);
+    const int E = (int)((u >> 23) & 0xFFu) - 127;
+    const int up = E + 1;
+    if (up == 0) return E;
+    const int au = up < 0 ? -up : up;
+    int jb = 31 - __builtin_clz((unsigned)au);
+    if (up > 0 && (au & (au - 1)) == 0) jb -= 1;
+    const uint32_t lo = 0x02010000u;                                // jb + 1 = 0..3: 0, 0, 1, 2 (both dtypes)
+    const uint32_t hi = (DT == 1) ? 0x2B160B05u : 0x28150A05u;      // jb + 1 = 4..7: fp16 5, 11, 22, 43; bf16 5, 10, 21, 40
+    const uint32_t top = (DT == 1) ? 86u : 74u;                     // jb + 1 = 8
+    const int idx = jb + 1;
+    const uint32_t w = idx < 4 ? lo : hi;
+    uint32_t dmax = (w >> (8 * (idx & 3))) & 0xFFu;
+    dmax = idx >= 8 ? top : dmax;
+    constexpr int SH = (DT == 1) ? 13 : 16;                         // fraction bits below the T significand
+    const uint32_t d = (0x800000u - (u & 0x7FFFFFu)) >> SH;         // T-ulps below 2.0 (1 ... 2^(p-1))
+    return E + ((d <= dmax) ? 1 : 0);
+}
+
+struct MxLowpArgs {
+    int64_t pre, axis_len, post, nblk;
+    Fmt f;
+    int scale_bits, rmode, flush;
+    int* status;
+};
+
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_mx_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
+    const int64_t total = A.pre * A.nblk * A.post;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = t % A.post;
+    const int64_t nb = (t / A.post) % A.nblk;
+    const int64_t p = t / (A.post * A.nblk);
+    const int64_t a0 = nb * BS;
+    const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    float a[BS];
+    const bool vec = (BS % 8 == 0) && A.post == 1 && (A.axis_len % BS) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < BS / 8; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+            v.u = *reinterpret_cast<const uint4*>(in + base + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[c * 8 + j] = ld16<DT>(v.h, j);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+            a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;     // zero padding (_reshape_to_blocks)
+    }
+    float mx = 0.f;
+    bool nan = false;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) { const float v = __builtin_fabsf(a[b]); nan |= (v != v); mx = v > mx ? v : mx; }
+    if (nan) mx = u2f(0x7FC00000u);
+    float se = shared_exp_lowp<DT>(mx);                                  // :428-430
+    const bool fl = A.flush && !(se > -127.f);                           // :433-434
+    se = Rr<DT>(se - (float)A.f.emax);                                   // :438
+    const float semax = (float)((1 << (A.scale_bits - 1)) - 1);          // :440-442
+    if (se > semax) se = u2f(0x7FC00000u);
+    if (se < -semax) se = -semax;
+    int status = (se != se) ? MSQ_STATUS_NAN : 0;
+    const float sc = pow2_lowp<DT>(se);                                  // 2**shared_exp as a T tensor
+    const float den = Rr<DT>(sc + 1e-6f);                                // :444
+    const Div dv = make_div(den);
+    // Fast path (round to nearest, a finite block whose scale is a normal power of two in T, element formats with exponent bits):
+    // the scalings by powers of two are exact in T as long as nothing leaves T's range -- guaranteed here by the bounds on se --,
+    // so only the roundings that can change a value are kept: R(|x| + 0.5) before the floor, and the exponent rule.
+    constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;     // smallest subnormal / largest binade of T
+    const int min_exp = 2 - (1 << (A.f.ebits > 0 ? A.f.ebits - 1 : 0));
+    const int sei = (int)se;
+    const bool fast = A.rmode == 0 && A.f.ebits > 0 && !fl && se == se && mx < 3.0e38f && dv.fast && den == sc &&
+                      sei + min_exp + 2 - A.f.mbits >= TMINE && sei + A.f.emax + 2 <= TMAXE && sei - 1 >= TMINE + 11 && mx != 0.f;
+    if (fast) {
+        const float mn = A.f.max_norm;
+        const float sh = pow2i(A.f.mbits - 2), rsh = pow2i(2 - A.f.mbits);
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            const float x = a[b];
+            float v = x * dv.r;                                          // exact: |v| < 2^(emax + 2), and not below T's grid
+            float r = 0.f;
+            if (v != 0.f) {
+                int pe = floor_log2_fast<DT>(__builtin_fabsf(v));
+                pe = pe < min_exp ? min_exp : pe;
+                const float ip2 = u2f((uint32_t)(127 - pe) << 23), p2 = u2f((uint32_t)(127 + pe) << 23);
+                const float m = __builtin_fabsf(v) * ip2 * sh;           // exact
+                const float q = __builtin_floorf(Rr<DT>(m + 0.5f));      // the one rounding that matters (ties just below n + 1/2)
+                r = q * rsh * p2;                                        // exact
+                r = r > mn ? mn : r;
+                r = __builtin_copysignf(r, v);                           // sign(v) * floor(...): -0 where a negative value rounds to zero
+            }
+            a[b] = r * sc;                                               // exact (bounds on se)
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            float v = a[b];
+            if (fl) v = Rr<DT>(v * 0.f);
+            v = Rr<DT>(divp(v, dv));
+            v = core_lowp<DT>(v, A.f, A.rmode);                          // :446-449
+            a[b] = Rr<DT>(v * sc);                                       // :451
+        }
+    }
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < BS / 8; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, a[c * 8 + j]);
+            *reinterpret_cast<uint4*>(out + base + c * 8) = v.u;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+            if (a0 + b < A.axis_len) st16<DT>(out, base + (int64_t)b * A.post, a[b]);
+    }
+    if (status && A.status) atomicOr(A.status, status);
+}
+
+extern "C" void msq_set_error_(const char* msg);
+
+// in / out: fp16 (dtype 1) or bf16 (dtype 2) tensors [pre, axis_len, post]; blocks of `block` (8 ... 128) along the axis, the
+// last one zero padded; status_flag (device int, may be NULL) receives MSQ_STATUS_NAN when a shared exponent exceeds the
+// scale range (the reference stores NaN there).
+extern "C" int msq_quantize_mx_lowp(const void* in, void* out, int dtype, int64_t pre, int64_t axis_len, int64_t post, int block,
+                                    int scale_bits, int elem_fmt, int rmode, int flush_fp32_subnorms, int* status_flag, void* stream) {
+    if (pre <= 0 || axis_len <= 0 || post <= 0) return (pre == 0 || axis_len == 0 || post == 0) ? MSQ_OK : MSQ_ERR_BAD_ARG;
+    if (!in || !out) { msq_set_error_("msq_quantize_mx_lowp: null buffer"); return MSQ_ERR_BAD_ARG; }
+    if (dtype != 1 && dtype != 2) { msq_set_error_("msq_quantize_mx_lowp: dtype must be 1 (fp16) or 2 (bf16)"); return MSQ_ERR_BAD_ARG; }
+    if (scale_bits <= 0 || scale_bits > 8 || rmode < 0 || rmode > 2) { msq_set_error_("msq_quantize_mx_lowp: bad scale bits / rounding mode"); return MSQ_ERR_BAD_ARG; }
+    msq_host::FmtInfo fi;
+    if (!msq_host::format_info(elem_fmt, &fi)) { msq_set_error_("msq_quantize_mx_lowp: unknown element format"); return MSQ_ERR_BAD_ARG; }
+    if (fi.kind != 0) { msq_set_error_("msq_quantize_mx_lowp: float / int element formats only"); return MSQ_ERR_UNSUPPORTED; }
+    MxLowpArgs A;
+    A.pre = pre; A.axis_len = axis_len; A.post = post; A.nblk = (axis_len + block - 1) / block;
+    A.f = Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm};
+    A.scale_bits = scale_bits; A.rmode = rmode; A.flush = flush_fp32_subnorms; A.status = status_flag;
+    const int64_t n = A.pre * A.nblk * A.post;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MSQ_MXLP(BS)                                                                                                    \
+    case BS:                                                                                                           \
+        if (dtype == 1) hipLaunchKernelGGL((k_mx_lowp<BS, 1>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
+        else hipLaunchKernelGGL((k_mx_lowp<BS, 2>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A);           \
+        break;
+    switch (block) { MSQ_MXLP(8) MSQ_MXLP(16) MSQ_MXLP(32) MSQ_MXLP(64) MSQ_MXLP(128)
+        default: msq_set_error_("msq_quantize_mx_lowp: block must be 8, 16, 32, 64 or 128"); return MSQ_ERR_UNSUPPORTED; }
+#undef MSQ_MXLP
+    return hipGetLastError() == hipSuccess ? MSQ_OK : MSQ_ERR_LAUNCH;
 }
 
 // test hook kernels: the two rules the exhaustive fixtures pin

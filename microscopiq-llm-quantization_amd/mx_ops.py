@@ -35,9 +35,17 @@ class reference_python_divisor:
         return False
 
 
+_LOWP_BLOCKS = (8, 16, 32, 64, 128)
+
+
 def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None, block_size=0, round="nearest",
-                 flush_fp32_subnorms=False, custom_cuda=False):
-    """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile."""
+                 flush_fp32_subnorms=False, custom_cuda=False, compute_dtype="input"):
+    """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile.
+
+    fp16 / bf16 tensors (``compute_dtype="input"``, the default): one launch of msq_quantize_mx_lowp, which computes IN the
+    tensor dtype op by op -- what the reference does with a half tensor (its native kernel is float32 only, so the Python path
+    runs on the Half tensor, `+ 1e-6` included) -- bit-exact against reference-made fixtures (tests/golden/quantize_mx_lowp.npz).
+    ``compute_dtype="float32"`` keeps the upcast -> fp32 kernel -> downcast route (three passes, one rounding)."""
     if elem_format == None:
         return A
     assert (scale_bits > 0)
@@ -53,6 +61,26 @@ def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None,
     axis = axes[0]
     tile = block_size if block_size > 0 else A.shape[axis]
     x = A.contiguous()
+    if compute_dtype not in ("input", "float32"):
+        raise MsqError("compute_dtype must be 'input' or 'float32'")
+    if (compute_dtype == "input" and x.dtype in (torch.float16, torch.bfloat16) and x.is_cuda and tile in _LOWP_BLOCKS
+            and not str(elem_format).lower().replace("elemformat.", "").startswith("posit")):
+        from ._lib import check, current_stream, lib, ptr
+        from .formats import format_id
+        from . import quant as _quant
+        pre = 1
+        for s_ in x.shape[:axis]:
+            pre *= int(s_)
+        post = 1
+        for s_ in x.shape[axis + 1:]:
+            post *= int(s_)
+        out = torch.empty_like(x)
+        status = torch.zeros(1, dtype=torch.int32, device=x.device) if _quant.CHECK_NAN else None
+        fname = elem_format.name if isinstance(elem_format, ElemFormat) else str(elem_format)
+        check(lib().msq_quantize_mx_lowp(ptr(x), ptr(out), 1 if x.dtype == torch.float16 else 2, pre, int(x.shape[axis]), post, int(tile),
+                                         int(scale_bits), format_id(fname), int(RoundingMode[round]), int(bool(flush_fp32_subnorms)),
+                                         ptr(status), current_stream(x.device)), "msq_quantize_mx_lowp")
+        return out
     y = funcs.quantize_mx_by_tile_func_cuda(x.float() if x.dtype != torch.float32 else x, scale_bits, ebits, mbits,
                                             max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]),
                                             python_divisor=_PY_DIVISOR[0])

@@ -833,6 +833,54 @@ int msq_oracle_quantize_mx(const float* in, float* out, int64_t pre, int64_t axi
 }
 
 /* ------------------------------------------------------------------------
+ * a9 on HALF-PRECISION tensors: number_system/mx/mx_ops.py:332-457 `_quantize_mx`, Python path (custom_cuda False: what the
+ * CPU executes), run op by op on a Half / BFloat16 tensor -- the KV-cache variant of BASELINE config 4 and MXLinear inside a
+ * half-precision model hand it such tensors.  R_() is ATen's per-op rounding to the tensor dtype (see the lowp block above).
+ * What differs from "upcast, fp32, round once": floor(log2) of the block maximum and of every element's private exponent
+ * rounds values just under a power of two UP (floor_log2_lowp); the `+ 1e-6` of :444 is absorbed by the rounding of
+ * `2**e + 1e-6` for e > -9 in fp16 (e > -12 in bf16) -- above that the divisor IS the scale --, and 2^e underflows / overflows the
+ * fp16 range.  Pinned by tests/golden/quantize_mx_lowp.npz (made by the imported reference).  dtype 1 = fp16, 2 = bf16.
+ * ---------------------------------------------------------------------- */
+int msq_oracle_quantize_mx_lowp(const float* in, float* out, int dtype, int64_t pre, int64_t axis_len, int64_t post,
+                                int block, const char* elem_fmt, int scale_bits, int round_mode, int flush_fp32_subnorms) {
+    fmt_t f; float mn;
+    if (msq_oracle_format_params(elem_fmt, &f.ebits, &f.mbits, &f.emax, &f.max_norm, &mn, &f.kind)) return -1;
+    if (f.kind != 0 || (dtype != 1 && dtype != 2)) return -2;
+    const int dt = dtype;
+    if (block <= 0) block = (int)axis_len;
+    const int64_t nblk = (axis_len + block - 1) / block;
+    int status = 0;
+    for (int64_t p = 0; p < pre; ++p) for (int64_t nb = 0; nb < nblk; ++nb) for (int64_t q = 0; q < post; ++q) {
+        float mx = 0.0f;
+        for (int b = 0; b < block; ++b) {
+            int64_t ai = nb * block + b;
+            float v = (ai < axis_len) ? in[(p * axis_len + ai) * post + q] : 0.0f;
+            float t = fabsf(v); if (t > mx || t != t) mx = t;
+        }
+        float se = shared_exp_lowp(mx, dt);                            /* :428-430 (_shared_exponents :525-529) */
+        const int flush = flush_fp32_subnorms && !(se > -127.0f);      /* :433-434 */
+        se = R_(se - (float)f.emax, dt);                               /* :438 */
+        const float semax = (float)((1 << (scale_bits - 1)) - 1);      /* :440-442 */
+        if (se > semax) se = NAN;
+        if (se < -semax) se = -semax;
+        if (se != se) status |= 1;
+        const float sc = pow2_lowp(se, dt);                            /* 2**shared_exp, a T tensor */
+        const float den = R_(sc + 1e-6f, dt);                          /* :444 */
+        for (int b = 0; b < block; ++b) {
+            int64_t ai = nb * block + b;
+            if (ai >= axis_len) continue;
+            int64_t idx = (p * axis_len + ai) * post + q;
+            float v = in[idx];
+            if (flush) v = R_(v * 0.0f, dt);
+            v = R_(v / den, dt);
+            v = quantize_elemwise_core_lowp(v, f.mbits, f.ebits, f.max_norm, round_mode, dt);   /* :446-449 */
+            out[idx] = R_(v * sc, dt);                                 /* :451 */
+        }
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------------
  * a12  cpp/shared_exp.cuh:14-53 + cpp/mx.cuh:107-170  native MX quant
  * (quantize_mx_by_tile / quantize_mx_func_cpp semantics: biased-exponent max,
  * NaN scale on overflow, ragged last tile NOT padded, integer codec).

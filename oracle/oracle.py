@@ -161,6 +161,20 @@ def quantize_mx(a, scale_bits, elem_fmt, axis=-1, block_size=0, round="nearest",
     return out
 
 
+def quantize_mx_lowp(a, dtype, scale_bits, elem_fmt, axis=-1, block_size=0, round="nearest", flush_fp32_subnorms=False):
+    """mx_ops.py:332-457 (_quantize_mx, Python path) computed IN the tensor dtype (fp16 / bf16): `a` holds the tensor's values
+    as float32."""
+    a = _f32(a)
+    pre, axis_len, post = _pap(a.shape, axis)
+    out = np.empty_like(a)
+    st = lib().msq_oracle_quantize_mx_lowp(_p(a), _p(out), C.c_int(LOWP[str(dtype).replace("torch.", "")]), C.c_int64(pre),
+                                           C.c_int64(axis_len), C.c_int64(post), C.c_int(block_size), elem_fmt.lower().encode(),
+                                           C.c_int(scale_bits), C.c_int(RD[round]), C.c_int(bool(flush_fp32_subnorms)))
+    if st < 0:
+        raise Exception("Undefined elem format / unsupported dtype", elem_fmt, dtype)
+    return out
+
+
 def quantize_mx_native(a, scale_bits, ebits, mbits, max_norm, tile, axis, flush=False, rmode=0):
     a = _f32(a)
     pre, axis_len, post = _pap(a.shape, axis)
