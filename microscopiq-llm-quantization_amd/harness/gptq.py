@@ -23,6 +23,13 @@ import time
 import torch
 import torch.nn as nn
 
+# Arithmetic of the two dense steps around the block kernel (scripts/experiments/gptq_exactness.py measures what they change):
+# the inverse-Hessian factor is computed in float64 and rounded once (the correctly rounded factor; rocSOLVER's float32
+# factorisation carries its own noise, different from the CPU LAPACK noise of the reference), the block-to-block update
+# (llm/gptq.py:163) stays a float32 library GEMM unless UPDATE_FP64 (float64 accumulation, rounded once).
+FACTOR_FP64 = True
+UPDATE_FP64 = False
+
 from ..quant import quantize_mx_outlier_hessian
 
 DEBUG = False
@@ -70,6 +77,10 @@ class GPTQ:
         """Damped H -> upper Cholesky factor of H^-1 (llm/gptq.py:96-103)."""
         idx = torch.arange(self.columns, device=self.dev)
         H[idx, idx] += percdamp * torch.mean(torch.diag(H))
+        if FACTOR_FP64:
+            Hd = H.double()
+            L = torch.linalg.cholesky(Hd)
+            return torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True).float()
         L = torch.linalg.cholesky(H)
         return torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
 
@@ -199,7 +210,10 @@ class GPTQ:
                                    current_stream(self.dev)), "msq_gptq_block")
             Q[:, c0:c1] = Qt.t()
             if c1 < K:
-                W[:, c1:] -= Et.t().matmul(U[c0:c1, c1:])                              # llm/gptq.py:163
+                if UPDATE_FP64:
+                    W[:, c1:] -= Et.t().double().matmul(U[c0:c1, c1:].double()).float()
+                else:
+                    W[:, c1:] -= Et.t().matmul(U[c0:c1, c1:])                          # llm/gptq.py:163
         self._status = status
         return loss, pruned
 

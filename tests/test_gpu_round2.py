@@ -654,7 +654,8 @@ def test_gptq_block_kernel_bit_exact_vs_reference(msq):
       column), one and three workgroups, ragged last quantiser block, quantiser blocks of 16 and 32;
     * the per-column path (round 1's, kept for configurations the kernel does not take) gives the same bits;
     * several column blocks: the block-to-block update is a GEMM whose summation order differs from the CPU's, so single
-      elements may flip a rounding decision: >= 99 % identical, loss within 1 %."""
+      elements COULD flip a rounding decision; on the fixtures none does (round 3, scripts/experiments/gptq_exactness.py: 0 of
+      46080 / 3072 entries differ, with the library fp32 GEMM and with fp64 accumulation alike): the exact count is asserted."""
     z = np.load(os.path.join(G, "gptq_exact.npz"))
     names = sorted({k.split("|")[0] for k in z.files})
     assert len(names) >= 8
@@ -668,20 +669,26 @@ def test_gptq_block_kernel_bit_exact_vs_reference(msq):
             Qc, gpc, _ = _gptq_case(msq, z, name, per_column=True)
             assert (Qc == ref).all(), (name, "per-column path", int((Qc != ref).sum()))
         else:
-            assert (Q == ref).mean() >= 0.99, (name, float((Q == ref).mean()))
-            assert abs(gp.error - float(z[f"{name}|error"])) <= 0.01 * float(z[f"{name}|error"]), name
-    # the solver's own Cholesky factor (rocSOLVER) instead of the CPU's: same algorithm, fp32 factorisation noise only
-    Q, gp, _ = _gptq_case(msq, z, "single_fp4_fp8", own_hinv=True)
-    assert (Q == z["single_fp4_fp8|Q"]).mean() >= 0.97
-    assert abs(gp.error - float(z["single_fp4_fp8|error"])) <= 0.03 * float(z["single_fp4_fp8|error"])
+            nd = int((Q != ref).sum())
+            print("GPTQ fixture %s: %d of %d entries differ from the reference's CPU result" % (name, nd, ref.size))
+            assert nd == 0, (name, nd, sorted(set(np.argwhere(Q != ref)[:, 0].tolist()))[:8])
+            assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-5 * float(z[f"{name}|error"]), name
+    # the solver's own inverse-Hessian factor (computed in float64 and rounded once, harness/gptq.py FACTOR_FP64) instead of the
+    # CPU's float32 LAPACK factor: the factors differ in their last bits, the quantised weights on every fixture do not
+    for name in names:
+        Q, gp, _ = _gptq_case(msq, z, name, own_hinv=True)
+        nd = int((Q != z[f"{name}|Q"]).sum())
+        print("GPTQ fixture %s, own factor: %d of %d entries differ" % (name, nd, Q.size))
+        assert nd == 0, (name, nd)
+        assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-4 * float(z[f"{name}|error"]), name
 
 
 def test_gptq_block_kernel_speed_and_llama_layer(msq):
     """A Llama-2-7B attention projection (4096 x 4096, 128-column blocks, harness default quantiser): the block kernel
     and the per-column path agree (inside a block bit for bit, see the test above; across 32 blocks the two paths hand
     differently laid out operands to the block-to-block GEMM, so single rounding decisions may flip: >= 99.5 % identical (measured 99.87 %),
-    loss within 0.1 %), and the layer takes >= 10x less time than round 1's 0.84 s (asserted loosely: < 0.2 s; the
-    measured figure is printed)."""
+    loss within 0.1 %).  Times are printed, and only their RATIO is asserted (the block kernel against the per-column path in the
+    same run; measured 12x): an absolute bound is flaky on a shared pool (advisor, round 2)."""
     import time
     from msq.harness.gptq import GPTQ
     torch.manual_seed(1)
@@ -710,7 +717,7 @@ def test_gptq_block_kernel_speed_and_llama_layer(msq):
     same = float((outs[1][0] == outs[2][0]).float().mean())
     assert same >= 0.995, same
     assert abs(outs[1][2] - outs[2][2]) <= 1e-3 * outs[2][2]
-    assert outs[1][1] < 0.3, outs[1][1]            # 0.070 s typical (was 0.84-0.88 s with one torch launch chain per column)
+    assert outs[1][1] * 2.0 < outs[2][1], (outs[1][1], outs[2][1])      # 0.070 s against 0.85 s typical
 
 
 @pytest.mark.parametrize("family", ["llama", "opt"])
