@@ -87,24 +87,28 @@ def gelu(input, mx_specs=None, first_order_gelu=False, approximate=None, name=No
 
 
 def simd_add(in1, in2, mx_specs=None):
-    """simd_ops.py:427-433 (tensor + tensor of the same shape, or tensor + python scalar)"""
+    """simd_ops.py:427-433, :80-106 (tensor + tensor with full two-way broadcasting -- "Shape broadcasting is fully supported" --, or
+    tensor + python scalar); the result has the broadcast shape and torch's promoted dtype, as `in1 + in2` has in the reference."""
     mx_assert_test(mx_specs)
     if mx_specs is None:
         return in1 + in2
     mx_specs = apply_mx_specs(mx_specs)
     assert isinstance(in1, torch.Tensor)
-    a = _f32c(in1, "simd_add")
     bits, eb, mn, rm, dn = _rounding(mx_specs)
     if isinstance(in2, torch.Tensor):
+        out_dtype = torch.result_type(in1, in2)
         if in2.shape != in1.shape:
-            in2 = in2.expand_as(in1)
+            in1, in2 = torch.broadcast_tensors(in1, in2)
+        a = _f32c(in1, "simd_add")
         b, bs = _f32c(in2, "simd_add"), 0.0
     else:
+        out_dtype = torch.result_type(in1, in2)
+        a = _f32c(in1, "simd_add")
         b, bs = None, float(in2)
     out = torch.empty_like(a)
     check(lib().msq_vec_add(ptr(a), ptr(b), bs, ptr(out), a.numel(), bits, eb, mn, rm, dn, current_stream(a.device)),
           "msq_vec_add")
-    return out if in1.dtype == torch.float32 else out.to(in1.dtype)
+    return out if out_dtype == torch.float32 else out.to(out_dtype)
 
 
 def simd_split(in1, mx_specs=None):

@@ -442,3 +442,18 @@ def test_kv_cache_mx_variant_is_one_launch_in_the_cache_dtype(msq, O, dtype):
         ko = O.quantize_mx_lowp(K_.float().numpy(), dn, 8, "fp8_e4m3", 2, 32)
         vo = O.quantize_mx_lowp(V_.float().numpy(), dn, 8, "fp8_e4m3", 3, 32)
         assert kq.dtype == dtype and (kq.float().cpu().numpy() == ko).all() and (vq.float().cpu().numpy() == vo).all()
+
+
+def test_simd_add_broadcasts_both_ways(msq):
+    """mx.simd_add (simd_ops.py:80-106: "Shape broadcasting is fully supported"): an in1 of [1, H] plus an in2 of [B, S, H], the result
+    in the broadcast shape and torch's promoted dtype (advisor, round 2)."""
+    sp = msq.specs.finalize_mx_specs({"bfloat": 16, "custom_cuda": True})
+    a = torch.randn(1, 64, device=dev())
+    b = torch.randn(2, 5, 64, device=dev())
+    y = msq.vector_ops.simd_add(a, b, sp)
+    y2 = msq.vector_ops.simd_add(b, a, sp)
+    assert y.shape == (2, 5, 64) and torch.equal(y, y2)
+    ref = msq.vector_ops.simd_add(a.expand(2, 5, 64).contiguous(), b, sp)
+    assert torch.equal(y, ref)
+    assert msq.vector_ops.simd_add(a.half(), b, sp).dtype == torch.float32          # promotion, as `in1 + in2`
+    assert msq.vector_ops.simd_add(a.half(), 1.5, sp).dtype == torch.float16
