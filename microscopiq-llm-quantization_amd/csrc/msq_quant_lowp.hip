@@ -276,14 +276,14 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
 // floor(R(log2f(t))) for a finite T value t > 0, integer form of floor_log2_lowp: the exact exponent E, plus one when the
 // significand sits within dmax T-ulps below 2.0 (d = 2^(p-1) - fraction <= dmax), dmax = what c[jb + 1] of floor_log2_lowp
 // allows for the binade of |E + 1| (checked against the reference-made fixtures through k_mx_lowp).
-template <int DT> MSQ_D int floor_log2_fast(float t) {
+template <int DT> MSQ_D int floor_log2_fast(float t) {                   // branch-free
     const uint32_t u = f2u(t);
     const int E = (int)((u >> 23) & 0xFFu) - 127;
     const int up = E + 1;
-    if (up == 0) return E;
-    const int au = up < 0 ? -up : up;
+    int au = up < 0 ? -up : up;
+    au |= (up == 0) ? 1 : 0;                                        // up == 0: jb + 1 = 1 -> dmax 0 -> no bump
     int jb = 31 - __builtin_clz((unsigned)au);
-    if (up > 0 && (au & (au - 1)) == 0) jb -= 1;
+    jb -= (up > 0 && (au & (au - 1)) == 0) ? 1 : 0;
     const uint32_t lo = 0x02010000u;                                // jb + 1 = 0..3: 0, 0, 1, 2 (both dtypes)
     const uint32_t hi = (DT == 1) ? 0x2B160B05u : 0x28150A05u;      // jb + 1 = 4..7: fp16 5, 11, 22, 43; bf16 5, 10, 21, 40
     const uint32_t top = (DT == 1) ? 86u : 74u;                     // jb + 1 = 8
@@ -303,6 +303,68 @@ struct MxLowpArgs {
     int* status;
 };
 
+// block-level quantities of one MX block (maximum mx already reduced) and the per-element arithmetic
+template <int DT> struct MxBlk {
+    float sc, mn, sh, rsh, dr;
+    Div dv;
+    int min_exp, status;
+    bool fast, fl, pow2den, has_pe;
+};
+template <int DT> MSQ_D MxBlk<DT> mx_block_setup(float mx, const MxLowpArgs& A) {
+    MxBlk<DT> B;
+    float se = shared_exp_lowp<DT>(mx);                                  // :428-430
+    B.fl = A.flush && !(se > -127.f);                                    // :433-434
+    se = Rr<DT>(se - (float)A.f.emax);                                   // :438
+    const float semax = (float)((1 << (A.scale_bits - 1)) - 1);          // :440-442
+    if (se > semax) se = u2f(0x7FC00000u);
+    if (se < -semax) se = -semax;
+    B.status = (se != se) ? MSQ_STATUS_NAN : 0;
+    B.sc = pow2_lowp<DT>(se);                                            // 2**shared_exp as a T tensor
+    const float den = Rr<DT>(B.sc + 1e-6f);                              // :444
+    B.dv = make_div(den);
+    B.dr = B.dv.r;
+    // Fast path (round to nearest, a finite block whose scale is a normal power of two in T, element formats with exponent bits):
+    // the scalings by powers of two are exact in T as long as nothing leaves T's range -- guaranteed here by the bounds on se --,
+    // so only the roundings that can change a value are kept: R(|x| + 0.5) before the floor, and the exponent rule.
+    constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;     // smallest subnormal / largest binade of T
+    B.has_pe = A.f.ebits > 0;
+    B.min_exp = B.has_pe ? 2 - (1 << (A.f.ebits - 1)) : 0;
+    const int sei = (int)se;
+    // den is the scale itself (a power of two: the division is an exact multiply) or, for small scales, the scale plus 1e-6
+    // rounded to T: then x / den is a real division, rounded to T, and everything after it is unchanged
+    B.pow2den = B.dv.fast && den == B.sc;
+    const uint32_t de = (f2u(den) >> 23) & 0xFFu;
+    B.fast = A.rmode == 0 && !B.fl && se == se && mx < 3.0e38f && de >= 1u && de <= 253u && f2u(B.sc) == ((uint32_t)(sei + 127) << 23) &&
+             sei + B.min_exp + 2 - A.f.mbits >= TMINE && sei + A.f.emax + 2 <= TMAXE && sei - 1 >= TMINE + 11 && mx != 0.f;
+    B.mn = A.f.max_norm;
+    B.sh = pow2i(A.f.mbits - 2); B.rsh = pow2i(2 - A.f.mbits);
+    return B;
+}
+// fast path of one element (straight-line; the caller has made sure the whole wave takes it)
+template <int DT> MSQ_D float mx_elem_fast(float x, const MxBlk<DT>& B) {
+    const float v = B.pow2den ? x * B.dr : Rr<DT>(x / B.dv.d);           // exact, or the rounded quotient by scale + 1e-6 (:444)
+    const float av = __builtin_fabsf(v);
+    int pe = floor_log2_fast<DT>(av);                                    // v == 0: some small exponent, m = 0 below
+    pe = pe < B.min_exp ? B.min_exp : pe;
+    pe = B.has_pe ? pe : 0;                                              // integer element formats: no private exponent
+    const float ip2 = u2f((uint32_t)(127 - pe) << 23), p2 = u2f((uint32_t)(127 + pe) << 23);
+    const float m = av * ip2 * B.sh;                                     // exact
+    const float q = __builtin_floorf(Rr<DT>(m + 0.5f));                  // the one rounding that matters (ties just below n + 1/2)
+    float r = q * B.rsh * p2;                                            // exact
+    r = r > B.mn ? B.mn : r;
+    r = __builtin_copysignf(r, v);                                       // sign(v) * floor(...): -0 where a negative value rounds to zero
+    r = (v == 0.f) ? 0.f : r;                                            // sign(+-0) = 0: 0 * floor(...) = +0
+    return r * B.sc;                                                     // exact (bounds on se)
+}
+template <int DT> MSQ_D float mx_elem(float x, const MxBlk<DT>& B, const MxLowpArgs& A) {
+    if (B.fast) return mx_elem_fast<DT>(x, B);
+    float v = x;
+    if (B.fl) v = Rr<DT>(v * 0.f);
+    v = Rr<DT>(divp(v, B.dv));
+    v = core_lowp<DT>(v, A.f, A.rmode);                                  // :446-449
+    return Rr<DT>(v * B.sc);                                             // :451
+}
+
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
@@ -315,88 +377,106 @@ k_mx_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArg
     const int64_t a0 = nb * BS;
     const int64_t base = (p * A.axis_len + a0) * A.post + q;
     float a[BS];
-    const bool vec = (BS % 8 == 0) && A.post == 1 && (A.axis_len % BS) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    if (vec) {
 #pragma unroll
-        for (int c = 0; c < BS / 8; ++c) {
-            union { uint4 u; uint16_t h[8]; } v;
-            v.u = *reinterpret_cast<const uint4*>(in + base + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[c * 8 + j] = ld16<DT>(v.h, j);
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < BS; ++b)
-            a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;     // zero padding (_reshape_to_blocks)
-    }
+    for (int b = 0; b < BS; ++b)
+        a[b] = (a0 + b < A.axis_len) ? ld16<DT>(in, base + (int64_t)b * A.post) : 0.f;         // zero padding (_reshape_to_blocks)
     float mx = 0.f;
     bool nan = false;
 #pragma unroll
     for (int b = 0; b < BS; ++b) { const float v = __builtin_fabsf(a[b]); nan |= (v != v); mx = v > mx ? v : mx; }
     if (nan) mx = u2f(0x7FC00000u);
-    float se = shared_exp_lowp<DT>(mx);                                  // :428-430
-    const bool fl = A.flush && !(se > -127.f);                           // :433-434
-    se = Rr<DT>(se - (float)A.f.emax);                                   // :438
-    const float semax = (float)((1 << (A.scale_bits - 1)) - 1);          // :440-442
-    if (se > semax) se = u2f(0x7FC00000u);
-    if (se < -semax) se = -semax;
-    int status = (se != se) ? MSQ_STATUS_NAN : 0;
-    const float sc = pow2_lowp<DT>(se);                                  // 2**shared_exp as a T tensor
-    const float den = Rr<DT>(sc + 1e-6f);                                // :444
-    const Div dv = make_div(den);
-    // Fast path (round to nearest, a finite block whose scale is a normal power of two in T, element formats with exponent bits):
-    // the scalings by powers of two are exact in T as long as nothing leaves T's range -- guaranteed here by the bounds on se --,
-    // so only the roundings that can change a value are kept: R(|x| + 0.5) before the floor, and the exponent rule.
-    constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;     // smallest subnormal / largest binade of T
-    const int min_exp = 2 - (1 << (A.f.ebits > 0 ? A.f.ebits - 1 : 0));
-    const int sei = (int)se;
-    const bool fast = A.rmode == 0 && A.f.ebits > 0 && !fl && se == se && mx < 3.0e38f && dv.fast && den == sc &&
-                      sei + min_exp + 2 - A.f.mbits >= TMINE && sei + A.f.emax + 2 <= TMAXE && sei - 1 >= TMINE + 11 && mx != 0.f;
-    if (fast) {
-        const float mn = A.f.max_norm;
-        const float sh = pow2i(A.f.mbits - 2), rsh = pow2i(2 - A.f.mbits);
+    const MxBlk<DT> B = mx_block_setup<DT>(mx, A);
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+        if (a0 + b < A.axis_len) st16<DT>(out, base + (int64_t)b * A.post, mx_elem<DT>(a[b], B, A));
+    if (B.status && A.status) atomicOr(A.status, B.status);
+}
+
+// Contiguous axis (post == 1, axis_len % BS == 0, 16-byte aligned): BS / 8 lanes per block, 8 values = one 16-byte access per lane;
+// the block maximum crosses the lanes of a block with xor-shuffles (the lanes of a block are neighbours inside a wave).
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A, int64_t nchunks) {
+    constexpr int LPB = BS / 8;                                          // lanes per block: 1, 2, 4, 8, 16
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < nchunks;
+    union { uint4 u; uint16_t h[8]; } v;
+    v.u = live ? *reinterpret_cast<const uint4*>(in + t * 8) : make_uint4(0, 0, 0, 0);
+    float a[8];
+    float mx = 0.f;
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = ld16<DT>(v.h, j); const float w = __builtin_fabsf(a[j]); nan |= (w != w); mx = w > mx ? w : mx; }
+    if (nan) mx = u2f(0x7FC00000u);
+#pragma unroll
+    for (int o = 1; o < LPB; o <<= 1) {
+        const float other = __shfl_xor(mx, o, 64);
+        mx = (other != other) ? other : ((mx != mx) ? mx : (other > mx ? other : mx));
+    }
+    MxBlk<DT> B = mx_block_setup<DT>(mx, A);
+    if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {                     // the whole wave: straight-line code
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(a[j], B));
+    } else {
+        B.fast = false;                                                  // the general path is right for every block
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem<DT>(a[j], B, A));     // (unrolled: a run-time index would put a[] in scratch)
+    }
+    if (live) *reinterpret_cast<uint4*>(out + t * 8) = v.u;
+    if (live && B.status && A.status) atomicOr(A.status, B.status);
+}
+
+// Strided axis with an even contiguous extent (K cache: blocks of BS tokens of one channel, post = head_dim): one lane per PAIR of
+// neighbouring channels, 4-byte accesses (a wave moves 256 contiguous bytes per token row instead of 128).
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
+    const int64_t hp = A.post / 2;
+    const int64_t total = A.pre * A.nblk * hp;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = (t % hp) * 2;
+    const int64_t nb = (t / hp) % A.nblk;
+    const int64_t p = t / (hp * A.nblk);
+    const int64_t a0 = nb * BS;
+    const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    float a0v[BS], a1v[BS];
+    float m0 = 0.f, m1 = 0.f;
+    bool n0 = false, n1 = false;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        union { uint32_t u; uint16_t h[2]; } w;
+        w.u = (a0 + b < A.axis_len) ? *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post) : 0u;
+        a0v[b] = ld16<DT>(w.h, 0); a1v[b] = ld16<DT>(w.h, 1);
+        const float x0 = __builtin_fabsf(a0v[b]), x1 = __builtin_fabsf(a1v[b]);
+        n0 |= (x0 != x0); n1 |= (x1 != x1);
+        m0 = x0 > m0 ? x0 : m0; m1 = x1 > m1 ? x1 : m1;
+    }
+    if (n0) m0 = u2f(0x7FC00000u);
+    if (n1) m1 = u2f(0x7FC00000u);
+    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
+    if (__builtin_amdgcn_ballot_w64(!(B0.fast && B1.fast)) == 0) {
 #pragma unroll
         for (int b = 0; b < BS; ++b) {
-            const float x = a[b];
-            float v = x * dv.r;                                          // exact: |v| < 2^(emax + 2), and not below T's grid
-            float r = 0.f;
-            if (v != 0.f) {
-                int pe = floor_log2_fast<DT>(__builtin_fabsf(v));
-                pe = pe < min_exp ? min_exp : pe;
-                const float ip2 = u2f((uint32_t)(127 - pe) << 23), p2 = u2f((uint32_t)(127 + pe) << 23);
-                const float m = __builtin_fabsf(v) * ip2 * sh;           // exact
-                const float q = __builtin_floorf(Rr<DT>(m + 0.5f));      // the one rounding that matters (ties just below n + 1/2)
-                r = q * rsh * p2;                                        // exact
-                r = r > mn ? mn : r;
-                r = __builtin_copysignf(r, v);                           // sign(v) * floor(...): -0 where a negative value rounds to zero
-            }
-            a[b] = r * sc;                                               // exact (bounds on se)
+            if (a0 + b >= A.axis_len) continue;
+            union { uint32_t u; uint16_t h[2]; } w;
+            st16<DT>(w.h, 0, mx_elem_fast<DT>(a0v[b], B0));
+            st16<DT>(w.h, 1, mx_elem_fast<DT>(a1v[b], B1));
+            *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = w.u;
         }
     } else {
+        B0.fast = false; B1.fast = false;
 #pragma unroll
         for (int b = 0; b < BS; ++b) {
-            float v = a[b];
-            if (fl) v = Rr<DT>(v * 0.f);
-            v = Rr<DT>(divp(v, dv));
-            v = core_lowp<DT>(v, A.f, A.rmode);                          // :446-449
-            a[b] = Rr<DT>(v * sc);                                       // :451
+            if (a0 + b >= A.axis_len) continue;
+            union { uint32_t u; uint16_t h[2]; } w;
+            st16<DT>(w.h, 0, mx_elem<DT>(a0v[b], B0, A));
+            st16<DT>(w.h, 1, mx_elem<DT>(a1v[b], B1, A));
+            *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = w.u;
         }
     }
-    if (vec) {
-#pragma unroll
-        for (int c = 0; c < BS / 8; ++c) {
-            union { uint4 u; uint16_t h[8]; } v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, a[c * 8 + j]);
-            *reinterpret_cast<uint4*>(out + base + c * 8) = v.u;
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < BS; ++b)
-            if (a0 + b < A.axis_len) st16<DT>(out, base + (int64_t)b * A.post, a[b]);
-    }
-    if (status && A.status) atomicOr(A.status, status);
+    const int st = B0.status | B1.status;
+    if (st && A.status) atomicOr(A.status, st);
 }
 
 extern "C" void msq_set_error_(const char* msg);
@@ -418,16 +498,25 @@ extern "C" int msq_quantize_mx_lowp(const void* in, void* out, int dtype, int64_
     A.f = Fmt{fi.kind, fi.ebits, fi.mbits, fi.emax, fi.max_norm};
     A.scale_bits = scale_bits; A.rmode = rmode; A.flush = flush_fp32_subnorms; A.status = status_flag;
     const int64_t n = A.pre * A.nblk * A.post;
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    const bool vec = post == 1 && (axis_len % block) == 0 && aligned;                    // contiguous axis: 8 values per lane
+    const bool pair = !vec && post >= 2 && (post % 2) == 0 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0 && block <= 32;   // strided axis: two channels per lane
+    const int64_t nchunks = pre * axis_len / 8;
+    const int64_t nthreads = vec ? nchunks : (pair ? n / 2 : n);
+    const dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
+#define MSQ_MXLP1(BS, DTV)                                                                                              \
+        if (vec) hipLaunchKernelGGL((k_mx_lowp_vec<BS, DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, nchunks); \
+        else if (pair) hipLaunchKernelGGL((k_mx_lowp_pair<(BS <= 32 ? BS : 32), DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
+        else hipLaunchKernelGGL((k_mx_lowp<BS, DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A);
 #define MSQ_MXLP(BS)                                                                                                    \
     case BS:                                                                                                           \
-        if (dtype == 1) hipLaunchKernelGGL((k_mx_lowp<BS, 1>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
-        else hipLaunchKernelGGL((k_mx_lowp<BS, 2>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A);           \
+        if (dtype == 1) { MSQ_MXLP1(BS, 1) } else { MSQ_MXLP1(BS, 2) }                                                  \
         break;
     switch (block) { MSQ_MXLP(8) MSQ_MXLP(16) MSQ_MXLP(32) MSQ_MXLP(64) MSQ_MXLP(128)
         default: msq_set_error_("msq_quantize_mx_lowp: block must be 8, 16, 32, 64 or 128"); return MSQ_ERR_UNSUPPORTED; }
 #undef MSQ_MXLP
+#undef MSQ_MXLP1
     return hipGetLastError() == hipSuccess ? MSQ_OK : MSQ_ERR_LAUNCH;
 }
 
