@@ -1,5 +1,11 @@
-"""MX decode (M = 1 ... 32) from a HIP graph: raw activations through the public call (the decode kernel quantises them itself,
-msq_qlinear_mx_xq) against activation pack + decode kernel, Llama-2-7B shapes, MX-FP4 and exact e4m3 weight operands."""
+"""Round 3 experiment (NOT in the product): MX decode (M = 1 ... 32) from a HIP graph with the activation quantiser fused into the
+decode kernel (every wave quantised its own 128-k chunk of the raw activations in registers: 32 exponent extractions, two shuffles,
+16 scaled converts per tile and row group; an experimental `msq_qlinear_mx_xq` entry point, not kept) against activation pack +
+decode kernel.  Result on MI355X, MX-FP4, N16384 K4096: M = 1 fused 9.1 (fp32 input) / 10.8 us (bf16) against 9.6-9.9 us for pack +
+kernel (kernel alone 7.1); M = 16: 11.6-13.6 against 11.7; M = 32: 49-52 against 25.6.  The quantisation is repeated by each of the
+256 column strips (x 16 rows per fragment), which costs as much as the pack launch it saves at M = 1 and far more beyond: dropped.
+What would pay is a pack fused into the PRODUCER of the activations (the norm / residual add in front of the projections), which is
+outside this hot path.  (The script needs that experimental build to run the "fused" arm.)"""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import msq
