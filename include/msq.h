@@ -241,6 +241,12 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same call on fp16 activations (an fp16 model, llm/llama.py:33) at the decode sizes (M <= 32; <= 64 for the 4096 x 4096 class):
+ * the weight-streaming kernels convert them to bf16 (round to nearest even = x.to(bfloat16)) while loading: no cast launch in front of
+ * every projection.  Other shapes: MSQ_ERR_UNSUPPORTED (cast to bf16 and call msq_qlinear_bf16). */
+int msq_qlinear_f16x(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
+                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * W4A8 Linear -- NEW; replaces the activation quantisation + F.linear of

@@ -1176,7 +1176,7 @@ template <int IN_KIND, int OUT_KIND, int MG, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, const uint8_t* __restrict__ out_plane,
         const uint8_t* __restrict__ scl_plane, float* __restrict__ partial, int M, int N, int K, int scl_groups, int kc,
-        int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16) {
+        int direct, const float* __restrict__ bias, void* __restrict__ Y, int y_bf16, int x_f16) {
     extern __shared__ __attribute__((aligned(16))) char smem_v[];
     float (*red)[16 * MG][64] = reinterpret_cast<float (*)[16 * MG][64]>(smem_v);      // [WAVES - 1][16 MG][64]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1213,6 +1213,14 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int j = 0; j < MG; ++j)
+                if (x_f16) {     // fp16 activations (an fp16 model at decode sizes): converted here, half -> float (exact) -> bf16 (RNE) = x.to(bfloat16), no cast launch
+                    union { u32x4_t u; _Float16 h[8]; } r;
+                    r.u = *reinterpret_cast<const u32x4_t*>(xrow[j] + (int64_t)kt * TILE_K + kf * 32);
+                    bf16x8_t t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (__bf16)(float)r.h[e];
+                    xf[kf][j] = t;
+                } else
                 xf[kf][j] = *reinterpret_cast<const bf16x8_t*>(xrow[j] + (int64_t)kt * TILE_K + kf * 32);
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
@@ -1651,9 +1659,9 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
 
-int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
-                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream) {
+                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream, int x_f16) {
     if (M <= 0) return (M == 0) ? MSQ_OK : fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_bf16: negative M");
     int rc = msq_packed_sizes(N, K, block, in_kind, out_kind, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -1686,7 +1694,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             do { static DevOnce once_;                                                                         \
                  if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv<IK, OK, MGV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * MGV * 64 * 4); attr_done(once_); } \
                  hipLaunchKernelGGL((k_qgemv<IK, OK, MGV, WV>), vgrid, dim3(64 * WV), ldsv, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, (const uint8_t*)scale_plane, \
-                                    (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
+                                    (float*)workspace, (int)M, (int)N, (int)K, groups0, kc, kcd ? 1 : 0, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0), x_f16); } while (0)
 #define MSQ_GV(IK, OK) do { if (mg == 1) MSQ_GV1(IK, OK, 1, 4); else if (mg == 2) MSQ_GV1(IK, OK, 2, 4); else MSQ_GV1(IK, OK, 4, 4); } while (0)
             if (kcd) {
                 if (out_kind == MSQ_PLANE_U8) { if (mg == 1) MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 1, 16); else MSQ_GV1(MSQ_PLANE_NONE, MSQ_PLANE_U8, 2, 16); }
@@ -1711,6 +1719,7 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
             return check_launch2("msq_qlinear_bf16(gemv reduce)");
         }
     }
+    if (x_f16) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_f16x: fp16 activations are converted inside the decode kernels only (M <= 32; <= 64 for the 4096 x 4096 class): cast them to bf16 for this shape");
     const int mf_sel = pick_mf(M, N, out_kind);
     const int wm_sel = (mf_sel == 16) ? 1 : pick_wm(M, N);
     const int brow = 16 * mf_sel * wm_sel;
@@ -1842,6 +1851,21 @@ int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane
     if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, partial, bias, (float*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
     else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rgrid, dim3(256), 0, st, partial, bias, (uint16_t*)Y, MN, (int)N, ksplit, y_dtype == 1 ? 1 : 0);
     return check_launch2("msq_qlinear_bf16(split-K reduce)");
+}
+
+int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
+                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream) {
+    return qlinear_bf16_impl(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, block, in_kind, out_kind, workspace,
+                             workspace_bytes, stream, 0);
+}
+// the same Linear on fp16 activations at the decode sizes: the weight-streaming kernels convert them (half -> bf16, round to
+// nearest even: what x.to(bfloat16) gives) while they load them
+int msq_qlinear_f16x(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
+                     const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
+                     int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream) {
+    return qlinear_bf16_impl(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, block, in_kind, out_kind, workspace,
+                             workspace_bytes, stream, 1);
 }
 
 // ---------------------------------------------------------------------------

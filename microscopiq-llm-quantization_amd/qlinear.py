@@ -221,7 +221,10 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
         raise MsqError("qlinear: in_features mismatch (%d vs %d)" % (k, P.k))
     K = P.K
     xb = x.reshape(-1, k)
-    if xb.dtype != torch.bfloat16:
+    # fp16 activations at decode sizes go to the kernels as they are (msq_qlinear_f16x converts while loading); everything else is
+    # cast to bf16 first
+    f16x = xb.dtype == torch.float16 and xb.shape[0] <= 64
+    if xb.dtype != torch.bfloat16 and not f16x:
         xb = xb.to(torch.bfloat16)
     xb = _pad_k(xb, K).contiguous()
     M = xb.shape[0]
@@ -238,9 +241,18 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
             b = torch.nn.functional.pad(b, (0, P.N - P.n))
     wsb = lib().msq_qlinear_workspace_bytes(M, P.N, K)        # > 0 only for small M (split-K partial tiles)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb > 0 else None
-    check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
-                                 _YD[out_dtype], M, P.N, K, P.block, P.in_kind, P.out_kind,
-                                 ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
+    rc = -2
+    if f16x:
+        rc = lib().msq_qlinear_f16x(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y), _YD[out_dtype], M, P.N, K, P.block,
+                                    P.in_kind, P.out_kind, ptr(ws), wsb, current_stream(x.device))
+        if rc not in (0, -2):
+            check(rc, "msq_qlinear_f16x")
+        if rc == -2:                                                      # not a decode shape after all: cast
+            xb = xb.to(torch.bfloat16)
+    if rc != 0:
+        check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
+                                     _YD[out_dtype], M, P.N, K, P.block, P.in_kind, P.out_kind,
+                                     ptr(ws), wsb, current_stream(x.device)), "msq_qlinear_bf16")
     if padded_n:
         if out is not None:
             out.copy_(y[:, :P.n]); y = out

@@ -457,3 +457,19 @@ def test_simd_add_broadcasts_both_ways(msq):
     assert torch.equal(y, ref)
     assert msq.vector_ops.simd_add(a.half(), b, sp).dtype == torch.float32          # promotion, as `in1 + in2`
     assert msq.vector_ops.simd_add(a.half(), 1.5, sp).dtype == torch.float16
+
+
+@pytest.mark.parametrize("M", [1, 9, 16, 32, 64, 65])
+def test_decode_kernels_take_fp16_activations(msq, M):
+    """An fp16 model at decode sizes: qlinear on the fp16 tensor (converted inside the weight-streaming kernels, msq_qlinear_f16x) ==
+    qlinear on x.to(bfloat16), bit for bit, for every packed layout; M = 65 (and M = 64 on a wide layer) falls back to the cast."""
+    torch.manual_seed(50 + M)
+    for N, K in ((4096, 4096), (16384, 1024)):
+        W = _weights(N, K, 12).to(dev())
+        x = (torch.randn(M, K, device=dev()) * 2).half()
+        x[0, 0] = 65504.0; x[M - 1, 1] = 6e-8          # the largest fp16 value and an fp16 subnormal
+        b = torch.randn(N, device=dev())
+        for fo, layout in (("posit8_es1", "unified"), ("fp8_e4m3", "unified"), ("fp8_e4m3", "planes")):
+            P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
+            for od in (torch.float16, torch.float32):
+                assert torch.equal(msq.qlinear.qlinear(x, P, b, od), msq.qlinear.qlinear(x.to(torch.bfloat16), P, b, od)), (M, N, fo, layout)
