@@ -13,6 +13,7 @@
 // variance carry the same fp32 rounding as torch.sum on the CPU.  Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/msq.h"
 #include "msq_device.h"
@@ -41,9 +42,28 @@ MSQ_D float Q(float a, const VQ& q) {
     return quant_bits(a, q.bits, q.ebits, q.max_norm, q.rmode, false, q.dn != 0);
 }
 
-// FAST = 1: bfloat16, round to nearest (the run_mx_fp6.sh spec) with compile-time constants; 0: run-time parameters
-template <int FAST>
-MSQ_D float QT(float a, const VQ& q) { return FAST ? Qbf(a, 16, 0) : Q(a, q); }
+// FAST = 1: bfloat16, round to nearest (the run_mx_fp6.sh spec) as two integer instructions on the fp32 pattern: half a quantum
+// added to the whole word (the carry cannot reach the sign below the NaN range; up to Inf as in Qbf), low half cleared.  That is
+// Qbf(a, 16, 0) except for (i) NaNs whose payload sits in the low half / overflows, and (ii) negative values that round to zero
+// (-0 here, +0 there).  (i) is closed by Qin on every value that enters an op from memory (a NaN becomes the canonical quiet
+// NaN, which arithmetic propagates and the two instructions keep); (ii) by Qout on every value that leaves: in between a zero
+// of either sign gives the same non-zero results (no op of the three functions divides by, or takes the root of, such a value:
+// the variance is a sum of squares, phi >= 1), so the outputs are those of Qbf at every step.
+// tests/test_gpu_round3.py::test_vector_ops_fast_rounding_equals_generic runs both variants on every bfloat16 pattern.
+MSQ_D float Qmid16(float a) { return u2f((f2u(a) + 0x8000u) & 0xFFFF0000u); }
+MSQ_D float Qin16(float a) {
+    const uint32_t u = f2u(a);
+    uint32_t r = (u + 0x8000u) & 0xFFFF0000u;
+    r = ((u << 1) > 0xFF000000u) ? 0x7FC00000u : r;
+    return u2f(r == 0x80000000u ? 0u : r);
+}
+MSQ_D float Qout16(float a) {
+    const uint32_t r = (f2u(a) + 0x8000u) & 0xFFFF0000u;
+    return u2f(r == 0x80000000u ? 0u : r);
+}
+template <int FAST> MSQ_D float QT(float a, const VQ& q) { return FAST ? Qmid16(a) : Q(a, q); }
+template <int FAST> MSQ_D float QI(float a, const VQ& q) { return FAST ? Qin16(a) : Q(a, q); }
+template <int FAST> MSQ_D float QO(float a, const VQ& q) { return FAST ? Qout16(a) : Q(a, q); }
 
 MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
 
@@ -116,81 +136,106 @@ k_vec_layernorm(const float* __restrict__ x, const float* __restrict__ w, const 
     }
 }
 
-// Rows with H = 512 G, G <= 16 (one cascade level of ATen's sum): four waves per row.  Thread (k = tid / 32, t = tid % 32)
-// sums the 16-element groups g = k, k + 8 of interleave slot t sequentially from 0 (multi_row_sum's level 0), lane t of
-// wave 0 adds the G group sums in order (level 1), then the 32 slots are combined exactly as in row_sum_inner8.
-template <int FAST, typename F>
-MSQ_D float row_sum_inner8_par(F elem, int G, float* part /* [16][32] */, float* bcast, int tid) {
-    const int k = tid >> 5, t = tid & 31;
-    for (int g = k; g < G; g += 8) {
-        float s = 0.f;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = elem((g * 16 + j) * 32 + t);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += v[j];
-        part[g * 32 + t] = s;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float p = 0.f;
-        if (tid < 32) { for (int g = 0; g < G; ++g) p += part[g * 32 + tid]; p = 0.f + p; }
-        float p0 = p;
-        for (int kk = 1; kk < 4; ++kk) { const float o = __shfl(p, (tid & 7) + 8 * kk, 64); p0 += o; }
-        float fin = 0.f;
-        for (int l = 0; l < 8; ++l) fin += __shfl(p0, l, 64);
-        if (tid == 0) *bcast = fin;
-    }
-    __syncthreads();
-    return *bcast;
-}
-
-template <int FAST>
+// Rows with H = 512 G, G <= 16, held in registers in the layout of the sum itself: thread (k = tid / 32, t = tid % 32) owns the
+// sixteen elements (g * 16 + j) * 32 + t of groups g = k (and k + 8), i.e. exactly the addends of its level-0 partial sum, so the
+// row never goes through the LDS (only the G * 32 partial sums do).  Global accesses are 4 B per lane, two full 128 B lines per
+// wave instruction.  The rounded weight and bias of the thread's columns are kept for all rows of the block (FAST: as one
+// register per column, bfloat16 pair); the next row is fetched while the current one is reduced.
+template <int FAST, int GP>
 __global__ void __launch_bounds__(256)
-k_vec_layernorm_par(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+k_vec_layernorm_reg(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
                     int64_t rows, int H, float eps, VQ q) {
-    extern __shared__ float xs[];                       // H floats + 512 partials + 1
-    float* part = xs + H;
-    float* bc = part + 512;
-    const int64_t r = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int G = H / 512;
-    const float4* xr = reinterpret_cast<const float4*>(x + r * H);
-    for (int i = tid; i < H / 4; i += 256) {
-        float4 v = xr[i];
-        v.x = QT<FAST>(v.x, q); v.y = QT<FAST>(v.y, q); v.z = QT<FAST>(v.z, q); v.w = QT<FAST>(v.w, q);
-        reinterpret_cast<float4*>(xs)[i] = v;
-    }
-    __syncthreads();
-    float mean = QT<FAST>(row_sum_inner8_par<FAST>([&](int i) { return xs[i]; }, G, part, bc, tid), q);
-    mean = QT<FAST>(mean / (float)H, q);
-    for (int i = tid; i < H / 4; i += 256) {
-        float4 v = reinterpret_cast<float4*>(xs)[i];
-        v.x = QT<FAST>(v.x - mean, q); v.y = QT<FAST>(v.y - mean, q); v.z = QT<FAST>(v.z - mean, q); v.w = QT<FAST>(v.w - mean, q);
-        reinterpret_cast<float4*>(xs)[i] = v;
-    }
-    __syncthreads();
-    float var = QT<FAST>(row_sum_inner8_par<FAST>([&](int i) { return QT<FAST>(xs[i] * xs[i], q); }, G, part, bc, tid), q);
-    var = QT<FAST>(var / (float)H, q);
-    const float vare = QT<FAST>(var + eps, q);
-    const float sd = QT<FAST>(__builtin_sqrtf(vare), q);
-    const float inv = QT<FAST>(1.0f / sd, q);
-    float4* orow = reinterpret_cast<float4*>(out + r * H);
-    for (int i = tid; i < H / 4; i += 256) {
-        const float4 v = reinterpret_cast<float4*>(xs)[i];
-        const float4 ww = reinterpret_cast<const float4*>(w)[i], bb = reinterpret_cast<const float4*>(b)[i];
-        float4 o;
-        o.x = QT<FAST>(QT<FAST>(QT<FAST>(ww.x, q) * QT<FAST>(v.x * inv, q), q) + QT<FAST>(bb.x, q), q);
-        o.y = QT<FAST>(QT<FAST>(QT<FAST>(ww.y, q) * QT<FAST>(v.y * inv, q), q) + QT<FAST>(bb.y, q), q);
-        o.z = QT<FAST>(QT<FAST>(QT<FAST>(ww.z, q) * QT<FAST>(v.z * inv, q), q) + QT<FAST>(bb.z, q), q);
-        o.w = QT<FAST>(QT<FAST>(QT<FAST>(ww.w, q) * QT<FAST>(v.w * inv, q), q) + QT<FAST>(bb.w, q), q);
-        orow[i] = o;
+    __shared__ float part[512];
+    __shared__ float bc[1];
+    const int tid = threadIdx.x, k = tid >> 5, t = tid & 31, G = H / 512;
+    float wq[GP][16], bq[GP][16], cur[GP][16], nxt[GP][16];
+    uint32_t wb[GP][16];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi)
+        if (k + 8 * gi < G) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = ((k + 8 * gi) * 16 + j) * 32 + t;
+                const float a = QI<FAST>(w[c], q), d = QI<FAST>(b[c], q);
+                if (FAST) wb[gi][j] = f2u(a) | (f2u(d) >> 16);
+                else { wq[gi][j] = a; bq[gi][j] = d; }
+            }
+        }
+    auto fetch = [&](int64_t r) {
+        const float* xr = x + r * H;
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) nxt[gi][j] = xr[((k + 8 * gi) * 16 + j) * 32 + t];
+            }
+    };
+    // level 1 and the 32 interleave slots, combined as in row_sum_inner8 (ATen's order)
+    auto combine = [&]() -> float {
+        __syncthreads();
+        if (tid < 64) {
+            float p = 0.f;
+            if (tid < 32) { for (int g = 0; g < G; ++g) p += part[g * 32 + tid]; p = 0.f + p; }
+            float p0 = p;
+            for (int kk = 1; kk < 4; ++kk) { const float o = __shfl(p, (tid & 7) + 8 * kk, 64); p0 += o; }
+            float fin = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) fin += u2f(__builtin_amdgcn_readlane(f2u(p0), l));
+            if (tid == 0) bc[0] = fin;
+        }
+        __syncthreads();
+        return bc[0];
+    };
+    if ((int64_t)blockIdx.x < rows) fetch(blockIdx.x);
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[gi][j] = QI<FAST>(nxt[gi][j], q);
+        if (r + gridDim.x < rows) fetch(r + gridDim.x);
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sm += cur[gi][j];
+                part[(k + 8 * gi) * 32 + t] = sm;
+            }
+        float mean = QT<FAST>(combine(), q);
+        mean = QT<FAST>(mean / (float)H, q);
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    cur[gi][j] = QT<FAST>(cur[gi][j] - mean, q);
+                    sm += QT<FAST>(cur[gi][j] * cur[gi][j], q);
+                }
+                part[(k + 8 * gi) * 32 + t] = sm;
+            }
+        float var = QT<FAST>(combine(), q);
+        var = QT<FAST>(var / (float)H, q);
+        const float vare = QT<FAST>(var + eps, q);
+        const float sd = QT<FAST>(__builtin_sqrtf(vare), q);
+        const float inv = QT<FAST>(1.0f / sd, q);
+        float* orow = out + r * H;
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float ww = FAST ? u2f(wb[gi][j] & 0xFFFF0000u) : wq[gi][j];
+                    const float bb = FAST ? u2f(wb[gi][j] << 16) : bq[gi][j];
+                    orow[((k + 8 * gi) * 16 + j) * 32 + t] = QO<FAST>(QT<FAST>(ww * QT<FAST>(cur[gi][j] * inv, q), q) + bb, q);
+                }
+            }
     }
 }
 
 template <int FAST>
 MSQ_D float gelu_one(float x, int first_order, const VQ& q) {
-    const float qi = QT<FAST>(x, q);
+    const float qi = QI<FAST>(x, q);
     float s;
     if (first_order) s = QT<FAST>(1.703125f * qi, q);
     else {
@@ -199,8 +244,12 @@ MSQ_D float gelu_one(float x, int first_order, const VQ& q) {
     }
     float phi = QT<FAST>(expf(-s), q);                             // torch.exp (vec_use_exp2 off)
     phi = QT<FAST>(phi + 1.0f, q);
-    phi = QT<FAST>(1.0f / phi, q);
-    return QT<FAST>(qi * phi, q);
+    // 1 / phi: phi >= 1 carries 8 significant bits, so the exact quotient is at least 2^-17 (relative) away from every rounding
+    // boundary of the 8-bit result (1 / m = y needs m y = 2^e with both odd): v_rcp_f32's one ulp cannot move the rounded value.
+    // Quotients in fp32's subnormal range (phi > 2^126) and non-finite phi take the IEEE division.
+    if (FAST) phi = QT<FAST>((phi < 8.0e37f) ? __builtin_amdgcn_rcpf(phi) : 1.0f / phi, q);
+    else phi = QT<FAST>(1.0f / phi, q);
+    return QO<FAST>(qi * phi, q);
 }
 
 // 16-byte accesses (n4 float4 vectors; the tail goes through k_vec_gelu)
@@ -223,10 +272,10 @@ k_vec_add4(const float* __restrict__ a, const float* __restrict__ b, float* __re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 va = reinterpret_cast<const float4*>(a)[i];
         float4 vb = make_float4(bs, bs, bs, bs);
-        if (!b_is_scalar) { vb = reinterpret_cast<const float4*>(b)[i]; vb.x = QT<FAST>(vb.x, q); vb.y = QT<FAST>(vb.y, q); vb.z = QT<FAST>(vb.z, q); vb.w = QT<FAST>(vb.w, q); }
+        if (!b_is_scalar) { vb = reinterpret_cast<const float4*>(b)[i]; vb.x = QI<FAST>(vb.x, q); vb.y = QI<FAST>(vb.y, q); vb.z = QI<FAST>(vb.z, q); vb.w = QI<FAST>(vb.w, q); }
         float4 o;
-        o.x = QT<FAST>(QT<FAST>(va.x, q) + vb.x, q); o.y = QT<FAST>(QT<FAST>(va.y, q) + vb.y, q);
-        o.z = QT<FAST>(QT<FAST>(va.z, q) + vb.z, q); o.w = QT<FAST>(QT<FAST>(va.w, q) + vb.w, q);
+        o.x = QO<FAST>(QI<FAST>(va.x, q) + vb.x, q); o.y = QO<FAST>(QI<FAST>(va.y, q) + vb.y, q);
+        o.z = QO<FAST>(QI<FAST>(va.z, q) + vb.z, q); o.w = QO<FAST>(QI<FAST>(va.w, q) + vb.w, q);
         reinterpret_cast<float4*>(out)[i] = o;
     }
 }
@@ -266,7 +315,12 @@ static int vq_check(int bits, int exp_bits, int rmode) {
     if (rmode < 0 || rmode > 2) return vfail(MSQ_ERR_BAD_ARG, "vector op: bad rounding mode");
     return MSQ_OK;
 }
-static bool vq_is_fast(int bits, int exp_bits, int rmode, int allow_denorm) { return bits == 9 && exp_bits == 8 && allow_denorm && rmode == 0; }
+// MSQ_VEC_GENERIC=1 in the environment sends bfloat16 / nearest through the run-time-parameter kernels too (the parity tests compare the two)
+static bool vq_is_fast(int bits, int exp_bits, int rmode, int allow_denorm) {
+    const char* e = getenv("MSQ_VEC_GENERIC");
+    if (e && e[0] == '1') return false;
+    return bits == 9 && exp_bits == 8 && allow_denorm && rmode == 0;
+}
 static int grid1(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g)); }
 
 namespace {
@@ -297,13 +351,19 @@ int msq_vec_layernorm(const float* x, const float* weight, const float* bias, fl
     if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
     if (H * 4 > 160 * 1024 - 1024) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_layernorm: a row must fit the CU's LDS (H <= 40704)");
     const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
-    if (H % 512 == 0 && H <= 8192 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(weight) |
-                                       reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
-        const size_t l2 = (size_t)H * 4 + 513 * 4;
-        if (vq_is_fast(bits, exp_bits, rmode, allow_denorm))
-            hipLaunchKernelGGL(k_vec_layernorm_par<1>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
-        else
-            hipLaunchKernelGGL(k_vec_layernorm_par<0>, dim3((unsigned)rows), dim3(256), l2, (hipStream_t)stream, x, weight, bias, out, rows, (int)H, eps, vq);
+    if (H % 512 == 0 && H <= 8192) {
+        int rpb = rows >= 2048 ? 2 : 1;                                       // rows per block (see the kernel)
+        if (const char* e = getenv("MSQ_LN_RPB")) rpb = atoi(e) > 0 ? atoi(e) : rpb;
+        const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+        const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
+        const hipStream_t st = (hipStream_t)stream;
+        if (H <= 4096) {
+            if (fast) hipLaunchKernelGGL((k_vec_layernorm_reg<1, 1>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq);
+            else hipLaunchKernelGGL((k_vec_layernorm_reg<0, 1>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_vec_layernorm_reg<1, 2>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq);
+            else hipLaunchKernelGGL((k_vec_layernorm_reg<0, 2>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq);
+        }
         return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_layernorm: launch failed");
     }
     const size_t lds = (size_t)H * 4;

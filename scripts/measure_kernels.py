@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timings of every kernel on the hot path at the BASELINE sizes (run on the GPU box; HIP events on the
 launch stream, inputs resident in HBM).  Writes a text table to stdout; the committed copy lives in
-profiles/r02_kernel_timings.txt.  Usage: python scripts/measure_kernels.py [section ...]"""
+profiles/r03_kernel_timings.txt.  Usage: python scripts/measure_kernels.py [section ...]"""
 import os
 import sys
 

@@ -473,3 +473,54 @@ def test_decode_kernels_take_fp16_activations(msq, M):
             P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
             for od in (torch.float16, torch.float32):
                 assert torch.equal(msq.qlinear.qlinear(x, P, b, od), msq.qlinear.qlinear(x.to(torch.bfloat16), P, b, od)), (M, N, fo, layout)
+
+
+def test_vector_ops_fast_rounding_equals_generic(msq):
+    """The bfloat16 / nearest kernels round with two integer instructions between exact roundings at the loads and the store
+    (csrc/msq_vec.hip Qmid16 / Qin16 / Qout16, v_rcp_f32 for 1 / phi): bit for bit what the run-time-parameter kernels (element codec
+    at every step, IEEE division; MSQ_VEC_GENERIC=1) give, on every bfloat16 pattern, on fp32 values off the grid, NaNs with low
+    payloads, subnormals, zeros of both signs."""
+    specs = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32,
+                                         "bfloat": 16, "custom_cuda": True})
+    g = torch.Generator().manual_seed(77)
+    allbf = (torch.arange(65536, dtype=torch.int64) << 16).to(torch.int32).view(torch.float32)
+    rnd = torch.randint(-2**31, 2**31 - 1, (1 << 20,), generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    near = torch.randn(1 << 20, generator=g) * torch.tensor([1e-3, 1.0, 30.0, 90.0]).repeat(1 << 18)
+    special = torch.tensor([0x7F800001, 0x7FFFFFFF, 0xFF800001, 0x7FC00000, 0x80000000, 0x00000001, 0x80000001, 0x00007FFF, 0x80007FFF,
+                            0x80008000, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F7F8000, 0x7F800000, 0xFF800000], dtype=torch.int64).to(torch.int32).view(torch.float32)
+    x = torch.cat([allbf, rnd, near, special]).to(dev())
+    x = torch.cat([x, torch.zeros((-x.numel()) % 4096, device=dev())])
+    y = x.flip(0).contiguous()
+
+    def same(a, b):
+        na, nb = torch.isnan(a), torch.isnan(b)
+        return bool(torch.equal(na, nb)) and bool(torch.equal(a.view(torch.int32)[~na], b.view(torch.int32)[~nb]))
+
+    def both(fn):
+        os.environ.pop("MSQ_VEC_GENERIC", None)
+        fast = fn()
+        os.environ["MSQ_VEC_GENERIC"] = "1"
+        try:
+            gen = fn()
+        finally:
+            os.environ.pop("MSQ_VEC_GENERIC", None)
+        return fast, gen
+
+    for fo in (False, True):
+        a, b = both(lambda: msq.vector_ops.gelu(x, mx_specs=specs, first_order_gelu=fo))
+        assert same(a, b), ("gelu", fo, int((a.view(torch.int32) != b.view(torch.int32)).sum()))
+    a, b = both(lambda: msq.vector_ops.simd_add(x, y, mx_specs=specs))
+    assert same(a, b), "add"
+    a, b = both(lambda: msq.vector_ops.simd_add(x, 1.5, mx_specs=specs))
+    assert same(a, b), "add scalar"
+    for H in (512, 4096, 8192):
+        fin = x[torch.isfinite(x) & (x.abs() < 1e18)]
+        rows = fin[: (fin.numel() // H) * H].reshape(-1, H).clone()
+        rows[1::2] = torch.randn(rows[1::2].shape, device=dev()) * 3 + 0.5          # ordinary activations on every other row
+        rows[3, :7] = torch.tensor([float("nan"), 0.0, -0.0, 1e-40, -1e-40, 3e38, -3e38], device=dev())
+        rows[5] = 0.0                                                                # zero variance: 1 / sqrt(eps)
+        w = torch.randn(H, device=dev()); w[:4] = torch.tensor([0.0, -0.0, 1e-39, float("nan")], device=dev())
+        bias = torch.randn(H, device=dev()); bias[:3] = torch.tensor([-0.0, 0.0, -1e-41], device=dev())
+        for eps in (1e-12, 1e-5, 0.0):
+            a, b = both(lambda: msq.vector_ops.layer_norm(rows, w, bias, eps, specs))
+            assert same(a, b), ("layernorm", H, eps, int((a.view(torch.int32) != b.view(torch.int32)).sum()))
