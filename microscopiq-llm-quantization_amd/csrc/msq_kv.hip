@@ -48,6 +48,107 @@ MSQ_D float kv_codec(float x, float mn, float scale) {
     return v * scale + mn;                               // :30 / :61 (two roundings: compiled with -ffp-contract=off)
 }
 
+// The same value without the IEEE division in the common case.  t = (x - mn) * rcp(scale) is within levels * 2^-22 of the
+// quotient the reference rounds (v_rcp_f32: one ulp, the product: half an ulp, the IEEE quotient itself: half an ulp; x - mn <=
+// levels * scale), so round(t) is the reference's integer unless t lies within thr = levels * 2^-21 of k + 1/2: those elements,
+// and every group whose scale is zero, subnormal, huge or NaN (constant groups: 0 / 0; NaN / Inf members), go through kv_codec.
+// x - mn >= +0 in the fast case (mn is the group's minimum and no member is NaN): the relu is the identity there.
+struct KvG { float mn, scale, r, thr; bool fast; };
+MSQ_D KvG kv_group(float mx, float mn, float levels) {
+    KvG g;
+    g.mn = mn; g.scale = (mx - mn) / levels;                       // :26 / :57
+    g.fast = g.scale > 1e-30f && g.scale < 1e30f;
+    g.r = __builtin_amdgcn_rcpf(g.scale);
+    g.thr = levels * 4.76837158203125e-07f;
+    return g;
+}
+template <int N>
+MSQ_D void kv_codec_n(const float* x, float* y, const KvG& g) {
+    float v[N];
+    bool redo = !g.fast;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float t = (x[k] - g.mn) * g.r;
+        v[k] = __builtin_rintf(t);
+        redo |= __builtin_fabsf(__builtin_fabsf(t - v[k]) - 0.5f) < g.thr;
+    }
+    if (redo) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], g.mn, g.scale);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) y[k] = v[k] * g.scale + g.mn;
+    }
+}
+// one group per element (channel groups: a lane's N channels)
+template <int N>
+MSQ_D void kv_codec_each(const float* x, float* y, const KvG* g) {
+    float v[N];
+    bool redo = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float t = (x[k] - g[k].mn) * g[k].r;
+        v[k] = __builtin_rintf(t);
+        redo |= !g[k].fast | (__builtin_fabsf(__builtin_fabsf(t - v[k]) - 0.5f) < g[k].thr);
+    }
+    if (redo) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], g[k].mn, g[k].scale);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) y[k] = v[k] * g[k].scale + g[k].mn;
+    }
+}
+// min / max of a lane's own elements: plain v_max / v_min and a NaN flag (torch.max / torch.min propagate NaN: mm_done)
+struct MinMax { float mx, mn; bool nan; };
+MSQ_D MinMax mm_init() { return MinMax{-__builtin_inff(), __builtin_inff(), false}; }
+MSQ_D void mm_acc(MinMax& m, float x) { m.mx = x > m.mx ? x : m.mx; m.mn = x < m.mn ? x : m.mn; m.nan |= (x != x); }
+MSQ_D void mm_done(MinMax& m) { if (m.nan) { m.mx = u2f(0x7FC00000u); m.mn = u2f(0x7FC00000u); } }
+
+// the same on raw half-precision pairs: packed min / max (two entries per instruction, no conversion) and the largest magnitude
+// pattern, which exceeds Inf's exactly when a NaN was seen
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef uint16_t us2_t __attribute__((ext_vector_type(2)));
+struct MinMaxH { uint32_t mx, mn, mag; };
+MSQ_D MinMaxH mmh_init() { return MinMaxH{0xFC00FC00u, 0x7C007C00u, 0u}; }
+MSQ_D void mmh_acc(MinMaxH& m, uint32_t w) {
+    uint32_t a, b;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(a) : "v"(m.mx), "v"(w));
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(b) : "v"(m.mn), "v"(w));
+    m.mx = a; m.mn = b;
+    m.mag = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, m.mag), __builtin_bit_cast(us2_t, w & 0x7FFF7FFFu)));
+}
+MSQ_D MinMax mmh_done(const MinMaxH& m) {
+    const float a = (float)__builtin_bit_cast(_Float16, (uint16_t)(m.mx & 0xFFFFu)), b = (float)__builtin_bit_cast(_Float16, (uint16_t)(m.mx >> 16));
+    const float c = (float)__builtin_bit_cast(_Float16, (uint16_t)(m.mn & 0xFFFFu)), d = (float)__builtin_bit_cast(_Float16, (uint16_t)(m.mn >> 16));
+    MinMax r;
+    r.mx = a > b ? a : b; r.mn = c < d ? c : d;
+    r.nan = ((m.mag & 0xFFFFu) > 0x7C00u) | ((m.mag >> 16) > 0x7C00u);
+    mm_done(r);
+    return r;
+}
+template <int DT> MSQ_D MinMax minmax_chunk(const uint4& raw) {       // one 16-byte chunk
+    if constexpr (DT == 1) {
+        MinMaxH h = mmh_init();
+        mmh_acc(h, raw.x); mmh_acc(h, raw.y); mmh_acc(h, raw.z); mmh_acc(h, raw.w);
+        return mmh_done(h);
+    } else {
+        constexpr int N = DT == 0 ? 4 : 8;
+        float x[N];
+        MinMax m = mm_init();
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        if (DT == 0) { x[0] = u2f(w[0]); x[1] = u2f(w[1]); x[2] = u2f(w[2]); x[3] = u2f(w[3]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[2 * k] = u2f(w[k] << 16); x[2 * k + 1] = u2f(w[k] & 0xFFFF0000u); }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) mm_acc(m, x[k]);
+        mm_done(m);
+        return m;
+    }
+}
+
 // ---- groups along head.dim of one token.  A lane owns V = 8 consecutive head.dim entries (16 bytes of a half-precision
 // cache: one dwordx4 access; two for f32), LPG lanes share a group (LPG = gs / 8 rounded up to a power of two, at most 64;
 // longer groups loop), groups packed 64 / LPG per wave.  hd = g * gs + i -> address ((b * H + hd / D) * S + s) * D + hd % D;
@@ -196,22 +297,22 @@ k_kv_token_fast(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t 
         const uint32_t b = fdiv(row, sdiv), s = row - b * sdiv.d;
         const uint32_t a = ((b * H + h) * S + s) * dc.d + dv;          // in 16-byte chunks
         float x[N];
-        float mx = -__builtin_inff(), mn = __builtin_inff();
+        MinMax m = mm_init();
         if (live) {
-            unpack16<DT>(in[a], x);
-#pragma unroll
-            for (int k = 0; k < N; ++k) { mx = nmax(mx, x[k]); mn = nmin(mn, x[k]); }
+            const uint4 raw = in[a];
+            unpack16<DT>(raw, x);
+            m = minmax_chunk<DT>(raw);
         }
+        float mx = m.mx, mn = m.mn;
 #pragma unroll
         for (int o = 1; o < LPG; o <<= 1) {
             mx = nmax(mx, __shfl_xor(mx, o, 64));
             mn = nmin(mn, __shfl_xor(mn, o, 64));
         }
         if (live) {
-            const float scale = (mx - mn) / levels;                    // :26
+            const KvG g = kv_group(mx, mn, levels);
             float y[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn, scale);
+            kv_codec_n<N>(x, y, g);
             out[a] = pack16<DT>(y);
         }
     }
@@ -230,9 +331,9 @@ k_kv_channel_fast(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_
     const uint32_t bh = fdiv(u, ng), g = u - bh * ng.d;
     const uint32_t base = (bh * S + g * gs) * dc.d + dv;
     uint4 raw[32];
-    float mx[N], mn[N];
+    MinMax m[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) { mx[k] = -__builtin_inff(); mn[k] = __builtin_inff(); }
+    for (int k = 0; k < N; ++k) m[k] = mm_init();
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         raw[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -244,19 +345,18 @@ k_kv_channel_fast(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_
             float x[N];
             unpack16<DT>(raw[i], x);
 #pragma unroll
-            for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], x[k]); mn[k] = nmin(mn[k], x[k]); }
+            for (int k = 0; k < N; ++k) mm_acc(m[k], x[k]);
         }
     }
-    float scale[N];
+    KvG kg[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) scale[k] = (mx[k] - mn[k]) / levels;  // :57
+    for (int k = 0; k < N; ++k) { mm_done(m[k]); kg[k] = kv_group(m[k].mx, m[k].mn, levels); }
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         if ((uint32_t)i < gs) {
             float x[N], y[N];
             unpack16<DT>(raw[i], x);
-#pragma unroll
-            for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn[k], scale[k]);
+            kv_codec_each<N>(x, y, kg);
             out[base + (uint32_t)i * dc.d] = pack16<DT>(y);
         }
     }
@@ -278,18 +378,23 @@ k_kv_channel_fast8(const uint4* __restrict__ in, uint4* __restrict__ out, uint32
     const uint32_t base = (bh * S + g * (8u * LG) + j * 8u) * dc.d + dv;
     uint4 raw[8];
     float mx[N], mn[N];
+    {
+        MinMax m[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) { mx[k] = -__builtin_inff(); mn[k] = __builtin_inff(); }
-    if (live) {
+        for (int k = 0; k < N; ++k) m[k] = mm_init();
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) raw[i] = in[base + (uint32_t)i * dc.d];
+            for (int i = 0; i < 8; ++i) raw[i] = in[base + (uint32_t)i * dc.d];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float x[N];
-            unpack16<DT>(raw[i], x);
+            for (int i = 0; i < 8; ++i) {
+                float x[N];
+                unpack16<DT>(raw[i], x);
 #pragma unroll
-            for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], x[k]); mn[k] = nmin(mn[k], x[k]); }
+                for (int k = 0; k < N; ++k) mm_acc(m[k], x[k]);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < N; ++k) { mm_done(m[k]); mx[k] = m[k].mx; mn[k] = m[k].mn; }
     }
 #pragma unroll
     for (int o = 1; o < LG; o <<= 1) {
@@ -297,16 +402,70 @@ k_kv_channel_fast8(const uint4* __restrict__ in, uint4* __restrict__ out, uint32
         for (int k = 0; k < N; ++k) { mx[k] = nmax(mx[k], __shfl_xor(mx[k], o, 64)); mn[k] = nmin(mn[k], __shfl_xor(mn[k], o, 64)); }
     }
     if (!live) return;
-    float scale[N];
+    KvG kg[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) scale[k] = (mx[k] - mn[k]) / levels;  // :57
+    for (int k = 0; k < N; ++k) kg[k] = kv_group(mx[k], mn[k], levels);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float x[N], y[N];
         unpack16<DT>(raw[i], x);
-#pragma unroll
-        for (int k = 0; k < N; ++k) y[k] = kv_codec(x[k], mn[k], scale[k]);
+        kv_codec_each<N>(x, y, kg);
         out[base + (uint32_t)i * dc.d] = pack16<DT>(y);
+    }
+}
+
+// groups of exactly 64 * N * NIT entries along head.dim of one token (the whole token of a Llama-2-7B cache: 4096 = 64 * 8 * 8
+// half values): one wave per group, NIT 16-byte chunks per lane kept raw in registers between the min / max scan and the
+// quantisation, 32-bit index arithmetic.  chunk cr of token (b, s) -> head cr / DC, offset cr % DC.
+template <int DT, int NIT>
+__global__ void __launch_bounds__(256)
+k_kv_token_wide(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t ngroups, uint32_t H, uint32_t S, FastDiv gpt, FastDiv dc,
+                FastDiv sdiv, float levels) {
+    constexpr int N = Chunk<DT>::N;
+    const uint32_t grp = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (grp >= ngroups) return;                                       // whole waves
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = fdiv(grp, gpt), gi = grp - row * gpt.d;
+    const uint32_t b = fdiv(row, sdiv), s = row - b * sdiv.d;
+    uint4 raw[NIT];
+    uint32_t a[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const uint32_t cr = gi * (64u * NIT) + (uint32_t)i * 64u + lane;
+        const uint32_t h = fdiv(cr, dc), dv = cr - h * dc.d;
+        a[i] = ((b * H + h) * S + s) * dc.d + dv;
+        raw[i] = in[a[i]];
+    }
+    MinMax m;
+    if constexpr (DT == 1) {
+        MinMaxH h = mmh_init();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) { mmh_acc(h, raw[i].x); mmh_acc(h, raw[i].y); mmh_acc(h, raw[i].z); mmh_acc(h, raw[i].w); }
+        m = mmh_done(h);
+    } else {
+        m = mm_init();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            float x[N];
+            unpack16<DT>(raw[i], x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) mm_acc(m, x[k]);
+        }
+        mm_done(m);
+    }
+    float mx = m.mx, mn = m.mn;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        mx = nmax(mx, __shfl_xor(mx, o, 64));
+        mn = nmin(mn, __shfl_xor(mn, o, 64));
+    }
+    const KvG g = kv_group(mx, mn, levels);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        float x[N], y[N];
+        unpack16<DT>(raw[i], x);
+        kv_codec_n<N>(x, y, g);
+        out[a[i]] = pack16<DT>(y);
     }
 }
 
@@ -391,6 +550,23 @@ int msq_kv_group_quant(const void* in, void* out, int dtype, int64_t B, int64_t 
                 if (dtype == 0) MSQ_KVFL(0); else if (dtype == 1) MSQ_KVFL(1); else MSQ_KVFL(2);
 #undef MSQ_KVFL
 #undef MSQ_KVF
+                return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
+            }
+        }
+        {
+            const int cn = dtype == 0 ? 4 : 8;
+            const bool al = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+            const int64_t nit = group_size / (64 * cn);
+            if (al && D % cn == 0 && group_size == nit * 64 * cn && (nit == 2 || nit == 4 || nit == 8 || nit == 16) &&
+                B * H * S * D / cn < (int64_t)0x7FFFFFFF) {
+                const uint32_t ngroups = (uint32_t)(B * S * ((H * D) / group_size));
+                const FastDiv fgpt = make_fastdiv((uint32_t)((H * D) / group_size)), fdc = make_fastdiv((uint32_t)(D / cn)), fs = make_fastdiv((uint32_t)S);
+                const dim3 grid((ngroups + 3u) / 4u), blk(256);
+#define MSQ_KVW(DTV, NI) hipLaunchKernelGGL((k_kv_token_wide<DTV, NI>), grid, blk, 0, st, (const uint4*)in, (uint4*)out, ngroups, (uint32_t)H, (uint32_t)S, fgpt, fdc, fs, levels)
+#define MSQ_KVWL(DTV) do { switch ((int)nit) { case 2: MSQ_KVW(DTV, 2); break; case 4: MSQ_KVW(DTV, 4); break; case 8: MSQ_KVW(DTV, 8); break; default: MSQ_KVW(DTV, 16); break; } } while (0)
+                if (dtype == 0) MSQ_KVWL(0); else if (dtype == 1) MSQ_KVWL(1); else MSQ_KVWL(2);
+#undef MSQ_KVWL
+#undef MSQ_KVW
                 return hipGetLastError() == hipSuccess ? MSQ_OK : kv_fail(MSQ_ERR_LAUNCH, "msq_kv_group_quant: launch failed");
             }
         }

@@ -524,3 +524,36 @@ def test_vector_ops_fast_rounding_equals_generic(msq):
         for eps in (1e-12, 1e-5, 0.0):
             a, b = both(lambda: msq.vector_ops.layer_norm(rows, w, bias, eps, specs))
             assert same(a, b), ("layernorm", H, eps, int((a.view(torch.int32) != b.view(torch.int32)).sum()))
+
+
+@pytest.mark.parametrize("dn", ["float32", "float16", "bfloat16"])
+def test_kv_group_quant_division_free_path_is_exact(msq, O, dn):
+    """The group quantiser multiplies by v_rcp_f32(scale) and re-does, with the IEEE division, every chunk in which a value lands
+    within levels * 2^-21 of a rounding boundary (csrc/msq_kv.hip kv_codec_n): identical to the oracle on data BUILT to sit on the
+    boundaries (x = mn + scale * (k + 1/2) * (1 +- a few ulp)), on constant / NaN / Inf groups, for every kernel form (groups of 32,
+    128 and whole-token 4096 along head.dim; 32, 64, 128 tokens of a channel) and 1 ... 8 (and 16) bits."""
+    dt = getattr(torch, dn)
+    g = torch.Generator().manual_seed(5)
+    B, H, S, D = 1, 32, 256, 128
+    for bits in (1, 2, 3, 4, 8, 16):
+        L = float(2 ** bits - 1)
+        base = torch.randn(B, H, S, D, generator=g) * 0.7
+        # boundary data: per element k + 1/2 (k < levels) scaled into [a, a + L * sc], nudged by -2 ... 2 ulp
+        a = torch.randn(B, H, S, 1, generator=g); sc = torch.rand(B, H, S, 1, generator=g) * 0.3 + 0.01
+        k = torch.randint(0, int(min(L, 1 << 20)), (B, H, S, D), generator=g).float()
+        xb = a + sc * (k + 0.5)
+        xb = (xb.view(torch.int32) + torch.randint(-2, 3, xb.shape, generator=g, dtype=torch.int32)).view(torch.float32)
+        xb[..., 0] = a[..., 0]; xb[..., 1] = (a + sc * L)[..., 0]                       # the group's min and max (groups along head.dim)
+        x = torch.where(torch.rand(B, H, S, 1, generator=g) < 0.5, xb, base)
+        x[0, 0, 0, :] = 1.25                                                            # constant group: 0 / 0
+        x[0, 1, 1, 5] = float("nan"); x[0, 2, 2, 9] = float("inf"); x[0, 3, 3, 11] = -float("inf")
+        x[0, 4, 4, :] = 0.0; x[0, 5, 5, :64] = 1e-38; x[0, 5, 5, 64:] = 3e-38           # scale in the subnormal range
+        x = x.to(dt)
+        xd = x.to(dev())
+        xf = x.float().numpy()
+        for along, gs in ((False, 32), (False, 128), (False, 4096), (False, 1024), (True, 32), (True, 64), (True, 128), (True, 8)):
+            f = (msq.kvcache.fake_groupwise_channel_asymmetric_quantization_new if along else msq.kvcache.fake_groupwise_token_asymmetric_quantization)
+            y = f(xd, bits, gs).float().cpu().numpy()
+            ref = O.kv_group_quant(xf, bits, gs, along, dn)
+            same = (y == ref) | (np.isnan(y) & np.isnan(ref))
+            assert same.all(), (dn, bits, along, gs, int((~same).sum()))
