@@ -388,17 +388,8 @@ def e2e_main(args, dev):
         return (time.perf_counter() - t0) / n
 
     def decode(m, T):
-        times = []
-        with torch.no_grad():
-            past = None
-            for i in range(T):
-                torch.cuda.synchronize()
-                tick = time.perf_counter()
-                out = m(ids[:, i:i + 1], past_key_values=past, use_cache=True)
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - tick)
-                past = out.past_key_values
-        return float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
+        from msq.harness.benchmark import benchmark       # the harness's per-token loop (llm/opt.py:332-376)
+        return benchmark(m, ids[:, :T], dev=dev, log=lambda *a: None, skip=2 if T > 4 else 0)["median"]
 
     def linear_stack_graph(m, rows=1):
         """the seven Linears of every decoder layer at M = rows (through the public modules, fused slices included), one HIP graph"""

@@ -12,6 +12,7 @@
 //                (msq_pack_unified.hip); every code is decoded back and compared: MSQ_STATUS_INEXACT otherwise.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/msq.h"
 #include "msq_device.h"
@@ -255,6 +256,56 @@ k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t
     if (status && status_flag) atomicOr(status_flag, status);
 }
 
+// Activations (MODE 0 of k_mx_pack: e4m3 codes row-major + one scale byte per block), one lane per EIGHT consecutive values:
+// four neighbouring lanes hold a block, its largest exponent crosses them by two quad permutes, every lane converts its own
+// eight values and stores 8 bytes -- 32-byte loads, 8-byte stores, no LDS transpose.  Same scale rule, same converts, same
+// flags as k_mx_pack<0> (tests/test_gpu_round3.py::test_mx_act_pack_vec_equals_block_kernel).
+template <bool XBF16>
+__global__ void __launch_bounds__(256)
+k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t n8, int flush,
+                 int* status_flag) {
+    typedef short v2s_t __attribute__((ext_vector_type(2)));
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;                                         // n8 is a multiple of 4: quads are never split
+    float a[8];
+    if (XBF16) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        a[0] = u2f(v.x << 16); a[1] = u2f(v.x & 0xFFFF0000u); a[2] = u2f(v.y << 16); a[3] = u2f(v.y & 0xFFFF0000u);
+        a[4] = u2f(v.z << 16); a[5] = u2f(v.z & 0xFFFF0000u); a[6] = u2f(v.w << 16); a[7] = u2f(v.w & 0xFFFF0000u);
+    } else {
+        const float4 v0 = reinterpret_cast<const float4*>(src)[2 * i], v1 = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    }
+    uint32_t mag = 0u;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { const uint32_t t = f2u(a[b]) & 0x7F800000u; mag = t > mag ? t : mag; }
+    {
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+        mag = o1 > mag ? o1 : mag;
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+        mag = o2 > mag ? o2 : mag;
+    }
+    const int se = (int)(mag >> 23);
+    int status = 0;
+    const bool fl = (se == 0) && flush;
+    const int sb = mx_scale_byte(se, 8, status);
+    const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
+    const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
+    uint32_t cw[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | 1u), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | 1u);
+        x0 = __builtin_amdgcn_fmed3f(x0, -bound, bound); x1 = __builtin_amdgcn_fmed3f(x1, -bound, bound);   // e4m3 does not saturate
+        v2s_t cur = __builtin_bit_cast(v2s_t, (p & 1) ? cw[p >> 1] : 0u);
+        if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, false);
+        else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, true);
+        cw[p >> 1] = __builtin_bit_cast(uint32_t, cur);
+    }
+    reinterpret_cast<uint2*>(codes)[i] = make_uint2(cw[0], cw[1]);
+    if ((threadIdx.x & 3) == 0) scales[i >> 2] = (uint8_t)sb;
+    if (status && status_flag) atomicOr(status_flag, status);
+}
+
 }  // namespace
 
 extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
@@ -264,6 +315,10 @@ extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* st
     if (K % 128) { msq_set_error_("msq_mx_pack_a8: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
+    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
+        hipLaunchKernelGGL((k_mx_pack_a8_vec<false>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const void*)X,
+                           (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
+    else
     hipLaunchKernelGGL((k_mx_pack<0>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                        (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();
@@ -336,6 +391,10 @@ extern "C" int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int
     if (K % 128) { msq_set_error_("msq_mx_pack_a8_bf16: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
+    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
+        hipLaunchKernelGGL((k_mx_pack_a8_vec<true>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+                           (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
+    else
     hipLaunchKernelGGL((k_mx_pack<0, true>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)X,
                        (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
     const hipError_t e = hipGetLastError();

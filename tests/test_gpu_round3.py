@@ -557,3 +557,56 @@ def test_kv_group_quant_division_free_path_is_exact(msq, O, dn):
             ref = O.kv_group_quant(xf, bits, gs, along, dn)
             same = (y == ref) | (np.isnan(y) & np.isnan(ref))
             assert same.all(), (dn, bits, along, gs, int((~same).sum()))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mx_act_pack_vec_equals_block_kernel(msq, dt):
+    """The activation packer of the MX path (one lane per eight values, csrc/msq_mx.hip k_mx_pack_a8_vec) writes the codes, scale
+    bytes and status flags of the lane-per-block kernel (MSQ_MX_PACK_BLOCK=1), which the oracle tests pin: random rows, huge and
+    tiny blocks, zeros, fp32 subnormals with and without flushing, Inf / NaN blocks."""
+    from msq._lib import lib, ptr, current_stream
+    torch.manual_seed(61)
+    M, K = 333, 1024
+    x = torch.randn(M, K, device=dev()) * torch.exp(torch.randn(M, 1, device=dev()) * 4)
+    x[0] = 0.0; x[1, :32] = 1e-41; x[2, 32:64] = 3e38; x[3, 5] = float("inf"); x[4, 70] = float("nan"); x[5, :64] = -0.0
+    x[6, :32] = torch.linspace(-500, 500, 32, device=dev()); x[7, 64:96] = 2.0 ** -130
+    x = x.to(dt).contiguous()
+    fn = lib().msq_mx_pack_a8_bf16 if dt == torch.bfloat16 else lib().msq_mx_pack_a8
+
+    def run(flush):
+        codes = torch.zeros(M, K, dtype=torch.uint8, device=dev()); scales = torch.zeros(M, K // 32, dtype=torch.uint8, device=dev())
+        st = torch.zeros(1, dtype=torch.int32, device=dev())
+        assert fn(ptr(x), ptr(codes), ptr(scales), ptr(st), M, K, flush, current_stream(dev())) == 0
+        torch.cuda.synchronize()
+        return codes, scales, int(st.item())
+
+    for flush in (0, 1):
+        os.environ.pop("MSQ_MX_PACK_BLOCK", None)
+        a = run(flush)
+        os.environ["MSQ_MX_PACK_BLOCK"] = "1"
+        try:
+            b = run(flush)
+        finally:
+            os.environ.pop("MSQ_MX_PACK_BLOCK", None)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2], (dt, flush)
+
+
+def test_harness_benchmark_per_token_latency_and_ppl(msq):
+    """harness.benchmark (llm/opt.py:332-376): one token at a time with the KV cache, median latency, PPL with check=True -- on a
+    packed tiny Llama the per-token PPL equals the PPL of one full forward over the same tokens (same logits up to fp16 attention
+    order), and the fused projections keep working with a growing cache."""
+    from msq.harness.benchmark import benchmark
+    from msq.harness.evalppl import LLAMA_FUSE, pack_layers, quantize_layers_nearest
+    torch.manual_seed(3)
+    m = _tiny_llama(torch.float16).to(dev())
+    quantize_layers_nearest(m.model.layers, dev(), dict(inlier_elem_format="fp4_e2m1", outlier_elem_format="fp8_e4m3", axes=[-1], block_size=32))
+    n, kept = pack_layers(m.model.layers, fuse=LLAMA_FUSE)
+    assert n > 0 and kept == 0
+    ids = torch.randint(0, m.config.vocab_size, (1, 24), generator=torch.Generator().manual_seed(4))
+    lines = []
+    r = benchmark(m, ids, check=True, log=lambda *a: lines.append(a))
+    assert len(r["times"]) == 24 and r["median"] > 0 and lines[0] == ('Benchmarking ...',) and lines[-2][0] == 'Median:' and lines[-1][0] == 'PPL:'
+    with torch.no_grad():
+        lg = m(ids.to(dev())).logits[0, :-1].float()
+    ref = torch.exp(torch.nn.functional.cross_entropy(lg, ids[0, 1:].to(dev()))).item()
+    assert abs(r["ppl"] - ref) / ref < 2e-2, (r["ppl"], ref)
