@@ -1279,6 +1279,131 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// Decode kernel of the unified layouts (MSQ-U1 / U1X) for the wide projections (more than 128 strips of 64 columns), single
+// launch: one block = one strip over ALL of K, its WAVES waves take consecutive runs of kc tiles and meet in LDS.  What changed
+// against k_qgemv<..., 16> (measured with COLD weights, scripts/experiments/decode_cold.py: a graph that replays ONE weight
+// streams it from the Infinity Cache and hides all of this):
+//  * WAVES = 8 blocks run two per CU: the 344 strips of the fused gate / up projection are resident at once instead of taking a
+//    second, quarter-full round of sixteen-wave blocks (31.2 -> 27.0 us at M = 1);
+//  * any K (a wave's run is as long as it has to be);
+//  * the hand-over is summed by all waves (wave w owns results w, w + WAVES, ...; fixed order over the k-runs: bit-identical
+//    run to run), not by wave 0 alone;
+//  * XPF: the activation fragments of the next tile are requested one tile ahead (M > 1: sixteen different rows, an exposed L2
+//    round trip per tile otherwise).
+// Per tile a wave loads four code slots (16 B per lane), the scale pair and, for U1X, two extension dwords; three tiles in flight.
+// Half strips over all of K for the 4096-wide projections (128 blocks) were built and measured slower than the split-K planes
+// of k_qgemv (down projection 14.7 -> 17.3 us): a CU keeps only so many bytes in flight, 128 CUs cannot pull what 256 can.
+// ---------------------------------------------------------------------------
+template <int OUT_KIND, int MG, int WAVES, bool XPF>
+__global__ void __launch_bounds__(64 * WAVES)
+k_qgemv_u(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane, const uint8_t* __restrict__ code_plane,
+          const uint8_t* __restrict__ scl_plane, int M, int N, int K, int kc, const float* __restrict__ bias, void* __restrict__ Y,
+          int y_kind, int x_f16) {
+    constexpr bool EXT = (OUT_KIND == MSQ_PLANE_U8X);
+    constexpr int NFB = 4;                                       // 16-column fragments per block
+    constexpr int R = MG * NFB * 4;                              // results per lane
+    extern __shared__ __attribute__((aligned(16))) char smem_u[];
+    float (*red)[R][64] = reinterpret_cast<float (*)[R][64]>(smem_u);          // [WAVES][R][64]
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int KT = K / TILE_K;
+    const int strip = blockIdx.x;
+    const int kt_lo = wid * kc < KT ? wid * kc : KT;
+    const int kt_hi = (kt_lo + kc < KT) ? kt_lo + kc : KT;
+    const int64_t tile_row = (int64_t)strip * KT;
+
+    f32x4_t acc[NFB][MG];
+#pragma unroll
+    for (int i = 0; i < NFB; ++i)
+#pragma unroll
+        for (int j = 0; j < MG; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint16_t* xrow[MG];
+#pragma unroll
+    for (int j = 0; j < MG; ++j) { int m = j * 16 + c; m = m < M ? m : M - 1; xrow[j] = X + (int64_t)m * K + g * 8; }
+
+    struct UT { u32x4_t code[2][2]; uint32_t scl[2]; uint32_t ext[2]; };
+    struct XF { u32x4_t v[2][MG]; };
+    auto load_u = [&](UT& t, int kt) {
+        const int64_t tile = tile_row + kt;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                t.code[kf][p] = *reinterpret_cast<const u32x4_t*>(code_plane + ((tile * 4 + kf * 2 + p) * 64 + lane) * 16);
+        const uint2 sc = *reinterpret_cast<const uint2*>(scl_plane + (tile * 16 + c) * 8);
+        t.scl[0] = sc.x; t.scl[1] = sc.y;
+        if (EXT) {
+            t.ext[0] = *reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 0) * 64 + lane) * 4);
+            t.ext[1] = *reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 1) * 64 + lane) * 4);
+        }
+    };
+    auto load_x = [&](XF& x, int kt) {
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int j = 0; j < MG; ++j) x.v[kf][j] = *reinterpret_cast<const u32x4_t*>(xrow[j] + (int64_t)kt * TILE_K + kf * 32);
+    };
+    UT cur, nxt, nx2;
+    XF xc, xn;
+    const int kt_safe = kt_lo < KT ? kt_lo : KT - 1;
+    load_u(cur, kt_safe);
+    if (XPF) load_x(xc, kt_safe);
+    load_u(nxt, (kt_lo + 1 < kt_hi) ? kt_lo + 1 : kt_safe);
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        load_u(nx2, (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1);
+        if (XPF) load_x(xn, (kt + 1 < kt_hi) ? kt + 1 : kt);
+        else load_x(xc, kt);
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+            bf16x8_t xf[MG];
+#pragma unroll
+            for (int j = 0; j < MG; ++j) {
+                if (x_f16) {     // fp16 activations: half -> float (exact) -> bf16 (RNE) = x.to(bfloat16), no cast launch
+                    union { u32x4_t u; _Float16 h[8]; } r;
+                    r.u = xc.v[kf][j];
+                    bf16x8_t t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (__bf16)(float)r.h[e];
+                    xf[j] = t;
+                } else xf[j] = __builtin_bit_cast(bf16x8_t, xc.v[kf][j]);
+            }
+#pragma unroll
+            for (int nf = 0; nf < NFB; ++nf) {
+                const u32x4_t o = cur.code[kf][nf >> 1];
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, dequant_frag_unified<OUT_KIND>(o[(nf & 1) * 2], o[(nf & 1) * 2 + 1],
+                                                                                               scale_operand(cur.scl[kf], nf), cur.ext[kf], nf));
+#pragma unroll
+                for (int j = 0; j < MG; ++j)
+                    acc[nf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[j], acc[nf][j], 0, 0, 0);
+            }
+        }
+        cur = nxt; nxt = nx2;
+        if (XPF) xc = xn;
+    }
+    // hand-over: every wave leaves its partial results, wave w sums results w, w + WAVES, ... over the k-runs in order
+#pragma unroll
+    for (int j = 0; j < MG; ++j)
+#pragma unroll
+        for (int nf = 0; nf < NFB; ++nf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wid][(j * NFB + nf) * 4 + e][lane] = acc[nf][j][e];
+    __syncthreads();
+    for (int r = wid; r < R; r += WAVES) {
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        const int e = r & 3, nf = (r >> 2) % NFB, j = (r >> 2) / NFB;
+        const int m = j * 16 + c;
+        if (m >= M) continue;
+        const int n = strip * TILE_N + nf * 16 + g * 4 + e;      // D[n = 4 g + e][m = c]
+        if (bias) t += bias[n];
+        if (y_kind == 0) reinterpret_cast<float*>(Y)[(int64_t)m * N + n] = t;
+        else if (y_kind == 2) reinterpret_cast<uint16_t*>(Y)[(int64_t)m * N + n] = __builtin_bit_cast(uint16_t, (_Float16)t);
+        else reinterpret_cast<uint16_t*>(Y)[(int64_t)m * N + n] = __builtin_bit_cast(uint16_t, (__bf16)t);
+    }
+}
+
 // sum of the split-K partial tiles (+ bias) -> Y.  The grids are tiny at decode sizes (M N / 1024 workgroups), so
 // the kernel is one load round trip long only if all planes are requested before the first add: the loads are
 // issued 8 at a time, the sum keeps the k order.
@@ -1687,6 +1812,31 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
         const int kcd = unified ? direct_kc(M, N, K) : 0;                // > 0: one block of 16 waves covers all of K
         const int kc = kcd ? kcd : pick_kc(N, K);
         const int nks = kcd ? 1 : (int)(((K / BK + kc - 1) / kc + 3) / 4);    // partial planes: one per four k-chunks
+        // unified layouts, M <= 32, more than 128 strips: the single-launch kernel (MSQ_GEMV_U=0: the earlier kernels, tuning only)
+        static const int gvu = [] { const char* e = getenv("MSQ_GEMV_U"); return e ? atoi(e) : 1; }();
+        if (gvu && mg <= 2 && N / TILE_N > 128 && in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
+            const int64_t strips = N / TILE_N, KTv = K / TILE_K;
+            // <= 256 strips: one sixteen-wave block per CU; more: eight-wave blocks, two per CU (MSQ_GEMV_U_WAVES=8 / 16 forces)
+            static const int fw = [] { const char* e = getenv("MSQ_GEMV_U_WAVES"); return e ? atoi(e) : 0; }();
+            const int wv = (fw == 8 || fw == 16) ? fw : (strips <= 256 ? 16 : 8);
+            const int kcu = (int)((KTv + wv - 1) / wv);
+            const dim3 ugrid((unsigned)strips);
+            const int yk = y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0);
+#define MSQ_GVU1(OK, MGV, WV, XP)                                                                                         \
+            do { static DevOnce once_;                                                                                   \
+                 const size_t l_ = (size_t)WV * MGV * 16 * 64 * 4;                                                        \
+                 if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv_u<OK, MGV, WV, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); attr_done(once_); } \
+                 hipLaunchKernelGGL((k_qgemv_u<OK, MGV, WV, XP>), ugrid, dim3(64 * WV), l_, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, \
+                                    (const uint8_t*)scale_plane, (int)M, (int)N, (int)K, kcu, bias, Y, yk, x_f16); } while (0)
+            // activation prefetch: from two rows on (one row: every lane reads the same line, an L1 hit), where the registers allow
+#define MSQ_GVU(OK) do { if (mg == 1) { if (wv == 16) { if (M > 1) MSQ_GVU1(OK, 1, 16, true); else MSQ_GVU1(OK, 1, 16, false); }   \
+                                        else { if (M > 1) MSQ_GVU1(OK, 1, 8, true); else MSQ_GVU1(OK, 1, 8, false); } }            \
+                         else { if (wv == 16) MSQ_GVU1(OK, 2, 16, false); else MSQ_GVU1(OK, 2, 8, false); } } while (0)
+            if (out_kind == MSQ_PLANE_U8) MSQ_GVU(MSQ_PLANE_U8); else MSQ_GVU(MSQ_PLANE_U8X);
+#undef MSQ_GVU
+#undef MSQ_GVU1
+            return check_launch2("msq_qlinear_bf16(decode, unified layouts)");
+        }
         if (kcd || (workspace && workspace_bytes >= (int64_t)nks * M * N * 4)) {
             const dim3 vgrid((unsigned)((N / TILE_N) * nks));
             const size_t ldsv = (size_t)((kcd ? 16 : 4) - 1) * 16 * mg * 64 * 4;

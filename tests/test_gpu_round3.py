@@ -610,3 +610,31 @@ def test_harness_benchmark_per_token_latency_and_ppl(msq):
         lg = m(ids.to(dev())).logits[0, :-1].float()
     ref = torch.exp(torch.nn.functional.cross_entropy(lg, ids[0, 1:].to(dev()))).item()
     assert abs(r["ppl"] - ref) / ref < 2e-2, (r["ppl"], ref)
+
+
+@pytest.mark.parametrize("N,K", [(8256, 512), (12288, 1024), (22016, 704), (16448, 11008 // 64 * 64 // 43)])
+def test_wide_projection_decode_kernel(msq, N, K):
+    """k_qgemv_u (unified layouts, more than 128 strips, one launch: sixteen-wave blocks up to 256 strips, eight-wave blocks two per
+    CU above; K-runs of any length, activation prefetch from two rows on, hand-over summed by all waves): equal to the dense product of
+    the unpacked weight with the bf16 activations in fp32 within the accumulation-order tolerance, bit-identical run to run, for one
+    and two row groups, every output dtype, with and without bias."""
+    K = max(64, K // 64 * 64)
+    torch.manual_seed(N + K)
+    W = _weights(N, K, 7).to(dev())
+    for fo in ("fp8_e4m3", "posit8_es1"):
+        P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+        Wd = msq.qlinear.unpack_weight(P, torch.float32)
+        for M in (1, 2, 16, 17, 32):
+            x = torch.randn(M, K, device=dev()).to(torch.bfloat16)
+            b = torch.randn(N, device=dev())
+            ref = x.float() @ Wd.t()
+            tol = 2e-5 * (x.float().abs() @ Wd.abs().t()) + 1e-6
+            for bias in (None, b):
+                y = msq.qlinear.qlinear(x, P, bias, torch.float32)
+                r = ref if bias is None else ref + bias
+                assert bool(((y - r).abs() <= tol).all()), (N, K, fo, M, float((y - r).abs().max()))
+                assert torch.equal(y, msq.qlinear.qlinear(x, P, bias, torch.float32))
+            y16 = msq.qlinear.qlinear(x, P, b, torch.float16)
+            ybf = msq.qlinear.qlinear(x, P, b, torch.bfloat16)
+            y32 = msq.qlinear.qlinear(x, P, b, torch.float32)
+            assert torch.equal(y16, y32.half()) and torch.equal(ybf, y32.to(torch.bfloat16))
