@@ -30,6 +30,28 @@ def t(fn, n=20, warm=30):
     return e0.elapsed_time(e1) / n
 
 
+def tg(fn, reps=10, n=20):
+    """device time per call without the Python / ctypes floor (~15 us): `reps` calls captured into one HIP graph, the replay timed"""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n / reps
+
+
 def synth(N, K):
     W = torch.randn(N, K, device=dev) * 0.02
     W[torch.rand(N, K, device=dev) < 0.005] *= 16
@@ -110,8 +132,8 @@ def sec_w4a8():
     M, K, N = 2048, 4096, 16384
     X = torch.randn(M, K, device=dev)
     for variant, sd in ((0, 2), (1, 5)):
-        ms = t(lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant), 50)
-        print(f"act_quant variant {variant}: {ms*1e3:6.1f} us  {M*K*6/ms/1e6:5.0f} GB/s (host-side launch overhead included)")
+        ms = tg(lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant))
+        print(f"act_quant variant {variant}: {ms*1e3:6.1f} us  {M*K*6/ms/1e6:5.0f} GB/s (device time from HIP-graph replays; variant 1 = statistics pass + quantiser)")
     W = synth(N, K)
     from msq.mx_ops import _quantize_mx_outlier_v1
     P = qlinear.pack_values(_quantize_mx_outlier_v1(W, 8, 8, "fp4_e2m1", "fp4_e2m1", "max", 5, [1], 32))
@@ -192,28 +214,29 @@ def sec_lowp():
 
 def sec_kv():
     from msq import kvcache
-    print("# msq_kv_group_quant on a Llama-2-7B layer cache [1, 32, 4096, 128] (bytes = 2 * numel * sizeof)")
+    print("# msq_kv_group_quant on a Llama-2-7B layer cache [1, 32, 4096, 128] (bytes = 2 * numel * sizeof; device time from HIP-graph replays)")
     for dt in (torch.float16, torch.float32):
         k = torch.randn(1, 32, 4096, 128, device=dev).to(dt)
         for bits in (2, 4):
-            mc = t(lambda: kvcache.fake_groupwise_channel_asymmetric_quantization_new(k, bits, 32))
-            mt = t(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 32))
-            mw = t(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 4096))
+            mc = tg(lambda: kvcache.fake_groupwise_channel_asymmetric_quantization_new(k, bits, 32))
+            mt = tg(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 32))
+            mw = tg(lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, bits, 4096))
             b = 2 * k.numel() * k.element_size()
             print(f"{str(dt)[6:]:8s} {bits} bit: per-channel g32 {mc*1e3:6.1f} us {b/mc/1e6:5.0f} GB/s | per-token g32 {mt*1e3:6.1f} us {b/mt/1e6:5.0f} GB/s | per-token g4096 {mw*1e3:6.1f} us {b/mw/1e6:5.0f} GB/s")
-        mk = t(lambda: kvcache.mx_quantize_keys(k, "fp8_e4m3", 32)); mv = t(lambda: kvcache.mx_quantize_values(k, "fp8_e4m3", 32))
+        mk = tg(lambda: kvcache.mx_quantize_keys(k, "fp8_e4m3", 32)); mv = tg(lambda: kvcache.mx_quantize_values(k, "fp8_e4m3", 32))
         print(f"{str(dt)[6:]:8s} MX-FP8: keys (blocks along tokens) {mk*1e3:6.1f} us | values (blocks along head_dim) {mv*1e3:6.1f} us")
 
 
 def sec_vec():
     from msq import vector_ops
     sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": "fp6_e3m2", "scale_bits": 4, "block_size": 32, "bfloat": 16, "custom_cuda": True})
-    print("# bfloat-rounded vector ops, X[2048, 4096] f32 (bytes = 2 * numel * 4)")
+    print("# bfloat-rounded vector ops, X[2048, 4096] f32 (bytes = 2 * numel * 4; add: 3 * numel * 4; device time from HIP-graph replays)")
     X = torch.randn(2048, 4096, device=dev); w = torch.randn(4096, device=dev); b = torch.randn(4096, device=dev)
     n = X.numel()
-    ms = t(lambda: vector_ops.layer_norm(X, w, b, 1e-12, sp)); print(f"msq_vec_layernorm: {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
-    ms = t(lambda: vector_ops.gelu(X, mx_specs=sp)); print(f"msq_vec_gelu     : {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
-    ms = t(lambda: vector_ops.simd_add(X, X, mx_specs=sp)); print(f"msq_vec_add      : {ms*1e3:6.1f} us {3*n*4/ms/1e6:5.0f} GB/s")
+    ms = tg(lambda: vector_ops.layer_norm(X, w, b, 1e-12, sp)); print(f"msq_vec_layernorm: {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
+    ms = tg(lambda: vector_ops.gelu(X, mx_specs=sp)); print(f"msq_vec_gelu     : {ms*1e3:6.1f} us {2*n*4/ms/1e6:5.0f} GB/s")
+    Z = torch.randn(2048, 4096, device=dev)
+    ms = tg(lambda: vector_ops.simd_add(X, Z, mx_specs=sp)); print(f"msq_vec_add      : {ms*1e3:6.1f} us {3*n*4/ms/1e6:5.0f} GB/s")
 
 
 SECTIONS = {"a12": sec_a12, "lowp": sec_lowp, "kv": sec_kv, "vec": sec_vec, "fakequant": sec_fakequant, "pack": sec_pack, "gemm": sec_gemm, "cfgb": sec_cfgb, "w4a8": sec_w4a8, "mx": sec_mx, "mx8": lambda: sec_mx(True)}
