@@ -297,7 +297,13 @@ int msq_qlinear_w4a8_x16(const void* X, const void* inl_plane, const void* out_p
 int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
                    int flush_fp32_subnorms, void* stream);
 int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
-                        int flush_fp32_subnorms, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
+                        int flush_fp32_subnorms, void* stream);
+/* ... and with float16 activations (an fp16 model; buffers 16-byte aligned) */
+int msq_mx_pack_a8_f16(const void* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                       int flush_fp32_subnorms, void* stream);
+/* float16 -> bfloat16, round to nearest even (= Tensor.to(torch.bfloat16)): the activation cast in front of msq_qlinear_bf16 for
+ * an fp16 model at prefill sizes, one bandwidth-bound launch (the decode sizes need none: msq_qlinear_f16x) */
+int msq_cast_f16_bf16(const void* x, void* y, int64_t n, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode with partial planes, split-K); 0 for the single-launch decode */

@@ -60,6 +60,8 @@ _SIGS = {
     "msq_qlinear_mx_w4a8_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "msq_qlinear_mx_w4a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
     "msq_mx_pack_a8_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "msq_mx_pack_a8_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "msq_cast_f16_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msq_mx_pack_w8": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "msq_mx_pack_w6": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "msq_mx_pack_a6": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),

@@ -260,7 +260,7 @@ k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t
 // four neighbouring lanes hold a block, its largest exponent crosses them by two quad permutes, every lane converts its own
 // eight values and stores 8 bytes -- 32-byte loads, 8-byte stores, no LDS transpose.  Same scale rule, same converts, same
 // flags as k_mx_pack<0> (tests/test_gpu_round3.py::test_mx_act_pack_vec_equals_block_kernel).
-template <bool XBF16>
+template <int XS>      // source: 0 float32, 1 bfloat16, 2 float16 (every half value is an fp32 value: the codes of casting first)
 __global__ void __launch_bounds__(256)
 k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t n8, int flush,
                  int* status_flag) {
@@ -268,10 +268,15 @@ k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;                                         // n8 is a multiple of 4: quads are never split
     float a[8];
-    if (XBF16) {
+    if (XS == 1) {
         const uint4 v = reinterpret_cast<const uint4*>(src)[i];
         a[0] = u2f(v.x << 16); a[1] = u2f(v.x & 0xFFFF0000u); a[2] = u2f(v.y << 16); a[3] = u2f(v.y & 0xFFFF0000u);
         a[4] = u2f(v.z << 16); a[5] = u2f(v.z & 0xFFFF0000u); a[6] = u2f(v.w << 16); a[7] = u2f(v.w & 0xFFFF0000u);
+    } else if (XS == 2) {
+        union { uint4 u; _Float16 h[8]; } r;
+        r.u = reinterpret_cast<const uint4*>(src)[i];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a[b] = (float)r.h[b];
     } else {
         const float4 v0 = reinterpret_cast<const float4*>(src)[2 * i], v1 = reinterpret_cast<const float4*>(src)[2 * i + 1];
         a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
@@ -316,7 +321,7 @@ extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* st
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
     if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
-        hipLaunchKernelGGL((k_mx_pack_a8_vec<false>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const void*)X,
+        hipLaunchKernelGGL((k_mx_pack_a8_vec<0>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const void*)X,
                            (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
     else
     hipLaunchKernelGGL((k_mx_pack<0>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
@@ -392,11 +397,66 @@ extern "C" int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
     if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
-        hipLaunchKernelGGL((k_mx_pack_a8_vec<true>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+        hipLaunchKernelGGL((k_mx_pack_a8_vec<1>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                            (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
     else
     hipLaunchKernelGGL((k_mx_pack<0, true>), dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)X,
                        (uint8_t*)codes, (uint8_t*)scales, M, K, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+// as msq_mx_pack_a8 with float16 activations (an fp16 model, llm/llama.py:33): no cast pass in front of the packer
+extern "C" int msq_mx_pack_a8_f16(const void* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
+                                  int flush_fp32_subnorms, void* stream) {
+    if (M < 0 || K < 0) { msq_set_error_("msq_mx_pack_a8_f16: negative size"); return MSQ_ERR_BAD_ARG; }
+    if (M == 0 || K == 0) return MSQ_OK;
+    if (K % 128) { msq_set_error_("msq_mx_pack_a8_f16: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
+    if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8_f16: null buffer"); return MSQ_ERR_BAD_ARG; }
+    if ((((uintptr_t)X | (uintptr_t)codes) & 15) != 0) { msq_set_error_("msq_mx_pack_a8_f16: buffers must be 16-byte aligned"); return MSQ_ERR_UNSUPPORTED; }
+    const int64_t nblocks = M * (K / 32);
+    hipLaunchKernelGGL((k_mx_pack_a8_vec<2>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+                       (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
+
+namespace {
+// float16 -> bfloat16 (round to nearest even through fp32: what Tensor.to(torch.bfloat16) gives), 16 bytes per lane in and out
+__global__ void __launch_bounds__(256) k_cast_f16_bf16(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t n8) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        union { uint4 u; _Float16 h[8]; } r;
+        union { uint4 u; __bf16 b[8]; } o;
+        r.u = x[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.b[e] = (__bf16)(float)r.h[e];
+        y[i] = o.u;
+    }
+}
+__global__ void __launch_bounds__(256) k_cast_f16_bf16_tail(const _Float16* __restrict__ x, __bf16* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (__bf16)(float)x[i];
+}
+}  // namespace
+
+// the activation cast in front of the bf16 MFMA for an fp16 model at prefill sizes (the decode kernels convert while loading)
+extern "C" int msq_cast_f16_bf16(const void* x, void* y, int64_t n, void* stream) {
+    if (n < 0) { msq_set_error_("msq_cast_f16_bf16: negative size"); return MSQ_ERR_BAD_ARG; }
+    if (n == 0) return MSQ_OK;
+    if (!x || !y) { msq_set_error_("msq_cast_f16_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
+    int64_t done = 0;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && n >= 8) {
+        const int64_t n8 = n / 8;
+        int64_t g = (n8 + 255) / 256; if (g > 256 * 32) g = 256 * 32;
+        hipLaunchKernelGGL(k_cast_f16_bf16, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n8);
+        done = n8 * 8;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_cast_f16_bf16_tail, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)x + done, (__bf16*)y + done, n - done);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;

@@ -212,6 +212,14 @@ def _out_buffer(out, M, N, out_dtype, dev, who):
     return out
 
 
+def _cast_f16_bf16(x):
+    """x.to(torch.bfloat16) for a float16 tensor as one bandwidth-bound launch (msq_cast_f16_bf16: same values)"""
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().msq_cast_f16_bf16(ptr(xc), ptr(y), xc.numel(), current_stream(x.device)), "msq_cast_f16_bf16")
+    return y
+
+
 def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
     """y = x . Wq^T (+ bias): the fused unpack-dequant-GEMM.  x: [..., K] (cast to bf16)."""
     if not x.is_cuda:
@@ -224,7 +232,9 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
     # fp16 activations at decode sizes go to the kernels as they are (msq_qlinear_f16x converts while loading); everything else is
     # cast to bf16 first
     f16x = xb.dtype == torch.float16 and xb.shape[0] <= 64
-    if xb.dtype != torch.bfloat16 and not f16x:
+    if xb.dtype == torch.float16 and not f16x:
+        xb = _cast_f16_bf16(xb)
+    elif xb.dtype != torch.bfloat16 and not f16x:
         xb = xb.to(torch.bfloat16)
     xb = _pad_k(xb, K).contiguous()
     M = xb.shape[0]
@@ -248,7 +258,7 @@ def qlinear(x, P, bias=None, out_dtype=torch.bfloat16, out=None):
         if rc not in (0, -2):
             check(rc, "msq_qlinear_f16x")
         if rc == -2:                                                      # not a decode shape after all: cast
-            xb = xb.to(torch.bfloat16)
+            xb = _cast_f16_bf16(xb)
     if rc != 0:
         check(lib().msq_qlinear_bf16(ptr(xb), ptr(P.inl), ptr(P.out), ptr(P.scl), ptr(b), ptr(y),
                                      _YD[out_dtype], M, P.N, K, P.block, P.in_kind, P.out_kind,
@@ -423,7 +433,7 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False, a_fmt="e4m3"):
     if a_fmt == "e2m1":
         raise MsqError("mx_pack_act: the activation operand is e4m3 (or fp6 values as e4m3)")
     K = x.shape[-1]
-    bf = x.dtype == torch.bfloat16 and a_fmt == "e4m3"   # read as is (every bf16 is an fp32 value: same codes)
+    bf = x.dtype in (torch.bfloat16, torch.float16) and a_fmt == "e4m3"   # read as is (every half value is an fp32 value: same codes)
     xf = x.reshape(-1, K).contiguous() if bf else x.reshape(-1, K).float().contiguous()
     M = xf.shape[0]
     codes = torch.empty(M, K, dtype=torch.uint8, device=x.device)
@@ -435,7 +445,7 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False, a_fmt="e4m3"):
         if check_status:
             _mx_status(status, "mx_pack_act")
         return codes, scales
-    fn = lib().msq_mx_pack_a8_bf16 if bf else lib().msq_mx_pack_a8
+    fn = (lib().msq_mx_pack_a8_f16 if x.dtype == torch.float16 else lib().msq_mx_pack_a8_bf16) if bf else lib().msq_mx_pack_a8
     check(fn(ptr(xf), ptr(codes), ptr(scales), ptr(status), M, K, int(bool(flush_fp32_subnorms)),
              current_stream(x.device)), "msq_mx_pack_a8")
     if check_status:

@@ -638,3 +638,27 @@ def test_wide_projection_decode_kernel(msq, N, K):
             ybf = msq.qlinear.qlinear(x, P, b, torch.bfloat16)
             y32 = msq.qlinear.qlinear(x, P, b, torch.float32)
             assert torch.equal(y16, y32.half()) and torch.equal(ybf, y32.to(torch.bfloat16))
+
+
+def test_fp16_activation_cast_and_mx_pack(msq):
+    """An fp16 model at prefill sizes: msq_cast_f16_bf16 == Tensor.to(bfloat16) on every fp16 pattern (NaN payloads aside) and ragged
+    lengths; the MX activation packer reads fp16 directly with the codes and scales of packing x.float()."""
+    from msq._lib import lib, ptr, current_stream
+    allh = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.float16).to(dev())
+    for n in (65536, 65531, 7, 8, 1):
+        x = allh[:n].contiguous()
+        y = torch.empty(n, dtype=torch.bfloat16, device=dev())
+        assert lib().msq_cast_f16_bf16(ptr(x), ptr(y), n, current_stream(dev())) == 0
+        ref = x.to(torch.bfloat16)
+        nan = torch.isnan(ref)
+        assert torch.equal(torch.isnan(y), nan) and torch.equal(y.view(torch.int16)[~nan], ref.view(torch.int16)[~nan])
+    torch.manual_seed(8)
+    x = (torch.randn(300, 1024, device=dev()) * torch.exp(torch.randn(300, 1, device=dev()) * 3)).half()
+    x[0] = 0; x[1, :32] = 6e-8; x[2, 5] = 65504.0
+    c16, s16 = msq.qlinear.mx_pack_act(x)
+    c32, s32 = msq.qlinear.mx_pack_act(x.float())
+    assert torch.equal(c16, c32) and torch.equal(s16, s32)
+    # and through the Linear: an fp16 activation at M = 300 gives what its bf16 cast gives
+    W = _weights(512, 1024, 4).to(dev())
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="unified")
+    assert torch.equal(msq.qlinear.qlinear(x, P, None, torch.float16), msq.qlinear.qlinear(x.to(torch.bfloat16), P, None, torch.float16))
