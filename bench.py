@@ -427,6 +427,45 @@ def e2e_main(args, dev):
             torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 20
 
+    def decode_step_graph(m, cache_len=512, pos=256):
+        """one WHOLE decode step of the HF model (embedding, 32 layers with attention over a static KV cache of `cache_len` slots at
+        position `pos`, norms, lm_head) captured into one HIP graph: ms per token without the Python / launch floor.  None when this
+        transformers build cannot be captured (the eager figure and the Linear-stack graph stand)."""
+        try:
+            from transformers import StaticCache
+            with torch.no_grad():
+                cache = StaticCache(config=m.config, max_cache_len=cache_len)
+                tok = ids[:, :1].contiguous()
+                cp = torch.tensor([pos], device=dev)
+                m(ids[:, :8], past_key_values=cache, cache_position=torch.arange(8, device=dev), use_cache=True)      # allocates the cache
+                step = lambda: m(tok, past_key_values=cache, cache_position=cp, use_cache=True).logits
+                s_ = torch.cuda.Stream()
+                s_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s_):
+                    for _ in range(3):
+                        step()
+                torch.cuda.current_stream().wait_stream(s_)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    out_ = step()
+                for _ in range(3):
+                    gr.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    gr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ok = bool(torch.isfinite(out_.float()).all())
+            del gr, cache
+            return e0.elapsed_time(e1) / 10 if ok else None
+        except Exception as e:                                   # noqa: BLE001 -- capture support depends on the transformers build
+            sys.stderr.write("decode_step_graph: not captured (%s: %s)\n" % (type(e).__name__, str(e)[:200]))
+            torch.cuda.synchronize()
+            return None
+
     res = {}
     for tag, m in (("packed_fused", packed), ("fakequant_dense_fp16", dense)):
         m.config.use_cache = False
@@ -436,7 +475,11 @@ def e2e_main(args, dev):
         m.config.use_cache = False
         tg = linear_stack_graph(m)
         tgp = linear_stack_graph(m, S)
+        m.config.use_cache = True
+        tdg = decode_step_graph(m)
+        m.config.use_cache = False
         res[tag if tag != "fakequant_dense_fp16" else "fakequant_dense_" + args.model_dtype] = {"prefill_s": tp, "prefill_tokens_per_s": S / tp, "decode_ms_per_token_eager": td * 1e3,
+                    "decode_ms_per_token_whole_step_hip_graph": tdg,
                     "decode_linears_ms_per_token_hip_graph": tg, "prefill_linears_ms_hip_graph": tgp,
                     "prefill_linears_tflops": 2.0 * S * n_w / (tgp * 1e-3) / 1e12}
     # (iv) perplexity on synthetic tokens + logit error
