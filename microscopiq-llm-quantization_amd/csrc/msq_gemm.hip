@@ -1085,7 +1085,7 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
     };
     // tiles in flight ahead of the one being multiplied: 1 with four waves per block (~3000 waves in the grid), 2 with
     // sixteen (fewer, longer waves)
-    constexpr bool DEEP2 = (WAVES == 16);
+    constexpr bool DEEP2 = (WAVES >= 8);
     WT cur, nxt, nx2;
     if (kt_lo < kt_hi) load_w(cur, tile_row + kt_lo);
     if (DEEP2 && kt_lo < kt_hi) load_w(nxt, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : kt_lo));
@@ -2165,6 +2165,20 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
                 else { if (wf == 0) MSQ_MXH(0, 2); else if (wf == 1) MSQ_MXH(1, 2); else if (wf == 2) MSQ_MXH(2, 2); else MSQ_MXH(3, 2); }
 #undef MSQ_MXH
                 return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, half strips)");
+            }
+            if (kcd && wf != 0 && mg == 1 && N / 64 > 256) {
+                // the 24- / 32-byte operands need 92-94 registers: one sixteen-wave block per CU, and a grid of more than 256 strips
+                // (fused gate / up: 344) takes a second, quarter-full round.  Eight-wave blocks run two per CU (as k_qgemv_u).
+                const int kc8 = (int)((K / 128 + 7) / 8);
+                const size_t lds8 = (size_t)7 * 16 * 64 * 4;
+#define MSQ_MXV8(W8V)                                                                                                   \
+                do { static DevOnce once_;                                                                              \
+                     if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); attr_done(once_); } \
+                     hipLaunchKernelGGL((k_mxgemv<W8V, 1, 8>), dim3((unsigned)(N / 64)), dim3(512), lds8, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
+                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc8, 1, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
+                if (wf == 1) MSQ_MXV8(1); else if (wf == 2) MSQ_MXV8(2); else MSQ_MXV8(3);
+#undef MSQ_MXV8
+                return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, eight-wave blocks)");
             }
             if (kcd) {
                 if (mg == 1) { if (wf == 0) MSQ_MXV(0, 1, 16); else if (wf == 1) MSQ_MXV(1, 1, 16); else if (wf == 2) MSQ_MXV(2, 1, 16); else MSQ_MXV(3, 1, 16); }

@@ -14,13 +14,18 @@ from msq import qlinear
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-fmts = [a for a in sys.argv[1:] if a in ("fp8", "posit")] or ["fp8", "posit"]
+fmts = [a for a in sys.argv[1:] if a in ("fp8", "posit", "mx8", "mx4")] or ["fp8", "posit"]      # mx8 / mx4: the MX matrix path (e4m3 values / plain MX-FP4 operand)
 Ms = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 16]
 FO = {"fp8": "fp8_e4m3", "posit": "posit8_es1"}
 
 
 def clone(P):
     c = lambda t: None if t is None else t.clone()
+    if isinstance(P, qlinear.MXPackedWeight):
+        import copy
+        Q = copy.copy(P)
+        Q.codes, Q.scales = P.codes.clone(), P.scales.clone()
+        return Q
     return qlinear.PackedWeight(c(P.inl), c(P.out), c(P.scl), P.N, P.K, P.block, P.in_kind, P.out_kind, P.n, P.k)
 
 
@@ -50,12 +55,18 @@ for (name, N, K) in (("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016,
     W = torch.randn(N, K, device=dev) * 0.02
     W[torch.rand(N, K, device=dev) < 0.005] *= 16
     for f in fmts:
-        P0 = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", FO[f], 2, 32, layout="unified")
+        if f == "mx8":
+            P0 = qlinear.mx_pack_values(msq.quant.outlier_fakequant(W[:, :K // 128 * 128].contiguous(), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"])
+        elif f == "mx4":
+            P0 = qlinear.mx_pack_weight(W[:, :K // 128 * 128].contiguous())
+        else:
+            P0 = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", FO[f], 2, 32, layout="unified")
+        call = qlinear.qlinear_mx_w4a8 if f in ("mx8", "mx4") else qlinear.qlinear
         copies = max(4, int(1.2e9 // P0.nbytes) + 1)
         Ps = [P0] + [clone(P0) for _ in range(copies - 1)]
         for M in Ms:
-            X = torch.randn(M, K, device=dev).to(torch.bfloat16)
-            us = tgraph([(lambda P=P: qlinear.qlinear(X, P)) for P in Ps])
+            X = torch.randn(M, P0.k, device=dev).to(torch.bfloat16)
+            us = tgraph([(lambda P=P: call(X, P)) for P in Ps])
             tot[(f, M)] = tot.get((f, M), 0.0) + us
             print(f"{name:8s} N{N:6d} K{K:6d} {f:5s} M{M:3d}: {us:6.1f} us  {P0.nbytes/us/1e3:5.0f} GB/s of packed weight ({copies} copies, {P0.nbytes/1e6:.0f} MB each)", flush=True)
         del Ps

@@ -662,3 +662,22 @@ def test_fp16_activation_cast_and_mx_pack(msq):
     W = _weights(512, 1024, 4).to(dev())
     P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, 32, layout="unified")
     assert torch.equal(msq.qlinear.qlinear(x, P, None, torch.float16), msq.qlinear.qlinear(x.to(torch.bfloat16), P, None, torch.float16))
+
+
+def test_mx_decode_wide_projection_eight_wave_blocks(msq):
+    """MX decode kernels with the 24- / 32-byte weight operands on more than 256 strips (fused gate / up: 344) take eight-wave blocks,
+    two per CU: same tolerance against the exact product of the quantised operands as the other MX kernels, bit-identical run to run."""
+    torch.manual_seed(21)
+    N, K = 16640, 512                                                   # 260 strips
+    W = _weights(N, K, 3).to(dev())
+    W8 = msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"]
+    bias = torch.randn(N, device=dev())
+    for P, Wd in ((msq.qlinear.mx_pack_values(W8), W8.double()),
+                  (msq.qlinear.mx_pack_weight(W, w_fmt="e3m2"), msq.mx_ops._quantize_mx(W, 8, "fp6_e3m2", axes=[-1], block_size=32).double())):
+        for M in (1, 5, 16):
+            x = torch.randn(M, K, device=dev())
+            xq = msq.mx_ops._quantize_mx(x, 8, "fp8_e4m3", axes=[-1], block_size=32).double()
+            r = xq @ Wd.t() + bias.double()
+            y = msq.qlinear.qlinear_mx_w4a8(x, P, bias, torch.float32)
+            assert bool(((y.double() - r).abs() <= 2.0 ** -11 * (xq.abs() @ Wd.abs().t()) + 1e-6).all()), (P.w_fmt, M)
+            assert torch.equal(y, msq.qlinear.qlinear_mx_w4a8(x, P, bias, torch.float32))
