@@ -128,5 +128,18 @@ def ptr(t):
 
 
 def current_stream(device=None):
+    """raw hipStream_t of torch's current stream on `device` (the private accessor costs 0.3 us per call; building a
+    torch.cuda.Stream object 4.5 us -- a third of the host time of a decode-size Linear)"""
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if isinstance(device, torch.device):
+        idx = device.index
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = None if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return C.c_void_p(raw(idx))
