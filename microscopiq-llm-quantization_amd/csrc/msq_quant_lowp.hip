@@ -276,6 +276,32 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
 // floor(R(log2f(t))) for a finite T value t > 0, integer form of floor_log2_lowp: the exact exponent E, plus one when the
 // significand sits within dmax T-ulps below 2.0 (d = 2^(p-1) - fraction <= dmax), dmax = what c[jb + 1] of floor_log2_lowp
 // allows for the binade of |E + 1| (checked against the reference-made fixtures through k_mx_lowp).
+// bump allowance of exponent E (see floor_log2_fast): a function of E alone -- the vectorised kernels keep it as a byte table in LDS
+// (index = biased exponent) and look it up instead of recomputing it per element
+template <int DT> MSQ_D uint32_t floor_log2_dmax(int E) {
+    const int up = E + 1;
+    int au = up < 0 ? -up : up;
+    au |= (up == 0) ? 1 : 0;
+    int jb = 31 - __builtin_clz((unsigned)au);
+    jb -= (up > 0 && (au & (au - 1)) == 0) ? 1 : 0;
+    const uint32_t lo = 0x02010000u;
+    const uint32_t hi = (DT == 1) ? 0x2B160B05u : 0x28150A05u;
+    const uint32_t top = (DT == 1) ? 86u : 74u;
+    const int idx = jb + 1;
+    const uint32_t w = idx < 4 ? lo : hi;
+    uint32_t dmax = (w >> (8 * (idx & 3))) & 0xFFu;
+    return idx >= 8 ? top : dmax;
+}
+template <int DT> MSQ_D int floor_log2_tab(float t, const uint8_t* tab) {
+    const uint32_t u = f2u(t);
+    const uint32_t e8 = (u >> 23) & 0xFFu;
+    constexpr int SH = (DT == 1) ? 13 : 16;
+    const uint32_t d = (0x800000u - (u & 0x7FFFFFu)) >> SH;
+    return (int)e8 - 127 + ((d <= (uint32_t)tab[e8]) ? 1 : 0);
+}
+template <int DT> MSQ_D void floor_log2_tab_init(uint8_t* tab) {       // 256 entries; call from every thread, then __syncthreads()
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) tab[e] = (uint8_t)floor_log2_dmax<DT>(e - 127);
+}
 template <int DT> MSQ_D int floor_log2_fast(float t) {                   // branch-free
     const uint32_t u = f2u(t);
     const int E = (int)((u >> 23) & 0xFFu) - 127;
@@ -305,9 +331,9 @@ struct MxLowpArgs {
 
 // block-level quantities of one MX block (maximum mx already reduced) and the per-element arithmetic
 template <int DT> struct MxBlk {
-    float sc, mn, sh, rsh, dr;
+    float sc, mn, sh, rsh, dr, mnsc;
     Div dv;
-    int min_exp, status;
+    int min_exp, status, shexp, sei;
     bool fast, fl, pow2den, has_pe;
 };
 template <int DT> MSQ_D MxBlk<DT> mx_block_setup(float mx, const MxLowpArgs& A) {
@@ -338,23 +364,25 @@ template <int DT> MSQ_D MxBlk<DT> mx_block_setup(float mx, const MxLowpArgs& A) 
              sei + B.min_exp + 2 - A.f.mbits >= TMINE && sei + A.f.emax + 2 <= TMAXE && sei - 1 >= TMINE + 11 && mx != 0.f;
     B.mn = A.f.max_norm;
     B.sh = pow2i(A.f.mbits - 2); B.rsh = pow2i(2 - A.f.mbits);
+    B.shexp = A.f.mbits - 2; B.sei = sei;
+    B.mnsc = A.f.max_norm * B.sc;                                        // exact inside the fast path's bounds (only used there)
     return B;
 }
 // fast path of one element (straight-line; the caller has made sure the whole wave takes it)
-template <int DT> MSQ_D float mx_elem_fast(float x, const MxBlk<DT>& B) {
+template <int DT> MSQ_D float mx_elem_fast(float x, const MxBlk<DT>& B, const uint8_t* tab = nullptr) {
     const float v = B.pow2den ? x * B.dr : Rr<DT>(x / B.dv.d);           // exact, or the rounded quotient by scale + 1e-6 (:444)
     const float av = __builtin_fabsf(v);
-    int pe = floor_log2_fast<DT>(av);                                    // v == 0: some small exponent, m = 0 below
+    int pe = tab ? floor_log2_tab<DT>(av, tab) : floor_log2_fast<DT>(av);   // v == 0: some small exponent, m = 0 below
     pe = pe < B.min_exp ? B.min_exp : pe;
     pe = B.has_pe ? pe : 0;                                              // integer element formats: no private exponent
-    const float ip2 = u2f((uint32_t)(127 - pe) << 23), p2 = u2f((uint32_t)(127 + pe) << 23);
-    const float m = av * ip2 * B.sh;                                     // exact
+    const int sa = B.shexp - pe;
+    const float m = __builtin_ldexpf(av, sa);                            // |v| 2^-pe 2^(mbits - 2): exact (one v_ldexp_f32)
     const float q = __builtin_floorf(Rr<DT>(m + 0.5f));                  // the one rounding that matters (ties just below n + 1/2)
-    float r = q * B.rsh * p2;                                            // exact
-    r = r > B.mn ? B.mn : r;
+    float r = __builtin_ldexpf(q, B.sei - sa);                           // q 2^(2 - mbits) 2^pe 2^se: exact (bounds on se)
+    r = r > B.mnsc ? B.mnsc : r;                                         // clamp to max_norm (scaled: the scale is a power of two)
     r = __builtin_copysignf(r, v);                                       // sign(v) * floor(...): -0 where a negative value rounds to zero
     r = (v == 0.f) ? 0.f : r;                                            // sign(+-0) = 0: 0 * floor(...) = +0
-    return r * B.sc;                                                     // exact (bounds on se)
+    return r;
 }
 template <int DT> MSQ_D float mx_elem(float x, const MxBlk<DT>& B, const MxLowpArgs& A) {
     if (B.fast) return mx_elem_fast<DT>(x, B);
@@ -398,6 +426,9 @@ template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A, int64_t nchunks) {
     constexpr int LPB = BS / 8;                                          // lanes per block: 1, 2, 4, 8, 16
+    __shared__ uint8_t s_tab[256];
+    floor_log2_tab_init<DT>(s_tab);
+    __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < nchunks;
     union { uint4 u; uint16_t h[8]; } v;
@@ -416,7 +447,7 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
     MxBlk<DT> B = mx_block_setup<DT>(mx, A);
     if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {                     // the whole wave: straight-line code
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(a[j], B));
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(a[j], B, s_tab));
     } else {
         B.fast = false;                                                  // the general path is right for every block
 #pragma unroll
@@ -431,6 +462,9 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
+    __shared__ uint8_t s_tab[256];
+    floor_log2_tab_init<DT>(s_tab);
+    __syncthreads();
     const int64_t hp = A.post / 2;
     const int64_t total = A.pre * A.nblk * hp;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -460,8 +494,8 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
         for (int b = 0; b < BS; ++b) {
             if (a0 + b >= A.axis_len) continue;
             union { uint32_t u; uint16_t h[2]; } w;
-            st16<DT>(w.h, 0, mx_elem_fast<DT>(a0v[b], B0));
-            st16<DT>(w.h, 1, mx_elem_fast<DT>(a1v[b], B1));
+            st16<DT>(w.h, 0, mx_elem_fast<DT>(a0v[b], B0, s_tab));
+            st16<DT>(w.h, 1, mx_elem_fast<DT>(a1v[b], B1, s_tab));
             *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = w.u;
         }
     } else {
