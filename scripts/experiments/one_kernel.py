@@ -21,7 +21,17 @@ fn = {"layernorm": lambda: vector_ops.layer_norm(X, w, b, 1e-12, sp), "gelu": la
       "kv32": lambda: kvcache.fake_groupwise_token_asymmetric_quantization(C32, 2, 4096),
       "act0": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 2, 32, "nearest", False, 0),
       "act1": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1),
-      "pack_posit": lambda: qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified")}[what]
+      "pack_posit": lambda: qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified"), "gemv_gateup": None}[what]
+if what == "gemv_gateup":                                # ten COLD launches of the wide-projection decode kernel (distinct weight copies)
+    Wg = torch.randn(22016, 4096, device=dev) * 0.02
+    P0 = qlinear.pack_weight(Wg, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified")
+    c = lambda t: None if t is None else t.clone()
+    Ps = [qlinear.PackedWeight(c(P0.inl), c(P0.out), c(P0.scl), P0.N, P0.K, P0.block, P0.in_kind, P0.out_kind, P0.n, P0.k) for _ in range(10)]
+    x1 = torch.randn(1, 4096, device=dev).to(torch.bfloat16)
+    for P in Ps:
+        qlinear.qlinear(x1, P)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(10):
     fn()
 torch.cuda.synchronize()
