@@ -1284,18 +1284,19 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 // launch: one block = one strip over ALL of K, its WAVES waves take consecutive runs of kc tiles and meet in LDS.  What changed
 // against k_qgemv<..., 16> (measured with COLD weights, scripts/experiments/decode_cold.py: a graph that replays ONE weight
 // streams it from the Infinity Cache and hides all of this):
-//  * WAVES = 8 blocks run two per CU: the 344 strips of the fused gate / up projection are resident at once instead of taking a
-//    second, quarter-full round of sixteen-wave blocks (31.2 -> 27.0 us at M = 1);
+//  * WAVES = 8 / 4 / 2 blocks run two or more per CU: the 344 strips of the fused gate / up projection are resident at once instead
+//    of taking a second, quarter-full round of sixteen-wave blocks (31.2 -> 27.0 us at M = 1 with eight waves, 23.7 with four);
 //  * any K (a wave's run is as long as it has to be);
 //  * the hand-over is summed by all waves (wave w owns results w, w + WAVES, ...; fixed order over the k-runs: bit-identical
 //    run to run), not by wave 0 alone;
 //  * XPF: the activation fragments of the next tile are requested one tile ahead (M > 1: sixteen different rows, an exposed L2
 //    round trip per tile otherwise).
-// Per tile a wave loads four code slots (16 B per lane), the scale pair and, for U1X, two extension dwords; three tiles in flight.
+// Per tile a wave loads four code slots (16 B per lane), the scale pair and, for U1X, two extension dwords; two tiles in flight
+// (DEEP3: three -- slower with cold weights: more bytes in flight than the DRAM pages like, see the launcher).
 // Half strips over all of K for the 4096-wide projections (128 blocks) were built and measured slower than the split-K planes
 // of k_qgemv (down projection 14.7 -> 17.3 us): a CU keeps only so many bytes in flight, 128 CUs cannot pull what 256 can.
 // ---------------------------------------------------------------------------
-template <int OUT_KIND, int MG, int WAVES, bool XPF>
+template <int OUT_KIND, int MG, int WAVES, bool XPF, bool DEEP3 = false>
 __global__ void __launch_bounds__(64 * WAVES)
 k_qgemv_u(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane, const uint8_t* __restrict__ code_plane,
           const uint8_t* __restrict__ scl_plane, int M, int N, int K, int kc, const float* __restrict__ bias, void* __restrict__ Y,
@@ -1349,9 +1350,10 @@ k_qgemv_u(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane,
     const int kt_safe = kt_lo < KT ? kt_lo : KT - 1;
     load_u(cur, kt_safe);
     if (XPF) load_x(xc, kt_safe);
-    load_u(nxt, (kt_lo + 1 < kt_hi) ? kt_lo + 1 : kt_safe);
+    if (DEEP3) load_u(nxt, (kt_lo + 1 < kt_hi) ? kt_lo + 1 : kt_safe);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        load_u(nx2, (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1);
+        if (DEEP3) load_u(nx2, (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1);
+        else load_u(nxt, (kt + 1 < kt_hi) ? kt + 1 : kt);
         if (XPF) load_x(xn, (kt + 1 < kt_hi) ? kt + 1 : kt);
         else load_x(xc, kt);
 #pragma unroll
@@ -1378,7 +1380,8 @@ k_qgemv_u(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane,
                     acc[nf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[j], acc[nf][j], 0, 0, 0);
             }
         }
-        cur = nxt; nxt = nx2;
+        cur = nxt;
+        if (DEEP3) nxt = nx2;
         if (XPF) xc = xn;
     }
     // hand-over: every wave leaves its partial results, wave w sums results w, w + WAVES, ... over the k-runs in order
@@ -1771,7 +1774,8 @@ static int direct_kc(int64_t M, int64_t N, int64_t K) {
 }
 static int pick_kc(int64_t N, int64_t K) {
     const int64_t KT = K / BK, strips = N / TILE_N;
-    int64_t kc = (strips * KT + 3071) / 3072;
+    static const int tw = [] { const char* e = getenv("MSQ_GEMV_TARGET_WAVES"); return e ? atoi(e) : 3072; }();
+    int64_t kc = (strips * KT + tw - 1) / tw;
     if (kc < 1) kc = 1;
     while ((KT + kc - 1) / kc > 32) ++kc;
     return (int)kc;
@@ -1816,24 +1820,28 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
         static const int gvu = [] { const char* e = getenv("MSQ_GEMV_U"); return e ? atoi(e) : 1; }();
         if (gvu && mg <= 2 && N / TILE_N > 128 && in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
             const int64_t strips = N / TILE_N, KTv = K / TILE_K;
-            // <= 256 strips: one sixteen-wave block per CU; more: eight-wave blocks, two per CU (MSQ_GEMV_U_WAVES=8 / 16 forces)
+            // Waves per block (= k-runs per strip) so that the grid has ~1000-2000 waves, two tiles in flight each: a COLD read stream
+            // is fastest with a few MB in flight (scripts/experiments/hbm_read.hip: 1024 waves x 4 KB reach 6 TB/s, 8192 x 8 KB only
+            // 4.5 -- DRAM pages thrash); measured on the fused projections (waves x tiles in flight, us at M = 1): q/k/v 16 x 3
+            // 15.8, 8 x 3 14.8, 8 x 2 13.6, 4 x 2 18.3; gate / up 8 x 3 27.5, 4 x 3 24.5, 4 x 2 23.7, 2 x 2 36.3.
+            // MSQ_GEMV_U_WAVES=2 / 4 / 8 / 16 forces.
             static const int fw = [] { const char* e = getenv("MSQ_GEMV_U_WAVES"); return e ? atoi(e) : 0; }();
-            const int wv = (fw == 8 || fw == 16) ? fw : (strips <= 256 ? 16 : 8);
+            const int wv = (fw == 2 || fw == 4 || fw == 8 || fw == 16) ? fw : (strips <= 256 ? 8 : (strips <= 640 ? 4 : 2));
             const int kcu = (int)((KTv + wv - 1) / wv);
             const dim3 ugrid((unsigned)strips);
             const int yk = y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0);
 #define MSQ_GVU1(OK, MGV, WV, XP)                                                                                         \
             do { static DevOnce once_;                                                                                   \
                  const size_t l_ = (size_t)WV * MGV * 16 * 64 * 4;                                                        \
-                 if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv_u<OK, MGV, WV, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); attr_done(once_); } \
-                 hipLaunchKernelGGL((k_qgemv_u<OK, MGV, WV, XP>), ugrid, dim3(64 * WV), l_, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, \
+                 if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_qgemv_u<OK, MGV, WV, XP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); attr_done(once_); } \
+                 hipLaunchKernelGGL((k_qgemv_u<OK, MGV, WV, XP, false>), ugrid, dim3(64 * WV), l_, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, \
                                     (const uint8_t*)scale_plane, (int)M, (int)N, (int)K, kcu, bias, Y, yk, x_f16); } while (0)
             // activation prefetch: from two rows on (one row: every lane reads the same line, an L1 hit), where the registers allow
-#define MSQ_GVU(OK) do { if (mg == 1) { if (wv == 16) { if (M > 1) MSQ_GVU1(OK, 1, 16, true); else MSQ_GVU1(OK, 1, 16, false); }   \
-                                        else { if (M > 1) MSQ_GVU1(OK, 1, 8, true); else MSQ_GVU1(OK, 1, 8, false); } }            \
-                         else { if (wv == 16) MSQ_GVU1(OK, 2, 16, false); else MSQ_GVU1(OK, 2, 8, false); } } while (0)
+#define MSQ_GVUW(OK, WV) do { if (mg == 1) { if (M > 1) MSQ_GVU1(OK, 1, WV, true); else MSQ_GVU1(OK, 1, WV, false); } else MSQ_GVU1(OK, 2, WV, false); } while (0)
+#define MSQ_GVU(OK) do { if (wv == 2) MSQ_GVUW(OK, 2); else if (wv == 4) MSQ_GVUW(OK, 4); else if (wv == 8) MSQ_GVUW(OK, 8); else MSQ_GVUW(OK, 16); } while (0)
             if (out_kind == MSQ_PLANE_U8) MSQ_GVU(MSQ_PLANE_U8); else MSQ_GVU(MSQ_PLANE_U8X);
 #undef MSQ_GVU
+#undef MSQ_GVUW
 #undef MSQ_GVU1
             return check_launch2("msq_qlinear_bf16(decode, unified layouts)");
         }
