@@ -75,6 +75,8 @@ int main() {
     hipMemset(p, 1, bytes);
     hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, p, n16);          // not a constant pattern: a cheap hash of the index
     hipDeviceSynchronize();
+    // how much one CU can pull: fewer blocks than CUs (one block = 4 waves on one CU)
+    for (int blocks : {32, 64, 128, 192}) { run<8, false>(p, sink, n16 / 4, blocks); run<16, true>(p, sink, n16 / 4, blocks); }
     for (double mb : {19.0, 52.0, 104.0, 416.0})
         for (int blocks : {256, 512, 1024, 2048}) { run_slices<4>(p, sink, n16, mb, blocks); run_slices<8>(p, sink, n16, mb, blocks); }
     for (int blocks : {256, 512, 1024, 2048, 4096, 8192, 65536}) {
