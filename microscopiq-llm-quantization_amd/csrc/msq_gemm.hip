@@ -2174,19 +2174,25 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
 #undef MSQ_MXH
                 return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, half strips)");
             }
-            if (kcd && wf != 0 && mg == 1 && N / 64 > 256) {
-                // the 24- / 32-byte operands need 92-94 registers: one sixteen-wave block per CU, and a grid of more than 256 strips
-                // (fused gate / up: 344) takes a second, quarter-full round.  Eight-wave blocks run two per CU (as k_qgemv_u).
-                const int kc8 = (int)((K / 128 + 7) / 8);
-                const size_t lds8 = (size_t)7 * 16 * 64 * 4;
-#define MSQ_MXV8(W8V)                                                                                                   \
+            if (kcd && mg == 1 && (N / 64 > 256 || (wf != 0 && N / 64 > 128))) {
+                // Waves per block as for k_qgemv_u: with cold weights a grid of ~1000-2000 waves streams fastest, and more than 256
+                // strips of sixteen-wave blocks (the 24- / 32-byte operands need 92-94 registers: one block per CU) take a second,
+                // part-filled round.  Measured (scripts/experiments/decode_cold.py, M = 1, us; 16 / 8 / 4 waves): fused gate / up
+                // (344 strips) e4m3 operand 25.0 / 24.6 / 22.7, fp4 15.3 / 13.9 / 13.5; q/k/v (192 strips) e4m3 15.1 / 14.1 / 16.4,
+                // fp4 10.2 / 10.8 / 11.6 (stays at sixteen).
+                const bool w4 = N / 64 > 256;
+                const int wvx = w4 ? 4 : 8;
+                const int kcx = (int)((K / 128 + wvx - 1) / wvx);
+                const size_t ldsx = (size_t)(wvx - 1) * 16 * 64 * 4;
+#define MSQ_MXVX(W8V, WV)                                                                                               \
                 do { static DevOnce once_;                                                                              \
-                     if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); attr_done(once_); } \
-                     hipLaunchKernelGGL((k_mxgemv<W8V, 1, 8>), dim3((unsigned)(N / 64)), dim3(512), lds8, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
-                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kc8, 1, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
-                if (wf == 1) MSQ_MXV8(1); else if (wf == 2) MSQ_MXV8(2); else MSQ_MXV8(3);
-#undef MSQ_MXV8
-                return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, eight-wave blocks)");
+                     if (attr_needed(once_)) { hipFuncSetAttribute((const void*)k_mxgemv<W8V, 1, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (WV - 1) * 16 * 64 * 4); attr_done(once_); } \
+                     hipLaunchKernelGGL((k_mxgemv<W8V, 1, WV>), dim3((unsigned)(N / 64)), dim3(64 * WV), ldsx, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, \
+                                        (const uint8_t*)w_codes, (const uint8_t*)w_scales, (float*)workspace, (int)M, (int)N, (int)K, kcx, 1, bias, Y, y_dtype == 2 ? 1 : (y_dtype == 1 ? 2 : 0)); } while (0)
+                if (w4) { if (wf == 0) MSQ_MXVX(0, 4); else if (wf == 1) MSQ_MXVX(1, 4); else if (wf == 2) MSQ_MXVX(2, 4); else MSQ_MXVX(3, 4); }
+                else { if (wf == 1) MSQ_MXVX(1, 8); else if (wf == 2) MSQ_MXVX(2, 8); else MSQ_MXVX(3, 8); }
+#undef MSQ_MXVX
+                return check_launch2("msq_qlinear_mx_w4a8(decode, single launch, four- / eight-wave blocks)");
             }
             if (kcd) {
                 if (mg == 1) { if (wf == 0) MSQ_MXV(0, 1, 16); else if (wf == 1) MSQ_MXV(1, 1, 16); else if (wf == 2) MSQ_MXV(2, 1, 16); else MSQ_MXV(3, 1, 16); }
