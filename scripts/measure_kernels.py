@@ -95,6 +95,8 @@ def sec_pack():
 
 def sec_gemm():
     print("# msq_qlinear_bf16 (fused dequant-GEMM), bf16 out; hipBLASLt = torch bf16 matmul on the unpacked weight, same data")
+    print("#   (eager calls on ONE weight: rows with M <= 128 are bound by the ~14 us Python / launch floor and stream from the Infinity Cache;")
+    print("#    decode sizes with cold weights from HIP graphs: scripts/experiments/decode_cold.py -> profiles/r03_decode_cold*.txt)")
     for (N, K) in [(16384, 4096), (4096, 4096), (11008, 4096), (4096, 11008)]:
         W = synth(N, K)
         for fo in ("fp8_e4m3", "posit8_es1"):
