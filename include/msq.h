@@ -231,9 +231,10 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
 /* fused unpack-dequant-GEMM: Y[M,N] = X[M,K] (bf16) . W^T (+ bias f32 [N] or NULL), fp32 accumulate on
  * v_mfma_f32_16x16x32_bf16; y_dtype 0 = f32, 1 = fp16, 2 = bf16 (the 16-bit kinds share one kernel: the epilogue converts either way).  Replaces the dense F.linear the reference
  * runs on the fake-quantised weight (number_system/mx/linear.py:91, llm/llama.py:255-256).
- * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0.  M <= 32 (<= 64 for the 4096 x 4096 class) takes the decode
- * kernel: one wave per (64 columns, k-chunk), k-chunks summed in LDS; for the unified layouts with N >= 8192 and
- * K <= 4096 one launch writes Y directly, otherwise fp32 partial tiles go through `workspace`.
+ * Shapes: N % 256 == 0, K % 64 == 0, any M >= 0.  M <= 32 (<= 64 for the 4096 x 4096 class, <= 36 / 48 for the unified layouts
+ * with more than 16384 / 8192 columns) takes the decode kernels, which stream the packed weight once: for the unified layouts
+ * with more than 8192 columns one launch writes Y directly (one block per 64-column strip over all of K, its waves' k-runs summed
+ * in LDS), otherwise one wave per (64 columns, k-chunk) and fp32 partial tiles through `workspace`.
  * For larger M with a grid that does not fill the chip the GEMM splits K over several workgroups and reduces fp32
  * partial tiles from `workspace` (msq_qlinear_workspace_bytes(); NULL or too small = single pass, never an error).
  * Results are bit-identical from run to run on every path (fixed summation order). */

@@ -1765,7 +1765,11 @@ static bool use_gemv(int64_t M, int64_t N, int64_t K) {
     static int v = -2;
     if (v == -2) { const char* e = getenv("MSQ_GEMV_MAX_M"); v = e ? atoi(e) : -1; if (v > 64) v = 64; }
     if (v >= 0) return M <= v;
-    return M <= 32 || (M <= 64 && N <= 4096 && K <= 4096);
+    // four row groups through the wide-projection kernel (k_qgemv_u) while re-reading the activation rows per tile still costs less
+    // than the GEMM's 128-row tiles waste (cold weights, q/k/v 12288 x 4096: M = 33 / 48 / 64 21.0 / 23.2 / 26.1 us against 26.8 / 27.4 /
+    // 27.7; gate / up 22016 x 4096: 38.9 / 40.9 / 45.5 against 42.9 / 40.5 / 41.5)
+    const int64_t strips = N / TILE_N;
+    return M <= 32 || (M <= 64 && N <= 4096 && K <= 4096) || (M <= 48 && strips > 128 && strips <= 256) || (M <= 36 && strips > 256);
 }
 // single-launch decode (unified layouts): as mx_direct_kc; 64-k tiles: K <= 4096 = at most 4 tiles per wave.
 // MSQ_GEMV_DIRECT=0 (tuning only) disables it.
@@ -1822,7 +1826,7 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
         const int nks = kcd ? 1 : (int)(((K / BK + kc - 1) / kc + 3) / 4);    // partial planes: one per four k-chunks
         // unified layouts, M <= 32, more than 128 strips: the single-launch kernel (MSQ_GEMV_U=0: the earlier kernels, tuning only)
         static const int gvu = [] { const char* e = getenv("MSQ_GEMV_U"); return e ? atoi(e) : 1; }();
-        if (gvu && mg <= 2 && N / TILE_N > 128 && in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
+        if (gvu && N / TILE_N > 128 && in_kind == MSQ_PLANE_NONE && (out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X)) {
             const int64_t strips = N / TILE_N, KTv = K / TILE_K;
             // Waves per block (= k-runs per strip) so that the grid has ~1000-2000 waves, two tiles in flight each: a COLD read stream
             // is fastest with a few MB in flight (scripts/experiments/hbm_read.hip: 1024 waves x 4 KB reach 6 TB/s, 8192 x 8 KB only
@@ -1841,7 +1845,7 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
                  hipLaunchKernelGGL((k_qgemv_u<OK, MGV, WV, XP, false>), ugrid, dim3(64 * WV), l_, st0, (const uint16_t*)X, (const uint8_t*)inl_plane, (const uint8_t*)out_plane, \
                                     (const uint8_t*)scale_plane, (int)M, (int)N, (int)K, kcu, bias, Y, yk, x_f16); } while (0)
             // activation prefetch: from two rows on (one row: every lane reads the same line, an L1 hit), where the registers allow
-#define MSQ_GVUW(OK, WV) do { if (mg == 1) { if (M > 1) MSQ_GVU1(OK, 1, WV, true); else MSQ_GVU1(OK, 1, WV, false); } else MSQ_GVU1(OK, 2, WV, false); } while (0)
+#define MSQ_GVUW(OK, WV) do { if (mg == 1) { if (M > 1) MSQ_GVU1(OK, 1, WV, true); else MSQ_GVU1(OK, 1, WV, false); } else if (mg == 2) MSQ_GVU1(OK, 2, WV, false); else MSQ_GVU1(OK, 4, WV, false); } while (0)
 #define MSQ_GVU(OK) do { if (wv == 2) MSQ_GVUW(OK, 2); else if (wv == 4) MSQ_GVUW(OK, 4); else if (wv == 8) MSQ_GVUW(OK, 8); else MSQ_GVUW(OK, 16); } while (0)
             if (out_kind == MSQ_PLANE_U8) MSQ_GVU(MSQ_PLANE_U8); else MSQ_GVU(MSQ_PLANE_U8X);
 #undef MSQ_GVU

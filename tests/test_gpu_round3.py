@@ -624,7 +624,7 @@ def test_wide_projection_decode_kernel(msq, N, K):
     for fo in ("fp8_e4m3", "posit8_es1"):
         P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
         Wd = msq.qlinear.unpack_weight(P, torch.float32)
-        for M in (1, 2, 16, 17, 32):
+        for M in (1, 2, 16, 17, 32, 33, 36, 48):                       # 1, 2 and 4 row groups (four: up to 36 / 48 rows by width)
             x = torch.randn(M, K, device=dev()).to(torch.bfloat16)
             b = torch.randn(N, device=dev())
             ref = x.float() @ Wd.t()
