@@ -55,6 +55,9 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #endif
 #define TILE_N 64
 #define TILE_K 64
+#ifndef MSQ_GV_NT
+#define MSQ_GV_NT true     /* decode kernels: packed planes are read once -- non-temporal loads keep the activation rows in L2 */
+#endif
 
 // ---------------------------------------------------------------------------
 // fragment dequant: 8 elements (one MFMA operand fragment) -> 4 dwords of bf16x2
@@ -230,7 +233,7 @@ k_repack(const uint32_t* __restrict__ codes, const float* __restrict__ e_in, con
 }
 
 // load all packed data of a tile for this lane (coalesced: every slot is 64 lanes x 16 B)
-template <int IN_KIND, int OUT_KIND>
+template <int IN_KIND, int OUT_KIND, bool NT = false>
 MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_plane, const uint8_t* scl_plane,
                      int64_t tile, int lane, int scl_groups) {
     constexpr int OS = OutSlots<OUT_KIND>::n;
@@ -249,7 +252,8 @@ MSQ_D void load_tile(TileRegs& t, const uint8_t* inl_plane, const uint8_t* out_p
     }
 #pragma unroll
     for (int s = 0; s < OS; ++s)
-        t.out[s] = *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * OS + s) * 64 + lane) * 16);
+        t.out[s] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(out_plane + ((tile * OS + s) * 64 + lane) * 16))
+                      : *reinterpret_cast<const u32x4_t*>(out_plane + ((tile * OS + s) * 64 + lane) * 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -1203,11 +1207,11 @@ k_qgemv(const uint16_t* __restrict__ X, const uint8_t* __restrict__ inl_plane, c
 
     constexpr bool DEEP2 = (WAVES == 16);                      // tiles in flight ahead: 2 with few long waves, else 1
     TileRegs cur, nxt, nx2;
-    load_tile<IN_KIND, OUT_KIND>(cur, inl_plane, out_plane, scl_plane, tile_row + (kt_lo < KT ? kt_lo : KT - 1), lane, scl_groups);
-    if (DEEP2) load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : (kt_lo < KT ? kt_lo : KT - 1)), lane, scl_groups);
+    load_tile<IN_KIND, OUT_KIND, MSQ_GV_NT>(cur, inl_plane, out_plane, scl_plane, tile_row + (kt_lo < KT ? kt_lo : KT - 1), lane, scl_groups);
+    if (DEEP2) load_tile<IN_KIND, OUT_KIND, MSQ_GV_NT>(nxt, inl_plane, out_plane, scl_plane, tile_row + ((kt_lo + 1 < kt_hi) ? kt_lo + 1 : (kt_lo < KT ? kt_lo : KT - 1)), lane, scl_groups);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; load_tile<IN_KIND, OUT_KIND>(nx2, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
-        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; load_tile<IN_KIND, OUT_KIND>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
+        if (DEEP2) { const int ktn = (kt + 2 < kt_hi) ? kt + 2 : kt_hi - 1; load_tile<IN_KIND, OUT_KIND, MSQ_GV_NT>(nx2, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
+        else { const int ktn = (kt + 1 < kt_hi) ? kt + 1 : kt; load_tile<IN_KIND, OUT_KIND, MSQ_GV_NT>(nxt, inl_plane, out_plane, scl_plane, tile_row + ktn, lane, scl_groups); }
         bf16x8_t xf[2][MG];
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
@@ -1335,12 +1339,12 @@ k_qgemv_u(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane,
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                t.code[kf][p] = *reinterpret_cast<const u32x4_t*>(code_plane + ((tile * 4 + kf * 2 + p) * 64 + lane) * 16);
+                t.code[kf][p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(code_plane + ((tile * 4 + kf * 2 + p) * 64 + lane) * 16));   // streamed once: keep the activation rows in L2
         const uint2 sc = *reinterpret_cast<const uint2*>(scl_plane + (tile * 16 + c) * 8);
         t.scl[0] = sc.x; t.scl[1] = sc.y;
         if (EXT) {
-            t.ext[0] = *reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 0) * 64 + lane) * 4);
-            t.ext[1] = *reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 1) * 64 + lane) * 4);
+            t.ext[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 0) * 64 + lane) * 4));
+            t.ext[1] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(ext_plane + ((tile * 2 + 1) * 64 + lane) * 4));
         }
     };
     auto load_x = [&](XF& x, int kt) {
