@@ -1077,12 +1077,12 @@ k_mxgemv(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const u
 #pragma unroll
             for (int h = 0; h < WV; ++h) {
                 if (W6 && h == 1) {
-                    const u32x2_t t2 = *reinterpret_cast<const u32x2_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + 1024 + lane * 8);
+                    const u32x2_t t2 = MSQ_GV_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + 1024 + lane * 8)) : *reinterpret_cast<const u32x2_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + 1024 + lane * 8);
                     t.w[nf][1] = u32x4_t{t2[0], t2[1], 0u, 0u};
                 } else if (W6) {
-                    t.w[nf][0] = *reinterpret_cast<const u32x4_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + lane * 16);
+                    t.w[nf][0] = MSQ_GV_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + lane * 16)) : *reinterpret_cast<const u32x4_t*>(Wc + (tile * 4 + nf0 + nf) * 1536 + lane * 16);
                 } else {
-                    t.w[nf][h] = *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16);
+                    t.w[nf][h] = MSQ_GV_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16)) : *reinterpret_cast<const u32x4_t*>(Wc + (((tile * 4 + nf0 + nf) * WV + h) * 64 + lane) * 16);
                 }
             }
         t.s = *reinterpret_cast<const uint32_t*>(Ws + (tile * 64 + lane) * 4) >> (8 * nf0);       // byte nf of the dword = fragment nf0 + nf
