@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
-ROUND_TAG = "r03"
+ROUND_TAG = "r04"
 
 
 def parse_args(argv=None):
@@ -170,24 +170,42 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False, budget_s=10.0):
-    """The oracle (a C restatement of the reference's CPU fake-quant + the dense linear it feeds, OpenMP over
-    independent blocks / output elements) timed on ALL physical host cores on a bounded sample of the same workload.
-    Reported, never optimised.  `value` is the all-core figure of the linear; the fake-quant of the whole weight and
-    torch's own CPU F.linear (what the reference itself executes, number_system/mx/linear.py:91) ride beside it."""
+def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False, budget_s=8.0, W_host=None, gpu_values=None):
+    """The reference's CPU path timed on the GPU box's host cores on a bounded sample of the same workload.  Reported, never optimised.
+
+    `value` = torch's CPU float32 F.linear on the fake-quantised weight -- the op the reference itself executes for this GEMM
+    (number_system/mx/linear.py:91) -- on all M rows of X and the whole weight; the oracle's own dense linear (a C restatement,
+    double accumulate, OpenMP over outputs) and the oracle's fake-quant of the WHOLE weight (utils/quant.py:147-266 restated,
+    OpenMP over blocks) ride beside it.
+
+    Parity at full size: when the caller passes the GPU's weight (`W_host`, float32 [N, K]) and what the HIP path made of it
+    (`gpu_values`: name -> float32 [N, K] host array, e.g. the HIP fake-quant output and unpack(pack(W))), the oracle's
+    whole-weight result -- already computed for the timing -- is compared with each of them bit for bit
+    (`parity_checked`, `mismatches`)."""
     import numpy as np
     from oracle import oracle as O
     cores = physical_cores()
     threads = O.set_threads(cores)
     rng = np.random.RandomState(0)
-    Ws = (rng.randn(N, K) * 0.02).astype(np.float32)         # fake-quant sample: the whole [N, K] weight
-    Ws[rng.rand(N, K) < 0.005] *= 16
+    if W_host is None:
+        Ws = (rng.randn(N, K) * 0.02).astype(np.float32)         # fake-quant sample: the whole [N, K] weight
+        Ws[rng.rand(N, K) < 0.005] *= 16
+    else:
+        Ws = np.ascontiguousarray(W_host, dtype=np.float32)
     t0 = time.perf_counter()
     r = ({"out": O.quantize_mx(Ws, 8, fi.split()[0], axis=-1, block_size=bs)} if plain_mx
          else O.outlier_fakequant(Ws, 8, 8, fi, fo, 2, -1, bs))
     t_q = time.perf_counter() - t0
+    parity = None
+    if gpu_values:
+        parity = {}
+        ob = r["out"].view(np.uint32)
+        for k_, v in gpu_values.items():
+            gb = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32)
+            both_nan = np.isnan(r["out"]) & np.isnan(v)
+            parity[k_] = int(((ob != gb) & ~both_nan).sum())
     Xs = rng.randn(M, K).astype(np.float32)
-    # linear sample: probe, then as many of the N output columns as fit the time budget (all M rows)
+    # oracle linear sample: probe, then as many of the N output columns as fit the time budget (all M rows)
     t0 = time.perf_counter()
     O.linear(Xs[:256], r["out"][:1024])
     rate = 2.0 * 256 * 1024 * K / max(time.perf_counter() - t0, 1e-6)
@@ -196,27 +214,38 @@ def cpu_baseline(M, N, K, bs, fi, fo, plain_mx=False, budget_s=10.0):
     t0 = time.perf_counter()
     O.linear(Xs, r["out"][:ns])
     t_l = time.perf_counter() - t0
-    torch_tf, tthreads = None, None
-    try:
-        import torch
-        tthreads = torch.get_num_threads()
-        Xt = torch.randn(1024, K); Wt = torch.from_numpy(r["out"])
+    oracle_tf = 2.0 * M * ns * K / t_l / 1e12
+    import torch
+    tthreads = torch.get_num_threads()
+    Xt = torch.from_numpy(Xs); Wt = torch.from_numpy(r["out"])
+    torch.nn.functional.linear(Xt[:256], Wt)                      # warm-up (thread pool, allocator)
+    reps, t_t = 0, 0.0
+    t0 = time.perf_counter()
+    while reps < 3 or (t_t < 2.0 and reps < 20):
         torch.nn.functional.linear(Xt, Wt)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            torch.nn.functional.linear(Xt, Wt)
-        torch_tf = 3 * 2.0 * 1024 * N * K / (time.perf_counter() - t0) / 1e12
-        del Wt
-    except Exception:
-        pass
-    return {
-        "value": 2.0 * M * ns * K / t_l / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
-        "sample": "oracle dense linear X[%d,%d].Wq[%d,%d]^T (double accumulate, OpenMP over outputs, %d threads, %.1f s) after "
-                  "the oracle fake-quant of the whole W[%d,%d] (%d threads, %.2f s)" % (M, K, ns, K, threads, t_l, N, K, threads, t_q),
+        reps += 1
+        t_t = time.perf_counter() - t0
+    torch_tf = reps * 2.0 * M * N * K / t_t / 1e12
+    del Wt
+    out = {
+        "value": torch_tf, "unit": "TFLOP/s", "cores": tthreads, "kind": "port",
+        "sample": "torch CPU float32 F.linear X[%d,%d].Wq[%d,%d]^T (the reference's own GEMM op, number_system/mx/linear.py:91; %d torch threads, "
+                  "%d calls in %.1f s) on the oracle's fake-quant of the whole W[%d,%d] (%d OpenMP threads, %.2f s)"
+                  % (M, K, N, K, tthreads, reps, t_t, N, K, threads, t_q),
+        "oracle_linear_tflops": oracle_tf, "oracle_linear_threads": threads,
+        "oracle_linear_sample": "X[%d,%d].Wq[%d,%d]^T, double accumulate, %.1f s" % (M, K, ns, K, t_l),
         "fakequant_s_per_weight": t_q, "fakequant_GBps": 2.0 * N * K * 4 / t_q / 1e9,
         "torch_cpu_fp32_linear_tflops": torch_tf, "torch_cpu_threads": tthreads,
         "host_cpus": os.cpu_count(), "host_physical_cores": cores,
     }
+    if parity is not None:
+        out["parity_checked"] = True
+        out["mismatches"] = parity
+        out["parity_note"] = ("oracle fake-quant of the GPU run's own W[%d,%d] against the HIP results, bit for bit (NaN == NaN): "
+                              "elements that differ" % (N, K))
+    else:
+        out["parity_checked"] = False
+    return out
 
 
 def ppl_proxy(dev, fi, fo, bs):
@@ -247,53 +276,339 @@ def ppl_proxy(dev, fi, fo, bs):
             "equivalent_delta_at_ppl_5.5": 5.5 * abs(ppl_packed - ppl_fake) / ppl_fake}
 
 
-def ppl_delta_from_env(dev, fi, fo, bs):
-    """Metric half (ii), WikiText-2 PPL delta vs the CPU reference, when a checkpoint and the dataset are on local
-    disk:  MSQ_PPL_MODEL = a HuggingFace Llama checkpoint directory, MSQ_WIKITEXT2_DIR = a directory holding
-    wiki.train.raw / wiki.test.raw (or the HF `wikitext-2-raw-v1` parquet / arrow files); optional
-    MSQ_PPL_NSAMPLES bounds the number of test windows.  PPL_ref = the model with every decoder Linear replaced by the
-    ORACLE's CPU fake-quant (the reference's arithmetic) and evaluated densely; PPL_ours = the same checkpoint through
-    the HIP quantiser, packed, fused dequant-GEMM.  Returns None when the environment does not name both."""
+PPL_FIXTURE_MODEL = os.path.join(ROOT, "tests", "golden", "ppl_llama")          # tests/golden/make_ppl_fixture.py
+PPL_FIXTURE_DATA = os.path.join(ROOT, "tests", "golden", "ppl_wikitext2")
+
+
+def _logit_metrics(ref_logits, got_logits):
+    """Token-level agreement of two models on the same windows: mean KL(ref || got) in nats per token, the share of tokens
+    whose arg-max agrees, and the largest absolute logit difference (lists of [S, V] float32 tensors on one device)."""
+    import torch
+    kl = agree = n = 0.0
+    worst = 0.0
+    for a, b in zip(ref_logits, got_logits):
+        a = a.float(); b = b.float().to(a.device)
+        la, lb = torch.log_softmax(a, -1), torch.log_softmax(b, -1)
+        kl += float((la.exp() * (la - lb)).sum())
+        agree += float((a.argmax(-1) == b.argmax(-1)).sum())
+        n += a.shape[0]
+        worst = max(worst, float((a - b).abs().max()))
+    return {"mean_kl_nats_per_token": kl / n, "top1_agreement": agree / n, "max_logit_abs_err": worst, "tokens": int(n)}
+
+
+def _window_logits(model, ids, dev, seqlen, fp32=False):
+    import torch
+    out = []
+    with torch.no_grad():
+        for i in range(ids.numel() // seqlen):
+            lg = model(ids[:, i * seqlen:(i + 1) * seqlen].to(dev)).logits[0]
+            out.append(lg.float() if fp32 else lg)
+    return out
+
+
+def _ppl_from_logits(logits, ids, seqlen):
+    """llm/llama.py:264-282 on stored logits, fp32 cross entropy."""
+    import math
+    import torch
+    nll = 0.0
+    for i, lg in enumerate(logits):
+        tok = ids[0, i * seqlen:(i + 1) * seqlen].to(lg.device)
+        nll += float(torch.nn.functional.cross_entropy(lg[:-1].float(), tok[1:])) * seqlen
+    return math.exp(nll / (len(logits) * seqlen))
+
+
+def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
+    """Metric half (ii): perplexity delta of the HIP packed path against the CPU reference arithmetic, through the harness's own
+    calls -- get_llama (llm/llama.py:20-58), get_wikitext2 (utils/data_utils.py:36-56), the RTN loop (llm/llama.py:226-253) and
+    the PPL formula (:264-282).
+
+    Model and data: MSQ_PPL_MODEL / MSQ_WIKITEXT2_DIR (a HuggingFace Llama checkpoint directory; a directory holding
+    wiki.{train,test}.raw or the HF parquet / arrow files) when the environment names both; otherwise the committed fixture
+    tests/golden/ppl_llama + tests/golden/ppl_wikitext2 (a small TRAINED Llama and a WikiText-2-format synthetic corpus made by
+    tests/golden/make_ppl_fixture.py: neither WikiText-2 nor a Llama-2 checkpoint exists in the image).  MSQ_PPL_NSAMPLES bounds
+    the test windows, MSQ_PPL_SEQLEN sets the window.  Returns None when MSQ_PPL_DISABLE is set or the fixture is absent.
+
+      ppl_cpu_reference        every decoder Linear replaced by the ORACLE's CPU fake-quant of its weight (the reference's
+                               arithmetic, utils/quant.py:147-266), the model evaluated by torch on the HOST in float32
+      ppl_gpu_dense_fakequant  the same weights, evaluated densely on the GPU in the checkpoint dtype (hipBLASLt)
+      ppl_hip_packed_fused     the checkpoint through the HIP quantiser, packed, fused dequant-GEMM (q/k/v and gate/up fused)
+      delta                    ppl_hip_packed_fused - ppl_cpu_reference                      -> the bench line's `ppl_delta`
+      logits_vs_cpu_reference  mean KL per token, top-1 agreement, largest logit error of the packed model
+
+    ``paths`` may add "mx": W4A8 on the MX matrix path, scored against ITS reference semantics (number_system/mx/linear.py:29-91:
+    activations quantised to MX-FP8 by `_quantize_mx`, dense GEMM) -- the oracle's quantize_mx on the input of every decoder
+    Linear of the CPU model -- not against the weight-only model.
+    ``corrupt`` (tests): callable(packed_model) applied before the packed evaluation, e.g. flipping a scale byte."""
     model_dir, data_dir = os.environ.get("MSQ_PPL_MODEL"), os.environ.get("MSQ_WIKITEXT2_DIR")
-    if not (model_dir and data_dir):
+    fixture = not (model_dir and data_dir)
+    if os.environ.get("MSQ_PPL_DISABLE"):
         return None
+    if fixture:
+        model_dir, data_dir = PPL_FIXTURE_MODEL, PPL_FIXTURE_DATA
+        if not (os.path.exists(os.path.join(model_dir, "model.safetensors")) and os.path.exists(os.path.join(data_dir, "wiki.test.raw"))):
+            return None
     import copy
     import numpy as np
     import torch
     import msq
     from msq.harness import find_layers, llama
-    from msq.harness.data_utils import get_wikitext2, _Enc
-    from msq.harness.evalppl import perplexity
+    from msq.harness.data_utils import get_wikitext2
+    from msq.harness.evalppl import LLAMA_FUSE, pack_layers, perplexity, quantize_layers_nearest
     from oracle import oracle as O
     model = llama.get_llama(model_dir).eval()
-    seqlen = int(os.environ.get("MSQ_PPL_SEQLEN", model.seqlen))
+    info = {}
+    try:
+        info = json.load(open(os.path.join(model_dir, "fixture_info.json")))
+    except Exception:
+        pass
+    seqlen = int(os.environ.get("MSQ_PPL_SEQLEN", info.get("eval_seqlen", model.seqlen)))
     model.seqlen = seqlen
     _, testenc = get_wikitext2(0, 0, seqlen, model_dir, data_dir=data_dir)
     ids = testenc.input_ids
     ns = os.environ.get("MSQ_PPL_NSAMPLES")
     if ns:
         ids = ids[:, :int(ns) * seqlen]
-    tokens = _Enc(ids)
-    qc = dict(inlier_elem_format=fi, outlier_elem_format=fo, axes=[-1], block_size=bs)
-    ref = copy.deepcopy(model)
+    nwin = int(ids.numel() // seqlen)
+    mdt = next(model.parameters()).dtype
     O.set_threads(physical_cores())
-    for layer in ref.model.layers:                       # CPU reference arithmetic (oracle), evaluated densely
-        for name, lin in find_layers(layer).items():
-            W = lin.weight.data
-            Wq = O.outlier_fakequant(W.float().numpy(), 8, 8, fi, fo, 2, -1, bs)["out"]
-            lin.weight.data = torch.from_numpy(Wq).to(W.dtype)
-    ppl_ref = perplexity(ref.to(dev), tokens, dev, seqlen)
-    del ref
-    model.to(dev)
-    q = msq.quant.MXQuantizer(); q.configure(8, 8, **qc)
-    kept = 0                                             # shapes off the tile grid are padded at pack time: nothing stays dense
-    for layer in model.model.layers:
-        msq.qlinear.make_quant(layer, {n: q for n in find_layers(layer)})
-        kept += sum(isinstance(l, torch.nn.Linear) for l in layer.modules())
-    ppl_ours = perplexity(model, tokens, dev, seqlen)
-    return {"ppl_cpu_reference": ppl_ref, "ppl_hip_packed_fused": ppl_ours, "delta": ppl_ours - ppl_ref,
-            "windows": int(ids.numel() // seqlen), "seqlen": seqlen, "layers_kept_dense": kept,
-            "model": os.path.basename(os.path.normpath(model_dir))}
+
+    def cpu_reference(fo_):
+        """the checkpoint with every decoder Linear replaced by the oracle's CPU fake-quant of its weight (checkpoint dtype)"""
+        r = copy.deepcopy(model)
+        for layer in r.model.layers:
+            for lin in find_layers(layer).values():
+                W = lin.weight.data
+                lin.weight.data = torch.from_numpy(O.outlier_fakequant(W.float().numpy(), 8, 8, fi, fo_, 2, -1, bs)["out"]).to(W.dtype)
+        return r
+
+    out = {"model": ("tests/golden/ppl_llama: trained 4-layer hidden-256 Llama (tests/golden/make_ppl_fixture.py)" if fixture
+                     else os.path.basename(os.path.normpath(model_dir))),
+           "dataset": ("tests/golden/ppl_wikitext2: synthetic corpus in the raw WikiText-2 layout (same script); NOT WikiText-2" if fixture
+                       else data_dir),
+           "model_dtype": str(mdt).replace("torch.", ""), "windows": nwin, "seqlen": seqlen,
+           "ppl_unquantised_cpu_fp32": _ppl_from_logits(_window_logits(copy.deepcopy(model).float(), ids, "cpu", seqlen), ids, seqlen)}
+    for path in paths:
+        # the MX matrix path carries the weight as ONE e4m3 operand: posit outliers do not fit it, so it is scored with fp8_e4m3 outliers
+        fo_p = "fp8_e4m3" if path == "mx" else fo
+        qc = dict(inlier_elem_format=fi, outlier_elem_format=fo_p, axes=[-1], block_size=bs)
+        # ---- CPU reference: oracle fake-quant weights, the model evaluated by torch on the host in float32
+        ref = cpu_reference(fo_p)
+        ref_cpu = copy.deepcopy(ref).float()
+        if path == "mx":
+            # reference semantics of the W4A8 MX path (number_system/mx/linear.py:29-91): the activations of every decoder Linear
+            # quantised by _quantize_mx (oracle: MX-FP8 e4m3, block 32 along in_features), float32 GEMM on the fake-quant weight
+            def _aq(mod, args_):
+                x = args_[0]
+                xq = O.quantize_mx(x.detach().reshape(-1, x.shape[-1]).numpy(), 8, "fp8_e4m3", axis=-1, block_size=32)
+                return (torch.from_numpy(xq).reshape(x.shape),)
+            lg_wo = _window_logits(ref_cpu, ids, "cpu", seqlen)              # weight-only reference, for the size of the activation effect
+            hooks = [lin.register_forward_pre_hook(_aq) for layer in ref_cpu.model.layers for lin in find_layers(layer).values()]
+        lg_cpu = _window_logits(ref_cpu, ids, "cpu", seqlen)
+        ppl_cpu = _ppl_from_logits(lg_cpu, ids, seqlen)
+        del ref_cpu
+        # ---- HIP: RTN through the harness (llm/llama.py:226-253), packed, fused kernels
+        m = copy.deepcopy(model).to(dev)
+        quantize_layers_nearest(m.model.layers, dev, qc)
+        n_packed, kept = pack_layers(m.model.layers, path=path, fuse=LLAMA_FUSE)
+        kept += sum(isinstance(l, torch.nn.Linear) for layer in m.model.layers for l in layer.modules())
+        if corrupt is not None:
+            corrupt(m)
+        lg = _window_logits(m, ids, dev, seqlen)
+        ppl = _ppl_from_logits(lg, ids, seqlen)
+        if path == "bf16":
+            # the same reference weights densely on the GPU (hipBLASLt, checkpoint dtype)
+            lg_dense = _window_logits(ref.to(dev), ids, dev, seqlen)
+            out.update({"outlier": fo_p, "ppl_cpu_reference": ppl_cpu, "ppl_gpu_dense_fakequant": _ppl_from_logits(lg_dense, ids, seqlen),
+                        "ppl_hip_packed_fused": ppl, "delta": ppl - ppl_cpu, "relative_delta": (ppl - ppl_cpu) / ppl_cpu,
+                        "layers_packed": n_packed, "layers_kept_dense": kept,
+                        # loss in the model dtype, exactly llm/llama.py:264-282 (an fp16 loss moves in coarse steps)
+                        "ppl_gpu_dense_fakequant_reference_formula": perplexity(ref, ids, dev, seqlen),
+                        "ppl_hip_packed_fused_reference_formula": perplexity(m, ids, dev, seqlen),
+                        "logits_vs_cpu_reference": _logit_metrics(lg_cpu, lg), "logits_vs_gpu_dense_fakequant": _logit_metrics(lg_dense, lg)})
+            out["delta_vs_gpu_dense_fakequant"] = ppl - out["ppl_gpu_dense_fakequant"]
+        else:
+            mods = [mm for mm in m.modules() if isinstance(mm, msq.qlinear.MXLinearW4A8)]
+            out["mx_path"] = {"outlier": fo_p, "ppl_cpu_reference_mxlinear_semantics": ppl_cpu, "ppl_hip_packed_mx": ppl, "delta": ppl - ppl_cpu,
+                              "relative_delta": (ppl - ppl_cpu) / ppl_cpu, "layers_kept_dense": kept, "mx_modules": len(mods),
+                              "logits_vs_cpu_reference_mxlinear_semantics": _logit_metrics(lg_cpu, lg),
+                              "logits_vs_weight_only_cpu_reference": _logit_metrics(lg_wo, lg),
+                              "note": "reference = oracle _quantize_mx (MX-FP8 e4m3, block 32) on the input of every decoder Linear + float32 "
+                                      "GEMM on the oracle's fake-quant weight (number_system/mx/linear.py:29-91); the weight-only row shows "
+                                      "how much of the distance to the weight-only model is the activation quantisation itself"}
+        del m, ref
+    return out
+
+
+def _tgraph(fns, reps=10):
+    """Device time per call in ms: the calls of `fns` captured into ONE HIP graph on a side stream, `reps` replays timed with HIP
+    events (no Python / ctypes launch floor between the kernels)."""
+    import torch
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for f in fns[:3]:
+            f()
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for f in fns:
+                f()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps / len(fns)
+
+
+def _clone_packed(P):
+    from msq import qlinear
+    c = lambda t: None if t is None else t.clone()
+    if isinstance(P, qlinear.MXPackedWeight):
+        import copy
+        Q = copy.copy(P)
+        Q.codes, Q.scales = P.codes.clone(), P.scales.clone()
+        return Q
+    return qlinear.PackedWeight(c(P.inl), c(P.out), c(P.scl), P.N, P.K, P.block, P.in_kind, P.out_kind, P.n, P.k)
+
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 achievable)
+# sub-objects of the default line's `configs` (BASELINE.json configs 3, 4, 5 and decode) and of `rowparallel`: the --stub path emits
+# the same keys, tests/test_host_logic.py pins them
+CONFIG_KEYS = ("w4a8_mx", "w4a8_mx_plain_fp4", "w6a8_mx_plain_fp6", "w4a8_mxlinear", "kv_quant", "decode_cold", "rowparallel_70b_1gpu")
+ROWPAR_KEYS = ("step_ms", "gemm_ms", "comm_ms", "exposed_comm_ms", "chunks", "comm", "wire_dtype")
+
+
+def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
+    """BASELINE.json configs 3, 4, 5 and decode, measured in the SAME driver-run process as the headline (default workload, one
+    GPU): compact objects with `ms`, the achieved rate, the roofline fraction and the algorithmic flops / bytes they are priced on.
+    Device time from HIP-graph replays of back-to-back calls, inputs resident in HBM; ~2 s of GPU time in all."""
+    import torch
+    import msq
+    from msq import kvcache, qlinear, quant
+    from msq.mx_ops import _quantize_mx_outlier_v1
+    out = {}
+    N, K = 4 * H, H
+    W = synth_weight(N, K, dev, seed=0)
+    X = torch.randn(M, K, device=dev)
+    fl = 2.0 * M * N * K
+    # ---- config 3 on the CDNA4 fp8 / scaled MFMA (a step = activation pack + k_mxgemm), three weight operands
+    P_msq = qlinear.mx_pack_values(quant.outlier_fakequant(W, 8, 8, inlier, "fp8_e4m3", 2, -1, block)["out"])
+    for key, P, what in (("w4a8_mx", P_msq, "MicroScopiQ weight (MX-FP4 inliers + fp8_e4m3 outliers) as one exact e4m3 operand, 8.25 b/w"),
+                         ("w4a8_mx_plain_fp4", qlinear.mx_pack_weight(W, w_fmt="e2m1"), "plain OCP MX-FP4 weight, 4.25 b/w"),
+                         ("w6a8_mx_plain_fp6", qlinear.mx_pack_weight(W, w_fmt="e3m2"), "plain OCP MX-FP6 (e3m2) weight, 6.25 b/w")):
+        for _ in range(30):
+            qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
+        ms = _tgraph([lambda P=P: qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)] * 10)
+        out[key] = {"ms": ms, "tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_FP8_TFLOPS, "peak": PEAK_FP8_TFLOPS, "bound": "mfma (fp8 rate)",
+                    "flops": fl, "kernels": "k_mx_pack_a8 + k_mxgemm", "operand": what, "M": M, "N": N, "K": K,
+                    "activations": "fp32 in, MX-FP8 (e4m3, block 32) packed in the step"}
+        del P
+    del P_msq
+    # ---- config 3 as the reference composes it: MXLinear(w = fp4_e2m1, a = fp8_e4m3, block 32), mx_ops variant (std_dev 5) on BOTH operands
+    Pl = qlinear.pack_values(_quantize_mx_outlier_v1(W, 8, 8, inlier, "fp4_e2m1", "max", 5, [1], block))
+    f = lambda: qlinear.qlinear_w4a8(X, Pl, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5, a_block_size=block, a_variant=1)
+    for _ in range(30):
+        f()
+    ms = _tgraph([f] * 10)
+    fa = lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, block, variant=1)
+    ms_a = _tgraph([fa] * 10)
+    out["w4a8_mxlinear"] = {"ms": ms, "tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "peak": PEAK_BF16_TFLOPS, "bound": "mfma (bf16 rate)",
+                            "flops": fl, "kernels": "activation quantiser (mx_ops variant, two passes) + k_qgemm3", "act_quant_ms": ms_a,
+                            "semantics": "number_system/mx/linear.py:29-91", "M": M, "N": N, "K": K}
+    del Pl, W, X
+    # ---- config 4: KV-cache quantisation of one Llama-2-7B layer cache [1, 32, 4096, 128] fp16 (GEAR hook, compress_function.py:8-70)
+    k = torch.randn(1, 32, 4096, 128, device=dev).to(torch.float16)
+    byts = 2.0 * k.numel() * 2
+    kv = {}
+    for key, fn in (("keys_group_4bit_per_channel_g32", lambda: kvcache.fake_groupwise_channel_asymmetric_quantization_new(k, 4, 32)),
+                    ("values_group_4bit_per_token_g32", lambda: kvcache.fake_groupwise_token_asymmetric_quantization(k, 4, 32)),
+                    ("keys_mx_fp8_blocks_along_tokens", lambda: kvcache.mx_quantize_keys(k, "fp8_e4m3", 32)),
+                    ("values_mx_fp8_blocks_along_head_dim", lambda: kvcache.mx_quantize_values(k, "fp8_e4m3", 32))):
+        for _ in range(5):
+            fn()
+        ms = _tgraph([fn] * 10)
+        kv[key] = {"ms": ms, "GBps": byts / ms / 1e6, "frac": byts / ms / 1e6 / HBM_PEAK_GBPS}
+    out["kv_quant"] = dict(kv, bytes=byts, bound="hbm", peak=HBM_PEAK_GBPS, cache="[1, 32, 4096, 128] float16 (read once + written once)")
+    del k
+    # ---- decode, M = 1, COLD weights: one decoder layer's four fused projections, each walked over > 1 GB of distinct packed copies
+    dec = {}
+    tot_ms = tot_b = 0.0
+    for name, n_, k_ in (("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)):
+        Wp = synth_weight(n_, k_, dev, seed=1)
+        P0 = qlinear.pack_weight(Wp, 8, 8, inlier, "posit8_es1", 2, block, layout="unified")
+        del Wp
+        copies = max(4, int(1.05e9 // P0.nbytes) + 1)
+        Ps = [P0] + [_clone_packed(P0) for _ in range(copies - 1)]
+        x1 = torch.randn(1, P0.k, device=dev).to(torch.bfloat16)
+        ms = _tgraph([(lambda P=P: qlinear.qlinear(x1, P)) for P in Ps], reps=3)
+        dec[name] = {"ms": ms, "packed_MB": P0.nbytes / 1e6, "GBps": P0.nbytes / ms / 1e6}
+        tot_ms += ms
+        tot_b += P0.nbytes
+        del Ps, P0
+    out["decode_cold"] = dict(dec, layer_ms=tot_ms, packed_bytes=tot_b, GBps=tot_b / tot_ms / 1e6, frac=tot_b / tot_ms / 1e6 / HBM_PEAK_GBPS,
+                              bound="hbm", peak=HBM_PEAK_GBPS, M=1,
+                              what="Llama-2-7B layer, q/k/v and gate/up fused, fp4 + posit8 outliers (9.25 b/w); every launch reads a "
+                                   "different copy (> 1 GB per projection): neither L2 nor the 256 MB Infinity Cache holds the weights")
+    # ---- config 5 on ONE GPU: the whole 70B down_proj [8192 x 28672] at M = 2048 (what the K-split divides over the ranks)
+    Wd = synth_weight(8192, 28672, dev, seed=2)
+    Pd = qlinear.pack_weight(Wd, 8, 8, inlier, "posit8_es1", 2, block, layout="auto")
+    del Wd
+    Xd = torch.randn(M, 28672, device=dev).to(torch.bfloat16)
+    for _ in range(10):
+        qlinear.qlinear(Xd, Pd, None, torch.bfloat16)
+    ms = _tgraph([lambda: qlinear.qlinear(Xd, Pd, None, torch.bfloat16)] * 5)
+    fd = 2.0 * M * 8192 * 28672
+    out["rowparallel_70b_1gpu"] = {"ms": ms, "tflops": fd / ms / 1e9, "frac": fd / ms / 1e9 / PEAK_BF16_TFLOPS, "peak": PEAK_BF16_TFLOPS, "bound": "mfma",
+                                   "flops": fd, "M": M, "N": 8192, "K": 28672,
+                                   "what": "Llama-2-70B down_proj, unsharded, fp4 + posit8 outliers; with N GPUs the default line adds the K-split step (`rowparallel`)"}
+    return out
+
+
+def rowparallel_measure(rp, X, M, dev, group_on, world, comm):
+    """Where a row-parallel step's time goes: the whole step, its GEMM chunks (events on the compute stream) and the same collectives
+    alone on the same buffers; MAX over ranks beside rank 0's figures."""
+    import torch
+    import torch.distributed as dist
+    nt = 20
+    evs = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        rp(X)
+    if group_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(nt):
+        rp(X, gemm_events=evs)
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / nt
+    gemm_ms = sum(a.elapsed_time(b) for a, b in evs) / nt
+    comm_ms = None
+    if group_on:
+        for _ in range(3):
+            rp.comm_only(M, torch.bfloat16, dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nt):
+            rp.comm_only(M, torch.bfloat16, dev)
+        e1.record()
+        torch.cuda.synchronize()
+        comm_ms = e0.elapsed_time(e1) / nt
+    r = {"step_ms": step_ms, "gemm_ms": gemm_ms, "comm_ms": comm_ms, "exposed_comm_ms": max(0.0, step_ms - gemm_ms),
+         "chunks": rp.chunks_for(M), "comm": comm, "wire_dtype": "bf16",
+         "note": "gemm_ms: the shard's GEMM chunks (events on the compute stream); comm_ms: the same collectives alone "
+                 "(includes the zero fill of the buffer); exposed = step - gemm"}
+    if world > 1:
+        t = torch.tensor([step_ms, gemm_ms, comm_ms or 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        r["max_over_ranks"] = {"step_ms": float(t[0]), "gemm_ms": float(t[1]), "comm_ms": float(t[2])}
+    return r
 
 
 def e2e_main(args, dev):
@@ -482,20 +797,34 @@ def e2e_main(args, dev):
                     "decode_ms_per_token_whole_step_hip_graph": tdg,
                     "decode_linears_ms_per_token_hip_graph": tg, "prefill_linears_ms_hip_graph": tgp,
                     "prefill_linears_tflops": 2.0 * S * n_w / (tgp * 1e-3) / 1e12}
-    # (iv) perplexity on synthetic tokens + logit error
+    # (iv) perplexity on synthetic tokens + logit-level agreement.  The reference of the MX path is NOT the weight-only model: MXLinear
+    # quantises the activations of every Linear too (number_system/mx/linear.py:29-91), so the dense model gets `_quantize_mx`
+    # (MX-FP8 e4m3, block 32 along in_features; the HIP fake-quant kernel, bit-exact against the oracle in the unit tests) on the
+    # input of every decoder Linear before its hipBLASLt GEMM -- like for like with what the packed W4A8 modules compute.
     nwin = max(1, min(4, 8192 // S))
     toks = _Enc(torch.randint(0, 32000, (1, nwin * S), generator=torch.Generator().manual_seed(3)))
     import contextlib
+    hooks = []
+    if args.path == "mx":
+        from msq.mx_ops import _quantize_mx
+        def _aq(mod, a_):
+            return (_quantize_mx(a_[0], 8, "fp8_e4m3", axes=[-1], block_size=32, compute_dtype="float32"),)
+        with torch.no_grad():
+            ld_wo = dense(ids).logits[0].float()                     # weight-only dense model: how large the activation effect itself is
+        hooks = [lin.register_forward_pre_hook(_aq) for layer in dense.model.layers for lin in find_layers(layer).values()]
     with contextlib.redirect_stdout(sys.stderr):
         ppl_d = perplexity(dense, toks, dev, S, fp32_loss=True)       # fp32 cross entropy: the reference's fp16 loss moves in 0.8 % steps here
         ppl_p = perplexity(packed, toks, dev, S, fp32_loss=True)
         ppl_d16 = perplexity(dense, toks, dev, S)
         ppl_p16 = perplexity(packed, toks, dev, S)
     with torch.no_grad():
-        ld = dense(ids).logits.float()
-        lp = packed(ids).logits.float()
-    lerr = (ld - lp).abs().max().item()
-    lmax = ld.abs().max().item()
+        ld = dense(ids).logits[0].float()
+        lp = packed(ids).logits[0].float()
+    for h in hooks:
+        h.remove()
+    lm = _logit_metrics([ld], [lp])
+    lerr, lmax = lm["max_logit_abs_err"], ld.abs().max().item()
+    lm_wo = _logit_metrics([ld_wo], [lp]) if args.path == "mx" else None
     out = {
         "metric": "llama7b_e2e: prefill tokens/s of the packed model (side workload of bench.py; the headline metric is the default line)",
         "value": S / res["packed_fused"]["prefill_s"], "unit": "tokens/s", "n_gpus": 1, "steps": 5, "warmup": 2,
@@ -516,7 +845,12 @@ def e2e_main(args, dev):
                          "equivalent_delta_at_ppl_5.5": 5.5 * abs(ppl_p - ppl_d) / ppl_d, "windows": nwin, "seqlen": S,
                          "loss": "fp32 cross entropy of the model's logits", "ppl_fakequant_dense_reference_formula": ppl_d16,
                          "ppl_packed_fused_reference_formula": ppl_p16,
-                         "max_logit_abs_err": lerr, "max_abs_logit": lmax, "tokens": "uniform random ids (no dataset in the image)"},
+                         "max_logit_abs_err": lerr, "max_abs_logit": lmax, "tokens": "uniform random ids (no dataset in the image)",
+                         "mean_kl_nats_per_token": lm["mean_kl_nats_per_token"], "top1_agreement": lm["top1_agreement"],
+                         "reference": ("dense fake-quant model with _quantize_mx (MX-FP8) on the input of every decoder Linear (MXLinear semantics)"
+                                       if args.path == "mx" else "dense fake-quant model (weight-only)"),
+                         "vs_weight_only_dense": lm_wo,
+                         "note": "random weights: the perplexity is insensitive by construction (flat loss); read the KL / top-1 / logit rows"},
     }
     _emit_json(json.dumps(out))
 
@@ -594,6 +928,7 @@ def main(argv=None):
     mxw4a8 = args.workload == "llama7b_mx_w4a8" or mxw6
     msqmx = args.workload == "llama7b_msq_w4a8_mx" or (rowpar and args.mx)
     rp = None
+    parity_src = None
     if rowpar:
         # K splits on a multiple of 64 (128 on the MX path): the 32-blocks and the packed tiles stay whole, every shard's
         # operands equal the unsharded ones; partial outputs summed by reduce-scatter + all-gather (RCCL over xGMI),
@@ -648,6 +983,11 @@ def main(argv=None):
     else:
         P = qlinear.pack_weight(W, 8, 8, args.inlier, args.outlier, 2, args.block, layout=args.layout)
         X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # full-size parity material for cpu_baseline: the run's own weight, the HIP fake-quant of it and what the packed planes decode to
+            from msq import quant as _q
+            parity_src = (W.cpu().numpy(), {"hip_fakequant": _q.outlier_fakequant(W, 8, 8, args.inlier, args.outlier, 2, -1, args.block)["out"].cpu().numpy(),
+                                            "hip_unpack_of_packed_planes": qlinear.unpack_weight(P).cpu().numpy()})
     del W
     torch.cuda.synchronize()
 
@@ -703,40 +1043,25 @@ def main(argv=None):
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
     if rp is not None:
-        nt = 20
-        evs = []
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if group_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(nt):
-            rp(X, gemm_events=evs)
-        e1.record()
-        torch.cuda.synchronize()
-        step_ms = e0.elapsed_time(e1) / nt
-        gemm_ms = sum(a.elapsed_time(b) for a, b in evs) / nt
-        comm_ms = None
-        if group_on:
-            for _ in range(3):
-                rp.comm_only(M, torch.bfloat16, dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(nt):
-                rp.comm_only(M, torch.bfloat16, dev)
-            e1.record()
-            torch.cuda.synchronize()
-            comm_ms = e0.elapsed_time(e1) / nt
-        rowpar_times = {"step_ms": step_ms, "gemm_ms": gemm_ms, "comm_ms": comm_ms, "exposed_comm_ms": max(0.0, step_ms - gemm_ms),
-                        "chunks": rp.chunks_for(M), "comm": args.comm, "wire_dtype": "bf16",
-                        "note": "gemm_ms: the shard's GEMM chunks (events on the compute stream); comm_ms: the same collectives alone "
-                                "(includes the zero fill of the buffer); exposed = step - gemm"}
-        if world > 1:
-            t = torch.tensor([step_ms, gemm_ms, comm_ms or 0.0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            rowpar_times["max_over_ranks"] = {"step_ms": float(t[0]), "gemm_ms": float(t[1]), "comm_ms": float(t[2])}
-
+        rowpar_times = rowparallel_measure(rp, X, M, dev, group_on, world, args.comm)
+    elif world > 1 and args.workload == "llama7b_w4_fused_gemm":
+        # N > 1 on the DEFAULT workload (what the driver's scaling run launches): the headline stays N independent replicas, and the
+        # same processes then run BASELINE config 5 -- the 70B down_proj [8192 x 28672] K-split over the ranks, partial products
+        # summed by reduce-scatter + all-gather over RCCL -- so that a SCALE run measures the sharded path without extra flags
+        Wr = synth_weight(8192, 28672 // world, dev, seed=100 + rank) if 28672 % (world * 64) == 0 else None
+        if Wr is not None:
+            Pr = qlinear.pack_weight(Wr, 8, 8, args.inlier, args.outlier, 2, args.block, layout=args.layout)
+            del Wr
+            rp2 = qlinear.RowParallelQuantLinear(qlinear.QuantLinear.from_packed(Pr, None, out_dtype=torch.bfloat16), world, rank, None,
+                                                 comm=args.comm, chunks=args.chunks, reduce_dtype=torch.bfloat16)
+            Xr = torch.randn(M, 28672 // world, device=dev).to(torch.bfloat16)
+            rowpar_times = rowparallel_measure(rp2, Xr, M, dev, True, world, args.comm)
+            fr = 2.0 * M * 8192 * 28672
+            sm = rowpar_times["max_over_ranks"]["step_ms"]
+            rowpar_times.update({"workload": "Llama-2-70B down_proj [8192 x 28672], K split over %d GPUs, M = %d" % (world, M), "flops": fr,
+                                 "tflops_whole_job": fr / sm / 1e9, "frac_of_aggregate_bf16_peak": fr / sm / 1e9 / (PEAK_BF16_TFLOPS * world),
+                                 "scaling": "strong"})
+            del rp2, Pr, Xr
     flops_step = 2.0 * M * N * K                            # algorithmic: dequant flops not counted
     total_flops = flops_step * args.steps * world
     value = total_flops / wall / 1e12
@@ -787,19 +1112,21 @@ def main(argv=None):
         import contextlib
         try:
             with contextlib.redirect_stdout(sys.stderr):              # the harness prints progress: keep stdout to ONE JSON line
-                out["ppl_proxy"] = ppl_proxy(dev, args.inlier, args.outlier, args.block)
-        except Exception as e:                                     # the stand-in must never take the bench line down
-            out["ppl_proxy"] = {"error": repr(e)[:200]}
-        try:
-            with contextlib.redirect_stdout(sys.stderr):
-                pd = ppl_delta_from_env(dev, args.inlier, args.outlier, args.block)
+                pd = ppl_delta_from_env(dev, args.inlier, args.outlier, args.block, paths=("bf16", "mx"))
             if pd is not None:
                 out["ppl_delta"] = pd["delta"]
                 out["ppl_wikitext2"] = pd
-        except Exception as e:
+        except Exception as e:                                     # must never take the bench line down
             out["ppl_wikitext2"] = {"error": repr(e)[:300]}
+        if (M, H) == (2048, 4096):
+            try:
+                with contextlib.redirect_stdout(sys.stderr):
+                    out["configs"] = other_configs(dev, M, H, args.inlier, args.block)
+            except Exception as e:
+                out["configs"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier, plain_mx=(mxw4a8 and not msqmx))
+        out["cpu_baseline"] = cpu_baseline(M, N, K, args.block, args.inlier, args.outlier, plain_mx=(mxw4a8 and not msqmx),
+                                           W_host=parity_src[0] if parity_src else None, gpu_values=parity_src[1] if parity_src else None)
     if rank == 0:
         _emit_json(json.dumps(out))
     if world > 1 or src:
@@ -834,12 +1161,20 @@ def stub_main(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if rank == 0:
-        _emit_json(json.dumps({"metric": "stub (no GPU work)", "value": 0.0, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True,
-                          "scaling": "strong" if rowpar else "weak", "vs_baseline": None, "dtype": "none", "data": "none",
-                          "config": {"workload": "stub", "ranks_seen": seen},
-                          "rowparallel": ({"step_ms": 0.0, "gemm_ms": 0.0, "comm_ms": 0.0, "exposed_comm_ms": 0.0, "chunks": args.chunks,
-                                           "comm": args.comm, "wire_dtype": "none"} if rowpar else None)}))
+        rp_obj = None
+        if rowpar or world > 1:       # the default workload on N > 1 ranks carries the 70B K-split step too (main: rowparallel_measure)
+            rp_obj = dict({k: 0.0 for k in ROWPAR_KEYS}, chunks=args.chunks, comm=args.comm, wire_dtype="none")
+            if not rowpar:
+                rp_obj.update(workload="stub", flops=0.0, tflops_whole_job=0.0, frac_of_aggregate_bf16_peak=0.0, scaling="strong",
+                              max_over_ranks={"step_ms": 0.0, "gemm_ms": 0.0, "comm_ms": 0.0})
+        line = {"metric": "stub (no GPU work)", "value": 0.0, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                "scaling": "strong" if rowpar else "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                "config": {"workload": "stub", "ranks_seen": seen}, "rowparallel": rp_obj}
+        if world == 1 and not rowpar:
+            line["configs"] = {k: {"ms": 0.0, "frac": 0.0} for k in CONFIG_KEYS}
+            line["ppl_delta"] = None
+        _emit_json(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

@@ -11,6 +11,7 @@ _SO = os.environ.get("MSQ_LIB_OVERRIDE") or os.path.join(_HERE, "libmsq_hip.so")
 _lib = None
 
 MSQ_OK = 0
+MSQ_ERR_BAD_ARG, MSQ_ERR_UNSUPPORTED, MSQ_ERR_LAUNCH = -1, -2, -3      # include/msq.h status codes
 DTYPE_ID = {"torch.float32": 0, "torch.float16": 1, "torch.bfloat16": 2}
 
 _i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
@@ -76,7 +77,10 @@ _SIGS = {
 
 
 class MsqError(RuntimeError):
-    pass
+    """`rc` carries the C ABI's status code (include/msq.h: MSQ_ERR_*) when the error came from a library call, else None."""
+    def __init__(self, *args, rc=None):
+        super().__init__(*args)
+        self.rc = rc
 
 
 def so_path():
@@ -104,7 +108,7 @@ def lib():
 def check(rc, what=""):
     if rc != MSQ_OK:
         msg = lib().msq_last_error()
-        raise MsqError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+        raise MsqError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}", rc=rc)
 
 
 def format_id(name):

@@ -7,10 +7,16 @@ buffer of the model, and a JSON header in the metadata describing each packed la
 rebuilt without re-quantising (and, for the 70B row-parallel configuration, shard by shard: every rank saves
 and loads its own file, `shard` / `world_size` are recorded).
 
-    header = {"format": "msq-packed", "version": 1, "shard": r, "world_size": G,
+    header = {"format": "msq-packed", "version": 2, "shard": r, "world_size": G,
               "layers": {"<module name>": {"in_features", "out_features", "block_size", "layout",
                                             "in_kind", "out_kind", "inlier_elem_format",
                                             "outlier_elem_format", "bias", "out_dtype"}}}
+
+Version 2 (round 3 onwards) added: "fused" layer entries (q / k / v and gate / up packed as one weight, state_dict keys under
+``<first sibling>.fused.proj.*``), planes of off-grid shapes padded to the tile grid ("padded_out" / "padded_in" record the
+padded shape) and "values" layers for modules built from an existing PackedWeight.  A version-1 file has none of these and
+still loads; a file with a HIGHER version than this build's is refused by read_header with a clear message instead of a
+misleading "layer does not exist" / size mismatch.
 
 MX-operand layers (MXLinearW4A8: codes in the operand order of the scaled MFMA) are listed with
 ``"layout": "mx-operand"`` and ``"w_fmt"`` ("e2m1" plain MX-FP4, "e4m3" exactly packed fake-quant values).
@@ -21,9 +27,9 @@ import torch
 import torch.nn as nn
 
 from ._lib import MsqError
-from .qlinear import FusedProjections, MXLinearW4A8, ProjectionSlice, QuantLinear
+from .qlinear import K_MULT, N_MULT, FusedProjections, MXLinearW4A8, ProjectionSlice, QuantLinear, _ceil_to
 
-FORMAT, VERSION = "msq-packed", 1
+FORMAT, VERSION = "msq-packed", 2
 
 
 def _packed_layers(model):
@@ -58,7 +64,8 @@ def save_packed(model, path, shard=0, world_size=1):
         layers[name] = dict(in_features=m.in_features, out_features=m.out_features, block_size=m.block_size,
                             layout=m.layout, in_kind=m.in_kind, out_kind=m.out_kind,
                             inlier_elem_format=m.inlier_elem_format, outlier_elem_format=m.outlier_elem_format,
-                            bias=m.bias is not None, out_dtype=str(m.out_dtype).replace("torch.", ""))
+                            bias=m.bias is not None, out_dtype=str(m.out_dtype).replace("torch.", ""),
+                            padded_out=_ceil_to(m.out_features, N_MULT), padded_in=_ceil_to(m.in_features, K_MULT))
     for name, (parent, sibs, splits) in fused.items():            # fused q / k / v or gate / up: one packed weight, several stand-ins
         layers[name]["fused"] = dict(parent=parent, names=sibs, splits=splits)
     header = dict(format=FORMAT, version=VERSION, shard=int(shard), world_size=int(world_size), layers=layers)
@@ -75,7 +82,8 @@ def read_header(path):
         raise MsqError("%s is not an msq-packed checkpoint (no header)" % path)
     header = json.loads(meta["msq"])
     if header.get("format") != FORMAT or int(header.get("version", -1)) > VERSION:
-        raise MsqError("unsupported checkpoint format %r version %r" % (header.get("format"), header.get("version")))
+        raise MsqError("unsupported checkpoint format %r version %r (this build reads %s versions 1..%d)"
+                       % (header.get("format"), header.get("version"), FORMAT, VERSION))
     return header
 
 

@@ -1,0 +1,254 @@
+// msq_gemm256.hip -- k_qgemm256: the fused unpack-dequant-GEMM of the unified layouts (MSQ-U1 / U1X) with 256-row wave tiles and
+// hand-placed accumulators (msq_qlinear_bf16 at prefill sizes; replaces number_system/mx/linear.py:91 `F.linear` on weights whose
+// values are those of utils/quant.py:147-266).
+//
+// Why a second GEMM kernel.  k_qgemm3 (msq_gemm.hip: 128 x 64 wave tiles, two waves per SIMD) is bound by the SIMD's instruction
+// issue: per K-step of 64 a wave issues 64 MFMAs next to 32 scaled converts, 72 plain vector ops (posit extension bits), 16
+// ds_read_b128, 2 LDS-DMA pieces and 7 packed loads, and the costs add.  A 256 x 64 wave tile feeds every converted
+// weight fragment to SIXTEEN MFMAs instead of eight -- half the converts, rotates, and-ors and packed loads per MFMA -- but it needs
+// 256 accumulator registers: one wave per SIMD with the accumulators in AGPRs.  hipcc cannot hold that shape: with all 256 AGPRs
+// taken by accumulators every `v_mfma` whose result is a fresh virtual register needs a spare one, and its allocator shuttles
+// accumulators through v_accvgpr_read / _write inside the loop (200-676 copies per two K-steps, 238 us against 200).
+//
+// Here the compiler is taken out of exactly that part: every MFMA is an inline-asm statement whose accumulator operand is a TIED
+// "+a" register (`v_mfma_f32_16x16x32_bf16 a[i:i+3], v[A], v[B], a[i:i+3]`): the 64 accumulator quads are pinned to a[0:255] for
+// the whole loop, results in place, no copy can appear (scripts/check_isa.py counts v_accvgpr_* inside the loop: 0).  The rest of
+// the stream is placed by hand around them -- one wave per SIMD has no partner that fills its waits:
+//   * block 256(m) x 256(n), four waves 1 x 4, K-step 64 = two half-steps of sixteen groups {4 MFMAs on activation fragment mf};
+//   * activation fragments: ring of four registers quads, ds_read_b128 issued THREE groups (~200 cycles) ahead, across half-step
+//     and K-step boundaries (the block barrier sits three groups before the end of a K-step for that);
+//   * per group ONE dword (two weights) of the next half-step's weight fragments is converted: {v_cvt_scalef32_pk_bf16_fp8,
+//     v_alignbit, v_and_or} -- the vector work is spread evenly over the MFMA stream instead of in quarters;
+//   * the 32 LDS-DMA pieces of an activation tile (8 per wave) are issued one per four groups, never in a burst;
+//   * FOUR activation buffers (128 KiB): a tile is staged two K-steps ahead into the buffer read two K-steps ago, so the barrier
+//     needs no lgkmcnt(0) (another wave's DMA cannot reach a buffer this wave still reads: one whole K-step and a barrier lie between);
+//   * packed planes stream from global memory through buffer descriptors exactly as in k_qgemm3 (same planes, same tile order:
+//     nothing is re-packed), four half-step sets in flight.
+// Results are bit-identical to k_qgemm3's for the same planes: the same products accumulate in the same order (k ascending in steps
+// of 32 per accumulator, fp32), only the assignment of rows to waves differs.
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+
+#include "msq_gemm_common.h"
+
+#ifndef MSQ_Q256_PF
+#define MSQ_Q256_PF 3          /* activation-fragment reads in flight ahead of the MFMA group that consumes them (ring of 4) */
+#endif
+
+namespace {
+
+// D(a[..]) += A(weight fragment, v) x B(activation fragment, v): accumulator tied in place in an AGPR quad
+MSQ_D void mfma_acc(f32x4_t& acc, const u32x4_t& w, const bf16x8_t& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
+}
+
+// one dword (two weights) of fragment nf of a half-step: d = 0 .. 15 -> nf = d / 4, dword j = d % 4
+template <int OUT_KIND>
+MSQ_D void convert_dword(u32x4_t (&wf)[4], const HalfRegs<MSQ_PLANE_NONE, OUT_KIND>& h, const u32x4_t& scl, int kf, int d) {
+    const int nf = d >> 2, j = d & 3;
+    const float s = scale_operand(scl[kf], nf);
+    const uint32_t o = h.out[nf >> 1][(nf & 1) * 2 + (j >> 1)];
+    uint32_t r = __builtin_bit_cast(uint32_t, (j & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, true)
+                                                      : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, false));
+    if (OUT_KIND == MSQ_PLANE_U8X) r = ext_or(r, h.ext, nf, j);
+    wf[nf][j] = r;
+}
+
+template <int OUT_KIND, typename YT>
+__global__ void __launch_bounds__(256, 1)
+k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane, const uint8_t* __restrict__ code_plane,
+           const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
+           int scl_groups, int y16) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IN_KIND = MSQ_PLANE_NONE;
+    constexpr int A_TILE = 256 * BK * 2;                         // 32 KiB per activation buffer
+    constexpr int NBUF = 4;
+    constexpr int PF = MSQ_Q256_PF;
+    static_assert(PF >= 1 && PF <= 3, "fragment ring of four");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave = 64-column strip of the block
+    const int c = lane & 15, g = lane >> 4;
+    const int MT = (M + 255) / 256, NTB = N / 256;
+    const int bid = (int)blockIdx.x;
+    int bm, bn;
+    if ((NTB & 7) == 0) {
+        // XCD-aware order as k_qgemm3: XCD x owns the column panels bn = 8 cp + x and walks them in super-tiles of (up to) 8 row
+        // tiles x 4 panels, so the 32 blocks resident on an XCD share 4 packed W panels and 8 activation tiles out of its own L2
+        const int xcd = bid & 7, i = bid >> 3;
+        const int npx = NTB >> 3, per_group = 8 * npx, full = MT >> 3;
+        int rg, j, R;
+        if (i < full * per_group) { rg = i / per_group; j = i % per_group; R = 8; }
+        else { rg = full; j = i - full * per_group; R = MT - full * 8; }
+        bm = rg * 8 + j % R;
+        bn = (j / R) * 8 + xcd;
+    } else { bm = bid % MT; bn = bid / MT; }
+    const int m0 = bm * 256, n0 = bn * 256;
+    const int KT = K / BK;
+
+    const int64_t ntiles = (int64_t)(N / TILE_N) * KT;
+    PlaneRsrc pr;
+    pr.inl = make_rsrc(ext_plane, ntiles * 2 * (OUT_KIND == MSQ_PLANE_U8X ? 256 : 1024));
+    pr.out = make_rsrc(code_plane, ntiles * 2 * HalfSlots<OUT_KIND>::n * 1024);
+    constexpr int SCLB = SclBytes<OUT_KIND>::n;
+    pr.scl = make_rsrc(scl_plane, ntiles * scl_groups * SCLB);
+    const int lane16 = lane * 16;
+    const int scl_lane_off = (lane & (scl_groups - 1)) * SCLB;
+    const uint32_t scl_tile_bytes = (uint32_t)scl_groups * (uint32_t)SCLB;
+    auto load_scales = [&](uint32_t tile) -> u32x4_t {
+        const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(pr.scl, scl_lane_off, tile * scl_tile_bytes, 0));
+        return u32x4_t{v[0], v[1], 0u, 0u};
+    };
+    const uint32_t tile_row32 = (uint32_t)sgpr((n0 / TILE_N + wid) * KT);
+
+    // activation staging: wave w copies rows 64 w .. 64 w + 63 of the tile as eight 1 KiB pieces (8 rows each); lane l of piece p
+    // fetches row 8 p + l / 8, source chunk (l & 7) ^ ((row >> 1) & 7) -- the LDS image stays lane-linear, reads are conflict-free
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, (int64_t)M * K * 2);
+    int aoff[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = (wid * 8 + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < M ? gr : M - 1;
+        aoff[p] = (int)(((int64_t)gr * K + chunk * 8) * 2);
+    }
+    auto stage_piece = [&](int kt, int buf, int p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 8 + p) * 1024),
+                                                 16, aoff[p], (uint32_t)kt * (BK * 2), 0, 0);
+    };
+    // LDS read address of this lane: row mf * 16 + c, 16-byte chunk (4 kf + g) ^ ((c >> 1) & 7)
+    const int sw = (c >> 1) & 7;
+    const int rd0 = c * 128 + (((0 + g) ^ sw) << 4);
+    const int rd1 = c * 128 + (((4 + g) ^ sw) << 4);
+
+    f32x4_t acc[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    HalfRegs<IN_KIND, OUT_KIND> pk0, pk1, pk2, pk3;             // ring of four half-step sets, as k_qgemm3 (DEEP)
+    u32x4_t wfA[4], wfB[4];
+    u32x4_t sc_cur = {0, 0, 0, 0}, sc_nxt = {0, 0, 0, 0}, sc_nn = {0, 0, 0, 0};
+    bf16x8_t xf[4];
+
+    const int kt_last = sgpr(KT - 1);
+    const int kt1 = (1 <= kt_last) ? 1 : kt_last;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_piece(0, 0, p);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_piece(kt1, 1, p);
+    load_half_buf<IN_KIND, OUT_KIND>(pk0, pr, lane16, (tile_row32 + 0u) * 2u + 0u);
+    load_half_buf<IN_KIND, OUT_KIND>(pk1, pr, lane16, (tile_row32 + 0u) * 2u + 1u);
+    load_half_buf<IN_KIND, OUT_KIND>(pk2, pr, lane16, (tile_row32 + (uint32_t)kt1) * 2u + 0u);
+    load_half_buf<IN_KIND, OUT_KIND>(pk3, pr, lane16, (tile_row32 + (uint32_t)kt1) * 2u + 1u);
+    sc_cur = load_scales(tile_row32 + 0u);
+    sc_nxt = load_scales(tile_row32 + (uint32_t)kt1);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 16; ++d) convert_dword<OUT_KIND>(wfA, pk0, sc_cur, 0, d);
+#pragma unroll
+    for (int f = 0; f < PF; ++f) xf[f] = *reinterpret_cast<const bf16x8_t*>(smem + rd0 + f * 2048);
+
+    // packed loads + LDS-DMA ops a K-step has issued when it reaches its barrier (group 16 - PF of the second half-step): the scale
+    // load, both packed sets and the pieces of groups 1, 5, 9, (13) of both half-steps -- they all belong to tile kt + 2 and may stay
+    // in flight; everything older (this wave's pieces of tile kt + 1, staged during the previous K-step) has landed
+    constexpr int HL = HalfLoads<IN_KIND, OUT_KIND>::n;          // 2 (U8) / 3 (U8X)
+    constexpr int BAR_G = 16 - PF;                               // group in front of which the barrier sits
+    constexpr int N_WAIT = 1 + 2 * HL + 4 + (BAR_G > 13 ? 4 : (BAR_G > 9 ? 3 : (BAR_G > 5 ? 2 : 1)));
+
+    // One half-step: sixteen groups.  Group mf = { read fragment mf + PF (of this half-step, or of the next one through RDN / ANXT),
+    // 4 MFMAs on fragment mf, one dword of the next half-step's weight fragments, every fourth group an LDS-DMA piece }.
+#define Q256_HALF(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, ACUR, RDC, ANXT, RDN, PIECE0, KT_ST, BUF_ST, LOADSET, LOADTILE, BARRIER)   \
+    {                                                                                                              \
+        _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                        \
+            if ((BARRIER) && mf == BAR_G) {                                                                        \
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));   /* vmcnt(N_WAIT) only */       \
+                __builtin_amdgcn_s_barrier();                                                                      \
+            }                                                                                                      \
+            if (mf + PF < 16) xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ACUR) + (RDC) + (mf + PF) * 2048);   \
+            else xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ANXT) + (RDN) + (mf + PF - 16) * 2048);   \
+            if (mf == 2) load_half_buf<IN_KIND, OUT_KIND>(LOADSET, pr, lane16, LOADTILE);                          \
+            mfma_acc(acc[mf][0], WF_USE[0], xf[mf & 3]);                                                           \
+            convert_dword<OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);                                         \
+            mfma_acc(acc[mf][1], WF_USE[1], xf[mf & 3]);                                                           \
+            mfma_acc(acc[mf][2], WF_USE[2], xf[mf & 3]);                                                           \
+            if ((mf & 3) == 1) stage_piece(KT_ST, BUF_ST, (PIECE0) + (mf >> 2));                                   \
+            mfma_acc(acc[mf][3], WF_USE[3], xf[mf & 3]);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+    }
+    // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted one half-step
+    // earlier (LOAD1, LOAD2) receive (kt + 2, kf 0) and (kt + 2, kf 1).
+#define Q256_KSTEP(KT_CUR, CONV1, LOAD1, CONV2, LOAD2)                                                             \
+    {                                                                                                              \
+        const int kt_ = sgpr(KT_CUR);                                                                              \
+        const int buf = abuf, bufn = (abuf + 1) & 3, buf2 = (abuf + 2) & 3;                                        \
+        abuf = bufn;                                                                                               \
+        const char* acur = smem + buf * A_TILE;                                                                    \
+        const char* anxt = smem + bufn * A_TILE;                                                                   \
+        const int ktnn = (kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last;      /* branch-free tail: re-stage / re-load the last tile */ \
+        sc_nn = load_scales(tile_row32 + (uint32_t)ktnn);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        Q256_HALF(wfA, wfB, CONV1, sc_cur, 1, acur, rd0, acur, rd1, 0, ktnn, buf2, LOAD1, (tile_row32 + (uint32_t)ktnn) * 2u + 0u, false)   \
+        Q256_HALF(wfB, wfA, CONV2, sc_nxt, 0, acur, rd1, anxt, rd0, 4, ktnn, buf2, LOAD2, (tile_row32 + (uint32_t)ktnn) * 2u + 1u, true)    \
+        sc_cur = sc_nxt; sc_nxt = sc_nn;                                                                           \
+    }
+
+    int abuf = 0;
+    {
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            Q256_KSTEP(kt, pk1, pk0, pk2, pk1)
+            Q256_KSTEP(kt + 1, pk3, pk2, pk0, pk3)
+        }
+        if (kt < KT) Q256_KSTEP(kt, pk1, pk0, pk2, pk1)
+    }
+#undef Q256_KSTEP
+#undef Q256_HALF
+
+    // the MFMAs are opaque to hipcc's hazard recogniser: give the last of them their passes before the epilogue reads a[...]
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
+    __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                // 128 rows at a time through the wave's 8 KiB slice
+        const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
+        store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
+    }
+}
+
+struct DevOnce256 { std::atomic<uint64_t> mask{0}; };
+inline bool attr_needed256(const DevOnce256& o) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    return !(o.mask.load(std::memory_order_acquire) & (1ull << d));
+}
+inline void attr_done256(DevOnce256& o) {
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) o.mask.fetch_or(1ull << d, std::memory_order_release);
+}
+
+}  // namespace
+
+// Launcher (called by qlinear_bf16_impl, msq_gemm.hip).  Preconditions checked by the caller: unified layout, N % 256 == 0,
+// K % 64 == 0, every buffer offset below 4 GiB.  Returns hipGetLastError() of the launch.
+extern "C" int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
+                        int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* stream) {
+    const int MT = (int)((M + 255) / 256), NTB = (int)(N / 256);
+    const dim3 grid((unsigned)(MT * NTB)), blk(256);
+    const size_t lds = 4 * 32768;
+    const int y16 = (y_dtype == 1) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define Q256_LAUNCH(OK, YT)                                                                                            \
+    do { static DevOnce256 once_;                                                                                      \
+         if (attr_needed256(once_)) { (void)hipFuncSetAttribute((const void*)k_qgemm256<OK, YT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done256(once_); } \
+         hipLaunchKernelGGL((k_qgemm256<OK, YT>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)ext_plane, (const uint8_t*)code_plane, \
+                            (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, scl_groups, y16); } while (0)
+    if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) Q256_LAUNCH(MSQ_PLANE_U8, float); else Q256_LAUNCH(MSQ_PLANE_U8, uint16_t); }
+    else { if (y_dtype == 0) Q256_LAUNCH(MSQ_PLANE_U8X, float); else Q256_LAUNCH(MSQ_PLANE_U8X, uint16_t); }
+#undef Q256_LAUNCH
+    return (int)hipGetLastError();
+}

@@ -149,13 +149,13 @@ class GPTQ:
         try:
             done = False
             if not per_column and not grouped and self._block_kernel_ok(qz, blocksize):
-                from .._lib import MsqError
+                from .._lib import MSQ_ERR_UNSUPPORTED, MsqError
                 W0 = W.clone()
                 try:
                     loss, pruned = self._solve_blocks(W, U.contiguous(), Q, qz, blocksize)
                     done = True
                 except MsqError as e:            # the grid does not fit this device (partitioned / CU-masked GPU): per-column path
-                    if "status -2" not in str(e):
+                    if e.rc != MSQ_ERR_UNSUPPORTED:
                         raise
                     W = W0
                     Q.zero_()

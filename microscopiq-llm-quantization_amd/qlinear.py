@@ -97,7 +97,8 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
     ``compute_dtype`` as quant.outlier_fakequant: an fp16 / bf16 weight is by default quantised IN its dtype (what the
     reference's RTN harness does with a half checkpoint, llm/llama.py:238), so that the packed layer holds exactly the
     values ``MXQuantizer.quantize`` / ``quantize_mx_outlier_v1`` give for the same tensor; those values are then packed
-    as they are (pack_values).  "float32" upcasts first (one fused quantise + pack launch)."""
+    as they are (pack_values; layout "planes": MSQ-T1 planes of those values, verified exact, MsqError otherwise -- never a
+    16-bit plane).  "float32" upcasts first (one fused quantise + pack launch)."""
     if not W.is_cuda:
         raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
     if W.ndim != 2:
@@ -110,7 +111,19 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
         from .quant import outlier_fakequant
         Wq = outlier_fakequant(W.detach(), inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
                                std_dev, -1, block_size, round, flush_fp32_subnorms, compute_dtype="input")["out"]
-        kinds = {"unified": (PLANE_U8, PLANE_U8X), "auto": (PLANE_U8, PLANE_U8X, PLANE_BF16), "planes": (PLANE_BF16,)}[layout]
+        if layout == "planes":
+            # MSQ-T1 (fp4 plane + outlier plane + two scales per block) is what "planes" promises -- never a silent 16-bit
+            # plane: the in-dtype values are handed to the T1 packer (which quantises them once more in float32) and the
+            # result is kept only if it reproduces them exactly; a matrix on which re-quantisation moves a value (an
+            # element that changes sides of the outlier bounds once its block is quantised) is refused.
+            P = _pack(_pad2d(Wq.detach().contiguous().float(), N_MULT, K_MULT), inlier_scale_bits, outlier_scale_bits,
+                      inlier_elem_format, outlier_elem_format, std_dev, block_size, round, flush_fp32_subnorms, variant, "planes", n, k)
+            if not bool((unpack_weight(P) == Wq.float()).all()):
+                raise MsqError("pack_weight(layout='planes'): the %s weight's in-dtype fake-quant values are not reproduced exactly by "
+                               "the MSQ-T1 planes; use layout='auto' / 'unified' (packs those values as they are) or "
+                               "compute_dtype='float32'" % str(W.dtype).replace("torch.", ""))
+            return P
+        kinds = {"unified": (PLANE_U8, PLANE_U8X), "auto": (PLANE_U8, PLANE_U8X, PLANE_BF16)}[layout]
         return pack_values(Wq, kinds)
     Wf = _pad2d(W.detach().contiguous().float(), N_MULT, K_MULT)
     if layout == "auto":
@@ -435,6 +448,8 @@ def mx_pack_act(x, flush_fp32_subnorms=False, check_status=False, a_fmt="e4m3"):
     K = x.shape[-1]
     bf = x.dtype in (torch.bfloat16, torch.float16) and a_fmt == "e4m3"   # read as is (every half value is an fp32 value: same codes)
     xf = x.reshape(-1, K).contiguous() if bf else x.reshape(-1, K).float().contiguous()
+    if xf.data_ptr() % 16:                                # a contiguous view at an odd storage offset: the vector packers read 16-byte pieces
+        xf = xf.clone()
     M = xf.shape[0]
     codes = torch.empty(M, K, dtype=torch.uint8, device=x.device)
     scales = torch.empty(M, K // 32, dtype=torch.uint8, device=x.device)
@@ -733,9 +748,12 @@ class FusedProjections(nn.Module):
     def slice(self, i, x):
         # the cached result is valid for this very tensor object only (holding the reference keeps its storage from being
         # reused by another tensor) at the same version counter, and for one read per sibling
-        if self._x is not x or self._ver != x._version or self._left <= 0:
+        # (inference tensors carry no version counter -- `x._version` raises under torch.inference_mode() -- and cannot be
+        # written in place outside inference mode: identity alone is a sufficient key for them)
+        ver = None if x.is_inference() else x._version
+        if self._x is not x or self._ver != ver or self._left <= 0:
             self._y = self.proj(x)
-            self._x, self._ver, self._left = x, x._version, len(self.splits)
+            self._x, self._ver, self._left = x, ver, len(self.splits)
         y = self._y[..., self.offsets[i]:self.offsets[i + 1]]
         self._left -= 1
         if self._left == 0:

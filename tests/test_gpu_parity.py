@@ -5,6 +5,7 @@ Integer / bit work (masks, codes, exponents, fp32 fake-quant values) is compared
 floating-point GEMM output within the tolerance written next to each check."""
 import json
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -92,7 +93,7 @@ def test_hessian_num_outliers_golden(msq):
 @pytest.mark.parametrize("fi,fo", [("fp4_e2m1", "fp8_e4m3"), ("int2", "fp4"), ("fp4_e2m1", "posit8_es1"),
                                    ("fp6_e3m2", "fp8_e5m2"), ("int4", "int8")])
 def test_outlier_fakequant_vs_oracle(msq, O, shape, axis, bs, fi, fo):
-    g = torch.Generator().manual_seed(hash((shape, axis, bs, fi, fo)) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr((shape, axis, bs, fi, fo)).encode()) % (2 ** 31))   # replayable: str hashes are salted per process
     A = torch.randn(*shape, generator=g) * 0.02
     A[torch.rand(*shape, generator=g) < 0.01] *= 20
     if A.numel() > 64:

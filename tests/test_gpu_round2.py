@@ -819,7 +819,7 @@ def test_bench_ppl_delta_hook_with_local_checkpoint(msq, tmp_path, monkeypatch):
     assert r["windows"] == 880 // 64 and r["layers_kept_dense"] == 0
     assert np.isfinite(r["ppl_cpu_reference"]) and np.isfinite(r["ppl_hip_packed_fused"])
     assert abs(r["delta"]) / r["ppl_cpu_reference"] < 0.05 / 5.5, r               # BASELINE's 0.05 at PPL ~5.5, as a ratio
-    monkeypatch.delenv("MSQ_PPL_MODEL")
+    monkeypatch.setenv("MSQ_PPL_DISABLE", "1")             # (without MSQ_PPL_MODEL the committed trained fixture is used: tests/test_gpu_round4.py)
     assert bench.ppl_delta_from_env(dev(), "fp4_e2m1", "fp8_e4m3", 32) is None
 
 
