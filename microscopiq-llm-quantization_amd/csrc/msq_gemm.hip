@@ -1479,7 +1479,7 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 #ifndef MSQ_Q256_DEFAULT
-#define MSQ_Q256_DEFAULT 0     /* 1: k_qgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
+#define MSQ_Q256_DEFAULT 1     /* 1: k_qgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
 #endif
 int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* stream);   // msq_gemm256.hip

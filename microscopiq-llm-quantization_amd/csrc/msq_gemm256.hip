@@ -32,8 +32,13 @@
 
 #include "msq_gemm_common.h"
 
+#ifndef MSQ_Q256_ABL
+#define MSQ_Q256_ABL 0
+/* timing experiments (results are wrong by construction; scripts/experiments/build_q256.sh): 1 no activation-fragment reads, 2 no converts,
+   4 no packed / scale loads, 8 no activation staging, 16 no barrier, 32 no output stores, 64 no MFMAs */
+#endif
 #ifndef MSQ_Q256_PF
-#define MSQ_Q256_PF 3          /* activation-fragment reads in flight ahead of the MFMA group that consumes them (ring of 4) */
+#define MSQ_Q256_PF 2          /* activation-fragment reads in flight ahead of the MFMA group that consumes them (ring of 4) */
 #endif
 
 namespace {
@@ -43,16 +48,19 @@ MSQ_D void mfma_acc(f32x4_t& acc, const u32x4_t& w, const bf16x8_t& x) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
 }
 
-// one dword (two weights) of fragment nf of a half-step: d = 0 .. 15 -> nf = d / 4, dword j = d % 4
+// one dword (two weights) of fragment nf of a half-step, in two parts so that each fits the issue shadow of ONE MFMA (8 cycles):
+// d = 0 .. 15 -> nf = d / 4, dword j = d % 4.  cvt_dword: the scaled convert (8 cycles); ext_dword: shift + and-or of the posit
+// extension bits (2 x 4 cycles; nothing for MSQ-U1).  `sop` = scale_operand(scl[kf], nf), prepared in an earlier shadow.
 template <int OUT_KIND>
-MSQ_D void convert_dword(u32x4_t (&wf)[4], const HalfRegs<MSQ_PLANE_NONE, OUT_KIND>& h, const u32x4_t& scl, int kf, int d) {
+MSQ_D uint32_t cvt_dword(const HalfRegs<MSQ_PLANE_NONE, OUT_KIND>& h, float sop, int d) {
     const int nf = d >> 2, j = d & 3;
-    const float s = scale_operand(scl[kf], nf);
     const uint32_t o = h.out[nf >> 1][(nf & 1) * 2 + (j >> 1)];
-    uint32_t r = __builtin_bit_cast(uint32_t, (j & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, true)
-                                                      : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, s, false));
-    if (OUT_KIND == MSQ_PLANE_U8X) r = ext_or(r, h.ext, nf, j);
-    wf[nf][j] = r;
+    return __builtin_bit_cast(uint32_t, (j & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, sop, true)
+                                                : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(o, sop, false));
+}
+template <int OUT_KIND>
+MSQ_D uint32_t ext_dword(uint32_t r, const HalfRegs<MSQ_PLANE_NONE, OUT_KIND>& h, int d) {
+    return (OUT_KIND == MSQ_PLANE_U8X) ? ext_or(r, h.ext, d >> 2, d & 3) : r;
 }
 
 template <int OUT_KIND, typename YT>
@@ -112,9 +120,17 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
         aoff[p] = (int)(((int64_t)gr * K + chunk * 8) * 2);
     }
+    // (A register-staged form -- buffer_load_dwordx4 one K-step ahead, ds_write_b128 -- was built and measured: 200.5 us against 194.3
+    // for k_qgemm3 and ~191 for the LDS-DMA form on the same box; the DMA piece costs this wave ~30 issue cycles, load + write more.)
     auto stage_piece = [&](int kt, int buf, int p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 8 + p) * 1024),
                                                  16, aoff[p], (uint32_t)kt * (BK * 2), 0, 0);
+    };
+    // the three / two packed loads of a half-step and the scale load, one per MFMA shadow (load_half_buf issues them back to back:
+    // measured 25 us of 195 for seven loads per K-step -- a burst of vector-memory instructions stalls the only wave of the SIMD)
+    auto load_part = [&](HalfRegs<IN_KIND, OUT_KIND>& h, uint32_t tile2kf, int part) {
+        if (part < 2) h.out[part] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pr.out, lane16, (tile2kf * 2u + (uint32_t)part) * 1024u, 0));
+        else if (OUT_KIND == MSQ_PLANE_U8X) h.ext = __builtin_amdgcn_raw_buffer_load_b32(pr.inl, lane16 >> 2, tile2kf * 256u, 0);
     };
     // LDS read address of this lane: row mf * 16 + c, 16-byte chunk (4 kf + g) ^ ((c >> 1) & 7)
     const int sw = (c >> 1) & 7;
@@ -147,36 +163,61 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < 16; ++d) convert_dword<OUT_KIND>(wfA, pk0, sc_cur, 0, d);
+    for (int d = 0; d < 16; ++d) wfA[d >> 2][d & 3] = ext_dword<OUT_KIND>(cvt_dword<OUT_KIND>(pk0, scale_operand(sc_cur[0], d >> 2), d), pk0, d);
+    float sop = scale_operand(sc_cur[1], 0);                     // scale operand of the fragment the next converts belong to
 #pragma unroll
     for (int f = 0; f < PF; ++f) xf[f] = *reinterpret_cast<const bf16x8_t*>(smem + rd0 + f * 2048);
 
-    // packed loads + LDS-DMA ops a K-step has issued when it reaches its barrier (group 16 - PF of the second half-step): the scale
-    // load, both packed sets and the pieces of groups 1, 5, 9, (13) of both half-steps -- they all belong to tile kt + 2 and may stay
-    // in flight; everything older (this wave's pieces of tile kt + 1, staged during the previous K-step) has landed
+    // vector-memory ops a K-step has issued when it reaches its barrier (in front of group BAR_G of the second half-step): the scale
+    // load (group 14 of the first half-step), both packed sets (groups 2, 6, 10) and the LDS-DMA pieces of groups 1, 5, 9, 13 of the
+    // first and 1, 5, 9 (13 if BAR_G > 13) of the second half-step.  They all belong to tile kt + 2 and may stay in flight; everything
+    // older -- this wave's pieces of tile kt + 1, staged during the previous K-step -- has landed.
     constexpr int HL = HalfLoads<IN_KIND, OUT_KIND>::n;          // 2 (U8) / 3 (U8X)
     constexpr int BAR_G = 16 - PF;                               // group in front of which the barrier sits
     constexpr int N_WAIT = 1 + 2 * HL + 4 + (BAR_G > 13 ? 4 : (BAR_G > 9 ? 3 : (BAR_G > 5 ? 2 : 1)));
 
-    // One half-step: sixteen groups.  Group mf = { read fragment mf + PF (of this half-step, or of the next one through RDN / ANXT),
-    // 4 MFMAs on fragment mf, one dword of the next half-step's weight fragments, every fourth group an LDS-DMA piece }.
-#define Q256_HALF(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, ACUR, RDC, ANXT, RDN, PIECE0, KT_ST, BUF_ST, LOADSET, LOADTILE, BARRIER)   \
+    // One half-step = sixteen groups of four MFMAs (activation fragment mf against the four weight fragments).  One wave per SIMD: an
+    // MFMA occupies the matrix pipe for 16 cycles and the issue port for 8 -- whatever is issued in the other 8 is free, whatever
+    // exceeds them adds to the step (ablation of the first build: MFMAs alone 131 us, everything else alone 57 us, together 195 us:
+    // hipcc had put the fillers in front of the groups, not between the MFMAs).  So every MFMA is followed by ONE filler of at most
+    // ~8 issue cycles, fenced by sched_barriers so that it stays there:
+    //   MFMA 0 | ds_read_b128 of fragment mf + PF (this half-step, or the next one through RDN / ANXT)
+    //   MFMA 1 | v_cvt_scalef32_pk_bf16_fp8 of dword mf of the NEXT half-step's weight fragments
+    //   MFMA 2 | shift + and-or of that dword's extension bits (MSQ-U1X; nothing for U1)
+    //   MFMA 3 | one of: LDS-DMA piece (mf % 4 == 1), packed load (2, 6, 10; scale load 14 in the first half-step), scale operand of
+    //            the next fragment (3, 7, 11, 15)
+#define Q256_SB() __builtin_amdgcn_sched_barrier(0)
+#define Q256_HALF(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, SC_NEXT, KF_NEXT, ACUR, RDC, ANXT, RDN, HS1, KT_ST, BUF_ST, LOADSET, LOADTILE)    \
     {                                                                                                              \
         _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                        \
-            if ((BARRIER) && mf == BAR_G) {                                                                        \
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));   /* vmcnt(N_WAIT) only */       \
-                __builtin_amdgcn_s_barrier();                                                                      \
+            if ((HS1) && mf == BAR_G) {                                                                            \
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));   /* vmcnt(N_WAIT) only */ \
+                if (!(MSQ_Q256_ABL & 16)) __builtin_amdgcn_s_barrier();                                            \
             }                                                                                                      \
-            if (mf + PF < 16) xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ACUR) + (RDC) + (mf + PF) * 2048);   \
+            uint32_t cv_ = 0;                                                                                      \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][0], WF_USE[0], xf[mf & 3]);                                 \
+            Q256_SB();                                                                                             \
+            if (MSQ_Q256_ABL & 1) { }                                                                              \
+            else if (mf + PF < 16) xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ACUR) + (RDC) + (mf + PF) * 2048);   \
             else xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ANXT) + (RDN) + (mf + PF - 16) * 2048);   \
-            if (mf == 2) load_half_buf<IN_KIND, OUT_KIND>(LOADSET, pr, lane16, LOADTILE);                          \
-            mfma_acc(acc[mf][0], WF_USE[0], xf[mf & 3]);                                                           \
-            convert_dword<OUT_KIND>(WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, mf);                                         \
-            mfma_acc(acc[mf][1], WF_USE[1], xf[mf & 3]);                                                           \
-            mfma_acc(acc[mf][2], WF_USE[2], xf[mf & 3]);                                                           \
-            if ((mf & 3) == 1) stage_piece(KT_ST, BUF_ST, (PIECE0) + (mf >> 2));                                   \
-            mfma_acc(acc[mf][3], WF_USE[3], xf[mf & 3]);                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][1], WF_USE[1], xf[mf & 3]);                                 \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 2)) cv_ = cvt_dword<OUT_KIND>(PK_SRC, sop, mf);                                   \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][2], WF_USE[2], xf[mf & 3]);                                 \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 2)) WF_MAKE[mf >> 2][mf & 3] = ext_dword<OUT_KIND>(cv_, PK_SRC, mf);              \
+            Q256_SB();                                                                                             \
+            if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][3], WF_USE[3], xf[mf & 3]);                                 \
+            Q256_SB();                                                                                             \
+            if ((mf & 3) == 1) { if (!(MSQ_Q256_ABL & 8)) stage_piece(KT_ST, BUF_ST, ((HS1) ? 4 : 0) + (mf >> 2)); } \
+            else if ((mf & 3) == 2) {                                                                              \
+                if (MSQ_Q256_ABL & 4) { }                                                                          \
+                else if (mf < 14) load_part(LOADSET, LOADTILE, mf >> 2);                                           \
+                else if (!(HS1)) sc_nn = load_scales(tile_row32 + (uint32_t)(KT_ST));                              \
+            } else if ((mf & 3) == 3) sop = (mf < 15) ? scale_operand(SC_SRC[KF_MAKE], (mf >> 2) + 1) : scale_operand(SC_NEXT[KF_NEXT], 0); \
         }                                                                                                          \
     }
     // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted one half-step
@@ -189,10 +230,8 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
         const char* acur = smem + buf * A_TILE;                                                                    \
         const char* anxt = smem + bufn * A_TILE;                                                                   \
         const int ktnn = (kt_ + 2 <= kt_last) ? kt_ + 2 : kt_last;      /* branch-free tail: re-stage / re-load the last tile */ \
-        sc_nn = load_scales(tile_row32 + (uint32_t)ktnn);                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        Q256_HALF(wfA, wfB, CONV1, sc_cur, 1, acur, rd0, acur, rd1, 0, ktnn, buf2, LOAD1, (tile_row32 + (uint32_t)ktnn) * 2u + 0u, false)   \
-        Q256_HALF(wfB, wfA, CONV2, sc_nxt, 0, acur, rd1, anxt, rd0, 4, ktnn, buf2, LOAD2, (tile_row32 + (uint32_t)ktnn) * 2u + 1u, true)    \
+        Q256_HALF(wfA, wfB, CONV1, sc_cur, 1, sc_nxt, 0, acur, rd0, acur, rd1, false, ktnn, buf2, LOAD1, (tile_row32 + (uint32_t)ktnn) * 2u + 0u)   \
+        Q256_HALF(wfB, wfA, CONV2, sc_nxt, 0, sc_nxt, 1, acur, rd1, anxt, rd0, true, ktnn, buf2, LOAD2, (tile_row32 + (uint32_t)ktnn) * 2u + 1u)    \
         sc_cur = sc_nxt; sc_nxt = sc_nn;                                                                           \
     }
 
@@ -207,12 +246,14 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     }
 #undef Q256_KSTEP
 #undef Q256_HALF
+#undef Q256_SB
 
     // the MFMAs are opaque to hipcc's hazard recogniser: give the last of them their passes before the epilogue reads a[...]
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
+    if (MSQ_Q256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 16; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                                // 128 rows at a time through the wave's 8 KiB slice
         const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
