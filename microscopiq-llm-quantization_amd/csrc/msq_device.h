@@ -39,6 +39,33 @@ MSQ_HD int ilog2f(float x) {
     return 31 - __builtin_clz(u) - 149;   // subnormal: position of the leading one
 }
 
+// floor(torch.log2(x)) as the reference's PYTHON path computes it in float32 (utils/quant.py:525-529, elemwise_ops.py:139-140): torch.log2
+// returns the float32 nearest to the true logarithm, so the K largest floats below a power of two 2^u give exactly u and the floor is one
+// binade high.  K depends on the spacing of float32 next to u: 0 for |u| <= 1, 1 (2..3), 2 (4..7), 5 (8..15), 11 (16..31), 22 (32..63), 44
+// (64..127), 88 (128..), and the count of the next smaller class when u is a POSITIVE power of two (the result approaches it from the finer
+// binade).  K = ceil(2^jb ln 2) - 1.  The reference's native kernels (and ilog2f above) use the exact exponent instead.  Pinned by
+// tests/golden/log2_f32.npz through the oracle (oracle/msq_oracle.c floor_log2_torch, an independent double-precision restatement).
+MSQ_HD int ilog2f_torch(float x) {
+    const uint32_t u = f2u(x) & 0x7FFFFFFFu;
+    const int E = (int)(u >> 23);
+    int k, dist;                                     // exact floor; distance (in units of 2^-24 relative) to the power of two above, minus one
+    if (E) { k = E - 127; dist = (int)(0x7FFFFFu - (u & 0x7FFFFFu)); }
+    else {                                           // subnormal: leading one at bit p, the value is (2^(p+1) - d) 2^-149: relative distance d 2^-(p+1)
+        const int p = 31 - __builtin_clz(u);
+        k = p - 149;
+        const uint32_t d = (2u << p) - u;            // >= 1
+        // as a count of 2^-24 steps: d 2^(23 - p) (rounded up: a coarser grid can only be farther away)
+        dist = (p >= 23 - 7) ? (int)(d << (23 - p)) - 1 : 1 << 20;
+    }
+    const int up = k + 1;
+    const int au = up < 0 ? -up : up;
+    if (au <= 1) return k;
+    int jb = 31 - __builtin_clz((uint32_t)au);
+    if (up > 0 && (au & (au - 1)) == 0) jb -= 1;
+    const int K = (jb <= 0) ? 0 : ((jb == 1) ? 1 : ((jb == 2) ? 2 : ((jb == 3) ? 5 : ((jb == 4) ? 11 : ((jb == 5) ? 22 : ((jb == 6) ? 44 : 88))))));
+    return dist < K ? up : k;
+}
+
 // ---------------------------------------------------------------------------
 // elemwise_ops.py:47-78 _round_mantissa + :84-174 _quantize_elemwise_core with
 // allow_denorm=True, saturate_normals=True (the only way MicroScopiQ calls it:
@@ -64,7 +91,9 @@ MSQ_HD float quant_core_sat(float a, int bits, int ebits, float max_norm, int rm
         const float t = __builtin_fabsf(a) + ((a == 0.f) ? 1.f : 0.f);
         if (t != t) return t;                       // NaN in -> NaN out
         if (__builtin_isinf(t)) return a;           // elemwise_ops.py:165-166
-        int pe = ilog2f(t);
+        // the Python path's private exponent is floor(torch.log2(t)): for the floats just below a power of two it is one too high, which
+        // changes the result only under truncation (nearest / even: both exponents round such a value to the power of two itself)
+        int pe = (rmode == 1) ? ilog2f_torch(t) : ilog2f(t);
         const int min_exp = 2 - (1 << (ebits - 1));
         pe = pe < min_exp ? min_exp : pe;
         const float inv = pow2i(-pe), fwd = pow2i(pe);
@@ -203,7 +232,7 @@ MSQ_HD float shared_exp_of_max(float mx) {
     if (mx != mx) return mx;
     if (__builtin_isinf(mx)) return mx;
     const float t = (mx == 0.f) ? pow2i(-126) : mx;    // + FP32_MIN_NORMAL * (max == 0)
-    return (float)ilog2f(t);
+    return (float)ilog2f_torch(t);                     // floor(torch.log2(.)), utils/quant.py:525-529
 }
 
 MSQ_HD float clamp_scale_exp(float e, int scale_bits, int variant) {

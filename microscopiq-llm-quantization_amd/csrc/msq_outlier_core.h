@@ -185,13 +185,16 @@ MSQ_D float quant_core_fast(float a, int shift, int pe_lo, int pe_hi, float max_
     // elemwise_ops.py:84-174 with saturate_normals, allow_denorm.  The private exponent is clamped to
     // [pe_lo, pe_hi]: (min_exp, 127) for float formats, (0, 0) for the integer formats.
     const uint32_t ua = f2u(a);
+    const int rm = (RM >= 0) ? RM : rmode;
     int pe = __builtin_amdgcn_frexp_expf(a) - 1;           // exact floor(log2|a|), subnormals included; a == 0 -> -1 (harmless)
+    // the reference's private exponent is floor(torch.log2(|a|)) (elemwise_ops.py:139-140): one too high for the floats just below a
+    // power of two -- which changes the result only under truncation (msq_device.h ilog2f_torch)
+    if (rm == 1 && (ua & 0x7FFFFFFFu) != 0u && (ua & 0x7F800000u) != 0x7F800000u) pe = ilog2f_torch(a);
     pe = pe < pe_lo ? pe_lo : pe;
     pe = pe > pe_hi ? pe_hi : pe;
     const float x = __builtin_ldexpf(a, shift - pe);        // == a / 2^pe * 2^(bits-2) (first product exact)
     const float m = __builtin_fabsf(x);
     float r;
-    const int rm = (RM >= 0) ? RM : rmode;
     if (rm == 0) r = __builtin_floorf(m + 0.5f);
     else if (rm == 1) r = __builtin_floorf(m);
     else {

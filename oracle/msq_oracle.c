@@ -18,11 +18,10 @@
  * reference does fp32 tensor ops, and in binary64 where ATen's CPU kernels do
  * (torch.std accumulates Welford in double: aten WelfordOps<float,double>).
  *
- * Two documented deviations from the literal Python (both measure-zero):
- *  (D1) floor(log2(x)) is computed exactly from the binary exponent (as the
- *       reference's own native kernels do, cpp/mx.cuh:81-85, cpp/quantize.cuh:97)
- *       whereas torch.log2 in fp32 rounds the two floats just below a power of
- *       two up to it (utils/quant.py:525-529, elemwise_ops.py:139-140).
+ * One documented deviation from the literal Python:
+ *  (D1, REMOVED in round 4) floor(log2(x)) of the Python path is torch.log2 rounded to float32 and floored (floor_log2_torch
+ *       below): the largest few floats under a power of two come out one binade high.  The native surfaces keep the exact
+ *       exponent, as the reference's own native kernels do (cpp/mx.cuh:81-85, cpp/quantize.cuh:97).
  *  (D2) the `+1e-6` of mx_ops.py:444 is a reference defect (SURVEY.md section 4:
  *       it breaks 3 of the reference's own KATs); it is only applied when the
  *       caller passes plus_eps_defect=1 (used to pin the defect variant).
@@ -56,11 +55,35 @@ static float exp2_float(float e) {
     return ldexpf(1.0f, (int)e);
 }
 
-/* exact floor(log2(x)) for finite x > 0, subnormals included (deviation D1) */
+/* exact floor(log2(x)) for finite x > 0, subnormals included: what the reference's NATIVE kernels compute from the exponent field
+ * (cpp/mx.cuh:81-85, cpp/quantize.cuh:97) */
 static int floor_log2_exact(float x) {
     int e;
     (void)frexpf(x, &e); /* x = m * 2^e, m in [0.5,1) */
     return e - 1;
+}
+/* floor(torch.log2(x)) as the reference's PYTHON path computes it on a float32 tensor (utils/quant.py:525-529 shared exponents,
+ * elemwise_ops.py:139-140 private exponents): torch.log2 returns the float32 NEAREST to the true logarithm, so for the few floats
+ * just below a power of two 2^u -- log2 x = u - d with d below half a float32 spacing next to u -- the result IS u and the floor
+ * lands one binade too high.  x = m 2^e (m in [0.5, 1)), u = e: bumped iff -log2(m) < h, h = half the spacing of float32 on the
+ * side of u the result approaches from (toward zero for u > 0: the binade below a power of two is finer).  That is the 1 (|u| 2..3),
+ * 2 (4..7), 5 (8..15), 11 (16..31), 22 (32..63), 44, 88 largest floats below 2^u (one step less at u = 2, 4, 8, ... > 0).
+ * Pinned by tests/golden/log2_f32.npz (made with torch, vector and scalar paths, every binade).  Round 1-3 of this build used the
+ * exact exponent here ("deviation D1, measure-zero"); an OPT-125M-shaped fixture of 14 M weights hit it (two values of one block),
+ * so it is restated exactly now. */
+static float floor_log2_torch(float x) {
+    if (x != x) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (isinf(x)) return INFINITY;
+    int e;
+    const double m = frexp((double)x, &e);                 /* x = m 2^e, m in [0.5, 1) */
+    const int k = e - 1, u = e;
+    if (u == 0) return (float)k;                           /* results in (-1, 0): every float there is exact enough */
+    const int au = u < 0 ? -u : u;
+    int jb = 0; while ((1 << (jb + 1)) <= au) jb++;        /* floor(log2 |u|) */
+    if (u > 0 && (au & (au - 1)) == 0) jb -= 1;            /* approaching a positive power of two from below: the finer binade */
+    const double h = ldexp(1.0, jb - 24);                  /* half a float32 spacing next to u */
+    return (-log2(m) < h) ? (float)u : (float)k;
 }
 
 /* ------------------------------------------------------------------------
@@ -139,7 +162,7 @@ static float quantize_elemwise_core_1(float a, int bits, int exp_bits, float max
         float t = fabsf(a) + ((a == 0.0f) ? 1.0f : 0.0f);
         if (t != t) pe = NAN;
         else if (isinf(t)) pe = INFINITY;
-        else pe = (float)floor_log2_exact(t);
+        else pe = floor_log2_torch(t);
         float min_exp = (float)(-(1 << (exp_bits - 1)) + 2);
         if (pe == pe && pe < min_exp) pe = min_exp;
     }
@@ -453,7 +476,7 @@ static float shared_exp_of_max(float mx) {
     if (mx != mx) return NAN;
     float t = mx + ((mx == 0.0f) ? ldexpf(1.0f, -126) : 0.0f); /* FP32_MIN_NORMAL formats.py:12 */
     if (isinf(t)) return INFINITY;
-    return (float)floor_log2_exact(t);
+    return floor_log2_torch(t);
 }
 
 /* clamp of utils/quant.py:207-211 / :237-242 (variant 0) and mx_ops.py:269-273 (variant 1) */
@@ -784,6 +807,10 @@ int msq_oracle_outlier_fakequant_lowp(const float* in, float* out, uint8_t* mask
 }
 
 /* test hooks of the pieces above */
+/* floor(torch.log2(v)) on a float32 tensor (floor_log2_torch): exported for tests/test_oracle_golden.py (log2_f32.npz) */
+void msq_oracle_floor_log2_f32(const float* v, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = floor_log2_torch(v[i]);
+}
 void msq_oracle_floor_log2_lowp(const float* v, float* out, int64_t n, int dtype) {
     for (int64_t i = 0; i < n; ++i) out[i] = floor_log2_lowp(v[i], dtype);
 }

