@@ -504,7 +504,7 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
             qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)
         ms = _tgraph([lambda P=P: qlinear.qlinear_mx_w4a8(X, P, None, torch.bfloat16)] * 10)
         out[key] = {"ms": ms, "tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_FP8_TFLOPS, "peak": PEAK_FP8_TFLOPS, "bound": "mfma (fp8 rate)",
-                    "flops": fl, "kernels": "k_mx_pack_a8 + k_mxgemm", "operand": what, "M": M, "N": N, "K": K,
+                    "flops": fl, "kernels": "k_mx_pack_a8 + k_mxgemm256", "operand": what, "M": M, "N": N, "K": K,
                     "activations": "fp32 in, MX-FP8 (e4m3, block 32) packed in the step"}
         del P
     del P_msq
@@ -517,7 +517,7 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
     fa = lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, block, variant=1)
     ms_a = _tgraph([fa] * 10)
     out["w4a8_mxlinear"] = {"ms": ms, "tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "peak": PEAK_BF16_TFLOPS, "bound": "mfma (bf16 rate)",
-                            "flops": fl, "kernels": "activation quantiser (mx_ops variant, two passes) + k_qgemm3", "act_quant_ms": ms_a,
+                            "flops": fl, "kernels": "activation quantiser (mx_ops variant, two passes) + k_qgemm256", "act_quant_ms": ms_a,
                             "semantics": "number_system/mx/linear.py:29-91", "M": M, "N": N, "K": K}
     del Pl, W, X
     # ---- config 4: KV-cache quantisation of one Llama-2-7B layer cache [1, 32, 4096, 128] fp16 (GEAR hook, compress_function.py:8-70)

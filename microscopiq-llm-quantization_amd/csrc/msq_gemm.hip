@@ -1478,6 +1478,11 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
 
+#ifndef MSQ_MX256_DEFAULT
+#define MSQ_MX256_DEFAULT 1    /* 1: k_mxgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
+#endif
+int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
+                         void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream);   // msq_mxgemm256.hip
 #ifndef MSQ_Q256_DEFAULT
 #define MSQ_Q256_DEFAULT 1     /* 1: k_qgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
 #endif
@@ -1918,6 +1923,19 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
             if (y_dtype == 0) hipLaunchKernelGGL(k_splitk_reduce<float>, rg, dim3(256), 0, st, (const float*)workspace, bias, (float*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
             else hipLaunchKernelGGL(k_splitk_reduce<uint16_t>, rg, dim3(256), 0, st, (const float*)workspace, bias, (uint16_t*)Y, MN0, (int)N, nks, y_dtype == 1 ? 1 : 0);
             return check_launch2("msq_qlinear_mx_w4a8(decode reduce)");
+        }
+    }
+    // 256-row wave tiles, one wave per SIMD, accumulators placed by hand (k_mxgemm256, msq_mxgemm256.hip): full grids of 256 x 256
+    // blocks.  MSQ_MX_256=1 / 0 forces / disables (read per call: tests and A/B scripts flip it inside one process).
+    {
+        const char* e256 = getenv("MSQ_MX_256");
+        const int forced256 = e256 ? atoi(e256) : -1;
+        const int64_t b256 = ((M + 255) / 256) * (N / 256);
+        const bool dflt256 = MSQ_MX256_DEFAULT && b256 >= 256 && b256 * 100 >= 85 * 256 * ((b256 + 255) / 256);
+        if (forced256 == 1 || (forced256 != 0 && dflt256)) {
+            const int e = msq_launch_mxgemm256(wf, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, stream);
+            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_mx_w4a8(256-row wave tiles, k_mxgemm256): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+            return MSQ_OK;
         }
     }
     const int MT = (int)((M + 127) / 128), NTB = (int)(N / BN);

@@ -37,6 +37,9 @@
 /* timing experiments (results are wrong by construction; scripts/experiments/build_q256.sh): 1 no activation-fragment reads, 2 no converts,
    4 no packed / scale loads, 8 no activation staging, 16 no barrier, 32 no output stores, 64 no MFMAs */
 #endif
+#ifndef MSQ_Q256_RT
+#define MSQ_Q256_RT 4          /* row tiles per XCD super-tile (see the block order in the kernel) */
+#endif
 #ifndef MSQ_Q256_PF
 #define MSQ_Q256_PF 2          /* activation-fragment reads in flight ahead of the MFMA group that consumes them (ring of 4) */
 #endif
@@ -81,14 +84,17 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     const int bid = (int)blockIdx.x;
     int bm, bn;
     if ((NTB & 7) == 0) {
-        // XCD-aware order as k_qgemm3: XCD x owns the column panels bn = 8 cp + x and walks them in super-tiles of (up to) 8 row
-        // tiles x 4 panels, so the 32 blocks resident on an XCD share 4 packed W panels and 8 activation tiles out of its own L2
+        // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): XCD x owns the column panels bn = 8 cp + x and walks them in
+        // super-tiles of (up to) RT row tiles x all its panels, row tiles fastest.  With 256 x 256 blocks the 32 blocks resident on an
+        // XCD are best cut as 4 row tiles x 8 panels (8.4 MB of X + 9.7 MB of packed W per round at K = 4096) rather than k_qgemm3's
+        // 8 x 4 (16.8 + 4.9 MB): 357 instead of 414 MB of fabric traffic per launch at M2048 N16384 (rocprofv3 FETCH / WRITE_SIZE).
+        constexpr int RT = MSQ_Q256_RT;
         const int xcd = bid & 7, i = bid >> 3;
-        const int npx = NTB >> 3, per_group = 8 * npx, full = MT >> 3;
+        const int npx = NTB >> 3, per_group = RT * npx, full = MT / RT;
         int rg, j, R;
-        if (i < full * per_group) { rg = i / per_group; j = i % per_group; R = 8; }
-        else { rg = full; j = i - full * per_group; R = MT - full * 8; }
-        bm = rg * 8 + j % R;
+        if (i < full * per_group) { rg = i / per_group; j = i % per_group; R = RT; }
+        else { rg = full; j = i - full * per_group; R = MT - full * RT; }
+        bm = rg * RT + j % R;
         bn = (j / R) * 8 + xcd;
     } else { bm = bid % MT; bn = bid / MT; }
     const int m0 = bm * 256, n0 = bn * 256;
