@@ -2,8 +2,8 @@
 # Runs on the GPU box (through gpurun): the measurements the per-round profile set is built from.
 # Usage: scripts/round_profiles.sh <rNN> [part ...]   parts: timings decode side mx w4a8 rowpar prefill e2e   (default: all)
 set -u
-R=${1:-r03}; shift || true
-PARTS=${*:-timings decode side mx w4a8 rowpar prefill e2e}
+R=${1:-r04}; shift || true
+PARTS=${*:-timings decode side mx w4a8 rowpar prefill e2e e2emx}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round_$R; mkdir -p $O
 for p in $PARTS; do
@@ -18,6 +18,8 @@ for p in $PARTS; do
     prefill) python3 scripts/experiments/layer_prefill.py 2> $O/prefill.err | grep -v amdgpu.ids > $O/${R}_layer_prefill.txt ;;
     e2e)     python3 bench.py --workload llama7b_e2e --no-cpu-baseline 2> /dev/null > $O/${R}_bench_e2e.json
              python3 bench.py --workload llama7b_e2e --model-dtype bf16 --no-cpu-baseline 2> /dev/null > $O/${R}_bench_e2e_bf16model.json ;;
+    e2emx)   python3 bench.py --workload llama7b_e2e --model-dtype bf16 --outlier fp8_e4m3 --path mx --no-cpu-baseline 2> /dev/null > $O/${R}_bench_e2e_bf16model_mx_fp8.json
+             python3 bench.py --workload llama7b_e2e --model-dtype fp16 --outlier fp8_e4m3 --path mx --no-cpu-baseline 2> /dev/null > $O/${R}_bench_e2e_fp16model_mx_fp8.json ;;
   esac
 done
 ls -la $O | tail -20
