@@ -133,6 +133,55 @@ template <int DT> MSQ_D float shared_exp_lowp(float mx) {
     return floor_log2_lowp<DT>(Rr<DT>(mx + t));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path of one block (round 4; the op-by-op path below is ~200 vector instructions per element: 358 GB/s on a 16384 x 4096 fp16
+// weight).  Same values, fewer instructions -- nothing is approximated:
+//  * every scaling of utils/quant.py:214-258 is by R(2^e) with an integer e: inside the bounds checked below the scale IS 2^e in T
+//    and the product / quotient is exact in float32, so `R(x / R(2^e))` is `R(ldexp(x, -e))` (one v_ldexp + the rounding pair);
+//  * roundings to T that cannot change the value are dropped: a T value scaled UP by a power of two, the quotient by the private
+//    exponent's power of two, the short significand coming out of the element codec (see the derivation next to each line);
+//    those that can are kept: into the element domain (:214, :216, :247), R(|v| + 0.5) in front of the floor, back out (:224, :258);
+//  * an element is an inlier or an outlier, never both: ONE trip through the codec with the parameters of its side (the other side
+//    of the reference computes on a zero and contributes +0; the final `inl + o` only turns a -0 into +0);
+//  * max |R(o 2^e_in)| over the outliers is R(max |o| 2^e_in) (both maps are monotone): no second array, no second pass;
+//  * floor(R(log2 t)): the integer rule floor_log2_fast (pinned exhaustively by tests/golden/log2_lowp.npz through k_mx_lowp).
+// Taken when the WHOLE wave qualifies: round to nearest, no flush, finite block, both shared exponents inside T's exact range.
+// Everything else -- NaN / Inf members, scales at the edge of fp16, other rounding modes -- takes the op-by-op path.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT> MSQ_D int floor_log2_fast(float t);                  // defined with the MX kernels below
+struct LowpSide { int mine, shexp; float mn; bool has_pe; };
+MSQ_D LowpSide lowp_side(const Fmt& f) {
+    LowpSide s;
+    s.has_pe = f.ebits != 0;
+    s.mine = s.has_pe ? 2 - (1 << (f.ebits - 1)) : 0;
+    s.shexp = f.mbits - 2;
+    s.mn = f.max_norm;
+    return s;
+}
+template <int DT>
+MSQ_D float outlier_elem_fast(float x, bool m, int ei, int eo, const LowpSide& si, const LowpSide& so) {
+    // into the element domain: inlier R(x / sc_in) (:214); outlier R(R(x sc_in) / sc_out) (:216, :247)
+    float t = Rr<DT>(__builtin_ldexpf(x, m ? ei : -ei));
+    t = Rr<DT>(__builtin_ldexpf(t, m ? -eo : 0));                      // (an inlier is a T value already: R is the identity)
+    // elemwise_ops.py:84-174 with the side's parameters
+    const float av = __builtin_fabsf(t);
+    int pe = floor_log2_fast<DT>(av);                                  // t == 0: some exponent, the mantissa below is 0
+    const int mine = m ? so.mine : si.mine;
+    pe = pe < mine ? mine : pe;
+    pe = (m ? so.has_pe : si.has_pe) ? pe : 0;
+    const int sa = (m ? so.shexp : si.shexp) - pe;
+    const float mm = __builtin_ldexpf(av, sa);                         // |t| / 2^pe * 2^(bits - 2): a T value scaled by powers of two, exact
+    const float q = __builtin_floorf(Rr<DT>(mm + 0.5f));               // the rounding that matters (ties just below n + 1/2)
+    float r = __builtin_ldexpf(q, -sa);                                // q 2^(2 - bits) 2^pe: at most bits - 1 significant bits, exact in T
+    const float mn = m ? so.mn : si.mn;
+    r = r > mn ? mn : r;                                               // saturate_normals
+    r = __builtin_copysignf(r, t);
+    // back: inlier R(v sc_in) (:224); outlier R(R(o sc_out) / sc_in) (:258)
+    r = Rr<DT>(__builtin_ldexpf(r, m ? eo : ei));
+    r = Rr<DT>(__builtin_ldexpf(r, m ? -ei : 0));
+    return r + 0.0f;                                                   // :262 inl + o with the other side +0: a -0 becomes +0
+}
+
 template <int BS, int DT>
 MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
                              const OutlierArgs& A, int order) {
@@ -153,12 +202,44 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     }
 #pragma unroll
     for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
+    {
+        // ---- fast path: qualification on block-level quantities only
+        float mxi = 0.f, mxo = 0.f;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            const bool m = (a[b] < lo) || (a[b] > hi);                  // :492
+            mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
+            const float t = __builtin_fabsf(a[b]);
+            mxi = (!m && (t > mxi || t != t)) ? t : mxi;
+            mxo = (m && (t > mxo || t != t)) ? t : mxo;
+        }
+        constexpr int ELO = (DT == 1) ? -24 : -100, EHI = (DT == 1) ? 15 : 100;     // R(2^e) is exactly 2^e and nothing leaves float32
+        float se_in = shared_exp_lowp<DT>(mxi);                         // :196-198
+        se_in = Rr<DT>(se_in - (float)A.fi.emax);                       // :207
+        se_in = clamp_scale_exp(se_in, A.in_sb, 0);                     // :208-211
+        bool fast = A.rmode == 0 && !A.flush && se_in == se_in && mxi < 3.0e38f && mxo < 3.0e38f && se_in >= (float)ELO && se_in <= (float)EHI;
+        const int ei = fast ? (int)se_in : 0;
+        const float mx_out = Rr<DT>(__builtin_ldexpf(mxo, ei));         // max over the block of R(o sc_in) (:216): monotone maps
+        float se_out = shared_exp_lowp<DT>(mx_out);                     // :229-231
+        se_out = Rr<DT>(se_out - (float)A.fo.emax);                     // :237
+        se_out = clamp_scale_exp(se_out, A.out_sb, 0);                  // :239-242
+        fast = fast && se_out == se_out && mx_out < 3.0e38f && se_out >= (float)ELO && se_out <= (float)EHI;
+        if (__builtin_amdgcn_ballot_w64(!fast) == 0ull) {
+            const int eo = (int)se_out;
+            const LowpSide si = lowp_side(A.fi), so = lowp_side(A.fo);
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+                a[b] = outlier_elem_fast<DT>(a[b], (mkw[b >> 5] >> (b & 31)) & 1u, ei, eo, si, so);
+            se_in_o = se_in; se_out_o = se_out;
+            return 0;
+        }
+    }
+    // ---- op-by-op path (utils/quant.py:147-266 literally, every op rounded to T)
     float mx_in = 0.f;
     float inl[BS];
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
-        const bool m = (a[b] < lo) || (a[b] > hi);                      // :492
-        mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
+        const bool m = (mkw[b >> 5] >> (b & 31)) & 1u;
         const float mf = m ? 1.f : 0.f;
         inl[b] = a[b] * (1.0f - mf);                                    // :192 (exact: x * 1 or x * 0)
         a[b] = a[b] * mf;                                               // :193
