@@ -149,6 +149,8 @@ template <int DT> MSQ_D float shared_exp_lowp(float mx) {
 // Everything else -- NaN / Inf members, scales at the edge of fp16, other rounding modes -- takes the op-by-op path.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DT> MSQ_D int floor_log2_fast(float t);                  // defined with the MX kernels below
+template <int DT> MSQ_D int floor_log2_tab(float t, const uint8_t* tab);
+template <int DT> MSQ_D void floor_log2_tab_init(uint8_t* tab);
 struct LowpSide { int mine, shexp; float mn; bool has_pe; };
 MSQ_D LowpSide lowp_side(const Fmt& f) {
     LowpSide s;
@@ -158,14 +160,17 @@ MSQ_D LowpSide lowp_side(const Fmt& f) {
     s.mn = f.max_norm;
     return s;
 }
-template <int DT>
-MSQ_D float outlier_elem_fast(float x, bool m, int ei, int eo, const LowpSide& si, const LowpSide& so) {
+// UPX: both shared exponents are <= 0 for every lane of the wave (weights below 1: the usual case) -- then the outlier's second scaling
+// into its domain (x 2^-eo) and the final scaling back (x 2^-ei) go UP by a power of two: exact for a T value, no rounding pair
+template <int DT, bool UPX>
+MSQ_D float outlier_elem_fast(float x, bool m, int ei, int eo, const LowpSide& si, const LowpSide& so, const uint8_t* tab) {
     // into the element domain: inlier R(x / sc_in) (:214); outlier R(R(x sc_in) / sc_out) (:216, :247)
     float t = Rr<DT>(__builtin_ldexpf(x, m ? ei : -ei));
-    t = Rr<DT>(__builtin_ldexpf(t, m ? -eo : 0));                      // (an inlier is a T value already: R is the identity)
+    t = __builtin_ldexpf(t, m ? -eo : 0);                              // (an inlier is a T value already: R is the identity)
+    if (!UPX) t = Rr<DT>(t);
     // elemwise_ops.py:84-174 with the side's parameters
     const float av = __builtin_fabsf(t);
-    int pe = floor_log2_fast<DT>(av);                                  // t == 0: some exponent, the mantissa below is 0
+    int pe = floor_log2_tab<DT>(av, tab);                              // floor(R(log2 |t|)); t == 0: some exponent, the mantissa below is 0
     const int mine = m ? so.mine : si.mine;
     pe = pe < mine ? mine : pe;
     pe = (m ? so.has_pe : si.has_pe) ? pe : 0;
@@ -178,13 +183,14 @@ MSQ_D float outlier_elem_fast(float x, bool m, int ei, int eo, const LowpSide& s
     r = __builtin_copysignf(r, t);
     // back: inlier R(v sc_in) (:224); outlier R(R(o sc_out) / sc_in) (:258)
     r = Rr<DT>(__builtin_ldexpf(r, m ? eo : ei));
-    r = Rr<DT>(__builtin_ldexpf(r, m ? -ei : 0));
+    r = __builtin_ldexpf(r, m ? -ei : 0);
+    if (!UPX) r = Rr<DT>(r);
     return r + 0.0f;                                                   // :262 inl + o with the other side +0: a -0 becomes +0
 }
 
 template <int BS, int DT>
 MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], float& se_in_o, float& se_out_o,
-                             const OutlierArgs& A, int order) {
+                             const OutlierArgs& A, int order, const uint8_t* l2tab) {
     int status = 0;
     float lo, hi;
     {
@@ -224,12 +230,26 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
         se_out = Rr<DT>(se_out - (float)A.fo.emax);                     // :237
         se_out = clamp_scale_exp(se_out, A.out_sb, 0);                  // :239-242
         fast = fast && se_out == se_out && mx_out < 3.0e38f && se_out >= (float)ELO && se_out <= (float)EHI;
+        // ... and neither side overflows T when it enters its element domain (a maximum just under a power of two whose exponent the
+        // log2 rule lifted can reach 2^(emax + 1): 65536 for an e5m2 side is Inf in fp16 -- the op-by-op path carries that Inf)
+        const int eo_ = fast ? (int)se_out : 0;
+        // ... nor does R(2^pe) of the largest private exponent (the rule may lift it to emax + 1 = 16 for e5m2: Inf in fp16, NaN results
+        // in the reference); floor_log2 is monotone, so the block maxima decide
+        constexpr int PEMAX = (DT == 1) ? 15 : 127;
+        const float ti_ = Rr<DT>(__builtin_ldexpf(mxi, -ei)), to_ = Rr<DT>(__builtin_ldexpf(mx_out, -eo_));
+        fast = fast && ti_ < 3.0e38f && to_ < 3.0e38f && (ti_ == 0.f || floor_log2_fast<DT>(ti_) <= PEMAX) && (to_ == 0.f || floor_log2_fast<DT>(to_) <= PEMAX);
         if (__builtin_amdgcn_ballot_w64(!fast) == 0ull) {
             const int eo = (int)se_out;
             const LowpSide si = lowp_side(A.fi), so = lowp_side(A.fo);
+            if (__builtin_amdgcn_ballot_w64(ei > 0 || eo > 0) == 0ull) {
 #pragma unroll
-            for (int b = 0; b < BS; ++b)
-                a[b] = outlier_elem_fast<DT>(a[b], (mkw[b >> 5] >> (b & 31)) & 1u, ei, eo, si, so);
+                for (int b = 0; b < BS; ++b)
+                    a[b] = outlier_elem_fast<DT, true>(a[b], (mkw[b >> 5] >> (b & 31)) & 1u, ei, eo, si, so, l2tab);
+            } else {
+#pragma unroll
+                for (int b = 0; b < BS; ++b)
+                    a[b] = outlier_elem_fast<DT, false>(a[b], (mkw[b >> 5] >> (b & 31)) & 1u, ei, eo, si, so, l2tab);
+            }
             se_in_o = se_in; se_out_o = se_out;
             return 0;
         }
@@ -290,6 +310,9 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A) {
+    __shared__ uint8_t l2tab[256];                          // bump allowance of floor(R(log2 .)) by biased exponent (fast path)
+    floor_log2_tab_init<DT>(l2tab);
+    __syncthreads();
     const int64_t total = A.pre * A.nblk * A.post;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -322,7 +345,7 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     }
     uint32_t mkw[(BS + 31) / 32];
     float se_in, se_out;
-    const int status = outlier_block_lowp<BS, DT>(a, mkw, se_in, se_out, A, order);
+    const int status = outlier_block_lowp<BS, DT>(a, mkw, se_in, se_out, A, order, l2tab);
     if (vec) {
 #pragma unroll
         for (int c = 0; c < BS / 8; ++c) {
