@@ -319,3 +319,21 @@ def test_shared_exponent_just_below_powers_of_two(msq, O, fi, fo, rnd):
     emax = O.format_params(fi)[2]
     e_field = (np.frexp(v.astype(np.float64))[1] - 1).astype(np.float32) - emax
     assert int((o["e_in"].reshape(-1)[:len(v)] != e_field).sum()) >= 1000
+
+
+def test_default_bench_line_rowparallel_leg_on_a_single_rank_rccl_group(msq):
+    """On N > 1 ranks the DEFAULT workload (what the driver's scaling run launches) also runs the 70B K-split step over RCCL and reports
+    it as `rowparallel`.  No multi-GPU box is available to the tests: the same code path on a real RCCL group of one rank
+    (--single-rank-collectives): shard pack, reduce-scatter + all-gather, timings, evidence keys."""
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-rank-collectives", "--steps", "10", "--warmup", "2", "--chunks", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["value"] > 500
+    seen = d["config"]["ranks_seen"]
+    assert len(seen) == 1 and seen[0]["backend"] == "nccl" and seen[0]["rccl"]
+    r = d["rowparallel"]
+    assert set(bench.ROWPAR_KEYS) <= set(r) and r["chunks"] == 2 and r["comm"] == "rs_ag" and r["scaling"] == "strong"
+    assert r["gemm_ms"] > 0 and r["comm_ms"] > 0 and r["step_ms"] >= 0.98 * r["gemm_ms"] and r["tflops_whole_job"] > 500
