@@ -337,3 +337,59 @@ def test_default_bench_line_rowparallel_leg_on_a_single_rank_rccl_group(msq):
     r = d["rowparallel"]
     assert set(bench.ROWPAR_KEYS) <= set(r) and r["chunks"] == 2 and r["comm"] == "rs_ag" and r["scaling"] == "strong"
     assert r["gemm_ms"] > 0 and r["comm_ms"] > 0 and r["step_ms"] >= 0.98 * r["gemm_ms"] and r["tflops_whole_job"] > 500
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the 256-row GEMM kernels (k_qgemm256, k_mxgemm256): bit-identical to the 128-row kernels they replace on full grids
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(2048, 16384, 256), (300, 512, 128), (2048 - 37, 2304, 320), (513, 256, 64), (1024, 4096, 1088)])
+@pytest.mark.parametrize("fo", ["posit8_es1", "fp8_e4m3"])
+def test_qgemm256_equals_qgemm3_and_the_dense_product(msq, M, N, K, fo, monkeypatch):
+    """k_qgemm256 (256-row wave tiles, accumulators pinned to AGPRs by tied inline-asm MFMAs, one filler per MFMA shadow) against
+    k_qgemm3 on the same planes: the same products accumulate in the same order per output element, so the results are EQUAL bit
+    for bit -- with a bias, for float32 / bfloat16 / float16 outputs, ragged M (rows clamped while staging, never stored), 1 ... 17
+    K-steps (odd counts take the tail step), panel counts that are not a multiple of 8 (plain block order) -- and repeat bit for
+    bit; against the dense product of the unpacked weight within 2e-5 max|y| (fp32 accumulation)."""
+    W = _weights(N, K, 11).to(dev())
+    X = torch.randn(M, K, generator=torch.Generator().manual_seed(12)).to(dev()).to(torch.bfloat16)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(13)).to(dev())
+    P = msq.qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
+    ref = X.float() @ msq.qlinear.unpack_weight(P).t() + bias
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        monkeypatch.setenv("MSQ_GEMM_256", "0")
+        a = msq.qlinear.qlinear(X, P, bias, dt)
+        monkeypatch.setenv("MSQ_GEMM_256", "1")
+        b = msq.qlinear.qlinear(X, P, bias, dt)
+        if not (M > 64 and M <= 512 and N * K >= 4096 * 4096):          # (k_qgemm3 may split K on small grids: another summation order)
+            assert torch.equal(a, b), (dt, (a.float() - b.float()).abs().max().item())
+        for _ in range(5):
+            assert torch.equal(msq.qlinear.qlinear(X, P, bias, dt), b)
+    monkeypatch.setenv("MSQ_GEMM_256", "1")
+    y = msq.qlinear.qlinear(X, P, bias, torch.float32)
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 16384, 256), (300, 512, 256), (2048 - 37, 2304, 640), (513, 256, 128), (1024, 4096, 1152)])
+def test_mxgemm256_equals_mxgemm(msq, M, N, K, monkeypatch):
+    """k_mxgemm256 against k_mxgemm for every weight operand (MX-FP4, exact e4m3 values, MX-FP6 e3m2 / e2m3) on the same packed
+    activations: equal bit for bit (bias, three output dtypes, ragged M, 1 ... 9 K-steps: the three-deep weight ring and the fragment
+    ring across K-step boundaries), repeatable."""
+    W = _weights(N, K, 21).to(dev())
+    X = torch.randn(M, K, generator=torch.Generator().manual_seed(22)).to(dev())
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(23)).to(dev())
+    xp = msq.qlinear.mx_pack_act(X)
+    ops = {"fp4": msq.qlinear.mx_pack_weight(W, w_fmt="e2m1"), "e3m2": msq.qlinear.mx_pack_weight(W, w_fmt="e3m2"),
+           "e2m3": msq.qlinear.mx_pack_weight(W, w_fmt="e2m3"),
+           "e4m3": msq.qlinear.mx_pack_values(msq.quant.outlier_fakequant(W, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32)["out"])}
+    for name, P in ops.items():
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            monkeypatch.setenv("MSQ_MX_256", "0")
+            a = msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt)
+            monkeypatch.setenv("MSQ_MX_256", "1")
+            b = msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt)
+            if not (M > 64 and M <= 1024 and N <= 4096):                 # (k_mxgemm may split K / use 64-row blocks: same sums, other order)
+                assert torch.equal(a, b), (name, dt, (a.float() - b.float()).abs().max().item())
+            else:
+                assert (a.float() - b.float()).abs().max().item() <= 1e-4 * a.float().abs().max().item() + 1e-6
+            for _ in range(3):
+                assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt), b)
