@@ -311,6 +311,7 @@ template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A) {
     __shared__ uint8_t l2tab[256];                          // bump allowance of floor(R(log2 .)) by biased exponent (fast path)
+    __shared__ __attribute__((aligned(16))) char xsm[(BS % 8 == 0) ? 4 * 64 * (BS * 2 + 16) : 16];   // one transposition slice per wave
     floor_log2_tab_init<DT>(l2tab);
     __syncthreads();
     const int64_t total = A.pre * A.nblk * A.post;
@@ -325,7 +326,34 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     // blocks along the contiguous axis: the lane's block is BS * 2 contiguous bytes -> 16-byte accesses
     const bool vec = (BS % 8 == 0) && A.post == 1 && (A.axis_len % BS) == 0 &&
                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    if (vec) {
+    // ... coalesced: the 64 blocks of a full wave are one contiguous run of 64 * BS * 2 bytes -- lane l loads 16-byte chunk c * 64 + l
+    // of it (a wave instruction = 1 KiB contiguous; lane-per-block loads touched every 128-byte line BS / 8 times, 34 % of the wave
+    // cycles were memory waits: profiles/r04_pmc_outlier_lowp.txt), the chunks cross to their block's lane through the wave's LDS
+    // slice (row stride BS * 2 + 16 bytes: conflict-free ds_read_b128), and back the same way for the stores
+    constexpr int CH = BS / 8;                                            // 16-byte chunks per block
+    constexpr int ROWB = BS * 2 + 16;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_t0 = t - lane;
+    const bool xpose = vec && (BS % 8 == 0) && (wave_t0 + 64 <= total);   // a full wave (wave-uniform)
+    char* const wsl = xsm + wv * (64 * ROWB);
+    const int64_t wave_base = wave_t0 * BS;                               // post == 1: block index t starts at element t * BS
+    if (xpose) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = c * 64 + lane;                                  // chunk of the wave's run
+            const uint4 u = *reinterpret_cast<const uint4*>(in + wave_base + (int64_t)j * 8);
+            *reinterpret_cast<uint4*>(wsl + (j / CH) * ROWB + (j % CH) * 16) = u;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               // this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+            v.u = *reinterpret_cast<const uint4*>(wsl + lane * ROWB + c * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[c * 8 + j] = ld16<DT>(v.h, j);
+        }
+    } else if (vec) {
 #pragma unroll
         for (int c = 0; c < BS / 8; ++c) {
             union { uint4 u; uint16_t h[8]; } v;
@@ -346,7 +374,24 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     uint32_t mkw[(BS + 31) / 32];
     float se_in, se_out;
     const int status = outlier_block_lowp<BS, DT>(a, mkw, se_in, se_out, A, order, l2tab);
-    if (vec) {
+    if (xpose) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               // (the reads of the input image are long done)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            union { uint4 u; uint16_t h[8]; } v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, a[c * 8 + j]);
+            *reinterpret_cast<uint4*>(wsl + lane * ROWB + c * 16) = v.u;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = c * 64 + lane;
+            *reinterpret_cast<uint4*>(out + wave_base + (int64_t)j * 8) = *reinterpret_cast<const uint4*>(wsl + (j / CH) * ROWB + (j % CH) * 16);
+        }
+    } else if (vec) {
 #pragma unroll
         for (int c = 0; c < BS / 8; ++c) {
             union { uint4 u; uint16_t h[8]; } v;
@@ -354,6 +399,8 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
             for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, a[c * 8 + j]);
             *reinterpret_cast<uint4*>(out + base + c * 8) = v.u;
         }
+    }
+    if (vec) {
         if (A.mask) {
 #pragma unroll
             for (int b = 0; b < BS; ++b) A.mask[base + b] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch one side kernel a few times (for rocprofv3 --pmc passes).  Usage: python3 scripts/experiments/one_kernel.py layernorm|gelu|kv16|kv32|act0|act1|pack_posit"""
+"""Launch one side kernel a few times (for rocprofv3 --pmc passes).  Usage: python3 scripts/experiments/one_kernel.py layernorm|gelu|kv16|kv32|act0|act1|pack_posit|lowp16"""
 import os
 import sys
 
@@ -16,11 +16,13 @@ sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp6_e3m2", "a_elem_format": 
 X = torch.randn(2048, 4096, device=dev); w = torch.randn(4096, device=dev); b = torch.randn(4096, device=dev)
 C16 = torch.randn(1, 32, 4096, 128, device=dev).half(); C32 = C16.float()
 W = torch.randn(16384, 4096, device=dev) * 0.02
+W16 = W.half()
 fn = {"layernorm": lambda: vector_ops.layer_norm(X, w, b, 1e-12, sp), "gelu": lambda: vector_ops.gelu(X, mx_specs=sp),
       "kv16": lambda: kvcache.fake_groupwise_token_asymmetric_quantization(C16, 2, 4096),
       "kv32": lambda: kvcache.fake_groupwise_token_asymmetric_quantization(C32, 2, 4096),
       "act0": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 2, 32, "nearest", False, 0),
       "act1": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1),
+      "lowp16": lambda: msq.quant.outlier_fakequant(W16, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32),
       "pack_posit": lambda: qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified"), "gemv_gateup": None}[what]
 if what == "gemv_gateup":                                # ten COLD launches of the wide-projection decode kernel (distinct weight copies)
     Wg = torch.randn(22016, 4096, device=dev) * 0.02
