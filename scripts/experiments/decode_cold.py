@@ -51,7 +51,10 @@ def tgraph(fns, reps=5):
 
 
 tot = {}
+ONLY = [a for a in os.environ.get("ONLY", "").split(",") if a]
 for (name, N, K) in (("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)):
+    if ONLY and name not in ONLY:
+        continue
     W = torch.randn(N, K, device=dev) * 0.02
     W[torch.rand(N, K, device=dev) < 0.005] *= 16
     for f in fmts:
