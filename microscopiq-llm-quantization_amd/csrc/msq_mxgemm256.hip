@@ -205,8 +205,21 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
         return n;
     }();
 
+    // The steps after the loop load weights nobody will use: hipcc deletes those loads, so such a step issues only its LDS-DMA ops and
+    // the loop's wait count would let ops of the PREVIOUS step -- the tile the next tail step reads -- stay in flight (seen as 25-28
+    // differing launches of 300 with K = 640 / 1024 and the five-load fp4 operand, scripts/experiments/stress_round4.py; the same
+    // trap as k_mxgemm's).  Tail steps therefore let only their own LDS-DMA ops stay in flight.
+    constexpr int N_WAIT_TAIL = [] {
+        int n = 0;
+        for (int mf = 0; mf < BAR_G; ++mf) {
+            if ((mf & 1) == 0) n += 1;
+            else if ((mf >> 1) == NPART) n += 1;
+            if (NPART + 1 > 8 && mf == 3) n += 1;
+        }
+        return n;
+    }();
 #define MX256_SB() __builtin_amdgcn_sched_barrier(0)
-#define MX256_STEP(KT_CUR, WCUR, WLOAD)                                                                              \
+#define MX256_STEP(KT_CUR, WCUR, WLOAD, NWAIT)                                                                       \
     {                                                                                                                \
         const int kt_ = sgpr(KT_CUR);                                                                                \
         const int buf = abuf, bufn = (abuf + 1) & 3, buf2 = (abuf + 2) & 3;                                          \
@@ -218,7 +231,7 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
         const int ktn = (kt_ + 2 <= kl) ? kt_ + 2 : kl;            /* branch-free tail: re-stage / re-load the last tile */ \
         _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                          \
             if (mf == BAR_G) {                                                                                       \
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));     /* vmcnt(N_WAIT) only */ \
+                __builtin_amdgcn_s_waitcnt(0x0F70 | ((NWAIT) & 15) | (((NWAIT) >> 4) << 14));   /* vmcnt(NWAIT) only */ \
                 if (!(MSQ_MX256_ABL & 16)) __builtin_amdgcn_s_barrier();                                             \
             }                                                                                                        \
             const u32x4_t lo_ = xl[mf & 3], hi_ = xh[mf & 3];                                                        \
@@ -248,9 +261,9 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     int abuf = 0;
     {
         int kt = 0;
-        for (; kt + 2 < KT; kt += 3) { MX256_STEP(kt, w0, w2) MX256_STEP(kt + 1, w1, w0) MX256_STEP(kt + 2, w2, w1) }
-        if (kt < KT) { MX256_STEP(kt, w0, w2) ++kt; }
-        if (kt < KT) { MX256_STEP(kt, w1, w0) ++kt; }
+        for (; kt + 2 < KT; kt += 3) { MX256_STEP(kt, w0, w2, N_WAIT) MX256_STEP(kt + 1, w1, w0, N_WAIT) MX256_STEP(kt + 2, w2, w1, N_WAIT) }
+        if (kt < KT) { MX256_STEP(kt, w0, w2, N_WAIT_TAIL) ++kt; }
+        if (kt < KT) { MX256_STEP(kt, w1, w0, N_WAIT_TAIL) ++kt; }
     }
 #undef MX256_STEP
 #undef MX256_SB

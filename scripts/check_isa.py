@@ -128,4 +128,45 @@ for nm in re.findall(r'^(_ZN\S*k_qgemm256\S*):', s2, re.M):
     print(("!! " if flag else "   ") + "%-50s K-loop: mfma %4d  v_accvgpr %d  scratch %d  in-place %s  vmem bursts %d  converts per MFMA gap <= %d  vmcnt over %s"
           % (nm[-50:], len(mf), acc, scr, inplace, burst, worst_cvt, over))
     bad += 1 if flag else 0
+
+# ---- k_mxgemm256 (csrc/msq_mxgemm256.hip): the same checks for the MX kernel; its K-loop is three steps long and up to TWO tail steps
+# follow it -- hipcc deletes the dead weight loads of the tail steps, so their barriers must wait with the count of their own LDS-DMA ops
+src3 = os.path.join(HERE, "..", "microscopiq-llm-quantization_amd", "csrc", "msq_mxgemm256.hip")
+out3 = os.path.join(tempfile.gettempdir(), "msq_mxgemm256_check.s")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+                       "--cuda-device-only", "-S", src3, "-o", out3] + sys.argv[1:], stderr=subprocess.DEVNULL)
+s3 = open(out3).read()
+for nm in re.findall(r'^(_ZN\S*k_mxgemm256\S*):', s3, re.M):
+    i = s3.index('\n' + nm + ':'); j = s3.index('s_endpgm', i)
+    lines = [l.strip() for l in s3[i:j].split('\n')]
+    blocks, curb = [], []
+    for l in lines:
+        if re.match(r'^\.LBB\S+:', l):
+            blocks.append(curb); curb = []
+        else:
+            curb.append(l)
+    blocks.append(curb)
+    region = [l for b in blocks if sum(1 for x in b if x.startswith('v_mfma')) >= 32 for l in b]
+    code = [l for l in region if l and not l.startswith(';')]
+    acc = sum(1 for l in code if l.startswith('v_accvgpr')); scr = sum(1 for l in code if l.startswith('scratch_'))
+    inplace = all(re.match(r'v_mfma_scale_f32_16x16x128_f8f6f4 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1,', l) for l in code if l.startswith('v_mfma'))
+    vm = lambda l: l.startswith('buffer_load') or l.startswith('global_load')
+    segs, curseg = [], {"loads": 0, "wait": None, "mfma": 0}
+    for l in code:
+        if vm(l):
+            curseg["loads"] += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l and 'lgkmcnt' not in l:
+            curseg["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
+        elif l.startswith('v_mfma'):
+            curseg["mfma"] += 1
+        elif l.startswith('s_barrier'):
+            segs.append(curseg); curseg = {"loads": 0, "wait": None, "mfma": 0}
+    segs.append(curseg)
+    # a K-step segment runs from one barrier to the next (64 MFMAs); its wait may not exceed the ops it issued IF the next segment multiplies a fresh tile
+    over = [(k, a["loads"], a["wait"]) for k, (a, b) in enumerate(zip(segs[1:], segs[2:]), 1)
+            if a["wait"] is not None and a["mfma"] >= 64 and b["mfma"] >= 32 and a["wait"] > a["loads"]]
+    flag = acc or scr or not inplace or over
+    print(("!! " if flag else "   ") + "%-48s K-loop: mfma %4d  v_accvgpr %d  scratch %d  in-place %s  vmcnt over %s"
+          % (nm[-48:], sum(1 for l in code if l.startswith('v_mfma')), acc, scr, inplace, over))
+    bad += 1 if flag else 0
 sys.exit(1 if bad else 0)
