@@ -393,3 +393,30 @@ def test_mxgemm256_equals_mxgemm(msq, M, N, K, monkeypatch):
                 assert (a.float() - b.float()).abs().max().item() <= 1e-4 * a.float().abs().max().item() + 1e-6
             for _ in range(3):
                 assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt), b)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 16384, 640), (4096, 8192, 1024)])
+def test_mxgemm256_tail_steps_repeat_under_uneven_load(msq, M, N, K, monkeypatch):
+    """K-step counts that leave TWO tail steps behind the three-step loop: hipcc deletes the dead weight loads of those steps, and with
+    the loop's wait count the first tail step let the LDS-DMA pieces of the tile the second one multiplies stay in flight (25-28 of 300
+    launches differed with the five-load MX-FP4 operand, scripts/experiments/stress_round4.py).  Tail steps now wait with the count of
+    their own LDS-DMA ops (scripts/check_isa.py checks it in the ISA): 150 launches, every second beside a bandwidth hog on another
+    stream, all equal to the first one, which equals k_mxgemm."""
+    monkeypatch.setenv("MSQ_MX_256", "1")
+    W = _weights(N, K, 31).to(dev())
+    X = torch.randn(M, K, generator=torch.Generator().manual_seed(32)).to(dev())
+    xp = msq.qlinear.mx_pack_act(X)
+    P = msq.qlinear.mx_pack_weight(W, w_fmt="e2m1")
+    hog_a = torch.empty(32 << 20, dtype=torch.float32, device=dev()); hog_b = torch.empty_like(hog_a)
+    side = torch.cuda.Stream()
+    y0 = msq.qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32)
+    d = torch.zeros((), dtype=torch.int64, device=dev())
+    for r in range(150):
+        if r % 2:
+            with torch.cuda.stream(side):
+                hog_b.copy_(hog_a)
+        d += (msq.qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32) != y0).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(d.item()) == 0
+    monkeypatch.setenv("MSQ_MX_256", "0")
+    assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32), y0)
