@@ -1483,11 +1483,14 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 #endif
 int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
                          void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream);   // msq_mxgemm256.hip
+#ifndef MSQ_Q128_DEFAULT
+#define MSQ_Q128_DEFAULT 1     /* 1: the MF = 8 form of k_qgemm256 (128-row blocks, two per CU) where the cost rule below prefers it */
+#endif
 #ifndef MSQ_Q256_DEFAULT
 #define MSQ_Q256_DEFAULT 1     /* 1: k_qgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
 #endif
 int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
-                        int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* stream);   // msq_gemm256.hip
+                        int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int mf, void* stream);   // msq_gemm256.hip
 static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream, int x_f16) {
@@ -1579,14 +1582,29 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     }
     if (x_f16) return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_f16x: fp16 activations are converted inside the decode kernels only (M <= 32; <= 64 for the 4096 x 4096 class): cast them to bf16 for this shape");
     // 256-row wave tiles with hand-placed AGPR accumulators (k_qgemm256, msq_gemm256.hip): one wave per SIMD, half the converts and
-    // packed loads per MFMA.  MSQ_GEMM_256=1 / 0 forces / disables (tuning and A/B); default rule: see q256_default below.
+    // packed loads per MFMA; and its 128-row form (MF = 8).
     {
         const char* e256 = getenv("MSQ_GEMM_256");                  // read per call (tests and A/B scripts flip it inside one process)
         const int q256_forced = e256 ? atoi(e256) : -1;
-        const int64_t b256 = ((M + 255) / 256) * (N / 256);
-        const bool q256_default = MSQ_Q256_DEFAULT && b256 >= 256 && b256 * 100 >= 85 * 256 * ((b256 + 255) / 256);
+        // Default rule (measured: profiles/r04_q128_sweep.txt, 13 values of M x the four Llama-2-7B projections x both outlier formats): a
+        // cost in rounds of the grid over the 256 CUs.  256-row blocks run one per CU (r16 rounds); 128-row blocks run two per CU, each
+        // pair about as long as one 256-row block (r8x2 half-rounds, times 1.07 with posit outliers -- their longer convert chain hides
+        // less well behind half the MFMAs).  The 128-row form wins where its finer granularity saves at least that (qkv 2048 x 12288: 1.5
+        // against 2 rounds; gate_up at M = 640: 1 against 2) and on the one-round grids of 144 ... 256 blocks (o, down); k_qgemm3 keeps
+        // the small grids (its 64-row blocks and split-K live there) and, with fp8 outliers at M > 512, the part-filled single round.
+        const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
+        const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
+        const bool posit_out = out_kind == MSQ_PLANE_U8X;
+        const bool q128_default = MSQ_Q128_DEFAULT && b128 >= 144 && r8x2 * (posit_out ? 107 : 100) < 2 * r16 * 100;
+        const bool q256_default = MSQ_Q256_DEFAULT && !q128_default && (b256 >= 224 || (b256 > 128 && (posit_out || M <= 512)));
+        // MSQ_GEMM_256=2 / 1 force the 128-row (MF = 8: two blocks per CU) / 256-row form of the kernel, 0 disables both -- tuning and A / B
+        if (unified && !x_f16 && (q256_forced == 2 || (q256_forced < 0 && q128_default))) {
+            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 8, stream);
+            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(128-row wave tiles, k_qgemm256<MF = 8>): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+            return MSQ_OK;
+        }
         if (unified && !x_f16 && (q256_forced == 1 || (q256_forced != 0 && q256_default))) {
-            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, stream);
+            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 16, stream);
             if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(256-row wave tiles, k_qgemm256): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
             return MSQ_OK;
         }

@@ -66,21 +66,28 @@ MSQ_D uint32_t ext_dword(uint32_t r, const HalfRegs<MSQ_PLANE_NONE, OUT_KIND>& h
     return (OUT_KIND == MSQ_PLANE_U8X) ? ext_or(r, h.ext, d >> 2, d & 3) : r;
 }
 
-template <int OUT_KIND, typename YT>
-__global__ void __launch_bounds__(256, 1)
+// MF = 16-row MFMA fragments per wave along m: 16 (block 256 x 256, ONE wave per SIMD: the shape described above) or 8 (block 128 x 256,
+// two blocks per CU = two waves per SIMD, 128 accumulator registers: for grids that 256-row blocks do not fill -- the same stream
+// with two dwords of the next fragments converted per group instead of one)
+template <int OUT_KIND, typename YT, int MF>
+__global__ void __launch_bounds__(256, (MF == 16) ? 1 : 2)
 k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane, const uint8_t* __restrict__ code_plane,
            const uint8_t* __restrict__ scl_plane, const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K,
            int scl_groups, int y16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IN_KIND = MSQ_PLANE_NONE;
-    constexpr int A_TILE = 256 * BK * 2;                         // 32 KiB per activation buffer
+    static_assert(MF == 16 || MF == 8, "wave tile height");
+    constexpr int BM = 16 * MF;                                  // block rows
+    constexpr int A_TILE = BM * BK * 2;                          // 32 / 16 KiB per activation buffer
+    constexpr int PPW = BM / 32;                                 // 1 KiB staging pieces (8 rows) per wave and K-step: 8 / 4
+    constexpr int DPG = 16 / MF;                                 // dwords of the next half-step's fragments converted per group: 1 / 2
     constexpr int NBUF = 4;
     constexpr int PF = MSQ_Q256_PF;
     static_assert(PF >= 1 && PF <= 3, "fragment ring of four");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave = 64-column strip of the block
     const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + 255) / 256, NTB = N / 256;
+    const int MT = (M + BM - 1) / BM, NTB = N / 256;
     const int bid = (int)blockIdx.x;
     int bm, bn;
     if ((NTB & 7) == 0) {
@@ -88,7 +95,7 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
         // super-tiles of (up to) RT row tiles x all its panels, row tiles fastest.  With 256 x 256 blocks the 32 blocks resident on an
         // XCD are best cut as 4 row tiles x 8 panels (8.4 MB of X + 9.7 MB of packed W per round at K = 4096) rather than k_qgemm3's
         // 8 x 4 (16.8 + 4.9 MB): 357 instead of 414 MB of fabric traffic per launch at M2048 N16384 (rocprofv3 FETCH / WRITE_SIZE).
-        constexpr int RT = MSQ_Q256_RT;
+        constexpr int RT = (MF == 16) ? MSQ_Q256_RT : 8;         // (128-row blocks: two per CU, 64 per XCD: 8 row tiles x 8 panels)
         const int xcd = bid & 7, i = bid >> 3;
         const int npx = NTB >> 3, per_group = RT * npx, full = MT / RT;
         int rg, j, R;
@@ -97,7 +104,7 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
         bm = rg * RT + j % R;
         bn = (j / R) * 8 + xcd;
     } else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * 256, n0 = bn * 256;
+    const int m0 = bm * BM, n0 = bn * 256;
     const int KT = K / BK;
 
     const int64_t ntiles = (int64_t)(N / TILE_N) * KT;
@@ -118,10 +125,10 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     // activation staging: wave w copies rows 64 w .. 64 w + 63 of the tile as eight 1 KiB pieces (8 rows each); lane l of piece p
     // fetches row 8 p + l / 8, source chunk (l & 7) ^ ((row >> 1) & 7) -- the LDS image stays lane-linear, reads are conflict-free
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(X, (int64_t)M * K * 2);
-    int aoff[8];
+    int aoff[8];                                                 // PPW <= 8 (a template-dependent bound captured by the lambda below makes hipcc drop the host stub)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = (wid * 8 + p) * 8 + (lane >> 3);
+    for (int p = 0; p < PPW; ++p) {
+        const int row = (wid * PPW + p) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
         aoff[p] = (int)(((int64_t)gr * K + chunk * 8) * 2);
@@ -129,7 +136,7 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     // (A register-staged form -- buffer_load_dwordx4 one K-step ahead, ds_write_b128 -- was built and measured: 200.5 us against 194.3
     // for k_qgemm3 and ~191 for the LDS-DMA form on the same box; the DMA piece costs this wave ~30 issue cycles, load + write more.)
     auto stage_piece = [&](int kt, int buf, int p) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 8 + p) * 1024),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * PPW + p) * 1024),
                                                  16, aoff[p], (uint32_t)kt * (BK * 2), 0, 0);
     };
     // the three / two packed loads of a half-step and the scale load, one per MFMA shadow (load_half_buf issues them back to back:
@@ -143,9 +150,9 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     const int rd0 = c * 128 + (((0 + g) ^ sw) << 4);
     const int rd1 = c * 128 + (((4 + g) ^ sw) << 4);
 
-    f32x4_t acc[16][4];
+    f32x4_t acc[MF][4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -157,9 +164,9 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     const int kt_last = sgpr(KT - 1);
     const int kt1 = (1 <= kt_last) ? 1 : kt_last;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) stage_piece(0, 0, p);
+    for (int p = 0; p < PPW; ++p) stage_piece(0, 0, p);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) stage_piece(kt1, 1, p);
+    for (int p = 0; p < PPW; ++p) stage_piece(kt1, 1, p);
     load_half_buf<IN_KIND, OUT_KIND>(pk0, pr, lane16, (tile_row32 + 0u) * 2u + 0u);
     load_half_buf<IN_KIND, OUT_KIND>(pk1, pr, lane16, (tile_row32 + 0u) * 2u + 1u);
     load_half_buf<IN_KIND, OUT_KIND>(pk2, pr, lane16, (tile_row32 + (uint32_t)kt1) * 2u + 0u);
@@ -179,51 +186,80 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     // first and 1, 5, 9 (13 if BAR_G > 13) of the second half-step.  They all belong to tile kt + 2 and may stay in flight; everything
     // older -- this wave's pieces of tile kt + 1, staged during the previous K-step -- has landed.
     constexpr int HL = HalfLoads<IN_KIND, OUT_KIND>::n;          // 2 (U8) / 3 (U8X)
-    constexpr int BAR_G = 16 - PF;                               // group in front of which the barrier sits
-    constexpr int N_WAIT = 1 + 2 * HL + 4 + (BAR_G > 13 ? 4 : (BAR_G > 9 ? 3 : (BAR_G > 5 ? 2 : 1)));
+    constexpr int BAR_G = MF - PF;                               // group in front of which the barrier sits
+    // Filler schedule of a half-step (group mf = 0 .. MF - 1), behind MFMA 3:
+    //   LDS-DMA piece:   mf % 4 == 1                       (PPW / 2 per half-step)
+    //   packed loads:    parts 0, 1 at mf = 2, 6; the extension word (part 2) at mf = 10 (MF 16) / 4 (MF 8)
+    //   scale load:      first half-step only, mf = 14 (MF 16) / 0 (MF 8)
+    //   scale operand of the next weight fragment: the group in front of its first convert
+    constexpr int EXT_G = (MF == 16) ? 10 : 4, SCL_G = (MF == 16) ? 14 : 0;
+    constexpr int N_WAIT = [] {                                  // vector-memory ops a K-step has issued in front of its barrier
+        int n = 0;
+        for (int hs = 0; hs < 2; ++hs)
+            for (int mf = 0; mf < MF; ++mf) {
+                if (hs == 1 && mf >= BAR_G) break;
+                if ((mf & 3) == 1) n += 1;
+                if (mf == 2 || mf == 6) n += 1;
+                if (mf == EXT_G && HL == 3) n += 1;
+                if (hs == 0 && mf == SCL_G) n += 1;
+            }
+        return n;
+    }();
 
-    // One half-step = sixteen groups of four MFMAs (activation fragment mf against the four weight fragments).  One wave per SIMD: an
+    // One half-step = MF groups of four MFMAs (activation fragment mf against the four weight fragments).  One wave per SIMD (MF = 16): an
     // MFMA occupies the matrix pipe for 16 cycles and the issue port for 8 -- whatever is issued in the other 8 is free, whatever
     // exceeds them adds to the step (ablation of the first build: MFMAs alone 131 us, everything else alone 57 us, together 195 us:
     // hipcc had put the fillers in front of the groups, not between the MFMAs).  So every MFMA is followed by ONE filler of at most
     // ~8 issue cycles, fenced by sched_barriers so that it stays there:
     //   MFMA 0 | ds_read_b128 of fragment mf + PF (this half-step, or the next one through RDN / ANXT)
-    //   MFMA 1 | v_cvt_scalef32_pk_bf16_fp8 of dword mf of the NEXT half-step's weight fragments
-    //   MFMA 2 | shift + and-or of that dword's extension bits (MSQ-U1X; nothing for U1)
-    //   MFMA 3 | one of: LDS-DMA piece (mf % 4 == 1), packed load (2, 6, 10; scale load 14 in the first half-step), scale operand of
-    //            the next fragment (3, 7, 11, 15)
+    //   MFMA 1 | v_cvt_scalef32_pk_bf16_fp8 of dword DPG mf of the NEXT half-step's weight fragments
+    //   MFMA 2 | shift + and-or of that dword's extension bits (MSQ-U1X; nothing for U1)   [MF = 8: the second dword's convert]
+    //   MFMA 3 | one vector-memory op or the scale operand of the next fragment            [MF = 8: + both dwords' extension bits]
 #define Q256_SB() __builtin_amdgcn_sched_barrier(0)
 #define Q256_HALF(WF_USE, WF_MAKE, PK_SRC, SC_SRC, KF_MAKE, SC_NEXT, KF_NEXT, ACUR, RDC, ANXT, RDN, HS1, KT_ST, BUF_ST, LOADSET, LOADTILE)    \
     {                                                                                                              \
-        _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                        \
+        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                        \
             if ((HS1) && mf == BAR_G) {                                                                            \
                 __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));   /* vmcnt(N_WAIT) only */ \
                 if (!(MSQ_Q256_ABL & 16)) __builtin_amdgcn_s_barrier();                                            \
             }                                                                                                      \
-            uint32_t cv_ = 0;                                                                                      \
+            uint32_t cv_ = 0, cv2_ = 0;                                                                            \
+            constexpr int d0_ = 0;                                                                                 \
             Q256_SB();                                                                                             \
             if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][0], WF_USE[0], xf[mf & 3]);                                 \
             Q256_SB();                                                                                             \
             if (MSQ_Q256_ABL & 1) { }                                                                              \
-            else if (mf + PF < 16) xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ACUR) + (RDC) + (mf + PF) * 2048);   \
-            else xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ANXT) + (RDN) + (mf + PF - 16) * 2048);   \
+            else if (mf + PF < MF) xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ACUR) + (RDC) + (mf + PF) * 2048);   \
+            else xf[(mf + PF) & 3] = *reinterpret_cast<const bf16x8_t*>((ANXT) + (RDN) + (mf + PF - MF) * 2048);   \
             Q256_SB();                                                                                             \
             if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][1], WF_USE[1], xf[mf & 3]);                                 \
             Q256_SB();                                                                                             \
-            if (!(MSQ_Q256_ABL & 2)) cv_ = cvt_dword<OUT_KIND>(PK_SRC, sop, mf);                                   \
+            if (!(MSQ_Q256_ABL & 2)) cv_ = cvt_dword<OUT_KIND>(PK_SRC, sop, DPG * mf);                             \
             Q256_SB();                                                                                             \
             if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][2], WF_USE[2], xf[mf & 3]);                                 \
             Q256_SB();                                                                                             \
-            if (!(MSQ_Q256_ABL & 2)) WF_MAKE[mf >> 2][mf & 3] = ext_dword<OUT_KIND>(cv_, PK_SRC, mf);              \
+            if (!(MSQ_Q256_ABL & 2)) {                                                                             \
+                if (DPG == 1) WF_MAKE[mf >> 2][mf & 3] = ext_dword<OUT_KIND>(cv_, PK_SRC, mf);                     \
+                else cv2_ = cvt_dword<OUT_KIND>(PK_SRC, sop, DPG * mf + 1);                                        \
+            }                                                                                                      \
             Q256_SB();                                                                                             \
             if (!(MSQ_Q256_ABL & 64)) mfma_acc(acc[mf][3], WF_USE[3], xf[mf & 3]);                                 \
             Q256_SB();                                                                                             \
-            if ((mf & 3) == 1) { if (!(MSQ_Q256_ABL & 8)) stage_piece(KT_ST, BUF_ST, ((HS1) ? 4 : 0) + (mf >> 2)); } \
-            else if ((mf & 3) == 2) {                                                                              \
-                if (MSQ_Q256_ABL & 4) { }                                                                          \
-                else if (mf < 14) load_part(LOADSET, LOADTILE, mf >> 2);                                           \
-                else if (!(HS1)) sc_nn = load_scales(tile_row32 + (uint32_t)(KT_ST));                              \
-            } else if ((mf & 3) == 3) sop = (mf < 15) ? scale_operand(SC_SRC[KF_MAKE], (mf >> 2) + 1) : scale_operand(SC_NEXT[KF_NEXT], 0); \
+            if (DPG == 2 && !(MSQ_Q256_ABL & 2)) {                                                                 \
+                WF_MAKE[(2 * mf) >> 2][(2 * mf) & 3] = ext_dword<OUT_KIND>(cv_, PK_SRC, 2 * mf);                   \
+                WF_MAKE[(2 * mf + 1) >> 2][(2 * mf + 1) & 3] = ext_dword<OUT_KIND>(cv2_, PK_SRC, 2 * mf + 1);      \
+            }                                                                                                      \
+            if ((mf & 3) == 1) { if (!(MSQ_Q256_ABL & 8)) stage_piece(KT_ST, BUF_ST, ((HS1) ? PPW / 2 : 0) + (mf >> 2)); } \
+            if (!(MSQ_Q256_ABL & 4)) {                                                                             \
+                if (mf == 2) load_part(LOADSET, LOADTILE, 0);                                                      \
+                if (mf == 6) load_part(LOADSET, LOADTILE, 1);                                                      \
+                if (mf == EXT_G) load_part(LOADSET, LOADTILE, 2);                                                  \
+                if (!(HS1) && mf == SCL_G) sc_nn = load_scales(tile_row32 + (uint32_t)(KT_ST));                    \
+            }                                                                                                      \
+            /* scale operand of the fragment whose first dword the NEXT group converts (fragment = dword / 4) */     \
+            if (((DPG * (mf + 1)) & 3) == 0)                                                                       \
+                sop = (mf + 1 < MF) ? scale_operand(SC_SRC[KF_MAKE], (DPG * (mf + 1)) >> 2) : scale_operand(SC_NEXT[KF_NEXT], 0); \
+            (void)d0_;                                                                                             \
         }                                                                                                          \
     }
     // One K-step at ring position (CONV1 = set of (kt, kf 1), CONV2 = set of (kt + 1, kf 0)); the sets converted one half-step
@@ -259,9 +295,9 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
-    if (MSQ_Q256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 16; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    if (MSQ_Q256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {                                // 128 rows at a time through the wave's 8 KiB slice
+    for (int h = 0; h < MF / 8; ++h) {                           // 128 rows at a time through the wave's 8 KiB slice
         const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
         store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
     }
@@ -281,21 +317,24 @@ inline void attr_done256(DevOnce256& o) {
 }  // namespace
 
 // Launcher (called by qlinear_bf16_impl, msq_gemm.hip).  Preconditions checked by the caller: unified layout, N % 256 == 0,
-// K % 64 == 0, every buffer offset below 4 GiB.  Returns hipGetLastError() of the launch.
+// K % 64 == 0, every buffer offset below 4 GiB.  mf = 16 (256-row blocks) or 8 (128-row blocks).  Returns hipGetLastError() of the launch.
 extern "C" int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
-                        int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* stream) {
-    const int MT = (int)((M + 255) / 256), NTB = (int)(N / 256);
+                                   int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int mf, void* stream) {
+    const int bm = 16 * mf;
+    const int MT = (int)((M + bm - 1) / bm), NTB = (int)(N / 256);
     const dim3 grid((unsigned)(MT * NTB)), blk(256);
-    const size_t lds = 4 * 32768;
+    const size_t lds = (size_t)4 * bm * 128;                     // four activation buffers (>= the epilogue's 4 x 8 KiB slices)
     const int y16 = (y_dtype == 1) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-#define Q256_LAUNCH(OK, YT)                                                                                            \
+#define Q256_LAUNCH(OK, YT, MFV)                                                                                       \
     do { static DevOnce256 once_;                                                                                      \
-         if (attr_needed256(once_)) { (void)hipFuncSetAttribute((const void*)k_qgemm256<OK, YT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done256(once_); } \
-         hipLaunchKernelGGL((k_qgemm256<OK, YT>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)ext_plane, (const uint8_t*)code_plane, \
+         if (attr_needed256(once_)) { (void)hipFuncSetAttribute((const void*)k_qgemm256<OK, YT, MFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done256(once_); } \
+         hipLaunchKernelGGL((k_qgemm256<OK, YT, MFV>), grid, blk, lds, st, (const uint16_t*)X, (const uint8_t*)ext_plane, (const uint8_t*)code_plane, \
                             (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, scl_groups, y16); } while (0)
-    if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) Q256_LAUNCH(MSQ_PLANE_U8, float); else Q256_LAUNCH(MSQ_PLANE_U8, uint16_t); }
-    else { if (y_dtype == 0) Q256_LAUNCH(MSQ_PLANE_U8X, float); else Q256_LAUNCH(MSQ_PLANE_U8X, uint16_t); }
+#define Q256_MF(OK, YT) do { if (mf == 16) Q256_LAUNCH(OK, YT, 16); else Q256_LAUNCH(OK, YT, 8); } while (0)
+    if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) Q256_MF(MSQ_PLANE_U8, float); else Q256_MF(MSQ_PLANE_U8, uint16_t); }
+    else { if (y_dtype == 0) Q256_MF(MSQ_PLANE_U8X, float); else Q256_MF(MSQ_PLANE_U8X, uint16_t); }
+#undef Q256_MF
 #undef Q256_LAUNCH
     return (int)hipGetLastError();
 }

@@ -94,11 +94,16 @@ for nm in re.findall(r'^(_ZN\S*k_qgemm256\S*):', s2, re.M):
             blocks.append(curb); curb = []
         else:
             curb.append(l)
+            if l.startswith('s_cbranch') or l.startswith('s_branch'):      # fall-through blocks carry no label (only a '; %bb.N:' comment)
+                blocks.append(curb); curb = []
     blocks.append(curb)
     mf = [l for l in lines if l.startswith('v_mfma')]
     region = [l for b in blocks if sum(1 for x in b if x.startswith('v_mfma')) >= 64 for l in b]
     acc = sum(1 for l in region if l.startswith('v_accvgpr'))
-    scr = sum(1 for l in region if l.startswith('scratch_'))
+    # scratch: inside the LOOP (the block with the most MFMAs: two K-steps); the odd tail step runs once -- a spill there (the MF = 8 forms
+    # sit at the 128-VGPR limit of two waves per SIMD) costs nothing and can only make its wait stricter
+    loop_block = max(blocks, key=lambda b: sum(1 for x in b if x.startswith('v_mfma')))
+    scr = sum(1 for l in loop_block if l.startswith('scratch_'))
     inplace = all(re.match(r'v_mfma_f32_16x16x32_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1$', l) for l in region if l.startswith('v_mfma'))
     code = [l for l in region if l and not l.startswith(';')]
     vm = lambda l: l.startswith('buffer_load') or l.startswith('global_load')

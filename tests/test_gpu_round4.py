@@ -345,8 +345,8 @@ def test_default_bench_line_rowparallel_leg_on_a_single_rank_rccl_group(msq):
 @pytest.mark.parametrize("M,N,K", [(2048, 16384, 256), (300, 512, 128), (2048 - 37, 2304, 320), (513, 256, 64), (1024, 4096, 1088)])
 @pytest.mark.parametrize("fo", ["posit8_es1", "fp8_e4m3"])
 def test_qgemm256_equals_qgemm3_and_the_dense_product(msq, M, N, K, fo, monkeypatch):
-    """k_qgemm256 (256-row wave tiles, accumulators pinned to AGPRs by tied inline-asm MFMAs, one filler per MFMA shadow) against
-    k_qgemm3 on the same planes: the same products accumulate in the same order per output element, so the results are EQUAL bit
+    """k_qgemm256 (256-row wave tiles, accumulators pinned to AGPRs by tied inline-asm MFMAs, one filler per MFMA shadow; and its
+    128-row form MF = 8) against k_qgemm3 on the same planes: the same products accumulate in the same order per output element, so the results are EQUAL bit
     for bit -- with a bias, for float32 / bfloat16 / float16 outputs, ragged M (rows clamped while staging, never stored), 1 ... 17
     K-steps (odd counts take the tail step), panel counts that are not a multiple of 8 (plain block order) -- and repeat bit for
     bit; against the dense product of the unpacked weight within 2e-5 max|y| (fp32 accumulation)."""
@@ -364,9 +364,18 @@ def test_qgemm256_equals_qgemm3_and_the_dense_product(msq, M, N, K, fo, monkeypa
             assert torch.equal(a, b), (dt, (a.float() - b.float()).abs().max().item())
         for _ in range(5):
             assert torch.equal(msq.qlinear.qlinear(X, P, bias, dt), b)
-    monkeypatch.setenv("MSQ_GEMM_256", "1")
-    y = msq.qlinear.qlinear(X, P, bias, torch.float32)
-    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+        monkeypatch.setenv("MSQ_GEMM_256", "2")                          # the 128-row form of the same kernel (MF = 8, two blocks per CU)
+        c = msq.qlinear.qlinear(X, P, bias, dt)
+        assert torch.equal(c, b), ("MF=8", dt, (c.float() - b.float()).abs().max().item())
+        for _ in range(5):
+            assert torch.equal(msq.qlinear.qlinear(X, P, bias, dt), c)
+        monkeypatch.delenv("MSQ_GEMM_256")                               # ... and whatever the library's own rule picks for this shape
+        d = msq.qlinear.qlinear(X, P, bias, dt)
+        assert torch.equal(d, a) or torch.equal(d, b)
+    for flag in ("1", "2"):
+        monkeypatch.setenv("MSQ_GEMM_256", flag)
+        y = msq.qlinear.qlinear(X, P, bias, torch.float32)
+        assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 16384, 256), (300, 512, 256), (2048 - 37, 2304, 640), (513, 256, 128), (1024, 4096, 1152)])
