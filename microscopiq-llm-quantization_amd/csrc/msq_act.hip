@@ -4,6 +4,7 @@
 // MSQ_STATUS_INEXACT otherwise).  HBM-bound: 4 B read + 2 B written per element.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/msq.h"
 #include "msq_device.h"
@@ -216,6 +217,228 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
     if (status && A.status) atomicOr(A.status, status);
 }
 
+// ---------------------------------------------------------------------------
+// variant 1 (mx_ops statistics, number_system/mx/mx_ops.py:225-233 on utils/quant.py:460-495's column mean / std) in ONE pass over X
+// for rows of at most 4096 elements: a wave owns a row, keeps it in registers (64 values per lane), computes the column statistics
+// exactly as k_mxops_stats_rows does (msq_quant.hip: torch's cascade order for the fp32 mean -- sixteen-block runs summed from zero,
+// folded in order; the std as a two-pass variance in double, rounded to float only when it provably lies on the same side of the
+// rounding boundary as torch's sequential Welford result, else redone sequentially), then runs the
+// quantiser of the kernel above over the row (64 blocks per round, from L2: the wave has just read it).  X leaves HBM once (4 B in, 2 B out per element) and the two launches
+// (statistics, quantiser) become one: [2048, 4096] fp32 35.0 -> see profiles/r04_side_kernels.txt.
+// Lane (j, q), j = lane / LPB, q = lane % LPB, LPB = BS / 4: columns 4 q ... 4 q + 3 of the blocks of run j (blocks 16 j ... 16 j + 15).
+// ---------------------------------------------------------------------------
+template <int BS, int RM, int HW, bool XBF16>
+__global__ void __launch_bounds__(256, 2)
+k_act_quant_rows(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs A) {
+    constexpr int LPB = BS / 4, RW = 64 / LPB;                      // lanes per block row, runs per wave (16 RW blocks = 4096 elements)
+    constexpr int STRIDE = BS + 4, HS = BS / 2 + 4;
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * STRIDE];
+    __shared__ __attribute__((aligned(16))) float tab[4][2][BS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wv;
+    if (p >= A.pre) return;
+    const int nblk = (int)A.nblk;
+    const int j = lane / LPB, q = lane % LPB;
+    const int nruns = nblk / 16, tail = nblk % 16;
+    const int len = j < nruns ? 16 : (j == nruns ? tail : 0);       // blocks of this lane's run
+    float* tl = tile[wv];
+    const float* rowf = X + p * A.axis_len;
+    const uint16_t* rowh = reinterpret_cast<const uint16_t*>(X) + p * A.axis_len;
+    int status = 0;
+    {
+        // ---- the row: 16 x 16 bytes per lane, all requested before the first use
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {          // (unconditional loads: a load under a lane-dependent branch is waited for at the join)
+            int blk = 16 * j + i; blk = blk < nblk ? blk : nblk - 1;
+            const int64_t at = (int64_t)blk * BS + 4 * q;
+            if (XBF16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(rowh + at);
+                v[i] = make_float4(u2f(u.x << 16), u2f(u.x & 0xFFFF0000u), u2f(u.y << 16), u2f(u.y & 0xFFFF0000u));
+            } else v[i] = *reinterpret_cast<const float4*>(rowf + at);
+        }
+        // ---- statistics of columns 4 q ... 4 q + 3 (every lane ends with the full-column values)
+        float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
+        double ds0 = 0.0, ds1 = 0.0, ds2 = 0.0, ds3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < len) {
+                rs0 += v[i].x; rs1 += v[i].y; rs2 += v[i].z; rs3 += v[i].w;
+                ds0 += (double)v[i].x; ds1 += (double)v[i].y; ds2 += (double)v[i].z; ds3 += (double)v[i].w;
+            }
+        auto xsum = [&](double d) {
+#pragma unroll
+            for (int o = LPB; o < 64; o <<= 1) d += __shfl_xor(d, o, 64);
+            return d;
+        };
+        const double n = (double)nblk;
+        const double m0 = xsum(ds0) / n, m1 = xsum(ds1) / n, m2_ = xsum(ds2) / n, m3 = xsum(ds3) / n;
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < len) {
+                const double e0 = (double)v[i].x - m0, e1 = (double)v[i].y - m1, e2 = (double)v[i].z - m2_, e3 = (double)v[i].w - m3;
+                q0 = __builtin_fma(e0, e0, q0); q1 = __builtin_fma(e1, e1, q1); q2 = __builtin_fma(e2, e2, q2); q3 = __builtin_fma(e3, e3, q3);
+                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+            }
+        // one column: cascade fold of the run sums (ATen: level-1 accumulator folded every 256 elements; <= 128 blocks never fold twice),
+        // two-pass std with the rounding-boundary check
+        auto column = [&](float rs, double dq, double dd, float& mean_out, double& sdd, bool& safe) {
+            float acc1 = 0.f, acc2 = 0.f, acc0 = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const float r = __shfl(rs, q + LPB * k, 64);
+                if (k < nruns) { acc1 += r; if ((((k + 1) * 16) & (15 << 4)) == 0) { acc2 += acc1; acc1 = 0.f; } }
+                else if (k == nruns) acc0 = r;                      // the tail run (0 when empty)
+            }
+            acc0 += acc1; acc0 += acc2; acc0 += 0.f;
+            mean_out = acc0 / (float)nblk;
+            dq = xsum(dq); dd = xsum(dd);
+            double den = n - 1.0; den = den < 0 ? 0 : den;
+            double m2 = dq - dd * dd / n; m2 = m2 < 0 ? 0 : m2;
+            sdd = __builtin_sqrt(m2 / den);
+            const uint64_t bits = __builtin_bit_cast(uint64_t, sdd);
+            const uint32_t dropped = (uint32_t)(bits & 0x1FFFFFFFull);
+            const uint32_t dist = dropped > 0x10000000u ? dropped - 0x10000000u : 0x10000000u - dropped;
+            safe = (dist > 4u * (uint32_t)nblk + 64u) && (sdd == sdd) && (sdd > 1e-150) && (sdd < 1e150);
+        };
+        float4 mean4, sd4;
+        double s0, s1, s2, s3;
+        bool f0, f1, f2, f3;
+        column(rs0, q0, d0, mean4.x, s0, f0); column(rs1, q1, d1, mean4.y, s1, f1);
+        column(rs2, q2, d2, mean4.z, s2, f2); column(rs3, q3, d3, mean4.w, s3, f3);
+        // A column whose two-pass value lies too close to a float rounding boundary (about one in 500 000) is redone as torch does it:
+        // sequential Welford in double over the blocks in order.  The whole wave walks the row together (the values come from the
+        // owning lanes' registers by ds_bpermute, which needs every lane active), only the flagged one of the four columns per lane.
+        // The chain of nblk dependent steps is the tail of the whole launch when it happens, so the division by the count -- a small
+        // integer b -- is the fma form: y = RN(1 / b) (one true division per lane, up front), q = RN(g y), two rounds of
+        // r = RN(g - q b) (exact), q = RN(q + r y): correctly rounded (Markstein: y is the correctly rounded reciprocal and b's
+        // significand is short), 5 dependent operations instead of the ~12 of the expanded IEEE division; checked against true
+        // division on the host (tests/test_host_logic.py).
+        const uint64_t unsafe = __builtin_amdgcn_ballot_w64(!(f0 && f1 && f2 && f3));
+        if (unsafe != 0) {
+            const double yA = 1.0 / (double)(lane + 1), yB = 1.0 / (double)(lane + 65);
+            auto rdl = [&](double a, int l) {
+                const uint64_t u = __builtin_bit_cast(uint64_t, a);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+                return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+            };
+            auto welford = [&](auto comp) {
+                double w = 0.0, t = 0.0;
+                for (int jj = 0; jj * 16 < nblk; ++jj) {
+                    double e[16];
+#pragma unroll
+                    for (int ii = 0; ii < 16; ++ii) e[ii] = (double)__shfl(comp(v[ii]), q + LPB * jj, 64);     // all sixteen in flight, then the chain
+#pragma unroll
+                    for (int ii = 0; ii < 16; ++ii) {
+                        const int s = jj * 16 + ii;
+                        if (s < nblk) {
+                            const double cnt = (double)(s + 1), y = s < 64 ? rdl(yA, s) : rdl(yB, s - 64);
+                            const double g = e[ii] - w;
+                            double qt = g * y;
+                            qt = __builtin_fma(__builtin_fma(-qt, cnt, g), y, qt);
+                            qt = __builtin_fma(__builtin_fma(-qt, cnt, g), y, qt);
+                            w = w + qt;
+                            t = t + g * (e[ii] - w);
+                        }
+                    }
+                }
+                double den = n - 1.0; den = den < 0 ? 0 : den;
+                return __builtin_sqrt(t / den);
+            };
+            if (__builtin_amdgcn_ballot_w64(!f0) != 0) { const double r = welford([](const float4& x) { return x.x; }); if (!f0) s0 = r; }
+            if (__builtin_amdgcn_ballot_w64(!f1) != 0) { const double r = welford([](const float4& x) { return x.y; }); if (!f1) s1 = r; }
+            if (__builtin_amdgcn_ballot_w64(!f2) != 0) { const double r = welford([](const float4& x) { return x.z; }); if (!f2) s2 = r; }
+            if (__builtin_amdgcn_ballot_w64(!f3) != 0) { const double r = welford([](const float4& x) { return x.w; }); if (!f3) s3 = r; }
+        }
+        sd4 = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+        if (sd4.x != sd4.x || sd4.y != sd4.y || sd4.z != sd4.z || sd4.w != sd4.w) status |= MSQ_STATUS_NAN;
+        if (j == 0) {
+            *reinterpret_cast<float4*>(&tab[wv][0][4 * q]) = mean4;
+            *reinterpret_cast<float4*>(&tab[wv][1][4 * q]) = sd4;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const float* vm = tab[wv][0];
+    const float* vs = tab[wv][1];
+    float tlo, thi;
+    { const int l = lane < BS ? lane : 0; const float ks = A.k * vs[l]; tlo = vm[l] - ks; thi = vm[l] + ks; }
+    // ---- the quantiser of k_act_quant over the row, 64 blocks at a time (the row comes from L2 now: this wave has just read it)
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int nb = nblk - b0 < 64 ? nblk - b0 : 64;             // blocks of this round
+        const int blk = b0 + lane;
+        float a[BS];
+        if (XBF16) {
+            const uint4* s8 = reinterpret_cast<const uint4*>(rowh + (int64_t)b0 * BS);
+            uint4 u8[BS / 8];
+#pragma unroll
+            for (int t = 0; t < BS / 8; ++t) { const int f = lane + 64 * t; u8[t] = s8[f < nb * (BS / 8) ? f : 0]; }
+#pragma unroll
+            for (int t = 0; t < BS / 8; ++t) {
+                const int f = lane + 64 * t;
+                if (f < nb * (BS / 8)) {
+                    const uint4 u = u8[t];
+                    float* d = tl + (f / (BS / 8)) * STRIDE + (f % (BS / 8)) * 8;
+                    *reinterpret_cast<float4*>(d) = make_float4(u2f(u.x << 16), u2f(u.x & 0xFFFF0000u), u2f(u.y << 16), u2f(u.y & 0xFFFF0000u));
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(u2f(u.z << 16), u2f(u.z & 0xFFFF0000u), u2f(u.w << 16), u2f(u.w & 0xFFFF0000u));
+                }
+            }
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(rowf + (int64_t)b0 * BS);
+            float4 u4[BS / 4];
+#pragma unroll
+            for (int t = 0; t < BS / 4; ++t) { const int f = lane + 64 * t; u4[t] = src[f < nb * (BS / 4) ? f : 0]; }
+#pragma unroll
+            for (int t = 0; t < BS / 4; ++t) {
+                const int f = lane + 64 * t;
+                if (f < nb * (BS / 4)) *reinterpret_cast<float4*>(tl + (f / (BS / 4)) * STRIDE + (f % (BS / 4)) * 4) = u4[t];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int c = 0; c < BS / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(tl + (lane < nb ? lane : 0) * STRIDE + c * 4);
+            a[c * 4 + 0] = t.x; a[c * 4 + 1] = t.y; a[c * 4 + 2] = t.z; a[c * 4 + 3] = t.w;
+        }
+        uint32_t h[BS / 2];
+        bool done = false;
+        if (HW == 1 && RM == 0) {
+            const int ki = hw_codec_kind(A.fi), ko = hw_codec_kind(A.fo);              // wave-uniform
+            if (ki == 1 && ko == 1) done = act_block_lean<BS, 1, 1>(a, h, A, vm, vs, true, tlo, thi, status);
+            else if (ki == 3 && ko == 3) done = act_block_lean<BS, 3, 3>(a, h, A, vm, vs, true, tlo, thi, status);
+            else if (ki == 3 && ko == 1) done = act_block_lean<BS, 3, 1>(a, h, A, vm, vs, true, tlo, thi, status);
+        }
+        if (!done) {
+            uint32_t mkw[(BS + 31) / 32];
+            float se_in = 0.f, se_out = 0.f;
+            int st = outlier_block_fast<BS, RM, false, HW>(a, mkw, se_in, se_out, A, /*inner order*/ 1, vm, vs, 1);
+#pragma unroll
+            for (int b = 0; b < BS / 2; ++b) h[b] = bf16_bits_exact(a[2 * b], st) | (bf16_bits_exact(a[2 * b + 1], st) << 16);
+            if (lane < nb) status |= st;
+        }
+        // bf16 rows back through LDS (the input tile is consumed), coalesced 16-byte stores
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nb) {
+#pragma unroll
+            for (int c = 0; c < BS / 8; ++c)
+                *reinterpret_cast<uint4*>(tl + lane * HS + c * 4) = make_uint4(h[c * 4], h[c * 4 + 1], h[c * 4 + 2], h[c * 4 + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        uint4* dst = reinterpret_cast<uint4*>(Xq + p * A.axis_len + (int64_t)b0 * BS);
+#pragma unroll
+        for (int t = 0; t < BS / 8; ++t) {
+            const int f = lane + 64 * t;
+            if (f < nb * (BS / 8)) dst[f] = *reinterpret_cast<const uint4*>(tl + (f / (BS / 8)) * HS + (f % (BS / 8)) * 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        (void)blk;
+    }
+    if (status && A.status) atomicOr(A.status, status);
+}
+
 }  // namespace
 
 extern "C" int64_t msq_act_quant_workspace_bytes(int64_t M, int64_t K, int block, int variant) {
@@ -255,6 +478,23 @@ static int act_quant_impl(const void* Xv, int x_bf16, void* Xq, int* status_flag
         float* vmean = (float*)workspace;
         float* vstd = vmean + M * block;
         if (x_bf16 && block == 16) { msq_set_error_("msq_act_quant_bf16_x16: the mx_ops variant on bfloat16 input needs block 32 or 64"); return MSQ_ERR_UNSUPPORTED; }
+        // rows of <= 4096 elements, blocks of 32, round-to-nearest: statistics and quantiser in one pass over X (k_act_quant_rows).
+        // MSQ_ACT_ROWS=0 (tuning and A / B, read per call) keeps the two launches.
+        const char* er = getenv("MSQ_ACT_ROWS");
+        if (K <= 4096 && block == 32 && rmode == 0 && K / block >= 2 && !(er && atoi(er) == 0)) {
+            const bool hw1 = hw_codec_kind(A.fi) && hw_codec_kind(A.fo);
+            const dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+            hipStream_t st = (hipStream_t)stream;
+#define MSQ_AQR(BS) do { if (x_bf16) { if (hw1) hipLaunchKernelGGL((k_act_quant_rows<BS, 0, 1, true>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                                          else hipLaunchKernelGGL((k_act_quant_rows<BS, 0, 0, true>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } \
+                         else if (hw1) hipLaunchKernelGGL((k_act_quant_rows<BS, 0, 1, false>), grid, blk, 0, st, X, (uint16_t*)Xq, A); \
+                         else hipLaunchKernelGGL((k_act_quant_rows<BS, 0, 0, false>), grid, blk, 0, st, X, (uint16_t*)Xq, A); } while (0)
+            MSQ_AQR(32);      // (block 64: 64 + 32 live values per lane on top of the row do not fit four waves per SIMD -- two launches)
+#undef MSQ_AQR
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
+            return MSQ_OK;
+        }
         const int rc = msq_mxops_stats_x_(Xv, x_bf16, vmean, vstd, M, K, 1, block, status_flag, stream);
         if (rc) return rc;
         A.vmean = vmean; A.vstd = vstd;

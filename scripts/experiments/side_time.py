@@ -57,7 +57,19 @@ def main():
     for variant, sd in ((0, 2), (1, 5)):
         us = tg(lambda: qlinear.act_quant(Xa, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant))
         print(f"act_quant variant {variant}: {us:6.1f} us  {Xa.numel()*6/us/1e3:5.0f} GB/s")
-
+    # variant 1 (mx_ops statistics) redoes a column sequentially when its std lies next to a float rounding boundary (about one column
+    # in 500 000: ~13 % of [2048, 4096] inputs have one); that chain is the tail of the launch, so the time depends on the data:
+    # eight inputs, the one-pass row kernel (k_act_quant_rows) against the statistics + quantiser launches (MSQ_ACT_ROWS=0)
+    rows, two = [], []
+    for seed in range(8):
+        Xs = torch.randn(2048, 4096, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + seed))
+        for flag, acc in (("1", rows), ("0", two)):
+            os.environ["MSQ_ACT_ROWS"] = flag
+            acc.append(tg(lambda: qlinear.act_quant(Xs, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1)))
+    os.environ.pop("MSQ_ACT_ROWS", None)
+    fmt = lambda v: " ".join(f"{x:5.1f}" for x in v)
+    print(f"act_quant variant 1, 8 inputs, one pass (k_act_quant_rows): {fmt(rows)}  median {sorted(rows)[4]:.1f} us  {Xa.numel()*6/sorted(rows)[4]/1e3:5.0f} GB/s")
+    print(f"act_quant variant 1, 8 inputs, statistics + quantiser      : {fmt(two)}  median {sorted(two)[4]:.1f} us")
 
 if __name__ == "__main__":
     main()

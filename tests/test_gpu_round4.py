@@ -429,3 +429,67 @@ def test_mxgemm256_tail_steps_repeat_under_uneven_load(msq, M, N, K, monkeypatch
     assert int(d.item()) == 0
     monkeypatch.setenv("MSQ_MX_256", "0")
     assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32), y0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# activation quantiser, mx_ops variant: statistics + quantiser in one pass over X (k_act_quant_rows) == the two launches
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,bs", [(64, 32), (608, 32), (2048, 32), (3072, 32), (4096, 32), (4096, 64), (1088, 64), (128, 64)])
+@pytest.mark.parametrize("afmt", ["fp8_e4m3", "fp8_e5m2", "int8"])
+def test_act_quant_rows_kernel_equals_two_launches_and_oracle(msq, O, K, bs, afmt, monkeypatch):
+    """Rows of <= 4096 elements take k_act_quant_rows (a wave keeps its row in registers: column statistics in torch's cascade order,
+    then the quantiser, X read once).  Equal bit for bit to the statistics kernel + quantiser pair (MSQ_ACT_ROWS=0) for float32 and
+    bfloat16 rows, ragged M, 2 ... 128 blocks per row (tail runs, one / two blocks per lane), outliers, an all-zero row and a
+    constant column; and to the oracle's mx_ops variant (number_system/mx/mx_ops.py:225-233) on the float32 case."""
+    g = torch.Generator().manual_seed(zlib.crc32(repr((K, bs, afmt)).encode()))
+    M = 37
+    X = torch.randn(M, K, generator=g)
+    X[torch.rand(M, K, generator=g) < 0.02] *= 12
+    X[5] = 0.0
+    X[:, 3] = 0.75
+    for x in (X.to(dev()), X.to(dev()).to(torch.bfloat16)):
+        monkeypatch.setenv("MSQ_ACT_ROWS", "0")
+        a, sa = msq.qlinear.act_quant(x, 8, 8, afmt, afmt, 5, bs, "nearest", False, 1)
+        monkeypatch.setenv("MSQ_ACT_ROWS", "1")
+        b, sb = msq.qlinear.act_quant(x, 8, 8, afmt, afmt, 5, bs, "nearest", False, 1)
+        assert int(sa.item()) == int(sb.item()) == 0
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (x.dtype, (a.float() - b.float()).abs().max().item())
+        if x.dtype == torch.float32:
+            Xo = O.outlier_fakequant(X.numpy(), 8, 8, afmt, afmt, 5, -1, bs, variant="mx_ops")["out"]
+            assert (b.float().cpu().numpy() == Xo).all()
+
+
+def test_act_quant_rows_sequential_recompute_of_boundary_columns(msq, O, monkeypatch):
+    """The rare path of the mx_ops statistics: a column whose two-pass std lies within a few hundred double ulps of a float rounding
+    boundary is redone as sequential Welford (torch's order) -- in k_act_quant_rows by the whole wave from registers, with the fma
+    form of the division by the count.  Such columns (about one in 500 000) are searched for here on the GPU with float64 torch ops
+    and planted into rows of 4096 (128 blocks of 32) and 2048 + 96 elements; the result must equal the two-launch path and the
+    oracle's sequential statistics bit for bit, for float32 and bfloat16 rows."""
+    g = torch.Generator(device=dev()).manual_seed(5)
+    for K, src_dtype in ((4096, torch.float32), (2144, torch.float32), (4096, torch.bfloat16)):
+        nblk = K // 32
+        found = []
+        for _ in range(60):
+            C = torch.randn(1 << 18, nblk, device=dev(), generator=g).to(src_dtype).float()
+            C64 = C.double()
+            d = C64 - C64.mean(1, keepdim=True)
+            sd = ((d * d).sum(1) / (nblk - 1)).sqrt()
+            low = sd.view(torch.int64) & 0x1FFFFFFF
+            near = ((low - 0x10000000).abs() < 200).nonzero().flatten()
+            found += [C[i] for i in near.tolist()]
+            if len(found) >= 3:
+                break
+        assert len(found) >= 1, "no boundary column found"
+        M = 6
+        X = torch.randn(M, K, device=dev(), generator=g).to(src_dtype).float()
+        for i, col in enumerate(found[:6]):
+            X[i % M, (7 * i + 3) % 32::32] = col                        # block position (7 i + 3) % 32 of row i
+        xs = [X] if src_dtype == torch.float32 else [X, X.to(torch.bfloat16)]
+        Xo = O.outlier_fakequant(X.cpu().numpy(), 8, 8, "fp8_e4m3", "fp8_e4m3", 5, -1, 32, variant="mx_ops")["out"]
+        for x in xs:
+            monkeypatch.setenv("MSQ_ACT_ROWS", "0")
+            a, _ = msq.qlinear.act_quant(x, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1)
+            monkeypatch.setenv("MSQ_ACT_ROWS", "1")
+            b, _ = msq.qlinear.act_quant(x, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1)
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (K, x.dtype)
+            assert (b.float().cpu().numpy() == Xo).all(), (K, x.dtype)

@@ -441,3 +441,29 @@ def test_get_wikitext2_windowing_golden(msq):
         del os.environ["MSQ_WIKITEXT2_DIR"]
     with pytest.raises(ValueError):
         data_utils.get_loaders("c4")
+
+
+def test_fma_division_by_small_integers_is_correctly_rounded():
+    """csrc/msq_act.hip (k_act_quant_rows, the sequential recompute of a boundary column) divides by the running count b <= 4096 as
+    y = RN(1 / b), q = RN(a y), then twice r = RN(a - q b) (one fma, exact), q = RN(q + r y): equal to the IEEE quotient a / b for
+    random operands, operands across the exponent range and operands planted next to a rounding tie (exact rational arithmetic)."""
+    import random
+    import struct
+    from fractions import Fraction
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))          # float(Fraction) rounds to nearest even
+    rnd = random.Random(1)
+    for t in range(6000):
+        b = rnd.randint(1, 4096)
+        if t % 3 == 0:
+            a = rnd.uniform(-4, 4)
+        elif t % 3 == 1:
+            a = struct.unpack("d", struct.pack("Q", rnd.getrandbits(52) | (rnd.randint(700, 1300) << 52)))[0]
+        else:
+            a = rnd.uniform(1, 2) * b * (1 + rnd.choice([-1, 1]) * 2.0 ** -53)
+        y = 1.0 / b
+        q = a * y
+        q1 = fma(fma(-q, float(b), a), y, q)
+        q2 = fma(fma(-q1, float(b), a), y, q1)
+        assert q2 == a / b and q1 == a / b, (a, b)
