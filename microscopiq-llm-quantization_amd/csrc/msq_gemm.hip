@@ -1478,11 +1478,14 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
 }
 
+#ifndef MSQ_MX128_DEFAULT
+#define MSQ_MX128_DEFAULT 1    /* 1: the MF = 8 form of k_mxgemm256 where the cost rule prefers it */
+#endif
 #ifndef MSQ_MX256_DEFAULT
 #define MSQ_MX256_DEFAULT 1    /* 1: k_mxgemm256 is the default for full grids of 256 x 256 blocks (set once measured faster) */
 #endif
 int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
-                         void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream);   // msq_mxgemm256.hip
+                         void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int mf, void* stream);   // msq_mxgemm256.hip
 #ifndef MSQ_Q128_DEFAULT
 #define MSQ_Q128_DEFAULT 1     /* 1: the MF = 8 form of k_qgemm256 (128-row blocks, two per CU) where the cost rule below prefers it */
 #endif
@@ -1943,16 +1946,26 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
             return check_launch2("msq_qlinear_mx_w4a8(decode reduce)");
         }
     }
-    // 256-row wave tiles, one wave per SIMD, accumulators placed by hand (k_mxgemm256, msq_mxgemm256.hip): full grids of 256 x 256
-    // blocks.  MSQ_MX_256=1 / 0 forces / disables (read per call: tests and A/B scripts flip it inside one process).
+    // 256-row wave tiles, one wave per SIMD, accumulators placed by hand (k_mxgemm256, msq_mxgemm256.hip), and its 128-row form (MF = 8,
+    // two blocks per CU) for the grids 256-row blocks do not fill.  MSQ_MX_256=1 / 2 force the 256- / 128-row form, 0 disables both
+    // (read per call: tests and A / B scripts flip it inside one process).  Default rule: the cost in rounds of msq_qlinear_bf16.
     {
         const char* e256 = getenv("MSQ_MX_256");
         const int forced256 = e256 ? atoi(e256) : -1;
-        const int64_t b256 = ((M + 255) / 256) * (N / 256);
-        const bool dflt256 = MSQ_MX256_DEFAULT && b256 >= 256 && b256 * 100 >= 85 * 256 * ((b256 + 255) / 256);
-        if (forced256 == 1 || (forced256 != 0 && dflt256)) {
-            const int e = msq_launch_mxgemm256(wf, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, stream);
-            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_mx_w4a8(256-row wave tiles, k_mxgemm256): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+        const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
+        const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
+        // measured (profiles/r04_mx128_sweep.txt): 256-row blocks win from 144 blocks on -- also on part-filled rounds, where k_mxgemm's
+        // 128-row blocks run two per CU on part of the chip (M512 N22016: 43.6 against 59.7 us; e4m3 operand M1024 N22016: 95.3
+        // against 114.8).  The 128-row form pays with the 16-byte MX-FP4 operand only, where a second round would be less than half
+        // full (q/k/v 2048 x 12288, 384 blocks: 74.7 us against 88.4, k_mxgemm 79.5); with the 24- / 32-byte operands its two-deep
+        // weight ring costs more than the saved half round (116.7 against 95.3), so those never take it.  One-round grids of <= 128
+        // blocks of 256 rows (o, down at M = 2048) stay on k_mxgemm.
+        const bool dflt128 = MSQ_MX128_DEFAULT && wf == 0 && b128 >= 144 && r16 >= 2 && r8x2 < 2 * r16;
+        const bool dflt256 = MSQ_MX256_DEFAULT && !dflt128 && b256 > 128;
+        const int mfsel = (forced256 == 2 || (forced256 < 0 && dflt128)) ? 8 : ((forced256 == 1 || (forced256 != 0 && dflt256)) ? 16 : 0);
+        if (mfsel) {
+            const int e = msq_launch_mxgemm256(wf, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, mfsel, stream);
+            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_mx_w4a8(k_mxgemm256, MF = %d): %s", mfsel, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
             return MSQ_OK;
         }
     }

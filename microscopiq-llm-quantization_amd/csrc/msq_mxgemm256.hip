@@ -52,10 +52,42 @@ template <> struct WOperand<1> { typedef v8i_t type; static constexpr int loads 
 template <> struct WOperand<2> { typedef v6i_t type; static constexpr int loads = 2; static constexpr int frag_bytes = 1536; };
 template <> struct WOperand<3> { typedef v6i_t type; static constexpr int loads = 2; static constexpr int frag_bytes = 1536; };
 
+// The vector-memory op behind MFMA `slot` (2 or 3) of group mf: 0 .. PPW - 1 an LDS-DMA piece, 100 + part a weight load, 200 the scale-tile
+// DMA, -1 nothing (see the kernel); count(): ops in groups < upto, `dma_only` for the tail steps whose weight loads hipcc deletes.
+template <int MF, int NPART> struct MxSched {
+    static constexpr int op(int mf, int slot) {
+        if (MF == 16) {
+            if (slot == 3) {
+                if ((mf & 1) == 0) return mf >> 1;
+                const int part = mf >> 1;
+                return part < NPART ? 100 + part : (part == NPART ? 200 : -1);
+            }
+            if (NPART + 1 > 8) { if (mf == 1) return 100 + 8; if (mf == 3) return 200; }
+            return -1;
+        }
+        if (slot == 3) return (mf & 1) == 0 ? (mf >> 1) : 100 + (mf >> 1);
+        const int part = 4 + mf;
+        return part < NPART ? 100 + part : (part == NPART ? 200 : -1);
+    }
+    static constexpr int count(int upto, bool dma_only) {
+        int n = 0;
+        for (int mf = 0; mf < upto; ++mf)
+            for (int slot = 2; slot <= 3; ++slot) {
+                const int o = op(mf, slot);
+                if (o >= 0 && (!dma_only || o < 100 || o >= 200)) n += 1;
+            }
+        return n;
+    }
+};
+
 // WF = weight operand format as k_mxgemm: 0 e2m1 (16 B per lane and 16 n), 1 e4m3 (32 B in two half-slots), 2 / 3 = fp6 e2m3 / e3m2
 // (24 B per lane: a 16-byte and an 8-byte piece, 1.5 KiB per fragment slot)
-template <typename YT, int WF>
-__global__ void __launch_bounds__(256, 1)
+// MF = activation fragments per wave tile: 16 = the 256-row block above (one block per CU); 8 = its 128-row form, two blocks per
+// CU -- for grids that 256-row blocks do not fill (q/k/v 2048 x 12288: 1.5 rounds instead of 2; o and down: one round of 256 blocks).
+// With 128 accumulators + 128 other registers per lane the weight ring is two K-steps deep there (three sets of the 32-byte operand
+// do not fit); the second block of the CU covers what that exposes.
+template <typename YT, int WF, int MF>
+__global__ void __launch_bounds__(256, (MF == 16) ? 1 : 2)
 k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, const uint8_t* __restrict__ Wc, const uint8_t* __restrict__ Ws,
             const float* __restrict__ bias, YT* __restrict__ Y, int M, int N, int K, int y16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,19 +95,22 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     constexpr int WL = WOperand<WF>::loads;                      // vector-memory loads per weight fragment
     constexpr int FB = WOperand<WF>::frag_bytes;
     constexpr int CBSZ = (WF >= 2) ? WF : (WF == 1 ? 0 : 4);
-    constexpr int KS = 128, A_TILE = 256 * KS;                   // 32 KiB of activation codes per buffer
+    constexpr int BM = 16 * MF;                                  // rows per block
+    constexpr int PPW = MF / 2;                                  // 1 KiB staging pieces per wave and K-step
+    constexpr int WD = (MF == 16) ? 3 : 2;                       // weight ring depth in K-steps
+    constexpr int KS = 128, A_TILE = BM * KS;                    // 32 / 16 KiB of activation codes per buffer
     constexpr int XS_BASE = 4 * A_TILE;                          // four 1 KiB scale tiles behind the code buffers: [row][4 bytes]
     constexpr int PF = MSQ_MX256_PF;
     static_assert(PF >= 1 && PF <= 3, "fragment ring of four");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int MT = (M + 255) / 256, NTB = N / 256;
+    const int MT = (M + BM - 1) / BM, NTB = N / 256;
     const int KT = K / KS;
     const int bid = (int)blockIdx.x;
     int bm, bn;
     if ((NTB & 7) == 0) {                                        // XCD-aware order, as k_qgemm256
-        constexpr int RT = MSQ_MX256_RT;
+        constexpr int RT = MSQ_MX256_RT * (16 / MF);
         const int xcd = bid & 7, i = bid >> 3;
         const int npx = NTB >> 3, per_group = RT * npx, full = MT / RT;
         int rg, j, R;
@@ -84,7 +119,7 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
         bm = rg * RT + j % R;
         bn = (j / R) * 8 + xcd;
     } else { bm = bid % MT; bn = bid / MT; }
-    const int m0 = bm * 256, n0 = bn * 256;
+    const int m0 = bm * BM, n0 = bn * 256;
     const int64_t wtiles = (int64_t)(N / 64) * KT;
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(Wc, wtiles * 4 * FB);
     const __amdgpu_buffer_rsrc_t wsr = make_rsrc(Ws, wtiles * 256);
@@ -93,23 +128,25 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     const uint32_t tile_row32 = (uint32_t)sgpr((n0 / 64 + wid) * KT);
     const int lane16 = lane * 16, lane8 = lane * 8, lane4 = lane * 4;
 
-    // activation staging: wave w copies rows 64 w .. + 63 as eight 1 KiB pieces (8 rows x 128 B; lane l: row 8 p + l / 8, source chunk
-    // (l & 7) ^ ((row >> 1) & 7)) and the 64 scale dwords of its rows (one per lane)
-    int aoff[8];
+    // activation staging: wave w copies rows (BM / 4) w .. as PPW 1 KiB pieces (8 rows x 128 B; lane l: row 8 p + l / 8, source chunk
+    // (l & 7) ^ ((row >> 1) & 7)) and 64 scale dwords (one per lane; with 128-row blocks waves 2 / 3 write the rows of waves 0 / 1
+    // again -- the same bytes to the same place: every wave issues the same number of vector-memory ops, which the wait counts rely on)
+    int aoff[8];                                                 // (first PPW used; a dependent array bound captured by the staging lambda fails to instantiate on the host pass)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = (wid * 8 + p) * 8 + (lane >> 3);
+    for (int p = 0; p < PPW; ++p) {
+        const int row = (wid * PPW + p) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row; gr = gr < M ? gr : M - 1;
         aoff[p] = (int)((int64_t)gr * K + chunk * 16);
     }
-    int xs_goff = m0 + wid * 64 + lane; xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
+    const int xs_row0 = (wid * 64) % BM;
+    int xs_goff = m0 + xs_row0 + lane; xs_goff = (xs_goff < M ? xs_goff : M - 1) * (K / 32);
     auto stage_piece = [&](int kt, int buf, int p) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * 8 + p) * 1024),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem + buf * A_TILE + (wid * PPW + p) * 1024),
                                                  16, aoff[p], (uint32_t)kt * KS, 0, 0);
     };
     auto stage_scales = [&](int kt, int buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem + XS_BASE + buf * 1024 + wid * 256),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (void __attribute__((address_space(3)))*)(smem + XS_BASE + buf * 1024 + xs_row0 * 4),
                                                  4, xs_goff, (uint32_t)kt * 4u, 0, 0);
     };
     // fragment mf of this lane: row mf * 16 + c, chunks g and 4 + g (k = 16 g .. and 64 + 16 g ..); scale byte g of that row
@@ -117,9 +154,9 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     const int rdl = c * 128 + ((g ^ sw) << 4), rdh = c * 128 + (((4 + g) ^ sw) << 4);
     const int xs_rd = XS_BASE + c * 4 + g;
 
-    f32x4_t acc[16][4];
+    f32x4_t acc[MF][4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -153,18 +190,18 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     const int kl = sgpr(KT - 1);
     const int k1 = (1 <= kl) ? 1 : kl;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) stage_piece(0, 0, p);
+    for (int p = 0; p < PPW; ++p) stage_piece(0, 0, p);
     stage_scales(0, 0);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) stage_piece(k1, 1, p);
+    for (int p = 0; p < PPW; ++p) stage_piece(k1, 1, p);
     stage_scales(k1, 1);
     load_w_all(w0, 0);
-    load_w_all(w1, k1);
+    if constexpr (WD == 3) load_w_all(w1, k1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
-    // fragment ring: four slots of {low half, high half, scale byte} (a power of two that divides the sixteen groups of a K-step: the
-    // slot of fragment mf + PF of the NEXT K-step is the slot its group mf + PF - 16 will read)
+    // fragment ring: four slots of {low half, high half, scale byte} (a power of two that divides the MF groups of a K-step: the
+    // slot of fragment mf + PF of the NEXT K-step is the slot its group mf + PF - MF will read)
     u32x4_t xl[4], xh[4];
     uint32_t xsc[4];
 #pragma unroll
@@ -174,50 +211,30 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
         xsc[f] = *reinterpret_cast<const uint8_t*>(smem + xs_rd + f * 64);
     }
 
-    // Schedule of the filler behind MFMA 3 of group mf (one vector-memory op each; W8 / W6 operands have nine weight loads: the last
-    // ones share a slot with the scale-byte read behind MFMA 2): even mf -> LDS-DMA piece mf / 2 of tile kt + 2; odd mf -> weight load
-    // (mf - 1) / 2 of K-step kt + 2, then the scale-tile DMA.  vector-memory ops issued in front of the barrier (group BAR_G): counted
-    // by n_before(), the wait lets exactly those stay in flight.
+    // Vector-memory ops of a K-step: PPW LDS-DMA pieces of the activation tile two K-steps ahead, NPART weight loads of the K-step
+    // WD - 1 ahead, the scale-tile DMA.  Two filler slots per group take one op each: slot 3 (behind MFMA 3) and slot 2 (behind MFMA 2,
+    // next to the scale-byte read).  MxSched::op(mf, slot) names the op: 0 .. PPW - 1 a piece, 100 + part a weight load, 200 the scale
+    // DMA, -1 nothing -- the schedule, the wait counts in front of the barrier (group BAR_G) and the tail-step counts all read it.
+    //   MF = 16: slot 3 of even groups = piece mf / 2, of odd groups = weight part mf / 2 (then the scale DMA); a ninth weight load and
+    //            the scale DMA of the 24- / 32-byte operands ride in slot 2 of groups 1 and 3;
+    //   MF = 8 : slot 3 of even groups = piece mf / 2, of odd groups = weight part mf / 2 (0 .. 3); slot 2 of group mf = weight part
+    //            4 + mf (4 .. NPART - 1), then the scale DMA.
     constexpr int NPART = 4 * WL + 1;                            // weight loads per K-step: 5 (fp4) / 9
-    constexpr int BAR_G = 16 - PF;
-    auto misc3 = [&](int mf, WSet& wl, int ktn, int buf2) {      // behind MFMA 3
-        if ((mf & 1) == 0) { if (!(MSQ_MX256_ABL & 8)) stage_piece(ktn, buf2, mf >> 1); }
-        else {
-            const int part = mf >> 1;                            // 0 .. 7
-            if (part < NPART) { if (!(MSQ_MX256_ABL & 4)) load_w_part(wl, ktn, part); }
-            else if (part == NPART) { if (!(MSQ_MX256_ABL & 8)) stage_scales(ktn, buf2); }
-        }
+    constexpr int BAR_G = MF - PF;
+    typedef MxSched<MF, NPART> SCH;
+    auto issue = [&](int op, WSet& wl, int ktw, int ktn, int buf2) {
+        if (op < 0) return;
+        if (op < 100) { if (!(MSQ_MX256_ABL & 8)) stage_piece(ktn, buf2, op); }
+        else if (op < 200) { if (!(MSQ_MX256_ABL & 4)) load_w_part(wl, ktw, op - 100); }
+        else { if (!(MSQ_MX256_ABL & 8)) stage_scales(ktn, buf2); }
     };
-    auto misc2 = [&](int mf, WSet& wl, int ktn, int buf2) {      // behind MFMA 2, next to the scale-byte read: what did not fit above
-        if (NPART + 1 > 8) {                                     // nine weight loads + the scale DMA: parts 8, 9 ride here at mf = 1, 3
-            if (mf == 1) { if (!(MSQ_MX256_ABL & 4)) load_w_part(wl, ktn, 8); }
-            else if (mf == 3) { if (!(MSQ_MX256_ABL & 8)) stage_scales(ktn, buf2); }
-        }
-    };
-    // ops issued before the barrier in front of group BAR_G
-    constexpr int N_WAIT = [] {
-        int n = 0;
-        for (int mf = 0; mf < BAR_G; ++mf) {
-            if ((mf & 1) == 0) n += 1;
-            else { const int part = mf >> 1; if (part < NPART) n += 1; else if (part == NPART) n += 1; }
-            if (NPART + 1 > 8 && (mf == 1 || mf == 3)) n += 1;
-        }
-        return n;
-    }();
-
+    // ops issued before the barrier in front of group BAR_G: exactly those may stay in flight
+    constexpr int N_WAIT = SCH::count(BAR_G, false);
     // The steps after the loop load weights nobody will use: hipcc deletes those loads, so such a step issues only its LDS-DMA ops and
     // the loop's wait count would let ops of the PREVIOUS step -- the tile the next tail step reads -- stay in flight (seen as 25-28
     // differing launches of 300 with K = 640 / 1024 and the five-load fp4 operand, scripts/experiments/stress_round4.py; the same
     // trap as k_mxgemm's).  Tail steps therefore let only their own LDS-DMA ops stay in flight.
-    constexpr int N_WAIT_TAIL = [] {
-        int n = 0;
-        for (int mf = 0; mf < BAR_G; ++mf) {
-            if ((mf & 1) == 0) n += 1;
-            else if ((mf >> 1) == NPART) n += 1;
-            if (NPART + 1 > 8 && mf == 3) n += 1;
-        }
-        return n;
-    }();
+    constexpr int N_WAIT_TAIL = SCH::count(BAR_G, true);
 #define MX256_SB() __builtin_amdgcn_sched_barrier(0)
 #define MX256_STEP(KT_CUR, WCUR, WLOAD, NWAIT)                                                                       \
     {                                                                                                                \
@@ -229,7 +246,8 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
         const char* scur = smem + buf * 1024;                                                                        \
         const char* snxt = smem + bufn * 1024;                                                                       \
         const int ktn = (kt_ + 2 <= kl) ? kt_ + 2 : kl;            /* branch-free tail: re-stage / re-load the last tile */ \
-        _Pragma("unroll") for (int mf = 0; mf < 16; ++mf) {                                                          \
+        const int ktw = (kt_ + (WD - 1) <= kl) ? kt_ + (WD - 1) : kl;                                                \
+        _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                          \
             if (mf == BAR_G) {                                                                                       \
                 __builtin_amdgcn_s_waitcnt(0x0F70 | ((NWAIT) & 15) | (((NWAIT) >> 4) << 14));   /* vmcnt(NWAIT) only */ \
                 if (!(MSQ_MX256_ABL & 16)) __builtin_amdgcn_s_barrier();                                             \
@@ -241,29 +259,34 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
             MX256_SB();                                                                                              \
             if (!(MSQ_MX256_ABL & 64)) mfma_mx<CBSZ, 0>(acc[mf][0], WCUR.w[0], bfr, WCUR.s, sb_);                    \
             MX256_SB();                                                                                              \
-            if (!(MSQ_MX256_ABL & 1)) xl[f_ & 3] = *reinterpret_cast<const u32x4_t*>((f_ < 16 ? acur : anxt) + rdl + (f_ & 15) * 2048); \
+            if (!(MSQ_MX256_ABL & 1)) xl[f_ & 3] = *reinterpret_cast<const u32x4_t*>((f_ < MF ? acur : anxt) + rdl + (f_ & (MF - 1)) * 2048); \
             MX256_SB();                                                                                              \
             if (!(MSQ_MX256_ABL & 64)) mfma_mx<CBSZ, 1>(acc[mf][1], WCUR.w[1], bfr, WCUR.s, sb_);                    \
             MX256_SB();                                                                                              \
-            if (!(MSQ_MX256_ABL & 1)) xh[f_ & 3] = *reinterpret_cast<const u32x4_t*>((f_ < 16 ? acur : anxt) + rdh + (f_ & 15) * 2048); \
+            if (!(MSQ_MX256_ABL & 1)) xh[f_ & 3] = *reinterpret_cast<const u32x4_t*>((f_ < MF ? acur : anxt) + rdh + (f_ & (MF - 1)) * 2048); \
             MX256_SB();                                                                                              \
             if (!(MSQ_MX256_ABL & 64)) mfma_mx<CBSZ, 2>(acc[mf][2], WCUR.w[2], bfr, WCUR.s, sb_);                    \
             MX256_SB();                                                                                              \
-            if (!(MSQ_MX256_ABL & 1)) xsc[f_ & 3] = *reinterpret_cast<const uint8_t*>((f_ < 16 ? scur : snxt) + xs_rd + (f_ & 15) * 64); \
-            misc2(mf, WLOAD, ktn, buf2);                                                                             \
+            if (!(MSQ_MX256_ABL & 1)) xsc[f_ & 3] = *reinterpret_cast<const uint8_t*>((f_ < MF ? scur : snxt) + xs_rd + (f_ & (MF - 1)) * 64); \
+            issue(SCH::op(mf, 2), WLOAD, ktw, ktn, buf2);                                                              \
             MX256_SB();                                                                                              \
             if (!(MSQ_MX256_ABL & 64)) mfma_mx<CBSZ, 3>(acc[mf][3], WCUR.w[3], bfr, WCUR.s, sb_);                    \
             MX256_SB();                                                                                              \
-            misc3(mf, WLOAD, ktn, buf2);                                                                             \
+            issue(SCH::op(mf, 3), WLOAD, ktw, ktn, buf2);                                                              \
         }                                                                                                            \
     }
 
     int abuf = 0;
     {
         int kt = 0;
-        for (; kt + 2 < KT; kt += 3) { MX256_STEP(kt, w0, w2, N_WAIT) MX256_STEP(kt + 1, w1, w0, N_WAIT) MX256_STEP(kt + 2, w2, w1, N_WAIT) }
-        if (kt < KT) { MX256_STEP(kt, w0, w2, N_WAIT_TAIL) ++kt; }
-        if (kt < KT) { MX256_STEP(kt, w1, w0, N_WAIT_TAIL) ++kt; }
+        if constexpr (WD == 3) {
+            for (; kt + 2 < KT; kt += 3) { MX256_STEP(kt, w0, w2, N_WAIT) MX256_STEP(kt + 1, w1, w0, N_WAIT) MX256_STEP(kt + 2, w2, w1, N_WAIT) }
+            if (kt < KT) { MX256_STEP(kt, w0, w2, N_WAIT_TAIL) ++kt; }
+            if (kt < KT) { MX256_STEP(kt, w1, w0, N_WAIT_TAIL) ++kt; }
+        } else {
+            for (; kt + 1 < KT; kt += 2) { MX256_STEP(kt, w0, w1, N_WAIT) MX256_STEP(kt + 1, w1, w0, N_WAIT) }
+            if (kt < KT) { MX256_STEP(kt, w0, w1, N_WAIT_TAIL) ++kt; }
+        }
     }
 #undef MX256_STEP
 #undef MX256_SB
@@ -271,9 +294,9 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the MFMAs are opaque to hipcc's hazard recogniser
     __builtin_amdgcn_s_waitcnt(0x0070);                          // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
-    if (MSQ_MX256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < 16; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
+    if (MSQ_MX256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < MF / 8; ++h) {
         const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
         store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
     }
@@ -293,21 +316,25 @@ inline void attr_done_mx(DevOnceMx& o) {
 }  // namespace
 
 // Launcher (called by mx_linear, msq_gemm.hip).  Preconditions checked by the caller: N % 256 == 0, K % 128 == 0, offsets below 4 GiB.
+// mf = 16: 256-row blocks; 8: 128-row blocks, two per CU.
 extern "C" int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, const void* w_codes, const void* w_scales, const float* bias,
-                                    void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, void* stream) {
-    const int MT = (int)((M + 255) / 256), NTB = (int)(N / 256);
+                                    void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int mf, void* stream) {
+    const int bmr = 16 * mf;
+    const int MT = (int)((M + bmr - 1) / bmr), NTB = (int)(N / 256);
     const dim3 grid((unsigned)(MT * NTB)), blk(256);
-    const size_t lds = 4 * (32768 + 1024);
+    const size_t lds = 4 * ((size_t)bmr * 128 + 1024);
     const int y16 = (y_dtype == 1) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-#define MX256_LAUNCH(YT, WFV)                                                                                          \
+#define MX256_LAUNCH(YT, WFV, MFV)                                                                                     \
     do { static DevOnceMx once_;                                                                                       \
-         if (attr_needed_mx(once_)) { (void)hipFuncSetAttribute((const void*)k_mxgemm256<YT, WFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done_mx(once_); } \
-         hipLaunchKernelGGL((k_mxgemm256<YT, WFV>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
+         if (attr_needed_mx(once_)) { (void)hipFuncSetAttribute((const void*)k_mxgemm256<YT, WFV, MFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done_mx(once_); } \
+         hipLaunchKernelGGL((k_mxgemm256<YT, WFV, MFV>), grid, blk, lds, st, (const uint8_t*)x_codes, (const uint8_t*)x_scales, (const uint8_t*)w_codes, \
                             (const uint8_t*)w_scales, bias, (YT*)Y, (int)M, (int)N, (int)K, y16); } while (0)
-#define MX256_DISPATCH(YT) do { if (wf == 0) MX256_LAUNCH(YT, 0); else if (wf == 1) MX256_LAUNCH(YT, 1); else if (wf == 2) MX256_LAUNCH(YT, 2); else MX256_LAUNCH(YT, 3); } while (0)
+#define MX256_MF(YT, WFV) do { if (mf == 16) MX256_LAUNCH(YT, WFV, 16); else MX256_LAUNCH(YT, WFV, 8); } while (0)
+#define MX256_DISPATCH(YT) do { if (wf == 0) MX256_MF(YT, 0); else if (wf == 1) MX256_MF(YT, 1); else if (wf == 2) MX256_MF(YT, 2); else MX256_MF(YT, 3); } while (0)
     if (y_dtype == 0) MX256_DISPATCH(float); else MX256_DISPATCH(uint16_t);
 #undef MX256_DISPATCH
+#undef MX256_MF
 #undef MX256_LAUNCH
     return (int)hipGetLastError();
 }

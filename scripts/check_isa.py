@@ -144,16 +144,23 @@ s3 = open(out3).read()
 for nm in re.findall(r'^(_ZN\S*k_mxgemm256\S*):', s3, re.M):
     i = s3.index('\n' + nm + ':'); j = s3.index('s_endpgm', i)
     lines = [l.strip() for l in s3[i:j].split('\n')]
+    mfk = int(re.search(r'k_mxgemm256I\wLi\dELi(\d+)E', nm).group(1))      # 16: 256-row blocks (64 MFMAs per K-step), 8: 128-row blocks (32)
+    step = 4 * mfk
     blocks, curb = [], []
     for l in lines:
         if re.match(r'^\.LBB\S+:', l):
             blocks.append(curb); curb = []
         else:
             curb.append(l)
+            if l.startswith('s_cbranch') or l.startswith('s_branch'):      # fall-through blocks carry no label
+                blocks.append(curb); curb = []
     blocks.append(curb)
-    region = [l for b in blocks if sum(1 for x in b if x.startswith('v_mfma')) >= 32 for l in b]
+    region = [l for b in blocks if sum(1 for x in b if x.startswith('v_mfma')) >= step // 2 for l in b]
     code = [l for l in region if l and not l.startswith(';')]
-    acc = sum(1 for l in code if l.startswith('v_accvgpr')); scr = sum(1 for l in code if l.startswith('scratch_'))
+    acc = sum(1 for l in code if l.startswith('v_accvgpr'))
+    # scratch: inside the LOOP (the block with the most MFMAs); a tail step runs once (see k_qgemm256 above)
+    loop_block = max(blocks, key=lambda b: sum(1 for x in b if x.startswith('v_mfma')))
+    scr = sum(1 for l in loop_block if l.startswith('scratch_'))
     inplace = all(re.match(r'v_mfma_scale_f32_16x16x128_f8f6f4 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1,', l) for l in code if l.startswith('v_mfma'))
     vm = lambda l: l.startswith('buffer_load') or l.startswith('global_load')
     segs, curseg = [], {"loads": 0, "wait": None, "mfma": 0}
@@ -169,7 +176,7 @@ for nm in re.findall(r'^(_ZN\S*k_mxgemm256\S*):', s3, re.M):
     segs.append(curseg)
     # a K-step segment runs from one barrier to the next (64 MFMAs); its wait may not exceed the ops it issued IF the next segment multiplies a fresh tile
     over = [(k, a["loads"], a["wait"]) for k, (a, b) in enumerate(zip(segs[1:], segs[2:]), 1)
-            if a["wait"] is not None and a["mfma"] >= 64 and b["mfma"] >= 32 and a["wait"] > a["loads"]]
+            if a["wait"] is not None and a["mfma"] >= step and b["mfma"] >= step // 2 and a["wait"] > a["loads"]]
     flag = acc or scr or not inplace or over
     print(("!! " if flag else "   ") + "%-48s K-loop: mfma %4d  v_accvgpr %d  scratch %d  in-place %s  vmcnt over %s"
           % (nm[-48:], sum(1 for l in code if l.startswith('v_mfma')), acc, scr, inplace, over))

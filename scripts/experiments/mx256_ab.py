@@ -30,7 +30,10 @@ def operands(N, K):
 
 
 def run(flag, xp, P, dt):
-    os.environ["MSQ_MX_256"] = flag
+    if flag == "d":                                       # the library's own rule
+        os.environ.pop("MSQ_MX_256", None)
+    else:
+        os.environ["MSQ_MX_256"] = flag
     return qlinear.qlinear_mx_w4a8(xp, P, None, dt)
 
 
@@ -44,23 +47,29 @@ if do_check:
             for dt in (torch.float32, torch.bfloat16, torch.float16):
                 a = run("0", xp, P, dt)
                 b = run("1", xp, P, dt)
-                ok = torch.equal(a, b)
-                rep = all(torch.equal(run("1", xp, P, dt), b) for _ in range(5))
+                c8 = run("2", xp, P, dt)
+                ok = torch.equal(a, b) and torch.equal(b, c8)
+                rep = all(torch.equal(run("1", xp, P, dt), b) and torch.equal(run("2", xp, P, dt), c8) for _ in range(5))
                 print(f"M{M} N{N} K{K} {name:5s} {str(dt)[6:]:9s}: identical to k_mxgemm {ok}, repeatable {rep}, max|diff| {(a.float() - b.float()).abs().max().item():.3e} of {a.float().abs().max().item():.3e}", flush=True)
                 bad += (not ok) or (not rep)
     print("CHECK", "FAILED" if bad else "ok", bad)
 
 if do_time:
-    for (M, N, K) in ((2048, 16384, 4096), (4096, 16384, 4096), (2048, 22016, 4096), (2048, 8192, 28672)):
+    shapes = ((2048, 16384, 4096), (4096, 16384, 4096), (2048, 22016, 4096), (2048, 8192, 28672))
+    if os.environ.get("SHAPES"):                          # SHAPES="M,N,K;M,N,K;..."
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
+    for (M, N, K) in shapes:
         ops = operands(N, K)
+        if os.environ.get("OPS"):
+            ops = {k: v for k, v in ops.items() if k in os.environ["OPS"].split(",")}
         X = torch.randn(M, K, device=dev)
         xp = qlinear.mx_pack_act(X)
         for name, P in ops.items():
             for _ in range(100):
                 run("0", xp, P, torch.bfloat16)
-            res = {"0": [], "1": []}
+            res = {"0": [], "1": [], "2": [], "d": []}
             for rnd in range(6):
-                for flag in ("0", "1"):
+                for flag in ("0", "1", "2", "d"):
                     for _ in range(10):
                         run(flag, xp, P, torch.bfloat16)
                     torch.cuda.synchronize()
@@ -72,5 +81,5 @@ if do_time:
                     torch.cuda.synchronize()
                     res[flag].append(e0.elapsed_time(e1) / 30 * 1e3)
             fl = 2.0 * M * N * K
-            ma, mb = sorted(res["0"])[3], sorted(res["1"])[3]
-            print(f"M{M} N{N} K{K} {name:5s}: k_mxgemm median {ma:7.1f} us ({fl/ma/1e6:6.0f} TF = {fl/ma/1e6/5000:.3f}) | k_mxgemm256 median {mb:7.1f} us ({fl/mb/1e6:6.0f} TF = {fl/mb/1e6/5000:.3f})  ratio {ma/mb:.3f}", flush=True)
+            ma, mb, mc, md = sorted(res["0"])[3], sorted(res["1"])[3], sorted(res["2"])[3], sorted(res["d"])[3]
+            print(f"M{M} N{N} K{K} {name:5s}: k_mxgemm median {ma:7.1f} us ({fl/ma/1e6:6.0f} TF = {fl/ma/1e6/5000:.3f}) | k_mxgemm256 median {mb:7.1f} us ({fl/mb/1e6:6.0f} TF = {fl/mb/1e6/5000:.3f})  ratio {ma/mb:.3f} | MF=8 form {mc:7.1f} us ({fl/mc/1e6/5000:.3f}) ratio {ma/mc:.3f} | default rule {md:7.1f} (x{min(ma, mb, mc)/md:.3f} of the best)", flush=True)

@@ -402,16 +402,25 @@ def test_mxgemm256_equals_mxgemm(msq, M, N, K, monkeypatch):
                 assert (a.float() - b.float()).abs().max().item() <= 1e-4 * a.float().abs().max().item() + 1e-6
             for _ in range(3):
                 assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt), b)
+            monkeypatch.setenv("MSQ_MX_256", "2")                        # the 128-row form (MF = 8, two blocks per CU, weight ring two deep)
+            c = msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt)
+            assert torch.equal(c, b), ("MF=8", name, dt, (c.float() - b.float()).abs().max().item())
+            for _ in range(3):
+                assert torch.equal(msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt), c)
+            monkeypatch.delenv("MSQ_MX_256")                             # ... and the library's own choice
+            d = msq.qlinear.qlinear_mx_w4a8(xp, P, bias, dt)
+            assert torch.equal(d, a) or torch.equal(d, b)
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("M,N,K", [(2048, 16384, 640), (4096, 8192, 1024)])
-def test_mxgemm256_tail_steps_repeat_under_uneven_load(msq, M, N, K, monkeypatch):
+def test_mxgemm256_tail_steps_repeat_under_uneven_load(msq, M, N, K, form, monkeypatch):
     """K-step counts that leave TWO tail steps behind the three-step loop: hipcc deletes the dead weight loads of those steps, and with
     the loop's wait count the first tail step let the LDS-DMA pieces of the tile the second one multiplies stay in flight (25-28 of 300
     launches differed with the five-load MX-FP4 operand, scripts/experiments/stress_round4.py).  Tail steps now wait with the count of
     their own LDS-DMA ops (scripts/check_isa.py checks it in the ISA): 150 launches, every second beside a bandwidth hog on another
-    stream, all equal to the first one, which equals k_mxgemm."""
-    monkeypatch.setenv("MSQ_MX_256", "1")
+    stream, all equal to the first one, which equals k_mxgemm.  form 2 = the 128-row form: a two-step loop and ONE tail step (K = 640)."""
+    monkeypatch.setenv("MSQ_MX_256", form)
     W = _weights(N, K, 31).to(dev())
     X = torch.randn(M, K, generator=torch.Generator().manual_seed(32)).to(dev())
     xp = msq.qlinear.mx_pack_act(X)
