@@ -2,10 +2,11 @@
 MX-FP6 operands) over K-step counts 1, 2, 3, odd, even, ragged M, both output dtypes; half of the repetitions run beside a bandwidth hog on
 a second stream (uneven load).  REPS launches per case must equal the first one bit for bit, and the first one must equal the dense product
 of the operands (bf16 path: fp32 accumulation, 2e-5 max|y|; MX path: the scaled MFMA's own accumulation against float64, elementwise 2^-11 sum |products|, the bound of the MX tests).
-MSQ_GEMM_256 / MSQ_MX_256 = 1 force the kernels onto every shape."""
+MSQ_GEMM_256 / MSQ_MX_256 = FORM force the kernels onto every shape: FORM=1 (default) the 256-row form, FORM=2 the 128-row form (MF = 8)."""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-os.environ["MSQ_GEMM_256"] = "1"; os.environ["MSQ_MX_256"] = "1"
+FORM = os.environ.get("FORM", "1")
+os.environ["MSQ_GEMM_256"] = FORM; os.environ["MSQ_MX_256"] = FORM
 import msq
 from msq import qlinear, quant
 dev = torch.device("cuda:0"); torch.manual_seed(5)
@@ -37,7 +38,7 @@ for (M, N, K) in CASES:
         ref = Xb.float() @ qlinear.unpack_weight(P, torch.float32).t()
         for ydt in (torch.float32, torch.bfloat16):
             hammer(lambda: qlinear.qlinear(Xb, P, None, ydt), ref, (2e-5 if ydt == torch.float32 else 8e-3) * ref.abs().max().item(),
-                   "k_qgemm256 M%5d N%6d K%6d %-11s %-8s" % (M, N, K, fo, str(ydt)[6:]))
+                   ("k_qgemm256 MF%-2d M%5d N%6d K%6d %-11s %-8s" % (16 // int(FORM), M, N, K, fo, str(ydt)[6:])))
         del P, ref
     xp = qlinear.mx_pack_act(X)
     Xq = msq.mx_ops._quantize_mx(X, 8, "fp8_e4m3", axes=[-1], block_size=32)
@@ -49,7 +50,7 @@ for (M, N, K) in CASES:
             Wq = msq.mx_ops._quantize_mx(W, 8, ef, axes=[-1], block_size=32); P = qlinear.mx_pack_weight(W, w_fmt={"fp4": "e2m1", "e3m2": "e3m2"}[name])
         ref = Xq.double() @ Wq.double().t()
         bound = (Xq.abs() @ Wq.abs().t()) * 2.0 ** -11 + 1e-6
-        hammer(lambda: qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32), ref.float(), 1.0, "k_mxgemm256 M%5d N%6d K%6d %-5s f32 (err / bound)" % (M, N, K, name), bound)
+        hammer(lambda: qlinear.qlinear_mx_w4a8(xp, P, None, torch.float32), ref.float(), 1.0, "k_mxgemm256 MF%-2d M%5d N%6d K%6d %-5s f32 (err / bound)" % (16 // int(FORM), M, N, K, name), bound)
         del P, ref, Wq
 print("TOTAL bad:", bad)
 sys.exit(1 if bad else 0)
