@@ -239,6 +239,16 @@ int msq_outlier_unpack(const void* inl_plane, const void* out_plane, const void*
  * partial tiles from `workspace` (msq_qlinear_workspace_bytes(); NULL or too small = single pass, never an error).
  * Results are bit-identical from run to run on every path (fixed summation order). */
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* Which kernel family msq_qlinear_bf16 (mx_wf < 0, plane kind out_kind) or msq_qlinear_mx_w4a8 (mx_wf = weight operand format 0 .. 3)
+ * picks for a shape -- host logic only, no launch, no device needed: decode kernels (weight streaming, M <= 32-64), the 128- / 64-row
+ * GEMM with split-K (k_qgemm3 / k_mxgemm), or the hand-allocated kernels k_qgemm256 / k_mxgemm256 in their 256-row or 128-row
+ * form (whichever covers the grid in fewer rounds over the 256 CUs).  Negative: shape not supported.
+ * No reference counterpart (the reference has one dense F.linear, number_system/mx/linear.py:91); for tests and capacity planning. */
+#define MSQ_KERNEL_DECODE  0
+#define MSQ_KERNEL_GEMM128 1
+#define MSQ_KERNEL_T256    2
+#define MSQ_KERNEL_T128    3
+int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf);
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream);

@@ -1494,6 +1494,22 @@ int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, cons
 #endif
 int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int mf, void* stream);   // msq_gemm256.hip
+// The rule itself (also behind msq_qlinear_kernel_choice): wave-tile height of the hand-allocated kernel for a prefill-size grid, 0 = k_qgemm3.
+static int q256_rule(int64_t M, int64_t N, int out_kind) {
+    const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
+    const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
+    const bool posit_out = out_kind == MSQ_PLANE_U8X;
+    if (MSQ_Q128_DEFAULT && b128 >= 144 && r8x2 * (posit_out ? 107 : 100) < 2 * r16 * 100) return 8;
+    if (MSQ_Q256_DEFAULT && (b256 >= 224 || (b256 > 128 && (posit_out || M <= 512)))) return 16;
+    return 0;
+}
+static int mx256_rule(int64_t M, int64_t N, int wf) {
+    const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
+    const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
+    if (MSQ_MX128_DEFAULT && wf == 0 && b128 >= 144 && r16 >= 2 && r8x2 < 2 * r16) return 8;
+    if (MSQ_MX256_DEFAULT && b256 > 128) return 16;
+    return 0;
+}
 static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream, int x_f16) {
@@ -1595,11 +1611,8 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
         // less well behind half the MFMAs).  The 128-row form wins where its finer granularity saves at least that (qkv 2048 x 12288: 1.5
         // against 2 rounds; gate_up at M = 640: 1 against 2) and on the one-round grids of 144 ... 256 blocks (o, down); k_qgemm3 keeps
         // the small grids (its 64-row blocks and split-K live there) and, with fp8 outliers at M > 512, the part-filled single round.
-        const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
-        const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
-        const bool posit_out = out_kind == MSQ_PLANE_U8X;
-        const bool q128_default = MSQ_Q128_DEFAULT && b128 >= 144 && r8x2 * (posit_out ? 107 : 100) < 2 * r16 * 100;
-        const bool q256_default = MSQ_Q256_DEFAULT && !q128_default && (b256 >= 224 || (b256 > 128 && (posit_out || M <= 512)));
+        const int mf_rule = q256_rule(M, N, out_kind);              // 8, 16 or 0 (k_qgemm3)
+        const bool q128_default = mf_rule == 8, q256_default = mf_rule == 16;
         // MSQ_GEMM_256=2 / 1 force the 128-row (MF = 8: two blocks per CU) / 256-row form of the kernel, 0 disables both -- tuning and A / B
         if (unified && !x_f16 && (q256_forced == 2 || (q256_forced < 0 && q128_default))) {
             const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 8, stream);
@@ -1952,16 +1965,14 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     {
         const char* e256 = getenv("MSQ_MX_256");
         const int forced256 = e256 ? atoi(e256) : -1;
-        const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
-        const int64_t r16 = (b256 + 255) / 256, r8x2 = (b128 + 255) / 256;
         // measured (profiles/r04_mx128_sweep.txt): 256-row blocks win from 144 blocks on -- also on part-filled rounds, where k_mxgemm's
         // 128-row blocks run two per CU on part of the chip (M512 N22016: 43.6 against 59.7 us; e4m3 operand M1024 N22016: 95.3
         // against 114.8).  The 128-row form pays with the 16-byte MX-FP4 operand only, where a second round would be less than half
         // full (q/k/v 2048 x 12288, 384 blocks: 74.7 us against 88.4, k_mxgemm 79.5); with the 24- / 32-byte operands its two-deep
         // weight ring costs more than the saved half round (116.7 against 95.3), so those never take it.  One-round grids of <= 128
         // blocks of 256 rows (o, down at M = 2048) stay on k_mxgemm.
-        const bool dflt128 = MSQ_MX128_DEFAULT && wf == 0 && b128 >= 144 && r16 >= 2 && r8x2 < 2 * r16;
-        const bool dflt256 = MSQ_MX256_DEFAULT && !dflt128 && b256 > 128;
+        const int mf_rule = mx256_rule(M, N, wf);
+        const bool dflt128 = mf_rule == 8, dflt256 = mf_rule == 16;
         const int mfsel = (forced256 == 2 || (forced256 < 0 && dflt128)) ? 8 : ((forced256 == 1 || (forced256 != 0 && dflt256)) ? 16 : 0);
         if (mfsel) {
             const int e = msq_launch_mxgemm256(wf, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, mfsel, stream);
@@ -2055,6 +2066,25 @@ int msq_qlinear_mx_w6a8(const void* x_codes, const void* x_scales, const void* w
         return fail2(MSQ_ERR_BAD_ARG, "msq_qlinear_mx_w6a8: w_format must be MSQ_FMT_FP6_E3M2 or MSQ_FMT_FP6_E2M3");
     return mx_linear(w_format == MSQ_FMT_FP6_E3M2 ? 3 : 2, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, workspace,
                      workspace_bytes, stream);
+}
+
+
+// Which kernel family the dispatch rules pick for a shape (host logic only: no launch, no device needed; the environment switches
+// of the A / B scripts are not consulted).  mx_wf < 0: msq_qlinear_bf16 with plane kind `out_kind`; mx_wf = 0 .. 3: msq_qlinear_mx_w4a8
+// with that weight operand format.
+int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf) {
+    if (M <= 0 || N <= 0 || K <= 0 || (N % BN)) return -1;
+    if (mx_wf >= 0) {
+        if (mx_wf > 3 || (K % 128)) return -1;
+        if (use_mx_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
+        const int mf = mx256_rule(M, N, mx_wf);
+        return mf == 16 ? MSQ_KERNEL_T256 : (mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128);
+    }
+    if (K % BK) return -1;
+    if (use_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
+    if (out_kind != MSQ_PLANE_U8 && out_kind != MSQ_PLANE_U8X) return MSQ_KERNEL_GEMM128;
+    const int mf = q256_rule(M, N, out_kind);
+    return mf == 16 ? MSQ_KERNEL_T256 : (mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128);
 }
 
 }  // extern "C"

@@ -467,3 +467,28 @@ def test_fma_division_by_small_integers_is_correctly_rounded():
         q1 = fma(fma(-q, float(b), a), y, q)
         q2 = fma(fma(-q1, float(b), a), y, q1)
         assert q2 == a / b and q1 == a / b, (a, b)
+
+
+def test_kernel_choice_rule_for_llama_shapes():
+    """msq_qlinear_kernel_choice (host logic, no device): the dispatch rule in rounds of the grid over the 256 CUs on the
+    shapes it was measured on -- decode kernels at M = 1, the 256-row hand-allocated kernel for the headline shape and the full grids,
+    its 128-row form where a second round would be half empty (q/k/v at M = 2048) and on the one-round grids of o / down, the
+    128-row compiler-allocated GEMM for small grids; the MX path takes the 128-row form with the 16-byte operand only."""
+    import msq
+    L = msq._lib.lib()
+    DEC, G128, T256, T128 = 0, 1, 2, 3
+    U8, U8X = 5, 6
+    layer = ((12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008))
+    ch = lambda M, N, K, ok, wf=-1: L.msq_qlinear_kernel_choice(M, N, K, ok, wf)
+    assert ch(2048, 16384, 4096, U8X) == T256 and ch(2048, 16384, 4096, U8) == T256            # the bench default and its fp8 variant
+    assert [ch(1, N, K, U8X) for N, K in layer] == [DEC] * 4 and [ch(32, N, K, U8) for N, K in layer] == [DEC] * 4
+    assert [ch(2048, N, K, U8X) for N, K in layer] == [T128, T128, T256, T128]
+    assert [ch(4096, N, K, U8) for N, K in layer] == [T256, T256, T128, T256]
+    assert [ch(128, N, K, U8X) for N, K in layer] == [G128] * 4
+    assert ch(512, 22016, 4096, U8X) == T256 and ch(512, 22016, 4096, U8) == T256             # part-filled single round: M <= 512
+    assert ch(768, 12288, 4096, U8X) == T256 and ch(768, 12288, 4096, U8) == G128             # ... beyond: posit only
+    assert ch(2048, 16384, 4096, 2) == G128                                                   # two-plane layouts (MSQ-T1) stay on k_qgemm3
+    assert [ch(2048, N, K, 0, 0) for N, K in layer] == [T128, G128, T256, G128]               # MX-FP4 operand
+    assert [ch(2048, N, K, 0, 1) for N, K in layer] == [T256, G128, T256, G128]               # e4m3 operand: never the 128-row form
+    assert ch(512, 22016, 4096, 0, 1) == T256 and ch(1, 22016, 4096, 0, 0) == DEC
+    assert ch(2048, 16384 + 64, 4096, U8X) < 0 and ch(2048, 16384, 4096 + 64, 0, 0) < 0 and ch(0, 256, 64, U8X) < 0
