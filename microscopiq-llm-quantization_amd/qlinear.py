@@ -295,6 +295,8 @@ def act_quant(x, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format="
     K = x.shape[-1]
     x16 = x.dtype == torch.bfloat16 and (int(variant) == 0 or block_size in (32, 64))   # read as is: no cast pass
     xf = x.reshape(-1, K).contiguous() if x16 else x.reshape(-1, K).float().contiguous()
+    if xf.data_ptr() % 16:                                # a contiguous view at an odd storage offset: the kernels read 16-byte pieces
+        xf = xf.clone()
     M = xf.shape[0]
     xq = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
     wsb = lib().msq_act_quant_workspace_bytes(M, K, block_size, int(variant))

@@ -502,3 +502,15 @@ def test_act_quant_rows_sequential_recompute_of_boundary_columns(msq, O, monkeyp
             b, _ = msq.qlinear.act_quant(x, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1)
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (K, x.dtype)
             assert (b.float().cpu().numpy() == Xo).all(), (K, x.dtype)
+
+
+def test_act_quant_on_a_view_at_an_odd_storage_offset(msq):
+    """A contiguous bf16 / fp32 view that starts 2 / 4 bytes into its storage: the kernels read 16-byte pieces, the wrapper re-aligns."""
+    for dt in (torch.bfloat16, torch.float32):
+        base = torch.randn(8 * 256 + 1, device=dev()).to(dt)
+        x = base[1:].view(8, 256)
+        assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+        for variant, sd in ((0, 2), (1, 5)):
+            a, sa = msq.qlinear.act_quant(x, 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant)
+            b, sb = msq.qlinear.act_quant(x.clone(), 8, 8, "fp8_e4m3", "fp8_e4m3", sd, 32, "nearest", False, variant)
+            assert int(sa.item()) == int(sb.item()) == 0 and torch.equal(a.view(torch.int16), b.view(torch.int16))
