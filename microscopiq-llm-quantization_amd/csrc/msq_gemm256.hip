@@ -35,7 +35,8 @@
 #ifndef MSQ_Q256_ABL
 #define MSQ_Q256_ABL 0
 /* timing experiments (results are wrong by construction; scripts/experiments/build_q256.sh): 1 no activation-fragment reads, 2 no converts,
-   4 no packed / scale loads, 8 no activation staging, 16 no barrier, 32 no output stores, 64 no MFMAs */
+   4 no packed / scale loads, 8 no activation staging, 16 no barrier, 32 no output stores, 64 no MFMAs, 128 the barrier's vmcnt lets
+   seven more ops stay in flight, 256 no vmcnt wait in front of the barrier */
 #endif
 #ifndef MSQ_Q256_RT
 #define MSQ_Q256_RT 4          /* row tiles per XCD super-tile (see the block order in the kernel) */
@@ -220,7 +221,8 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     {                                                                                                              \
         _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) {                                                        \
             if ((HS1) && mf == BAR_G) {                                                                            \
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));   /* vmcnt(N_WAIT) only */ \
+                constexpr int NW_ = N_WAIT + ((MSQ_Q256_ABL & 128) ? 7 : 0);      /* (timing experiment: the previous step's trailing ops may stay in flight) */ \
+                if (!(MSQ_Q256_ABL & 256)) __builtin_amdgcn_s_waitcnt(0x0F70 | (NW_ & 15) | ((NW_ >> 4) << 14));   /* vmcnt(N_WAIT) only */ \
                 if (!(MSQ_Q256_ABL & 16)) __builtin_amdgcn_s_barrier();                                            \
             }                                                                                                      \
             uint32_t cv_ = 0, cv2_ = 0;                                                                            \
