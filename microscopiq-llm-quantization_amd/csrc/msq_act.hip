@@ -223,7 +223,7 @@ k_act_quant(const float* __restrict__ X, uint16_t* __restrict__ Xq, OutlierArgs 
 // exactly as k_mxops_stats_rows does (msq_quant.hip: torch's cascade order for the fp32 mean -- sixteen-block runs summed from zero,
 // folded in order; the std as a two-pass variance in double, rounded to float only when it provably lies on the same side of the
 // rounding boundary as torch's sequential Welford result, else redone sequentially), then runs the
-// quantiser of the kernel above over the row (64 blocks per round, from L2: the wave has just read it).  X leaves HBM once (4 B in, 2 B out per element) and the two launches
+// quantiser of the kernel above over the row (64 blocks per round, handed over through a 9 KB LDS tile).  X is read once (4 B in, 2 B out per element) and the two launches
 // (statistics, quantiser) become one: [2048, 4096] fp32 35.0 -> see profiles/r04_side_kernels.txt.
 // Lane (j, q), j = lane / LPB, q = lane % LPB, LPB = BS / 4: columns 4 q ... 4 q + 3 of the blocks of run j (blocks 16 j ... 16 j + 15).
 // ---------------------------------------------------------------------------
@@ -245,9 +245,9 @@ k_act_quant_rows(const float* __restrict__ X, uint16_t* __restrict__ Xq, Outlier
     const float* rowf = X + p * A.axis_len;
     const uint16_t* rowh = reinterpret_cast<const uint16_t*>(X) + p * A.axis_len;
     int status = 0;
+    float4 v[16];                                                   // the lane's part of the row: live until its round of the quantiser
     {
         // ---- the row: 16 x 16 bytes per lane, all requested before the first use
-        float4 v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {          // (unconditional loads: a load under a lane-dependent branch is waited for at the join)
             int blk = 16 * j + i; blk = blk < nblk ? blk : nblk - 1;
@@ -364,36 +364,16 @@ k_act_quant_rows(const float* __restrict__ X, uint16_t* __restrict__ Xq, Outlier
     const float* vs = tab[wv][1];
     float tlo, thi;
     { const int l = lane < BS ? lane : 0; const float ks = A.k * vs[l]; tlo = vm[l] - ks; thi = vm[l] + ks; }
-    // ---- the quantiser of k_act_quant over the row, 64 blocks at a time (the row comes from L2 now: this wave has just read it)
+    // ---- the quantiser of k_act_quant over the row, 64 blocks at a time, fed from the registers that hold the row
     for (int b0 = 0; b0 < nblk; b0 += 64) {
         const int nb = nblk - b0 < 64 ? nblk - b0 : 64;             // blocks of this round
         const int blk = b0 + lane;
         float a[BS];
-        if (XBF16) {
-            const uint4* s8 = reinterpret_cast<const uint4*>(rowh + (int64_t)b0 * BS);
-            uint4 u8[BS / 8];
+        // the 64 blocks of this round are the runs 4 r .. 4 r + 3: their lanes put their registers into the tile (block-major rows)
+        if ((j >> 2) == (b0 >> 6)) {
 #pragma unroll
-            for (int t = 0; t < BS / 8; ++t) { const int f = lane + 64 * t; u8[t] = s8[f < nb * (BS / 8) ? f : 0]; }
-#pragma unroll
-            for (int t = 0; t < BS / 8; ++t) {
-                const int f = lane + 64 * t;
-                if (f < nb * (BS / 8)) {
-                    const uint4 u = u8[t];
-                    float* d = tl + (f / (BS / 8)) * STRIDE + (f % (BS / 8)) * 8;
-                    *reinterpret_cast<float4*>(d) = make_float4(u2f(u.x << 16), u2f(u.x & 0xFFFF0000u), u2f(u.y << 16), u2f(u.y & 0xFFFF0000u));
-                    *reinterpret_cast<float4*>(d + 4) = make_float4(u2f(u.z << 16), u2f(u.z & 0xFFFF0000u), u2f(u.w << 16), u2f(u.w & 0xFFFF0000u));
-                }
-            }
-        } else {
-            const float4* src = reinterpret_cast<const float4*>(rowf + (int64_t)b0 * BS);
-            float4 u4[BS / 4];
-#pragma unroll
-            for (int t = 0; t < BS / 4; ++t) { const int f = lane + 64 * t; u4[t] = src[f < nb * (BS / 4) ? f : 0]; }
-#pragma unroll
-            for (int t = 0; t < BS / 4; ++t) {
-                const int f = lane + 64 * t;
-                if (f < nb * (BS / 4)) *reinterpret_cast<float4*>(tl + (f / (BS / 4)) * STRIDE + (f % (BS / 4)) * 4) = u4[t];
-            }
+            for (int i = 0; i < 16; ++i)
+                if (i < len) *reinterpret_cast<float4*>(tl + (16 * (j & 3) + i) * STRIDE + 4 * q) = v[i];
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
