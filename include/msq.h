@@ -249,6 +249,17 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 #define MSQ_KERNEL_T256    2
 #define MSQ_KERNEL_T128    3
 int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf);
+/* Schedule of the persistent fused GEMM k_qgemm256p (csrc/msq_gemm256p.hip) for a shape -- host arithmetic only, no device needed; for tests
+ * and capacity planning.  The T = ceil(M / 256) (N / 256) output tiles are dealt to P resident workgroups (one per CU; cus = CU count,
+ * 0 = 256): `full` = T / P whole rounds, and the R = T - full P tiles of the part-filled last round as a stream of R (K / 64) K-steps cut
+ * into runs of q K-steps, one run per workgroup (stream-K); a tile cut between runs is summed through 256 KiB fp32 slots in the
+ * workspace: ws_bytes = 4096 + 262144 per run, 0 when no tile is cut.  Returns 0, or -1 when the kernel does not apply (N % 256, K % 128).
+ * No reference counterpart (the reference has one dense F.linear, number_system/mx/linear.py:91). */
+int msq_qgemm256p_plan(int64_t M, int64_t N, int64_t K, int cus, int* P, int* full, int* R, int* q, int64_t* ws_bytes);
+/* The work list of workgroup b under such a plan (KT = K / 64): up to `cap` segments, 6 ints each {tile id, first K-step, end K-step, role,
+ * first peer, last peer}; role 0 = writes Y, 1 = leaves its fp32 partial tile in workspace slot b, 2 = adds the slots of workgroups
+ * peer0 .. peer1 (in that order) and writes Y.  Returns the number of segments.  The same code runs on the device. */
+int msq_qgemm256p_segments(int b, int P, int full, int R, int KT, int q, int* out, int cap);
 int msq_qlinear_bf16(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream);

@@ -1471,11 +1471,14 @@ static int pick_kc(int64_t N, int64_t K) {
     return (int)kc;
 }
 
+static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes);
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
     if (use_gemv(M, N, K)) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }
     const int ks = pick_ksplit(M, N, K);
-    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+    int64_t w = ks > 1 ? (int64_t)ks * M * N * 4 : 0, wp = 0;
+    if (qp_rule(M, N, K, &wp) && wp > w) w = wp;                 // flag words + partial-tile slots of the persistent kernel's stream-K round
+    return w;
 }
 
 #ifndef MSQ_MX128_DEFAULT
@@ -1494,6 +1497,29 @@ int msq_launch_mxgemm256(int wf, const void* x_codes, const void* x_scales, cons
 #endif
 int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int mf, void* stream);   // msq_gemm256.hip
+// the persistent stream-K form (msq_gemm256p.hip): plan = host arithmetic of the schedule (0 = applies) and the workspace it needs
+int msq_qgemm256p_plan(int64_t M, int64_t N, int64_t K, int cus, int* P, int* full, int* R, int* q, int64_t* ws_bytes);
+int msq_launch_qgemm256p(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
+                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* workspace, void* stream);
+#ifndef MSQ_QP_DEFAULT
+#define MSQ_QP_DEFAULT 0       /* 1: k_qgemm256p where qp_rule() prefers it */
+#endif
+// MSQ_GEMM_256 (tuning and A / B, read per call): 0 = k_qgemm3 only, 1 / 2 = force the 256- / 128-row form of k_qgemm256, 3 = force the
+// persistent kernel wherever its plan applies, unset = the rules
+static int q256_forced_env() { const char* e = getenv("MSQ_GEMM_256"); return e ? atoi(e) : -1; }
+// persistent kernel for this shape?  (M > 64: the decode kernels come first)
+static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes) {
+    int64_t wsb = 0;
+    if (ws_bytes) *ws_bytes = 0;
+    const int forced = q256_forced_env();
+    if (forced >= 0 && forced != 3) return false;
+    if (forced < 0 && !MSQ_QP_DEFAULT) return false;
+    if (msq_qgemm256p_plan(M, N, K, 0, nullptr, nullptr, nullptr, nullptr, &wsb)) return false;
+    const int64_t b256 = ((M + 255) / 256) * (N / 256);
+    if (forced < 0 && b256 < 96) return false;                  // small grids: k_qgemm3's 64-row blocks and split-K
+    if (ws_bytes) *ws_bytes = wsb;
+    return true;
+}
 // The rule itself (also behind msq_qlinear_kernel_choice): wave-tile height of the hand-allocated kernel for a prefill-size grid, 0 = k_qgemm3.
 static int q256_rule(int64_t M, int64_t N, int out_kind) {
     const int64_t b256 = ((M + 255) / 256) * (N / 256), b128 = ((M + 127) / 128) * (N / 256);
@@ -1603,8 +1629,13 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     // 256-row wave tiles with hand-placed AGPR accumulators (k_qgemm256, msq_gemm256.hip): one wave per SIMD, half the converts and
     // packed loads per MFMA; and its 128-row form (MF = 8).
     {
-        const char* e256 = getenv("MSQ_GEMM_256");                  // read per call (tests and A/B scripts flip it inside one process)
-        const int q256_forced = e256 ? atoi(e256) : -1;
+        const int q256_forced = q256_forced_env();                  // read per call (tests and A/B scripts flip it inside one process)
+        int64_t qp_ws = 0;
+        if (unified && !x_f16 && qp_rule(M, N, K, &qp_ws) && (qp_ws == 0 || (workspace && workspace_bytes >= qp_ws))) {
+            const int e = msq_launch_qgemm256p(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, workspace, stream);
+            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(persistent 256-row tiles, k_qgemm256p): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+            return MSQ_OK;
+        }
         // Default rule (measured: profiles/r04_q128_sweep.txt, 13 values of M x the four Llama-2-7B projections x both outlier formats): a
         // cost in rounds of the grid over the 256 CUs.  256-row blocks run one per CU (r16 rounds); 128-row blocks run two per CU, each
         // pair about as long as one 256-row block (r8x2 half-rounds, times 1.07 with posit outliers -- their longer convert chain hides
