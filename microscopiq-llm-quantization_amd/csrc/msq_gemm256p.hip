@@ -440,7 +440,9 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
             for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)                      // straight from the accumulator file (no copy through VGPRs: the K-loop's registers stay live)
-                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "a"(acc[i][j]), "v"(lane16), "s"(sr), "s"((wid * 64 + i * 4 + j) * 1024) : "memory");
+                    // (s_nop 4: hipcc may have just written the descriptor / offset SGPRs with v_readlane or v_readfirstlane, and pads no
+                    // hazard inside an asm statement: without it the store can go out with the previous offset)
+                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "a"(acc[i][j]), "v"(lane16), "s"(sr), "s"((wid * 64 + i * 4 + j) * 1024) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
             __syncthreads();                                     // ... before ONE lane signals for the block
             if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
