@@ -104,7 +104,7 @@ MSQ_D void tile_coords(int bid, int MT, int NTB, int& bm, int& bn) {
 // between register files at every join of the control flow).  `qbase` = first quad of this half (h * 32).
 template <typename YT>
 MSQ_D void store_half_tile(const f32x4_t (&acc)[8][4], char* wsm, __amdgpu_buffer_rsrc_t yr, int row0, int N,
-                           const float (&bv)[4][4], int lane, int y16, uint64_t slots, int peer0, int peer1, int wid, int qbase) {
+                           const float (&bv)[4][4], int lane, int y16, uint64_t slots, int peer0, int peer1, int wid, int qbase, u32x4_t (&pf)[8]) {
     const int c = lane & 15, g = lane >> 4;
     constexpr int ROW_B = 64 * (int)sizeof(YT);
     constexpr int RP = 8192 / ROW_B;
@@ -119,14 +119,23 @@ MSQ_D void store_half_tile(const f32x4_t (&acc)[8][4], char* wsm, __amdgpu_buffe
             f32x4_t v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = acc[p * MF_PER_PASS + sp * 2 + (k >> 2)][k & 3];
-            for (int pb = peer0; pb <= peer1; ++pb) {        // (no iteration unless this is a head piece)
-                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(slots + (uint64_t)pb * 262144ull), 0, 262144u, 0x00020000);
-                u32x4_t pv[8];
+            if (peer1 >= peer0) {                            // head piece: add the peers' partial tiles, in block order
+                const int sidx = (qbase >> 3) + p * (QP / 8) + sp;       // this batch of eight quads within the wave's 64
+                for (int pb = peer0; pb <= peer1; ++pb) {
+                    // the batch in `pf` was loaded one step ago; fetch the next one (next peer of this batch, else the first peer of the
+                    // next batch) before this one is added: sixteen 1 KiB loads in flight per wave instead of eight
+                    const bool more = pb < peer1;
+                    const int pbn = more ? pb + 1 : peer0, sn = more ? sidx : sidx + 1;
+                    const __amdgpu_buffer_rsrc_t srn = __builtin_amdgcn_make_buffer_rsrc((void*)(slots + (uint64_t)pbn * 262144ull), 0, 262144u, 0x00020000);
+                    u32x4_t nx[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    pv[k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sr, lane * 16, (wid * 64 + qbase + p * QP + sp * 8 + k) * 1024, 16));
+                    for (int k = 0; k < 8; ++k)
+                        nx[k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(srn, lane * 16, (wid * 64 + sn * 8 + k) * 1024, 16));
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += __builtin_bit_cast(f32x4_t, pv[k]);
+                    for (int k = 0; k < 8; ++k) v[k] += __builtin_bit_cast(f32x4_t, pf[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pf[k] = nx[k];
+                }
             }
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
@@ -197,8 +206,12 @@ __host__ __device__ inline Seg seg_get(int i, int b, int P, int full, int R, int
         lenB = u1 - u0 - lenA;
         nsk = 1 + (lenB > 0 ? 1 : 0);
     }
-    if (i >= nsk) { s.tile = b + (i - nsk) * P; s.kt0 = 0; s.kt1 = KT; s.role = 0; s.peer0 = 0; s.peer1 = -1; return s; }
-    if (i == 0) { s.tile = full * P + sA; s.kt0 = ka0; s.kt1 = ka0 + lenA; }
+    // order: the tail piece (if the run starts inside a tile) FIRST, the whole tiles, the piece that starts a tile LAST -- the partial
+    // tile a head piece needs was then written a whole round of tiles earlier by its neighbour
+    const int nfirst = (nsk > 0 && ka0 > 0) ? 1 : 0;
+    if (i >= nfirst && i < nfirst + full) { s.tile = b + (i - nfirst) * P; s.kt0 = 0; s.kt1 = KT; s.role = 0; s.peer0 = 0; s.peer1 = -1; return s; }
+    const bool pieceA = (i < nfirst) || (nfirst == 0);           // (a run that starts on a tile boundary has one piece: A)
+    if (pieceA) { s.tile = full * P + sA; s.kt0 = ka0; s.kt1 = ka0 + lenA; }
     else { s.tile = full * P + sA + 1; s.kt0 = 0; s.kt1 = lenB; }
     s.peer0 = 0; s.peer1 = -1;
     if (s.kt0 > 0) s.role = 1;
@@ -402,7 +415,7 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
 
     gu32* flags = (gu32*)ws;                                     // P flag words (zeroed by the launcher), then the partial-tile slots
     char* slots = ws + 4096;
-    int abuf = 0;
+    int abuf = 0, pend = 0;
     for (int si = 0; si < nseg; ++si) {
         // the segment after this one (its first two K-steps are fetched by this segment's last two)
         uint64_t xb_n = xb; uint32_t xn_n = xn; int trow_n = trow, ktn0 = kt1 - 2;
@@ -418,6 +431,10 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
             int kt = kt0;
             QP_KSTEP(kt, true, N_WAIT_FIRST, pk1, pk0, pk2, pk1)
             QP_KSTEP(kt + 1, false, N_WAIT, pk3, pk2, pk0, pk3)
+            if (pend) {                                          // the previous segment's partial tile: every wave's stores are behind a vmcnt(N_WAIT) + barrier now
+                if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = 0;
+            }
             for (kt += 2; kt < kt1; kt += 2) {
                 QP_KSTEP(kt, false, N_WAIT, pk1, pk0, pk2, pk1)
                 QP_KSTEP(kt + 1, false, N_WAIT, pk3, pk2, pk0, pk3)
@@ -434,18 +451,24 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
         const int4 tl = lds_read16(tab_addr + si * 32), th = lds_read16(tab_addr + si * 32 + 16);
         const int m0 = sgpr(tl.x), n0 = sgpr(tl.y), role = sgpr(th.x), peer0 = sgpr(th.y), peer1 = sgpr(th.z);
         if (role == 1) {
-            // tail piece: the accumulators go to this block's slot, lane-linear (1 KiB per wave instruction), write-through
+            // tail piece: the accumulators go to this block's slot, lane-linear (1 KiB per wave instruction), write-through (sc1).  The
+            // stores are NOT waited for here: the flag that publishes them is stored behind the second barrier of the next segment,
+            // whose vmcnt(N_WAIT) retires every older operation of every wave -- unless this is the block's last segment.
             const __amdgpu_buffer_rsrc_t sr = rsrc_of((uint64_t)slots + (uint64_t)b * 262144ull, 262144u);
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int i = 0; i < MF; i += 2) {
+                __builtin_amdgcn_sched_barrier(0);               // eight quads through VGPRs at a time (the K-loop's registers stay live)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)                      // straight from the accumulator file (no copy through VGPRs: the K-loop's registers stay live)
-                    // (s_nop 4: hipcc may have just written the descriptor / offset SGPRs with v_readlane or v_readfirstlane, and pads no
-                    // hazard inside an asm statement: without it the store can go out with the previous offset)
-                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "a"(acc[i][j]), "v"(lane16), "s"(sr), "s"((wid * 64 + i * 4 + j) * 1024) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
-            __syncthreads();                                     // ... before ONE lane signals for the block
-            if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i + (k >> 2)][k & 3]), sr, lane16, (wid * 64 + i * 4 + k) * 1024, 16);
+            }
+            pend = 1;
+            if (si + 1 == nseg) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its stores ...
+                __syncthreads();                                 // ... before ONE lane signals for the block
+                if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = 0;
+            }
         } else {
             if (role == 2) {
                 if (tid == 0) {                                  // one lane polls one word per peer (bounded: a missing producer shows as a wrong tile, not a hang)
@@ -461,6 +484,14 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
             const int rows = (M - m0 < BM) ? M - m0 : BM;
             const uint64_t yb = (uint64_t)Y + ((uint64_t)m0 * (uint64_t)N + (uint64_t)(n0 + wid * 64)) * sizeof(YT);
             const __amdgpu_buffer_rsrc_t yr = rsrc_of(yb, (uint32_t)rows * (uint32_t)N * (uint32_t)sizeof(YT));
+            u32x4_t pf[8];                                       // head piece: the batch of partial quads fetched ahead (store_half_tile)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pf[k] = u32x4_t{0u, 0u, 0u, 0u};
+            if (role == 2) {
+                const __amdgpu_buffer_rsrc_t sr0 = rsrc_of((uint64_t)slots + (uint64_t)peer0 * 262144ull, 262144u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pf[k] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sr0, lane16, (wid * 64 + k) * 1024, 16));
+            }
             float bv[4][4];
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
@@ -476,7 +507,7 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
-                store_half_tile<YT>(acch, epi, yr, h * 128, N, bv, lane, y16, (uint64_t)slots, peer0, peer1, wid, h * 32);
+                store_half_tile<YT>(acch, epi, yr, h * 128, N, bv, lane, y16, (uint64_t)slots, peer0, peer1, wid, h * 32, pf);
             }
         }
         // next segment
