@@ -301,7 +301,8 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
 #pragma unroll
     for (int h = 0; h < MF / 8; ++h) {                           // 128 rows at a time through the wave's 8 KiB slice
         const f32x4_t (&acch)[8][4] = *reinterpret_cast<const f32x4_t (*)[8][4]>(&acc[h * 8]);
-        store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
+        if (MSQ_EPI_DIRECT) store_wave_tile_direct<YT>(acch, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
+        else store_wave_tile_lds<YT>(acch, smem + wid * 8192, Y, m0 + h * 128, n0 + wid * 64, M, N, bias, lane, y16);
     }
 }
 

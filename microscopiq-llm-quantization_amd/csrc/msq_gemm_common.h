@@ -336,3 +336,73 @@ MSQ_D void store_wave_tile_lds(const f32x4_t (&acc)[NMF][4], char* wsm, YT* __re
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// ---------------------------------------------------------------------------
+// The same epilogue WITHOUT the trip through LDS (16-bit outputs): v_permlane16_swap_b32 exchanges, between two accumulator quads of
+// one row fragment, the odd 16-lane rows of one with the even rows of the other -- afterwards every lane holds 8 consecutive n of
+// its output row (16 bytes): lanes g = 0 / 2 the halves of quad a's 16 columns, lanes g = 1 / 3 those of quad b.  One 16-byte store
+// per quad pair writes 16 rows x 64 contiguous bytes (the pair's two stores cover the row's 128-byte line back to back); per tile
+// and wave 64 swaps replace 64 ds_write_b64 + 32 ds_read_b128 and their waits.  fp32 outputs already hold 16 bytes per lane.
+// Results are the same bits as store_wave_tile_lds.  With `bias == nullptr` the 256 additions of zero are not issued.
+// ---------------------------------------------------------------------------
+#ifndef MSQ_EPI_DIRECT
+#define MSQ_EPI_DIRECT 1     /* 0: the LDS-transposed epilogue (A / B) */
+#endif
+template <typename YT, int NMF, bool BIAS>
+MSQ_D void store_wave_tile_direct_(const f32x4_t (&acc)[NMF][4], YT* __restrict__ Y, int m_base, int n_base, int M, int N,
+                                   const float* __restrict__ bias, int lane, int y16) {
+    const int c = lane & 15, g = lane >> 4;
+    float bv[4][4];
+    if (BIAS) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const float4 t = *reinterpret_cast<const float4*>(bias + n_base + nf * 16 + g * 4);
+            bv[nf][0] = t.x; bv[nf][1] = t.y; bv[nf][2] = t.z; bv[nf][3] = t.w;
+        }
+    }
+    // this lane's column within the wave's 64 for pair (a, b = a + 1): even g -> quad a, columns 4 g .. 4 g + 7; odd g -> quad b, 4 (g - 1) ..
+    const int colp = (g & 1) ? 16 + (g - 1) * 4 : g * 4;
+#pragma unroll
+    for (int mf = 0; mf < NMF; ++mf) {
+        const int m = m_base + mf * 16 + c;
+        char* rowp = reinterpret_cast<char*>(Y) + ((int64_t)m * N + n_base) * (int64_t)sizeof(YT);
+        if (sizeof(YT) == 4) {
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                f32x4_t v = acc[mf][nf];
+                if (BIAS) { v[0] += bv[nf][0]; v[1] += bv[nf][1]; v[2] += bv[nf][2]; v[3] += bv[nf][3]; }
+                if (m < M) *reinterpret_cast<float4*>(rowp + (nf * 16 + g * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a += 2) {
+                uint32_t d[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4_t v = acc[mf][a + q];
+                    if (BIAS) { v[0] += bv[a + q][0]; v[1] += bv[a + q][1]; v[2] += bv[a + q][2]; v[3] += bv[a + q][3]; }
+                    if (y16) {
+                        f16x2_t lo, hi;
+                        lo[0] = (_Float16)v[0]; lo[1] = (_Float16)v[1]; hi[0] = (_Float16)v[2]; hi[1] = (_Float16)v[3];
+                        d[q][0] = __builtin_bit_cast(uint32_t, lo); d[q][1] = __builtin_bit_cast(uint32_t, hi);
+                    } else {
+                        bf16x2_t lo, hi;
+                        lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+                        d[q][0] = __builtin_bit_cast(uint32_t, lo); d[q][1] = __builtin_bit_cast(uint32_t, hi);
+                    }
+                }
+                // odd rows of quad a's dwords <-> even rows of quad b's
+                const auto r0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+                const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+                if (m < M) *reinterpret_cast<u32x4_t*>(rowp + (a * 16 + colp) * 2) = o;
+            }
+        }
+    }
+}
+template <typename YT, int NMF = 8>
+MSQ_D void store_wave_tile_direct(const f32x4_t (&acc)[NMF][4], YT* __restrict__ Y, int m_base, int n_base, int M, int N,
+                                  const float* __restrict__ bias, int lane, int y16 = 0) {
+    if (bias) store_wave_tile_direct_<YT, NMF, true>(acc, Y, m_base, n_base, M, N, bias, lane, y16);
+    else store_wave_tile_direct_<YT, NMF, false>(acc, Y, m_base, n_base, M, N, bias, lane, y16);
+}
