@@ -181,4 +181,68 @@ for nm in re.findall(r'^(_ZN\S*k_mxgemm256\S*):', s3, re.M):
     print(("!! " if flag else "   ") + "%-48s K-loop: mfma %4d  v_accvgpr %d  scratch %d  in-place %s  vmcnt over %s"
           % (nm[-48:], sum(1 for l in code if l.startswith('v_mfma')), acc, scr, inplace, over))
     bad += 1 if flag else 0
+
+# ---- k_qgemm256p (csrc/msq_gemm256p.hip): the persistent form.  Its K-steps appear four times (the two peeled first K-steps of a segment and
+# the loop's two); per kernel: no v_accvgpr_* / scratch / SGPR-spill lane traffic inside any K-step; every MFMA accumulates in place (srcC = vdst,
+# or the literal 0 in the first half-step of a segment); the vmcnt in front of each K-step barrier is at most the vector-memory ops the
+# step issued in front of it -- plus, in a segment's FIRST K-step only, the epilogue's global stores (32 per wave for 16-bit outputs; 63 =
+# the counter's width for fp32) -- and every K-step issues the SAME number of them (a compiler that deletes or adds one changes what the
+# hand-written count means: advisor, round 4).
+srcp = os.path.join(HERE, "..", "microscopiq-llm-quantization_amd", "csrc", "msq_gemm256p.hip")
+outp = os.path.join(tempfile.gettempdir(), "msq_gemm256p_check.s")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+                       "--cuda-device-only", "-S", srcp, "-o", outp] + sys.argv[1:], stderr=subprocess.DEVNULL)
+sp = open(outp).read()
+for nm in re.findall(r'^(_ZN\S*k_qgemm256p\S*):', sp, re.M):
+    i = sp.index('\n' + nm + ':'); j = sp.index('s_endpgm', i)
+    lines = [l.strip() for l in sp[i:j].split('\n')]
+    code = [l for l in lines if l and not l.startswith(';')]
+    f32out = 'EfEE' in nm
+    vm = lambda l: l.startswith('buffer_load')            # (the one global_store in a K-step interval is the deferred flag of a tail piece, on a branch)
+    # cut the stream at barriers; a K-step segment = one that holds >= 120 MFMAs (a K-step's groups in front of its barrier)
+    segs, cur = [], {"mfma": 0, "vm": 0, "wait": None, "acc": 0, "scr": 0, "lane": 0, "bad_mfma": 0, "c0": 0}
+    for l in code:
+        if l.startswith('v_mfma'):
+            cur["mfma"] += 1
+            m = re.match(r'v_mfma_f32_16x16x32_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (\S+)$', l)
+            if not m or (m.group(2) != m.group(1) and m.group(2) != '0'):
+                cur["bad_mfma"] += 1
+            elif m.group(2) == '0':
+                cur["c0"] += 1
+        elif vm(l):
+            cur["vm"] += 1
+        elif l.startswith('s_waitcnt') and 'vmcnt' in l and 'lgkmcnt' not in l:
+            cur["wait"] = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
+        elif l.startswith('v_accvgpr'):
+            cur["acc"] += 1
+        elif l.startswith('scratch_'):
+            cur["scr"] += 1
+        elif l.startswith('v_readlane') or l.startswith('v_writelane'):
+            cur["lane"] += 1
+        elif l.startswith('s_barrier'):
+            segs.append(cur); cur = {"mfma": 0, "vm": 0, "wait": None, "acc": 0, "scr": 0, "lane": 0, "bad_mfma": 0, "c0": 0}
+    ksteps = [x for x in segs if x["mfma"] >= 120]
+    # the first peeled K-step follows the epilogue / prologue in the same barrier interval: its own ops are the steady count
+    steady = [x for x in ksteps if x["c0"] == 0]
+    first = [x for x in ksteps if x["c0"] > 0]
+    nvm = sorted(set(x["vm"] for x in steady))
+    problems = []
+    if len(ksteps) != 4 or len(first) != 1 or first[0]["c0"] != 64:
+        problems.append("K-step count %d (first %d, C=0 MFMAs %s)" % (len(ksteps), len(first), [x["c0"] for x in first]))
+    if len(nvm) != 1:
+        problems.append("vector-memory ops per K-step differ: %s" % nvm)
+    for x in steady:
+        if x["acc"] or x["scr"] or x["lane"] or x["bad_mfma"]:
+            problems.append("K-step: v_accvgpr %d scratch %d lane %d foreign MFMA %d" % (x["acc"], x["scr"], x["lane"], x["bad_mfma"]))
+        if x["wait"] is None or x["wait"] > x["vm"]:
+            problems.append("K-step: vmcnt(%s) with %d ops issued" % (x["wait"], x["vm"]))
+    for x in first:
+        if x["bad_mfma"]:
+            problems.append("first K-step: foreign MFMA %d" % x["bad_mfma"])
+        cap = 63 if f32out else (nvm[0] if nvm else 0) + 32      # (vmcnt(63) = the counter's width: the assembler prints no wait; 64 younger stores retire everything older)
+        if (x["wait"] is None and not f32out) or (x["wait"] is not None and x["wait"] > min(63, cap)):
+            problems.append("first K-step: vmcnt(%s) over %d" % (x["wait"], cap))
+    print(("!! " if problems else "   ") + "%-44s K-steps %d  vm ops per K-step %s  waits %s  first-step wait %s  %s"
+          % (nm[-44:], len(ksteps), nvm, sorted(set(x["wait"] for x in steady)), [x["wait"] for x in first], "; ".join(problems)))
+    bad += 1 if problems else 0
 sys.exit(1 if bad else 0)

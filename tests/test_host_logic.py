@@ -492,3 +492,53 @@ def test_kernel_choice_rule_for_llama_shapes():
     assert [ch(2048, N, K, 0, 1) for N, K in layer] == [T256, G128, T256, G128]               # e4m3 operand: never the 128-row form
     assert ch(512, 22016, 4096, 0, 1) == T256 and ch(1, 22016, 4096, 0, 0) == DEC
     assert ch(2048, 16384 + 64, 4096, U8X) < 0 and ch(2048, 16384, 4096 + 64, 0, 0) < 0 and ch(0, 256, 64, U8X) < 0
+
+
+def test_persistent_kernel_schedule_covers_every_k_step_once():
+    """msq_qgemm256p_plan / msq_qgemm256p_segments (host logic, the same arithmetic the device runs, csrc/msq_gemm256p.hip): for the
+    Llama-2-7B projections (llm/llama.py:226-256 shapes), ragged and tiny shapes and other CU counts -- every (tile, K-step) belongs to
+    exactly one segment of one block; segments are whole pairs of K-steps; a tile that is cut has ONE head piece (K-step 0 onward, role 2)
+    whose peer list names, in block order, exactly the blocks that hold its other pieces (role 1), and a tail piece is always the FIRST
+    segment of its block (so no block waits for a block that waits); the workspace covers one slot per block that can hold a tail piece."""
+    import msq
+    L = msq._lib.lib()
+
+    def plan(M, N, K, cus=0):
+        v = [ctypes.c_int(0) for _ in range(4)]
+        ws = ctypes.c_int64(0)
+        rc = L.msq_qgemm256p_plan(M, N, K, cus, *[ctypes.byref(x) for x in v], ctypes.byref(ws))
+        return rc, [x.value for x in v], ws.value
+
+    buf = (ctypes.c_int * (6 * 300))()
+    shapes = [(2048, 16384, 4096), (2048, 12288, 4096), (2048, 4096, 4096), (2048, 22016, 4096), (2048, 4096, 11008), (300, 512, 256),
+              (256, 256, 384), (777, 16384, 4096), (513, 11008, 4096), (1000, 2304, 640), (256, 256, 8192), (8192, 16384, 4096),
+              (2048, 8192, 28672), (512, 22016, 4096), (130, 512, 1024)]
+    for (M, N, K), cus in [(s, 0) for s in shapes] + [((2048, 12288, 4096), 80), ((2048, 4096, 4096), 304)]:
+        rc, (P, full, R, q), ws = plan(M, N, K, cus)
+        assert rc == 0
+        KT, T = K // 64, ((M + 255) // 256) * (N // 256)
+        assert full * P + R == T and (R == 0 or (q % 2 == 0 and 2 <= q <= KT))
+        cover, pieces, tail_blocks = {}, {}, set()
+        for b in range(P):
+            n = L.msq_qgemm256p_segments(b, P, full, R, KT, q, buf, 300)
+            assert n <= 256
+            for i in range(n):
+                t, k0, k1, role, p0, p1 = [buf[i * 6 + j] for j in range(6)]
+                assert 0 <= t < T and 0 <= k0 < k1 <= KT and k0 % 2 == 0 and (k1 - k0) % 2 == 0
+                for k in range(k0, k1):
+                    assert (t, k) not in cover
+                    cover[(t, k)] = b
+                pieces.setdefault(t, []).append((k0, k1, role, b, p0, p1))
+                if role == 1:
+                    assert i == 0 and k0 > 0
+                    tail_blocks.add(b)
+        assert len(cover) == T * KT
+        for t, l in pieces.items():
+            l.sort()
+            if len(l) == 1:
+                assert l[0][:3] == (0, KT, 0)
+            else:
+                assert l[0][0] == 0 and l[0][2] == 2 and all(x[2] == 1 for x in l[1:])
+                assert [x[3] for x in l[1:]] == list(range(l[0][4], l[0][5] + 1))
+        assert (ws > 0) == bool(tail_blocks) and (not tail_blocks or ws >= 4096 + 262144 * (max(tail_blocks) + 1))
+    assert plan(2048, 16384 + 64, 4096)[0] != 0 and plan(2048, 16384, 4096 + 64)[0] != 0 and plan(0, 256, 128)[0] != 0
