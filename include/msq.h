@@ -248,7 +248,11 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 #define MSQ_KERNEL_GEMM128 1
 #define MSQ_KERNEL_T256    2
 #define MSQ_KERNEL_T128    3
+#define MSQ_KERNEL_PERSISTENT 4   /* k_qgemm256p: persistent 256-row blocks, stream-K over the part-filled last round (MSQ_GEMM_256=3) */
 int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf);
+/* The GEMM kernel instantiation the same call would launch, as text ("k_qgemm256<6, uint16_t, 16>"): the dispatcher's own decision function,
+ * tuning switches (MSQ_GEMM_256 / MSQ_MX_256) included; y_dtype 0 = float32 output, else 16-bit.  For measurement labels (bench.py). */
+int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf, int y_dtype, char* buf, int cap);
 /* Schedule of the persistent fused GEMM k_qgemm256p (csrc/msq_gemm256p.hip) for a shape -- host arithmetic only, no device needed; for tests
  * and capacity planning.  The T = ceil(M / 256) (N / 256) output tiles are dealt to P resident workgroups (one per CU; cus = CU count,
  * 0 = 256): `full` = T / P whole rounds, and the R = T - full P tiles of the part-filled last round as a stream of R (K / 64) K-steps cut

@@ -1536,6 +1536,32 @@ static int mx256_rule(int64_t M, int64_t N, int wf) {
     if (MSQ_MX256_DEFAULT && b256 > 128) return 16;
     return 0;
 }
+// The decision of the prefill-size dispatch in ONE place (dispatcher, msq_qlinear_kernel_choice, msq_qlinear_kernel_name): mf = 16 / 8 =
+// k_qgemm256 in its 256- / 128-row form, persistent = k_qgemm256p, neither = k_qgemm3.  Default rule: a cost in rounds of the grid over
+// the 256 CUs -- 256-row blocks run one per CU (r16 rounds); 128-row blocks two per CU, each pair about as long as one 256-row block
+// (r8x2 half-rounds, times 1.07 with posit outliers: their longer convert chain hides less well behind half the MFMAs); the 128-row form
+// wins where its finer granularity saves at least that (q/k/v 2048 x 12288: 1.5 against 2 rounds) and on the one-round grids of 144 ...
+// 256 blocks (o, down); k_qgemm3 keeps the small grids (64-row blocks, split-K).  `ws_bytes` = bytes of workspace the call may use.
+struct QFamily { int mf; bool persistent; };
+static QFamily q_family(int64_t M, int64_t N, int64_t K, bool unified_bf16x, int out_kind, int64_t ws_bytes) {
+    QFamily f = {0, false};
+    if (!unified_bf16x) return f;
+    const int forced = q256_forced_env();
+    int64_t qp_ws = 0;
+    if (qp_rule(M, N, K, &qp_ws) && ws_bytes >= qp_ws) { f.persistent = true; return f; }
+    const int mf_rule = q256_rule(M, N, out_kind);
+    if (forced == 2 || (forced < 0 && mf_rule == 8)) f.mf = 8;
+    else if (forced == 1 || forced == 3 || (forced < 0 && mf_rule == 16)) f.mf = 16;   // (3 without the persistent kernel's workspace: the 256-row form)
+    return f;
+}
+// k_mxgemm256 form for a shape (16 / 8 / 0 = k_mxgemm): mx256_rule and the MSQ_MX_256 switch (1 / 2 force the 256- / 128-row form, 0
+// disables both; read per call -- tests and A / B scripts flip it inside one process; not for concurrent use with setenv)
+static int mx256_family(int64_t M, int64_t N, int wf) {
+    const char* e256 = getenv("MSQ_MX_256");
+    const int forced = e256 ? atoi(e256) : -1;
+    const int mf_rule = mx256_rule(M, N, wf);
+    return (forced == 2 || (forced < 0 && mf_rule == 8)) ? 8 : ((forced == 1 || (forced != 0 && mf_rule == 16)) ? 16 : 0);
+}
 static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* out_plane, const void* scale_plane,
                      const float* bias, void* Y, int y_dtype, int64_t M, int64_t N, int64_t K, int block,
                      int in_kind, int out_kind, void* workspace, int64_t workspace_bytes, void* stream, int x_f16) {
@@ -1629,30 +1655,19 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     // 256-row wave tiles with hand-placed AGPR accumulators (k_qgemm256, msq_gemm256.hip): one wave per SIMD, half the converts and
     // packed loads per MFMA; and its 128-row form (MF = 8).
     {
-        const int q256_forced = q256_forced_env();                  // read per call (tests and A/B scripts flip it inside one process)
-        int64_t qp_ws = 0;
-        if (unified && !x_f16 && qp_rule(M, N, K, &qp_ws) && (qp_ws == 0 || (workspace && workspace_bytes >= qp_ws))) {
+        // Which hand-allocated kernel (msq_gemm256.hip / msq_gemm256p.hip), if any: q_family() -- the rule in rounds of the grid over the
+        // 256 CUs (measured: profiles/r04_q128_sweep.txt, 13 values of M x the four Llama-2-7B projections x both outlier formats), the
+        // MSQ_GEMM_256 switch (tuning and A / B) and the workspace the persistent kernel needs.  msq_qlinear_kernel_choice / _name report
+        // the same function's answer.
+        const QFamily qf = q_family(M, N, K, unified && !x_f16, out_kind, workspace ? workspace_bytes : 0);
+        if (qf.persistent) {
             const int e = msq_launch_qgemm256p(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, workspace, stream);
             if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(persistent 256-row tiles, k_qgemm256p): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
             return MSQ_OK;
         }
-        // Default rule (measured: profiles/r04_q128_sweep.txt, 13 values of M x the four Llama-2-7B projections x both outlier formats): a
-        // cost in rounds of the grid over the 256 CUs.  256-row blocks run one per CU (r16 rounds); 128-row blocks run two per CU, each
-        // pair about as long as one 256-row block (r8x2 half-rounds, times 1.07 with posit outliers -- their longer convert chain hides
-        // less well behind half the MFMAs).  The 128-row form wins where its finer granularity saves at least that (qkv 2048 x 12288: 1.5
-        // against 2 rounds; gate_up at M = 640: 1 against 2) and on the one-round grids of 144 ... 256 blocks (o, down); k_qgemm3 keeps
-        // the small grids (its 64-row blocks and split-K live there) and, with fp8 outliers at M > 512, the part-filled single round.
-        const int mf_rule = q256_rule(M, N, out_kind);              // 8, 16 or 0 (k_qgemm3)
-        const bool q128_default = mf_rule == 8, q256_default = mf_rule == 16;
-        // MSQ_GEMM_256=2 / 1 force the 128-row (MF = 8: two blocks per CU) / 256-row form of the kernel, 0 disables both -- tuning and A / B
-        if (unified && !x_f16 && (q256_forced == 2 || (q256_forced < 0 && q128_default))) {
-            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 8, stream);
-            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(128-row wave tiles, k_qgemm256<MF = 8>): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
-            return MSQ_OK;
-        }
-        if (unified && !x_f16 && (q256_forced == 1 || (q256_forced != 0 && q256_default))) {
-            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 16, stream);
-            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(256-row wave tiles, k_qgemm256): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+        if (qf.mf) {
+            const int e = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, qf.mf, stream);
+            if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(%d-row wave tiles, k_qgemm256<MF = %d>): %s", 16 * qf.mf, qf.mf, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
             return MSQ_OK;
         }
     }
@@ -1994,17 +2009,13 @@ static int mx_linear(int wf, const void* x_codes, const void* x_scales, const vo
     // two blocks per CU) for the grids 256-row blocks do not fill.  MSQ_MX_256=1 / 2 force the 256- / 128-row form, 0 disables both
     // (read per call: tests and A / B scripts flip it inside one process).  Default rule: the cost in rounds of msq_qlinear_bf16.
     {
-        const char* e256 = getenv("MSQ_MX_256");
-        const int forced256 = e256 ? atoi(e256) : -1;
         // measured (profiles/r04_mx128_sweep.txt): 256-row blocks win from 144 blocks on -- also on part-filled rounds, where k_mxgemm's
         // 128-row blocks run two per CU on part of the chip (M512 N22016: 43.6 against 59.7 us; e4m3 operand M1024 N22016: 95.3
         // against 114.8).  The 128-row form pays with the 16-byte MX-FP4 operand only, where a second round would be less than half
         // full (q/k/v 2048 x 12288, 384 blocks: 74.7 us against 88.4, k_mxgemm 79.5); with the 24- / 32-byte operands its two-deep
         // weight ring costs more than the saved half round (116.7 against 95.3), so those never take it.  One-round grids of <= 128
         // blocks of 256 rows (o, down at M = 2048) stay on k_mxgemm.
-        const int mf_rule = mx256_rule(M, N, wf);
-        const bool dflt128 = mf_rule == 8, dflt256 = mf_rule == 16;
-        const int mfsel = (forced256 == 2 || (forced256 < 0 && dflt128)) ? 8 : ((forced256 == 1 || (forced256 != 0 && dflt256)) ? 16 : 0);
+        const int mfsel = mx256_family(M, N, wf);                   // the rule + the MSQ_MX_256 switch (also behind msq_qlinear_kernel_choice)
         if (mfsel) {
             const int e = msq_launch_mxgemm256(wf, x_codes, x_scales, w_codes, w_scales, bias, Y, y_dtype, M, N, K, mfsel, stream);
             if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_mx_w4a8(k_mxgemm256, MF = %d): %s", mfsel, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
@@ -2108,14 +2119,32 @@ int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int
     if (mx_wf >= 0) {
         if (mx_wf > 3 || (K % 128)) return -1;
         if (use_mx_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
-        const int mf = mx256_rule(M, N, mx_wf);
+        const int mf = mx256_family(M, N, mx_wf);
         return mf == 16 ? MSQ_KERNEL_T256 : (mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128);
     }
     if (K % BK) return -1;
     if (use_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
-    if (out_kind != MSQ_PLANE_U8 && out_kind != MSQ_PLANE_U8X) return MSQ_KERNEL_GEMM128;
-    const int mf = q256_rule(M, N, out_kind);
-    return mf == 16 ? MSQ_KERNEL_T256 : (mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128);
+    const bool unified = out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X;
+    const QFamily f = q_family(M, N, K, unified, out_kind, msq_qlinear_workspace_bytes(M, N, K));
+    return f.persistent ? MSQ_KERNEL_PERSISTENT : (f.mf == 16 ? MSQ_KERNEL_T256 : (f.mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128));
+}
+// The kernel instantiation the same call launches for the GEMM itself, as text (bench.py's roofline.kernel): y_dtype 0 = float32 else 16-bit.
+int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf, int y_dtype, char* buf, int cap) {
+    if (!buf || cap < 1) return MSQ_ERR_BAD_ARG;
+    const int fam = msq_qlinear_kernel_choice(M, N, K, out_kind, mx_wf);
+    if (fam < 0) { buf[0] = 0; return MSQ_ERR_UNSUPPORTED; }
+    const char* yt = y_dtype == 0 ? "float" : "uint16_t";
+    if (mx_wf >= 0) {
+        if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_mxgemv<WF = %d>", mx_wf);
+        else if (fam == MSQ_KERNEL_GEMM128) snprintf(buf, cap, "k_mxgemm<%s, WF = %d>", yt, mx_wf);
+        else snprintf(buf, cap, "k_mxgemm256<%s, %d, %d>", yt, mx_wf, fam == MSQ_KERNEL_T256 ? 16 : 8);
+        return MSQ_OK;
+    }
+    if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_qgemv_u / k_qgemv<out kind %d>", out_kind);
+    else if (fam == MSQ_KERNEL_GEMM128) snprintf(buf, cap, "k_qgemm3<out kind %d, %s>", out_kind, yt);
+    else if (fam == MSQ_KERNEL_PERSISTENT) snprintf(buf, cap, "k_qgemm256p<%d, %s>", out_kind, yt);
+    else snprintf(buf, cap, "k_qgemm256<%d, %s, %d>", out_kind, yt, fam == MSQ_KERNEL_T256 ? 16 : 8);
+    return MSQ_OK;
 }
 
 }  // extern "C"
