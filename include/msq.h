@@ -123,6 +123,14 @@ int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t ax
 int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                                int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                                float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream);
+/* Both Python-path traits as switches.  py_exponent: the block's shared exponent is floor(torch.log2(max|A|)) in fp32
+ * (mx_ops.py:66-77 on the Python path) -- one HIGHER than the exponent field for the up to 88 largest floats under a power of two,
+ * where the native kernel (cpp/shared_exp.cuh:14-53) reads the field itself -- and, under round = "floor", the element's private
+ * exponent likewise (elemwise_ops.py:139-144).  py_divisor: as msq_quantize_mx_by_tile_py.  (0, 0) = msq_quantize_mx_by_tile,
+ * (1, 1) = msq_quantize_mx_by_tile_py; `_quantize_mx` of the package calls (its divisor switch, 1). */
+int msq_quantize_mx_by_tile_ex(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                               int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                               float elem_max_norm, int flush_fp32_subnorms, int rmode, int py_divisor, int py_exponent, void* stream);
 
 /* `_quantize_mx` (number_system/mx/mx_ops.py:332-457) on a HALF-PRECISION tensor, as the reference executes it: its native kernel
  * takes float32 only (cpp/mx.cu:124-125), so a Half / BFloat16 tensor runs the Python path op by op in the tensor dtype (ATen:

@@ -26,6 +26,7 @@ _SIGS = {
     "msq_quantize_mx": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_quantize_mx_by_tile": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_quantize_mx_by_tile_py": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "msq_quantize_mx_by_tile_ex": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp]),
     "msq_quantize_mx_lowp": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msq_reduce_sum_inner": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "msq_reduce_max_inner": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),

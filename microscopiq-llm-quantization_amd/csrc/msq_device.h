@@ -66,6 +66,19 @@ MSQ_HD int ilog2f_torch(float x) {
     return dist < K ? up : k;
 }
 
+// Biased exponent of a float as the reference's PYTHON path derives a block's shared exponent from it: floor(torch.log2(|v|)) + 127
+// (mx_ops.py:66-77 _shared_exponents on the block maximum; the maximum of this over a block = this of the maximum: it is monotone).
+// Only the 88 largest significands of a binade can round up to the next power of two (ilog2f_torch); zero / subnormals and Inf / NaN keep
+// their exponent field (the scale clamps swallow the former, the latter mark the block).  The reference's NATIVE kernels read the
+// exponent field alone (cpp/shared_exp.cuh:14-53): surfaces that replace those do not call this.
+MSQ_HD int biased_exp_py(uint32_t bits) {
+    const uint32_t u = bits & 0x7FFFFFFFu;
+    const int e = (int)(u >> 23);
+    if (e == 0 || e == 255 || (u & 0x7FFFFFu) < 0x7FFFA7u) return e;
+    const int t = ilog2f_torch(u2f(u)) + 127;
+    return t > 254 ? 254 : t;                        // (within 88 ulps of 2^128: no tensor holds such values; keep the block finite)
+}
+
 // ---------------------------------------------------------------------------
 // elemwise_ops.py:47-78 _round_mantissa + :84-174 _quantize_elemwise_core with
 // allow_denorm=True, saturate_normals=True (the only way MicroScopiQ calls it:

@@ -1,5 +1,5 @@
 // msq_mx.hip -- operand packing for the MX-native W4A8 GEMM (msq_gemm.hip k_mxgemm): plain OCP-MX block
-// quantisation (number_system/mx/mx_ops.py:332-457 _quantize_mx, native semantics cpp/mx.cuh / shared_exp.cuh,
+// quantisation (number_system/mx/mx_ops.py:332-457 _quantize_mx as its PYTHON path computes it: shared exponent = floor(torch.log2(max)),
 // block 32 along K, round to nearest = half away) emitting CODES + E8M0 scale bytes instead of fake-quant values:
 //   activations  X [M,K] f32 -> e4m3 codes [M][K] (row-major bytes) + scales [M][K/32]
 //   weights      W [N,K] f32 -> e2m1 codes in the operand order of v_mfma_scale_f32_16x16x128_f8f6f4
@@ -89,9 +89,13 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
         for (int b = 0; b < BS; ++b) a[b] = (g < nblocks) ? (XBF16 ? u2f((uint32_t)srch[g * BS + b] << 16) : src[g * BS + b]) : 0.f;
     }
     int status = 0;
-    int se = 0;
+    // shared exponent of the block as the reference's PYTHON path derives it -- floor(torch.log2(max|a|)), mx_ops.py:66-77: these
+    // operands stand in for `_quantize_mx` of the CPU fake-quant (custom_cuda = False) -- which is the exponent field of the maximum
+    // except just under a power of two (msq_device.h biased_exp_py)
+    uint32_t mbits_ = 0u;
 #pragma unroll
-    for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
+    for (int b = 0; b < BS; ++b) { const uint32_t t = f2u(a[b]) & 0x7FFFFFFFu; mbits_ = t > mbits_ ? t : mbits_; }
+    const int se = biased_exp_py(mbits_);
     const bool fl = (se == 0) && flush && !VAL;
     int sb = mx_scale_byte(se, FP4 ? 2 : (AF6 == 3 ? 4 : (AF6 == 2 ? 2 : 8)), status);
     if (VAL) {                                                   // MSQ-U1 rule: max |v| 2^-s in [256, 448] or (448, 512) -> s + 1
@@ -229,9 +233,11 @@ k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t
         const float4 v = *reinterpret_cast<const float4*>(tl + lane * LDS_STRIDE + c * 4);
         a[c * 4 + 0] = v.x; a[c * 4 + 1] = v.y; a[c * 4 + 2] = v.z; a[c * 4 + 3] = v.w;
     }
-    int status = 0, se = 0;
+    int status = 0;
+    uint32_t mbits_ = 0u;                                        // (shared exponent: Python-path rule, as k_mx_pack)
 #pragma unroll
-    for (int b = 0; b < BS; ++b) { const int e = (int)((f2u(a[b]) >> 23) & 0xFF); se = e > se ? e : se; }
+    for (int b = 0; b < BS; ++b) { const uint32_t t = f2u(a[b]) & 0x7FFFFFFFu; mbits_ = t > mbits_ ? t : mbits_; }
+    const int se = biased_exp_py(mbits_);
     const bool fl = (se == 0) && flush;
     const int sb = mx_scale_byte(se, EMAX, status);
     uint32_t w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
@@ -283,14 +289,14 @@ k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint
     }
     uint32_t mag = 0u;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { const uint32_t t = f2u(a[b]) & 0x7F800000u; mag = t > mag ? t : mag; }
+    for (int b = 0; b < 8; ++b) { const uint32_t t = f2u(a[b]) & 0x7FFFFFFFu; mag = t > mag ? t : mag; }   // whole magnitude: the Python-path exponent needs the significand
     {
         const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
         mag = o1 > mag ? o1 : mag;
         const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
         mag = o2 > mag ? o2 : mag;
     }
-    const int se = (int)(mag >> 23);
+    const int se = biased_exp_py(mag);
     int status = 0;
     const bool fl = (se == 0) && flush;
     const int sb = mx_scale_byte(se, 8, status);

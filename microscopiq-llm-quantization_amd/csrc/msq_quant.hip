@@ -100,6 +100,15 @@ MSQ_D float mx_shared_scale(int shared_exp, int scale_bits, float elem_max_norm)
     return u2f(((uint32_t)shared_exp << 23) | mant);
 }
 
+// exponent of one element for the block maximum: the exponent field (the reference's native kernels, cpp/shared_exp.cuh) or, with pyexp,
+// what its Python path gets from floor(torch.log2(.)) (msq_device.h biased_exp_py); and the element codec: the native bit codec, or --
+// Python path under truncation only, where the private exponent of elemwise_ops.py:139-144 decides the grid -- the arithmetic one
+MSQ_D int mx_exp_of(uint32_t bits, int pyexp) { return pyexp ? biased_exp_py(bits) : (int)((bits >> 23) & 0xFF); }
+MSQ_D float mx_elem(float si, int mbits, int ebits, float max_norm, int rmode, int pyexp) {
+    if (pyexp && rmode == 1) return quant_core_sat(si, mbits, ebits, max_norm, rmode);
+    return quant_bits(si, mbits, ebits, max_norm, rmode, true, true);
+}
+
 // quantize_mx with precomputed max values (replaces cpp/mx.cuh:15-53)
 __global__ void __launch_bounds__(256)
 k_mx_maxvals(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ maxv,
@@ -128,11 +137,11 @@ k_mx_maxvals(const float* __restrict__ in, float* __restrict__ out, const float*
 template <int TS, bool EPS = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t total, int scale_bits,
-                int ebits, int mbits, float max_norm, int flush, int rmode) {
+                int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
     // axis_len % TS == 0, TS power of two <= 64: element i belongs to tile i / TS
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float v = (i < total) ? in[i] : 0.f;
-    int se = (int)((f2u(v) >> 23) & 0xFF);
+    int se = mx_exp_of(f2u(v), pyexp);
 #pragma unroll
     for (int m = TS / 2; m > 0; m >>= 1) {
         const int o = __shfl_xor(se, m, 64);
@@ -141,14 +150,14 @@ k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t t
     const bool fl = (se == 0) && flush;
     const float scale = mx_shared_scale(se, scale_bits, max_norm);
     const float si = fl ? 0.f : v / (EPS ? scale + 1e-6f : scale);
-    if (i < total) out[i] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+    if (i < total) out[i] = mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
 }
 
 template <bool EPS = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len,
                   int64_t post, int tile, int64_t ntiles, int scale_bits, int ebits, int mbits,
-                  float max_norm, int flush, int rmode) {
+                  float max_norm, int flush, int rmode, int pyexp) {
     const int64_t total = pre * ntiles * post;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -160,14 +169,14 @@ k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t
         const int64_t base = (p * axis_len) * post + q;
         int se = 0;
         for (int64_t a = a0; a < a1; ++a) {
-            const int e = (int)((f2u(in[base + a * post]) >> 23) & 0xFF);
+            const int e = mx_exp_of(f2u(in[base + a * post]), pyexp);
             se = e > se ? e : se;
         }
         const bool fl = (se == 0) && flush;
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         for (int64_t a = a0; a < a1; ++a) {
             const float si = fl ? 0.f : in[base + a * post] / (EPS ? scale + 1e-6f : scale);
-            out[base + a * post] = quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+            out[base + a * post] = mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
         }
     }
 }
@@ -184,24 +193,24 @@ MSQ_D float mx_scale_recip(float scale) {
 }
 
 template <bool EPS>
-MSQ_D float mx_apply(float v, float scale, float rs, bool fl, int mbits, int ebits, float max_norm, int rmode) {
+MSQ_D float mx_apply(float v, float scale, float rs, bool fl, int mbits, int ebits, float max_norm, int rmode, int pyexp) {
     const float si = fl ? 0.f : (EPS ? v / (scale + 1e-6f) : v * rs);
-    return quant_bits(si, mbits, ebits, max_norm, rmode, true, true) * scale;
+    return mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
 }
 
 // tile innermost (post == 1), TS in {4, 8, 16, 32, 64}: TS / 4 neighbouring lanes share a tile
 template <int TS, bool EPS>
 __global__ void __launch_bounds__(256)
 k_mx_tile_inner4(const float* __restrict__ in, float* __restrict__ out, int64_t nvec, int scale_bits,
-                 int ebits, int mbits, float max_norm, int flush, int rmode) {
+                 int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < nvec; b += stride) {
         const int64_t i = b + threadIdx.x;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nvec) v = reinterpret_cast<const float4*>(in)[i];
-        const uint32_t m01 = max(f2u(v.x) & 0x7F800000u, f2u(v.y) & 0x7F800000u);
-        const uint32_t m23 = max(f2u(v.z) & 0x7F800000u, f2u(v.w) & 0x7F800000u);
-        int se = (int)(max(m01, m23) >> 23);
+        const int m01 = max(mx_exp_of(f2u(v.x), pyexp), mx_exp_of(f2u(v.y), pyexp));
+        const int m23 = max(mx_exp_of(f2u(v.z), pyexp), mx_exp_of(f2u(v.w), pyexp));
+        int se = max(m01, m23);
 #pragma unroll
         for (int m = TS / 8; m > 0; m >>= 1) {
             const int o = __shfl_xor(se, m, 64);
@@ -210,10 +219,10 @@ k_mx_tile_inner4(const float* __restrict__ in, float* __restrict__ out, int64_t 
         const bool fl = (se == 0) && flush;
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         const float rs = mx_scale_recip(scale);
-        v.x = mx_apply<EPS>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.y = mx_apply<EPS>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.z = mx_apply<EPS>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.w = mx_apply<EPS>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.x = mx_apply<EPS>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
+        v.y = mx_apply<EPS>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
+        v.z = mx_apply<EPS>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
+        v.w = mx_apply<EPS>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
         if (i < nvec) reinterpret_cast<float4*>(out)[i] = v;
     }
 }
@@ -223,7 +232,7 @@ k_mx_tile_inner4(const float* __restrict__ in, float* __restrict__ out, int64_t 
 template <int TILE, bool EPS>
 __global__ void __launch_bounds__(256)
 k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len, int64_t post4,
-                int tile, int64_t ntiles, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode) {
+                int tile, int64_t ntiles, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
     const int64_t total = pre * ntiles * post4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -235,15 +244,14 @@ k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t p
     const float4* src = reinterpret_cast<const float4*>(in) + (p * axis_len + a0) * post4 + q;
     float4* dst = reinterpret_cast<float4*>(out) + (p * axis_len + a0) * post4 + q;
     float4 r[TILE];
-    uint32_t mx = 0, my = 0, mz = 0, mw = 0;
+    int ex = 0, ey = 0, ez = 0, ew = 0;
 #pragma unroll
     for (int j = 0; j < TILE; ++j) {
         r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < rows) r[j] = src[(int64_t)j * post4];
-        mx = max(mx, f2u(r[j].x) & 0x7F800000u); my = max(my, f2u(r[j].y) & 0x7F800000u);
-        mz = max(mz, f2u(r[j].z) & 0x7F800000u); mw = max(mw, f2u(r[j].w) & 0x7F800000u);
+        ex = max(ex, mx_exp_of(f2u(r[j].x), pyexp)); ey = max(ey, mx_exp_of(f2u(r[j].y), pyexp));
+        ez = max(ez, mx_exp_of(f2u(r[j].z), pyexp)); ew = max(ew, mx_exp_of(f2u(r[j].w), pyexp));
     }
-    const int ex = (int)(mx >> 23), ey = (int)(my >> 23), ez = (int)(mz >> 23), ew = (int)(mw >> 23);
     const float sx = mx_shared_scale(ex, scale_bits, max_norm), sy = mx_shared_scale(ey, scale_bits, max_norm);
     const float sz = mx_shared_scale(ez, scale_bits, max_norm), sw = mx_shared_scale(ew, scale_bits, max_norm);
     const float rx = mx_scale_recip(sx), ry = mx_scale_recip(sy), rz = mx_scale_recip(sz), rw = mx_scale_recip(sw);
@@ -251,10 +259,10 @@ k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t p
 #pragma unroll
     for (int j = 0; j < TILE; ++j) {
         float4 o;
-        o.x = mx_apply<EPS>(r[j].x, sx, rx, fx, mbits, ebits, max_norm, rmode);
-        o.y = mx_apply<EPS>(r[j].y, sy, ry, fy, mbits, ebits, max_norm, rmode);
-        o.z = mx_apply<EPS>(r[j].z, sz, rz, fz, mbits, ebits, max_norm, rmode);
-        o.w = mx_apply<EPS>(r[j].w, sw, rw, fw, mbits, ebits, max_norm, rmode);
+        o.x = mx_apply<EPS>(r[j].x, sx, rx, fx, mbits, ebits, max_norm, rmode, pyexp);
+        o.y = mx_apply<EPS>(r[j].y, sy, ry, fy, mbits, ebits, max_norm, rmode, pyexp);
+        o.z = mx_apply<EPS>(r[j].z, sz, rz, fz, mbits, ebits, max_norm, rmode, pyexp);
+        o.w = mx_apply<EPS>(r[j].w, sw, rw, fw, mbits, ebits, max_norm, rmode, pyexp);
         if (j < rows) dst[(int64_t)j * post4] = o;
     }
 }
@@ -272,10 +280,10 @@ k_mx_maxvals_rows4(const float* __restrict__ in, float* __restrict__ out, const 
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         const float rs = mx_scale_recip(scale);
         float4 v = reinterpret_cast<const float4*>(in)[i];
-        v.x = mx_apply<false>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.y = mx_apply<false>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.z = mx_apply<false>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
-        v.w = mx_apply<false>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.x = mx_apply<false>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
+        v.y = mx_apply<false>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
+        v.z = mx_apply<false>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
+        v.w = mx_apply<false>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
         reinterpret_cast<float4*>(out)[i] = v;
     }
 }
@@ -586,7 +594,7 @@ static void launch_elemwise_16(const void* in, void* out, int64_t n, int bits, i
 template <bool EPS>
 static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                              int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
-                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
+                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream, int pyexp) {
     if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: negative size");
     const int64_t total = pre * axis_len * post;
     if (total == 0) return MSQ_OK;
@@ -600,7 +608,7 @@ static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t a
         const int64_t nvec = total / 4;
         const int g = grid_for(nvec, 256, 2048 * 4);
 #define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner4<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, nvec, \
-                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp); break;
         switch (tile_size) { MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
 #undef MSQ_TI
     } else if (post > 1 && post % 4 == 0 && tile_size <= 32 && al16 && pre * ((axis_len + tile_size - 1) / tile_size) * (post / 4) < (int64_t)0x7FFFFFFF * 256) {
@@ -609,21 +617,21 @@ static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t a
         const unsigned g = (unsigned)((nthreads + 255) / 256);
         if (tile_size <= 16)
             hipLaunchKernelGGL((k_mx_tile_cols4<16, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
-                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
         else
             hipLaunchKernelGGL((k_mx_tile_cols4<32, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
-                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
     } else if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
         const int g = grid_for(total, 256);
 #define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, total, \
-                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp); break;
         switch (tile_size) { MSQ_TI(1) MSQ_TI(2) MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
 #undef MSQ_TI
     } else {
         const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
         hipLaunchKernelGGL(k_mx_tile_generic<EPS>, dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
                            in, out, pre, axis_len, post, tile_size, ntiles, scale_bits, elem_ebits, elem_mbits,
-                           elem_max_norm, flush_fp32_subnorms, rmode);
+                           elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
     }
     return check_launch("msq_quantize_mx_by_tile");
 }
@@ -702,14 +710,24 @@ int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t ax
                             int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
     return launch_mx_by_tile<false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                    elem_max_norm, flush_fp32_subnorms, rmode, stream);
+                                    elem_max_norm, flush_fp32_subnorms, rmode, stream, 0);
 }
 
 int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                                int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                                float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
     return launch_mx_by_tile<true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                   elem_max_norm, flush_fp32_subnorms, rmode, stream);
+                                   elem_max_norm, flush_fp32_subnorms, rmode, stream, 1);
+}
+
+int msq_quantize_mx_by_tile_ex(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
+                               int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
+                               float elem_max_norm, int flush_fp32_subnorms, int rmode, int py_divisor, int py_exponent, void* stream) {
+    if (py_divisor)
+        return launch_mx_by_tile<true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                       elem_max_norm, flush_fp32_subnorms, rmode, stream, py_exponent ? 1 : 0);
+    return launch_mx_by_tile<false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                    elem_max_norm, flush_fp32_subnorms, rmode, stream, py_exponent ? 1 : 0);
 }
 
 int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream) {

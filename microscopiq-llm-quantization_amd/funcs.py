@@ -65,17 +65,19 @@ def quantize_mx_func_cuda(A, scale_bits, ebits, mbits, max_norm, max_values, axi
 
 
 def quantize_mx_by_tile_func_cuda(A, scale_bits, ebits, mbits, max_norm, tile_size, axis, flush_fp32_subnorms=False,
-                                  rmode=0, python_divisor=False):
+                                  rmode=0, python_divisor=False, python_exponent=False):
     """cpp/funcs.cpp:161-181.  python_divisor: divide by `2**e + 1e-6` like the reference's PYTHON path (mx_ops.py:444)
-    instead of by the scale like its native kernel (cpp/mx.cuh:132)."""
+    instead of by the scale like its native kernel (cpp/mx.cuh:132).  python_exponent: the shared exponent is
+    floor(torch.log2(max)) in fp32 like the Python path (mx_ops.py:66-77) instead of the exponent field of the maximum like the
+    native kernel (cpp/shared_exp.cuh:14-53) -- they differ for the 88 largest floats under a power of two."""
     _check_input(A, "A")
     if A.dtype != torch.float32:
         raise MsqError("quantize_mx_by_tile_func_cuda: only float32 is supported (cpp/mx.cu:124-125)")
     pre, axis_len, post = _pap(A.shape, int(axis))
     out = torch.empty_like(A)
-    f = lib().msq_quantize_mx_by_tile_py if python_divisor else lib().msq_quantize_mx_by_tile
-    check(f(ptr(A), ptr(out), pre, axis_len, post, int(tile_size), int(scale_bits), int(ebits), int(mbits), float(max_norm),
-            int(bool(flush_fp32_subnorms)), int(rmode), current_stream(A.device)), "quantize_mx_by_tile_func_cuda")
+    check(lib().msq_quantize_mx_by_tile_ex(ptr(A), ptr(out), pre, axis_len, post, int(tile_size), int(scale_bits), int(ebits), int(mbits),
+                                           float(max_norm), int(bool(flush_fp32_subnorms)), int(rmode), int(bool(python_divisor)),
+                                           int(bool(python_exponent)), current_stream(A.device)), "quantize_mx_by_tile_func_cuda")
     return out
 
 

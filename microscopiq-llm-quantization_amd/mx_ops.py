@@ -83,7 +83,7 @@ def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None,
         return out
     y = funcs.quantize_mx_by_tile_func_cuda(x.float() if x.dtype != torch.float32 else x, scale_bits, ebits, mbits,
                                             max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]),
-                                            python_divisor=_PY_DIVISOR[0])
+                                            python_divisor=_PY_DIVISOR[0], python_exponent=True)   # this IS the Python path (mx_ops.py:332-457)
     return y if A.dtype == torch.float32 else y.to(A.dtype)
 
 

@@ -120,7 +120,7 @@ def test_persistent_uncut_tiles_equal_qgemm256_bit_for_bit(msq, M, N, K, monkeyp
     beyond M are dropped by the range check of the tile's buffer descriptor), three output dtypes."""
     rc, (Pb, full, R, q), wsb = _plan(msq, M, N, K)
     assert rc == 0 and wsb == 0
-    W = _weights(N, K, 41).to(dev())
+    W = _weights(N, K, 11).to(dev())                              # (seed of the round-4 test: every group fits the unified layout)
     X = torch.randn(M, K, generator=torch.Generator().manual_seed(42)).to(dev()).to(torch.bfloat16)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(43)).to(dev())
     for fo in ("posit8_es1", "fp8_e4m3"):
@@ -152,3 +152,86 @@ def test_persistent_kernel_without_workspace_falls_back(msq, monkeypatch):
     ref = msq.qlinear.qlinear(X, P, None, torch.float32)
     assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
     monkeypatch.delenv("MSQ_GEMM_256")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# plain-MX surfaces just under powers of two (advisor, round 4): Python-path surfaces follow floor(torch.log2), native ones the exponent field
+# ----------------------------------------------------------------------------------------------------------------------
+def _planted(rows, K, seed, lo=-12, hi=12):
+    """[rows, K] float32 whose blocks of 32 each hold ONE maximum 1 .. 90 ulps under a power of two 2^u (u in lo .. hi, either sign) and
+    30 smaller values: floor(torch.log2(max)) is u for the nearest of them (up to 88 ulps for |u| >= 128, fewer near 1: msq_device.h
+    ilog2f_torch), u - 1 beyond -- the block scale of the reference's Python path doubles exactly there."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(rows, K).astype(np.float32)
+    nb = K // 32
+    for r in range(rows):
+        for b in range(nb):
+            u = int(rs.randint(lo, hi + 1))
+            d = int(rs.randint(1, 91))
+            top = np.float32(2.0 ** u).view(np.uint32) - np.uint32(d)
+            top = np.uint32(top).view(np.float32)
+            blk = x[r, b * 32:(b + 1) * 32]
+            blk *= np.float32(0.45 * 2.0 ** u / max(np.abs(blk).max(), 1e-30))
+            blk[rs.randint(0, 32)] = top if rs.rand() < 0.5 else -top
+    return x
+
+
+def _e4m3_decode(e):
+    e = e.astype(np.int32)
+    sgn = np.where(e & 0x80, -1.0, 1.0); ex = (e >> 3) & 15; mant = e & 7
+    return sgn * np.where(ex > 0, (1 + mant / 8.0) * np.exp2(ex - 7.0), mant / 8.0 * 2.0 ** -6)
+
+
+@pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp4_e2m1", "fp6_e3m2", "int8"])
+@pytest.mark.parametrize("rnd", ["nearest", "floor", "even"])
+def test_quantize_mx_python_path_just_below_powers_of_two(msq, O, fmt, rnd):
+    """`_quantize_mx` of the package (= the reference's Python path, mx_ops.py:332-457: shared exponent floor(torch.log2(max)) in fp32, under
+    `floor` the private exponents too) against the oracle on blocks whose maximum sits 1 .. 90 ulps under a power of two, along the inner
+    and along an outer axis (both kernel families), fp32; the NATIVE entry (quantize_mx_by_tile_func_cuda, cpp/shared_exp.cuh: the
+    exponent field) against the oracle's native restatement on the same data -- and the two must DIFFER here (the planted data bite)."""
+    A = _planted(24, 256, 7)
+    At = torch.from_numpy(A).to(dev())
+    y = msq.mx_ops._quantize_mx(At, 8, fmt, axes=[-1], block_size=32, round=rnd).cpu().numpy()
+    yo = O.quantize_mx(A, 8, fmt, axis=-1, block_size=32, round=rnd)
+    assert np.array_equal(y.view(np.uint32), yo.view(np.uint32))
+    B = np.ascontiguousarray(A.reshape(24, 8, 32).transpose(0, 2, 1))            # [24, 32, 8]: blocks of 32 along axis 1 (outer-axis kernels)
+    Bt = torch.from_numpy(B).to(dev())
+    yb = msq.mx_ops._quantize_mx(Bt, 8, fmt, axes=[1], block_size=32, round=rnd).cpu().numpy()
+    assert np.array_equal(yb.view(np.uint32), O.quantize_mx(B, 8, fmt, axis=1, block_size=32, round=rnd).view(np.uint32))
+    e, m, ex, mx, mn = msq.formats._get_format_params(fmt)
+    rm = {"nearest": 0, "floor": 1, "even": 2}[rnd]
+    yn = msq.funcs.quantize_mx_by_tile_func_cuda(At, 8, e, m, mx, 32, 1, False, rm).cpu().numpy()
+    assert np.array_equal(yn.view(np.uint32), O.quantize_mx_native(A, 8, e, m, mx, 32, 1, False, rm).view(np.uint32))
+    assert (yn != y).mean() > 0.05                                               # every bumped block differs in most of its elements
+
+
+def test_mx_operand_packers_and_kv_just_below_powers_of_two(msq, O):
+    """The MX operand packers (activations: e4m3 codes + scale bytes, both kernels; weights: fp4 / fp6 / e4m3-value planes) and the KV-cache MX
+    quantiser stand in for the reference's CPU `_quantize_mx` (custom_cuda = False): on planted blocks they decode to the oracle's
+    Python-path values bit for bit -- scale bytes included."""
+    X = _planted(40, 512, 9, -8, 8)
+    Xo = O.quantize_mx(X, 8, "fp8_e4m3", axis=-1, block_size=32)
+    for src in (torch.from_numpy(X).to(dev()),):
+        xc, xs = msq.qlinear.mx_pack_act(src, check_status=True)
+        dec = _e4m3_decode(xc.cpu().numpy()) * np.repeat(np.exp2(xs.cpu().numpy().astype(np.float64) - 127.0), 32, axis=1)
+        assert (dec == Xo.astype(np.float64)).all()
+    # bf16 activations: every bf16 is an fp32 value; a bf16 has 8 significand bits, so "just under a power of two" = its top code
+    Xb = torch.from_numpy(X).to(dev()).to(torch.bfloat16)
+    xc, xs = msq.qlinear.mx_pack_act(Xb, check_status=True)
+    dec = _e4m3_decode(xc.cpu().numpy()) * np.repeat(np.exp2(xs.cpu().numpy().astype(np.float64) - 127.0), 32, axis=1)
+    assert (dec == O.quantize_mx(Xb.float().cpu().numpy(), 8, "fp8_e4m3", axis=-1, block_size=32).astype(np.float64)).all()
+    # weights through the GEMM itself: x = identity rows pick the decoded weight columns back out (exact: one product per output)
+    W = _planted(256, 256, 11, -6, 6)
+    eye = torch.eye(256, device=dev())
+    for w_fmt, ofmt in (("e2m1", "fp4_e2m1"), ("e3m2", "fp6_e3m2")):
+        P = msq.qlinear.mx_pack_weight(torch.from_numpy(W).to(dev()), w_fmt=w_fmt)
+        Wd = msq.qlinear.qlinear_mx_w4a8(eye, P, None, torch.float32).t().cpu().numpy()      # y[i, n] = W_q[n, i]
+        Wo = O.quantize_mx(W, 8, ofmt, axis=-1, block_size=32)
+        assert np.array_equal(Wd, Wo), w_fmt
+    # KV cache, fp32: keys in blocks along the tokens, values along head_dim
+    k = torch.from_numpy(_planted(2 * 4 * 64, 64, 13, -6, 6).reshape(2, 4, 64, 64)).to(dev())
+    kq = msq.kvcache.mx_quantize_values(k, "fp8_e4m3", 32)                       # blocks along head_dim = the planted axis
+    assert np.array_equal(kq.cpu().numpy(), O.quantize_mx(k.cpu().numpy(), 8, "fp8_e4m3", axis=3, block_size=32))
+    kt = k.transpose(2, 3).contiguous()                                          # planted axis -> tokens
+    kq = msq.kvcache.mx_quantize_keys(kt, "fp4_e2m1", 32)
+    assert np.array_equal(kq.cpu().numpy(), O.quantize_mx(kt.cpu().numpy(), 8, "fp4_e2m1", axis=2, block_size=32))
