@@ -97,8 +97,9 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
     ``compute_dtype`` as quant.outlier_fakequant: an fp16 / bf16 weight is by default quantised IN its dtype (what the
     reference's RTN harness does with a half checkpoint, llm/llama.py:238), so that the packed layer holds exactly the
     values ``MXQuantizer.quantize`` / ``quantize_mx_outlier_v1`` give for the same tensor; those values are then packed
-    as they are (pack_values; layout "planes": MSQ-T1 planes of those values, verified exact, MsqError otherwise -- never a
-    16-bit plane).  "float32" upcasts first (one fused quantise + pack launch)."""
+    as they are (pack_values; layout "planes": MSQ-T1 planes of those values when they reproduce them exactly, else the unified
+    planes of those values, MsqError if neither fits -- never a 16-bit plane).  "float32" upcasts first (one fused quantise +
+    pack launch)."""
     if not W.is_cuda:
         raise MsqError("pack_weight needs a CUDA/HIP tensor (no CPU fallback)")
     if W.ndim != 2:
@@ -112,17 +113,26 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
         Wq = outlier_fakequant(W.detach(), inlier_scale_bits, outlier_scale_bits, inlier_elem_format, outlier_elem_format,
                                std_dev, -1, block_size, round, flush_fp32_subnorms, compute_dtype="input")["out"]
         if layout == "planes":
-            # MSQ-T1 (fp4 plane + outlier plane + two scales per block) is what "planes" promises -- never a silent 16-bit
-            # plane: the in-dtype values are handed to the T1 packer (which quantises them once more in float32) and the
-            # result is kept only if it reproduces them exactly; a matrix on which re-quantisation moves a value (an
-            # element that changes sides of the outlier bounds once its block is quantised) is refused.
-            P = _pack(_pad2d(Wq.detach().contiguous().float(), N_MULT, K_MULT), inlier_scale_bits, outlier_scale_bits,
-                      inlier_elem_format, outlier_elem_format, std_dev, block_size, round, flush_fp32_subnorms, variant, "planes", n, k)
-            if not bool((unpack_weight(P) == Wq.float()).all()):
-                raise MsqError("pack_weight(layout='planes'): the %s weight's in-dtype fake-quant values are not reproduced exactly by "
-                               "the MSQ-T1 planes; use layout='auto' / 'unified' (packs those values as they are) or "
+            # MSQ-T1 (fp4 plane + outlier plane + two scales per block) is what "planes" names -- and never a silent 16-bit plane.
+            # The T1 packer quantises once more in float32; its result is kept only if it reproduces the in-dtype values exactly.
+            # On a real matrix that often fails (an element changes sides of the outlier bounds once its block is quantised: among
+            # the 524288 blocks of a 4096 x 4096 weight practically always), so the values are then packed AS THEY ARE into the
+            # unified planes (8.25 / 9.25 bits per weight: smaller than T1's 12.5, the same GEMM kernels) -- the default call on a
+            # half weight succeeds and decodes to exactly what `MXQuantizer.quantize` gives for it (advisor, round 4).  Only a tensor
+            # whose groups fit neither raises.
+            try:
+                P = _pack(_pad2d(Wq.detach().contiguous().float(), N_MULT, K_MULT), inlier_scale_bits, outlier_scale_bits,
+                          inlier_elem_format, outlier_elem_format, std_dev, block_size, round, flush_fp32_subnorms, variant, "planes", n, k)
+                if bool((unpack_weight(P) == Wq.float()).all()):
+                    return P
+            except MsqError:
+                pass
+            try:
+                return pack_values(Wq, (PLANE_U8, PLANE_U8X))
+            except MsqError:
+                raise MsqError("pack_weight(layout='planes'): the %s weight's in-dtype fake-quant values fit neither the MSQ-T1 planes nor "
+                               "the unified planes exactly; use layout='auto' (falls back to a 16-bit plane of those values) or "
                                "compute_dtype='float32'" % str(W.dtype).replace("torch.", ""))
-            return P
         kinds = {"unified": (PLANE_U8, PLANE_U8X), "auto": (PLANE_U8, PLANE_U8X, PLANE_BF16)}[layout]
         return pack_values(Wq, kinds)
     Wf = _pad2d(W.detach().contiguous().float(), N_MULT, K_MULT)
