@@ -23,11 +23,14 @@ import time
 import torch
 import torch.nn as nn
 
-# Arithmetic of the two dense steps around the block kernel (scripts/experiments/gptq_exactness.py measures what they change):
-# the inverse-Hessian factor is computed in float64 and rounded once (the correctly rounded factor; rocSOLVER's float32
-# factorisation carries its own noise, different from the CPU LAPACK noise of the reference), the block-to-block update
-# (llm/gptq.py:163) stays a float32 library GEMM unless UPDATE_FP64 (float64 accumulation, rounded once).
-FACTOR_FP64 = True
+# Arithmetic of the two dense steps around the block kernel (scripts/experiments/gptq_exactness.py measures what they change).
+# DEFAULTS = the reference's behaviour: the inverse-Hessian factor is torch's float32 Cholesky / cholesky_inverse / Cholesky
+# (llm/gptq.py:98-104), including its error on a Hessian that is not positive-definite in float32
+# (`linalg.cholesky: ... not positive-definite`); the block-to-block update (llm/gptq.py:163) is a float32 library GEMM.
+# Opt-in: FACTOR_FP64 computes the factor in float64 and rounds it once (the correctly rounded factor: rocSOLVER's float32
+# factorisation carries its own rounding noise, different from the CPU LAPACK noise of the reference -- and it accepts Hessians
+# that are singular only in float32); UPDATE_FP64 accumulates the update in float64 and rounds once.
+FACTOR_FP64 = False
 UPDATE_FP64 = False
 
 from ..quant import quantize_mx_outlier_hessian

@@ -673,14 +673,21 @@ def test_gptq_block_kernel_bit_exact_vs_reference(msq):
             print("GPTQ fixture %s: %d of %d entries differ from the reference's CPU result" % (name, nd, ref.size))
             assert nd == 0, (name, nd, sorted(set(np.argwhere(Q != ref)[:, 0].tolist()))[:8])
             assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-5 * float(z[f"{name}|error"]), name
-    # the solver's own inverse-Hessian factor (computed in float64 and rounded once, harness/gptq.py FACTOR_FP64) instead of the
-    # CPU's float32 LAPACK factor: the factors differ in their last bits, the quantised weights on every fixture do not
-    for name in names:
-        Q, gp, _ = _gptq_case(msq, z, name, own_hinv=True)
-        nd = int((Q != z[f"{name}|Q"]).sum())
-        print("GPTQ fixture %s, own factor: %d of %d entries differ" % (name, nd, Q.size))
-        assert nd == 0, (name, nd)
-        assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-4 * float(z[f"{name}|error"]), name
+    # the solver's own inverse-Hessian factor instead of the CPU's float32 LAPACK factor -- the default float32 one (rocSOLVER: the
+    # reference's arithmetic, llm/gptq.py:98-104) and the float64 opt-in (harness/gptq.py FACTOR_FP64, rounded once): the factors differ
+    # in their last bits, the quantised weights on every fixture do not
+    import msq.harness.gptq as Gm
+    for f64 in (False, True):
+        prev, Gm.FACTOR_FP64 = Gm.FACTOR_FP64, f64
+        try:
+            for name in names:
+                Q, gp, _ = _gptq_case(msq, z, name, own_hinv=True)
+                nd = int((Q != z[f"{name}|Q"]).sum())
+                print("GPTQ fixture %s, own %s factor: %d of %d entries differ" % (name, "float64" if f64 else "float32", nd, Q.size))
+                assert nd == 0, (name, f64, nd)
+                assert abs(gp.error - float(z[f"{name}|error"])) <= 1e-4 * float(z[f"{name}|error"]), name
+        finally:
+            Gm.FACTOR_FP64 = prev
 
 
 def test_gptq_block_kernel_speed_and_llama_layer(msq):
