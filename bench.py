@@ -372,13 +372,13 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
     mdt = next(model.parameters()).dtype
     O.set_threads(physical_cores())
 
-    def cpu_reference(fo_):
+    def cpu_reference(fi_, fo_, axis_, bs_):
         """the checkpoint with every decoder Linear replaced by the oracle's CPU fake-quant of its weight (checkpoint dtype)"""
         r = copy.deepcopy(model)
         for layer in r.model.layers:
             for lin in find_layers(layer).values():
                 W = lin.weight.data
-                lin.weight.data = torch.from_numpy(O.outlier_fakequant(W.float().numpy(), 8, 8, fi, fo_, 2, -1, bs)["out"]).to(W.dtype)
+                lin.weight.data = torch.from_numpy(O.outlier_fakequant(W.float().numpy(), 8, 8, fi_, fo_, 2, axis_, bs_)["out"]).to(W.dtype)
         return r
 
     out = {"model": ("tests/golden/ppl_llama: trained 4-layer hidden-256 Llama (tests/golden/make_ppl_fixture.py)" if fixture
@@ -390,9 +390,15 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
     for path in paths:
         # the MX matrix path carries the weight as ONE e4m3 operand: posit outliers do not fit it, so it is scored with fp8_e4m3 outliers
         fo_p = "fp8_e4m3" if path == "mx" else fo
-        qc = dict(inlier_elem_format=fi, outlier_elem_format=fo_p, axes=[-1], block_size=bs)
+        fi_p, ax_p, bs_p = fi, -1, bs
+        if path == "harness_default":
+            # the harness's OWN default quantiser (llm/llama.py:229-237): int2 inliers, fp4 outliers, blocks of 16 along out_features
+            # (axes = [0]) -- a 2-bit weight: the quantiser's error is large here and a wrong mask bit moves the perplexity visibly.
+            # The fake-quant values are packed as they are (pack_values, 8.25 b/w value plane) and run through the fused GEMM.
+            fi_p, fo_p, ax_p, bs_p = "int2", "fp4", 0, 16
+        qc = dict(inlier_elem_format=fi_p, outlier_elem_format=fo_p, axes=[ax_p], block_size=bs_p)
         # ---- CPU reference: oracle fake-quant weights, the model evaluated by torch on the host in float32
-        ref = cpu_reference(fo_p)
+        ref = cpu_reference(fi_p, fo_p, ax_p, bs_p)
         ref_cpu = copy.deepcopy(ref).float()
         if path == "mx":
             # reference semantics of the W4A8 MX path (number_system/mx/linear.py:29-91): the activations of every decoder Linear
@@ -409,7 +415,7 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
         # ---- HIP: RTN through the harness (llm/llama.py:226-253), packed, fused kernels
         m = copy.deepcopy(model).to(dev)
         quantize_layers_nearest(m.model.layers, dev, qc)
-        n_packed, kept = pack_layers(m.model.layers, path=path, fuse=LLAMA_FUSE)
+        n_packed, kept = pack_layers(m.model.layers, path="mx" if path == "mx" else "bf16", fuse=LLAMA_FUSE)
         kept += sum(isinstance(l, torch.nn.Linear) for layer in m.model.layers for l in layer.modules())
         if corrupt is not None:
             corrupt(m)
@@ -426,6 +432,13 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
                         "ppl_hip_packed_fused_reference_formula": perplexity(m, ids, dev, seqlen),
                         "logits_vs_cpu_reference": _logit_metrics(lg_cpu, lg), "logits_vs_gpu_dense_fakequant": _logit_metrics(lg_dense, lg)})
             out["delta_vs_gpu_dense_fakequant"] = ppl - out["ppl_gpu_dense_fakequant"]
+        elif path == "harness_default":
+            lg_dense = _window_logits(ref.to(dev), ids, dev, seqlen)
+            out["harness_default"] = {"config": "int2 inliers / fp4 outliers, axes=[0], block 16, std_dev 2 (llm/llama.py:229-237), packed as values (8.25 b/w)",
+                                      "ppl_cpu_reference": ppl_cpu, "ppl_gpu_dense_fakequant": _ppl_from_logits(lg_dense, ids, seqlen),
+                                      "ppl_hip_packed_fused": ppl, "delta": ppl - ppl_cpu, "relative_delta": (ppl - ppl_cpu) / ppl_cpu,
+                                      "layers_packed": n_packed, "layers_kept_dense": kept,
+                                      "logits_vs_cpu_reference": _logit_metrics(lg_cpu, lg), "logits_vs_gpu_dense_fakequant": _logit_metrics(lg_dense, lg)}
         else:
             mods = [mm for mm in m.modules() if isinstance(mm, msq.qlinear.MXLinearW4A8)]
             out["mx_path"] = {"outlier": fo_p, "ppl_cpu_reference_mxlinear_semantics": ppl_cpu, "ppl_hip_packed_mx": ppl, "delta": ppl - ppl_cpu,
@@ -1250,7 +1263,7 @@ def main(argv=None):
         import contextlib
         try:
             with contextlib.redirect_stdout(sys.stderr):              # the harness prints progress: keep stdout to ONE JSON line
-                pd = ppl_delta_from_env(dev, args.inlier, args.outlier, args.block, paths=("bf16", "mx"))
+                pd = ppl_delta_from_env(dev, args.inlier, args.outlier, args.block, paths=("bf16", "mx", "harness_default"))
             if pd is not None:
                 out["ppl_delta"] = pd["delta"]
                 out["ppl_wikitext2"] = pd

@@ -293,7 +293,7 @@ k_qgemm256(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
 #undef Q256_SB
 
     // the MFMAs are opaque to hipcc's hazard recogniser: give the last of them their passes before the epilogue reads a[...]
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    acc_fence<MF>(acc);
     // the re-staged tail tiles (and nothing else) may still be landing in LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();

@@ -441,7 +441,7 @@ k_qgemm256p(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plan
             }
         }
         // the MFMAs are opaque to hipcc's hazard recogniser: give the last of them their passes before the accumulators are read
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        acc_fence<MF>(acc);
         // Epilogue LDS: the activation buffer of the K-step just finished (the next K-step's tile sits in buffer `abuf`, the one after is
         // landing in abuf + 1, abuf + 2 is the target of the next K-step's DMA; abuf + 3 is rewritten only after the next K-step's barrier).
         // Every wave's last fragment reads of it must be back first: one more wait + barrier per tile.

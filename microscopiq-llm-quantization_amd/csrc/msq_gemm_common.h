@@ -268,6 +268,21 @@ MSQ_D void keep_live(HalfRegs<IN_KIND, OUT_KIND>& h) {
     for (int s = 0; s < HalfSlots<OUT_KIND>::n; ++s) keep_live4(h.out[s]);
 }
 
+// Between the last tied-accumulator MFMA of a K-loop and the first read of the accumulators.  The MFMAs are inline asm: hipcc's hazard
+// recogniser does not know that they write a[...], so (1) the passes of the last ones are given by hand (s_nop), and (2) every
+// accumulator is then REDEFINED by an empty asm statement -- volatile asm statements keep their order, so whatever hipcc itself does
+// with an accumulator afterwards (v_accvgpr_read, but also a register-allocator SPILL: `scratch_store_dwordx4 off, a[200:203]` was
+// placed right behind the last MFMA, in front of the s_nop, in the MX-FP6 kernels as soon as the epilogue's register needs changed,
+// and stored a half-written accumulator) is tied to the value defined AFTER the wait states.
+template <int MF>
+MSQ_D void acc_fence(f32x4_t (&acc)[MF][4]) {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+}
+
 // ---------------------------------------------------------------------------
 // Epilogue of a 128(m) x 64(n) wave tile through LDS: the MFMA result layout gives every lane 4
 // consecutive n of one row (8-byte pieces, 32-byte runs per row) -- stored directly they reach L2 as

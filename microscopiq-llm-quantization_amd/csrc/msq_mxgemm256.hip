@@ -291,7 +291,7 @@ k_mxgemm256(const uint8_t* __restrict__ Xc, const uint8_t* __restrict__ Xs, cons
 #undef MX256_STEP
 #undef MX256_SB
 
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the MFMAs are opaque to hipcc's hazard recogniser
+    acc_fence<MF>(acc);                                          // the MFMAs are opaque to hipcc's hazard recogniser (msq_gemm_common.h)
     __builtin_amdgcn_s_waitcnt(0x0070);                          // drain the re-staged tail tiles before the epilogue reuses LDS
     __builtin_amdgcn_s_barrier();
     if (MSQ_MX256_ABL & 32) { float t = 0.f; _Pragma("unroll") for (int i = 0; i < MF; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; if (t == 1.2345f) reinterpret_cast<float*>(Y)[0] = t; return; }
