@@ -325,7 +325,8 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
     Model and data: MSQ_PPL_MODEL / MSQ_WIKITEXT2_DIR (a HuggingFace Llama checkpoint directory; a directory holding
     wiki.{train,test}.raw or the HF parquet / arrow files) when the environment names both; otherwise the committed fixture
     tests/golden/ppl_llama + tests/golden/ppl_wikitext2 (a small TRAINED Llama and a WikiText-2-format synthetic corpus made by
-    tests/golden/make_ppl_fixture.py: neither WikiText-2 nor a Llama-2 checkpoint exists in the image).  MSQ_PPL_NSAMPLES bounds
+    tests/golden/make_ppl_fixture.py: neither WikiText-2 nor a Llama-2 checkpoint exists in the image; round 5: a gazetteer whose
+    tokens are mostly entity names, digits and world facts the model holds in its weights, test PPL 2.1).  MSQ_PPL_NSAMPLES bounds
     the test windows, MSQ_PPL_SEQLEN sets the window.  Returns None when MSQ_PPL_DISABLE is set or the fixture is absent.
 
       ppl_cpu_reference        every decoder Linear replaced by the ORACLE's CPU fake-quant of its weight (the reference's
@@ -338,6 +339,9 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
     ``paths`` may add "mx": W4A8 on the MX matrix path, scored against ITS reference semantics (number_system/mx/linear.py:29-91:
     activations quantised to MX-FP8 by `_quantize_mx`, dense GEMM) -- the oracle's quantize_mx on the input of every decoder
     Linear of the CPU model -- not against the weight-only model.
+    "harness_default": a further leg with the harness's OWN default quantiser (int2 inliers / fp4 outliers, axes = [0], block 16,
+    llm/llama.py:229-237) -- the configuration in which the quantiser is not near-lossless (the reference moves the fixture's
+    perplexity by ~2 %), values packed as they are.
     ``corrupt`` (tests): callable(packed_model) applied before the packed evaluation, e.g. flipping a scale byte."""
     model_dir, data_dir = os.environ.get("MSQ_PPL_MODEL"), os.environ.get("MSQ_WIKITEXT2_DIR")
     fixture = not (model_dir and data_dir)
@@ -381,7 +385,7 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
                 lin.weight.data = torch.from_numpy(O.outlier_fakequant(W.float().numpy(), 8, 8, fi_, fo_, 2, axis_, bs_)["out"]).to(W.dtype)
         return r
 
-    out = {"model": ("tests/golden/ppl_llama: trained 4-layer hidden-256 Llama (tests/golden/make_ppl_fixture.py)" if fixture
+    out = {"model": ("tests/golden/ppl_llama: trained 4-layer hidden-256 Llama (tests/golden/make_ppl_fixture.py, round 5 gazetteer corpus)" if fixture
                      else os.path.basename(os.path.normpath(model_dir))),
            "dataset": ("tests/golden/ppl_wikitext2: synthetic corpus in the raw WikiText-2 layout (same script); NOT WikiText-2" if fixture
                        else data_dir),

@@ -58,7 +58,7 @@ def ppl_clean(msq):
 
 
 def test_ppl_delta_on_trained_fixture(ppl_clean):
-    """The default bench line's `ppl_delta`: a trained model at PPL < 100 (the fixture's is ~2), every decoder Linear packed, and the
+    """The default bench line's `ppl_delta`: a trained model at PPL < 100 (the fixture's is 2.1), every decoder Linear packed, and the
     packed fused path within BASELINE's bound of the CPU reference -- 0.05 at PPL 5.5, applied as the ratio 0.9 % -- with the
     token-level metrics that a perplexity cannot hide behind: mean KL <= 1e-3 nats / token, top-1 agreement >= 98 %."""
     r = ppl_clean
