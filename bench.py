@@ -674,8 +674,9 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
     out["kv_quant"] = dict(kv, bytes=byts, bound="hbm", peak=HBM_PEAK_GBPS, cache="[1, 32, 4096, 128] float16 (read once + written once)")
     del k
     # ---- decode, M = 1, COLD weights: one decoder layer's four fused projections, each walked over > 1 GB of distinct packed copies
+    from msq import _lib
     dec = {}
-    tot_ms = tot_b = 0.0
+    tot_ms = tot_b = tot_rd = 0.0
     for name, n_, k_ in (("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)):
         Wp = synth_weight(n_, k_, dev, seed=1)
         P0 = qlinear.pack_weight(Wp, 8, 8, inlier, "posit8_es1", 2, block, layout="unified")
@@ -684,11 +685,25 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
         Ps = [P0] + [_clone_packed(P0) for _ in range(copies - 1)]
         x1 = torch.randn(1, P0.k, device=dev).to(torch.bfloat16)
         ms = _tgraph([(lambda P=P: qlinear.qlinear(x1, P)) for P in Ps], reps=3)
-        dec[name] = {"ms": ms, "packed_MB": P0.nbytes / 1e6, "GBps": P0.nbytes / ms / 1e6}
+        # the same cold bytes through a plain read stream (msq_read_stream_probe: every replay walks the code planes of all the copies, one
+        # launch per copy, best of three grids): what the box gives a read of this size right now -- the decode kernel's ceiling
+        sink = torch.zeros(4, dtype=torch.uint8, device=dev)
+        planes = [P.out for P in Ps]
+        nb_plane = planes[0].numel()
+        rd_ms = None
+        for blocks, infl in ((512, 4), (1024, 4), (256, 8)):
+            t_ = _tgraph([(lambda t=t, blocks=blocks, infl=infl: _lib.check(_lib.lib().msq_read_stream_probe(_lib.ptr(t), nb_plane, blocks, infl, _lib.ptr(sink),
+                                                                                                          _lib.current_stream(dev)), "msq_read_stream_probe")) for t in planes], reps=3)
+            rd_ms = t_ if rd_ms is None or t_ < rd_ms else rd_ms
+        rd_ms_packed = rd_ms * P0.nbytes / nb_plane                   # scaled to all planes of the packed weight (codes are 86 ... 97 % of them)
+        dec[name] = {"ms": ms, "packed_MB": P0.nbytes / 1e6, "GBps": P0.nbytes / ms / 1e6,
+                     "read_stream_ms": rd_ms_packed, "read_stream_GBps": P0.nbytes / rd_ms_packed / 1e6, "frac_of_read_stream": rd_ms_packed / ms}
         tot_ms += ms
         tot_b += P0.nbytes
-        del Ps, P0
+        tot_rd += rd_ms_packed
+        del Ps, P0, planes
     out["decode_cold"] = dict(dec, layer_ms=tot_ms, packed_bytes=tot_b, GBps=tot_b / tot_ms / 1e6, frac=tot_b / tot_ms / 1e6 / HBM_PEAK_GBPS,
+                              read_stream_layer_ms=tot_rd, frac_of_read_stream=tot_rd / tot_ms,
                               bound="hbm", peak=HBM_PEAK_GBPS, M=1,
                               what="Llama-2-7B layer, q/k/v and gate/up fused, fp4 + posit8 outliers (9.25 b/w); every launch reads a "
                                    "different copy (> 1 GB per projection): neither L2 nor the 256 MB Infinity Cache holds the weights")

@@ -337,7 +337,12 @@ int msq_mx_pack_a8_f16(const void* X, void* codes, void* scales, int* status_fla
                        int flush_fp32_subnorms, void* stream);
 /* float16 -> bfloat16, round to nearest even (= Tensor.to(torch.bfloat16)): the activation cast in front of msq_qlinear_bf16 for
  * an fp16 model at prefill sizes, one bandwidth-bound launch (the decode sizes need none: msq_qlinear_f16x) */
-int msq_cast_f16_bf16(const void* x, void* y, int64_t n, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
+int msq_cast_f16_bf16(const void* x, void* y, int64_t n, void* stream);
+/* Measurement aid, no reference counterpart: a plain read stream over `bytes` of `buf` (16-byte non-temporal loads, `inflight` = 4 or 8 per
+ * lane, `blocks` workgroups of 256, grid-stride), results folded away (`sink`: 4 writable bytes, never written in practice).  bench.py times
+ * it on the same cold bytes as the decode kernels (`decode_cold.frac_of_read_stream`: what the weight-streaming kernels reach of the read
+ * rate this box gives a stream of that size at that moment). */
+int msq_read_stream_probe(const void* buf, int64_t bytes, int blocks, int inflight, void* sink, void* stream);   /* X holds bfloat16: same codes as casting to f32 first */
 int msq_mx_pack_w4(const float* W, void* codes, void* scales, int* status_flag, int64_t N, int64_t K,
                    int flush_fp32_subnorms, void* stream);
 int64_t msq_qlinear_mx_w4a8_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* > 0 for small M (decode with partial planes, split-K); 0 for the single-launch decode */

@@ -68,6 +68,7 @@ _SIGS = {
     "msq_mx_pack_a8_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "msq_mx_pack_a8_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "msq_cast_f16_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "msq_read_stream_probe": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "msq_mx_pack_w8": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "msq_mx_pack_w6": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "msq_mx_pack_a6": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),

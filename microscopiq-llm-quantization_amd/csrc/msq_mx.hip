@@ -467,3 +467,41 @@ extern "C" int msq_cast_f16_bf16(const void* x, void* y, int64_t n, void* stream
     if (e != hipSuccess) { msq_set_error_(hipGetErrorString(e)); return MSQ_ERR_LAUNCH; }
     return MSQ_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py `decode_cold.frac_of_read_stream`): the plain read stream of this chip over `bytes` of a buffer -- 16-byte
+// loads, `inflight` (4 or 8) loads in flight per lane, grid-stride over `blocks` workgroups of 256 -- so that a weight-streaming
+// kernel's rate can be put beside what a read of the same bytes with the same grid reaches on the same box at the same moment.  The
+// loaded words are xor-folded; `sink` (4 bytes) is written only if the fold hits a constant, i.e. never in practice.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ void __launch_bounds__(256) k_read_probe(const probe_u32x4* __restrict__ p, uint32_t* __restrict__ sink, int64_t n16) {
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    int64_t i = tid;
+    for (; i + (U - 1) * nthreads < n16; i += U * nthreads) {
+        probe_u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * nthreads);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+    }
+    for (; i < n16; i += nthreads) { const probe_u32x4 v = __builtin_nontemporal_load(p + i); acc ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int msq_read_stream_probe(const void* buf, int64_t bytes, int blocks, int inflight, void* sink, void* stream) {
+    if (bytes < 0 || blocks <= 0) { msq_set_error_("msq_read_stream_probe: bad size"); return MSQ_ERR_BAD_ARG; }
+    if (bytes == 0) return MSQ_OK;
+    if (!buf || !sink || (reinterpret_cast<uintptr_t>(buf) & 15)) { msq_set_error_("msq_read_stream_probe: null or unaligned buffer"); return MSQ_ERR_BAD_ARG; }
+    const int64_t n16 = bytes / 16;
+    if (inflight >= 8) hipLaunchKernelGGL(k_read_probe<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const probe_u32x4*)buf, (uint32_t*)sink, n16);
+    else hipLaunchKernelGGL(k_read_probe<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const probe_u32x4*)buf, (uint32_t*)sink, n16);
+    if (hipGetLastError() != hipSuccess) { msq_set_error_("msq_read_stream_probe: launch failed"); return MSQ_ERR_LAUNCH; }
+    return MSQ_OK;
+}
