@@ -460,6 +460,8 @@ def _tgraph(fns, reps=10):
     """Device time per call in ms: the calls of `fns` captured into ONE HIP graph on a side stream, `reps` replays timed with HIP
     events (no Python / ctypes launch floor between the kernels)."""
     import torch
+    torch.cuda.synchronize()        # nothing of the caller's warm-up loop runs beside the side stream's first calls (two streams entering
+                                    # hipBLASLt at once stalled the whole device in layer7b_prefill: every later synchronize hung)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         for f in fns[:3]:
