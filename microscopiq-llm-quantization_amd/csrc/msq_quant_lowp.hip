@@ -544,6 +544,50 @@ template <int DT> MSQ_D float mx_elem(float x, const MxBlk<DT>& B, const MxLowpA
     return Rr<DT>(v * B.sc);                                             // :451
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MX-FP8 (e4m3) fast path through the gfx950 scaled converts: inside mx_elem_fast's conditions with a power-of-two divisor
+// (MxBlk::fast && pow2den) the element step is "round x / 2^se half away from zero onto the e4m3 grid (subnormals kept), clamp to
+// +-448, times 2^se" -- which is what v_cvt_scalef32_pk_fp8_{f16,f32} + v_cvt_scalef32_pk_{f16,bf16}_fp8 compute once (a) the
+// lowest significand bit of the source is set (a sticky bit: the converts round to nearest EVEN, and with it no input is a tie
+// any more while nothing else changes sides: T has >= 4 more significand bits than e4m3, and the bounds on se keep T's subnormal
+// spacing 8 times finer than the grid's), (b) the magnitude is clamped first (the converts do not saturate) and (c) -0 inputs are
+// made +0 (sign(+-0) = 0 in elemwise_ops.py:146-149; negative values that ROUND to zero keep -0 there and here).  Two values of ONE
+// block per call (one dword of T pairs): ~3 instructions per element instead of ~20 (the KV-cache MX quantiser was VALU-bound at
+// 0.3 of the HBM rate).  Pinned bit for bit by the half-tensor goldens (tests/golden/quantize_mx_lowp.npz) and the oracle tests.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short lp_v2s_t __attribute__((ext_vector_type(2)));
+typedef _Float16 lp_h2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 lp_b2_t __attribute__((ext_vector_type(2)));
+template <int DT> MSQ_D uint32_t mx_e4m3_hw_pair(uint32_t w, float sc, float bound) {
+    if (DT == 1) {
+        const lp_h2_t z = {(_Float16)0.f, (_Float16)0.f};
+        const lp_h2_t x = __builtin_bit_cast(lp_h2_t, w) + z;                                   // -0 -> +0
+        lp_h2_t y = __builtin_bit_cast(lp_h2_t, __builtin_bit_cast(uint32_t, x) | 0x00010001u);  // sticky bit
+        const lp_h2_t b = {(_Float16)bound, (_Float16)bound};
+        y = __builtin_elementwise_max(__builtin_elementwise_min(y, b), -b);
+        lp_v2s_t c = {0, 0};
+        c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, y, sc, false);
+        return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(uint32_t, c), sc, false));
+    }
+    float x0 = u2f(w << 16) + 0.f, x1 = u2f(w & 0xFFFF0000u) + 0.f;
+    x0 = __builtin_amdgcn_fmed3f(u2f(f2u(x0) | 1u), -bound, bound);
+    x1 = __builtin_amdgcn_fmed3f(u2f(f2u(x1) | 1u), -bound, bound);
+    lp_v2s_t c = {0, 0};
+    c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c, x0, x1, sc, false);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(__builtin_bit_cast(uint32_t, c), sc, false));
+}
+// largest magnitude of the two T values of a dword as T bits (non-negative T values order like their bit patterns; a NaN is > Inf's)
+typedef unsigned short lp_us2_t __attribute__((ext_vector_type(2)));
+template <int DT> MSQ_D uint32_t pk_absmax(uint32_t acc, uint32_t w) {    // v_and + v_pk_max_u16
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(lp_us2_t, acc), __builtin_bit_cast(lp_us2_t, w & 0x7FFF7FFFu)));
+}
+template <int DT> MSQ_D float absmax_to_float(uint32_t bits16) {          // T magnitude bits -> float (NaN stays NaN)
+    if (DT == 1) return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+    return u2f(bits16 << 16);
+}
+MSQ_D bool fmt_is_e4m3(const Fmt& f) { return f.kind == 0 && f.ebits == 4 && f.mbits == 5; }
+
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
@@ -584,25 +628,27 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
     const bool live = t < nchunks;
     union { uint4 u; uint16_t h[8]; } v;
     v.u = live ? *reinterpret_cast<const uint4*>(in + t * 8) : make_uint4(0, 0, 0, 0);
-    float a[8];
-    float mx = 0.f;
-    bool nan = false;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = ld16<DT>(v.h, j); const float w = __builtin_fabsf(a[j]); nan |= (w != w); mx = w > mx ? w : mx; }
-    if (nan) mx = u2f(0x7FC00000u);
+    // block maximum on the T bit patterns (non-negative T values order like their bits; a NaN's magnitude bits exceed Inf's, so a NaN
+    // element IS the maximum and stays one): four packed ops per lane instead of eight converts + compares
+    uint32_t am = pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(0u, v.u.x), v.u.y), v.u.z), v.u.w);
+    uint32_t mb = (am & 0xFFFFu) > (am >> 16) ? (am & 0xFFFFu) : (am >> 16);
 #pragma unroll
     for (int o = 1; o < LPB; o <<= 1) {
-        const float other = __shfl_xor(mx, o, 64);
-        mx = (other != other) ? other : ((mx != mx) ? mx : (other > mx ? other : mx));
+        const uint32_t other = (uint32_t)__shfl_xor((int)mb, o, 64);
+        mb = other > mb ? other : mb;
     }
+    const float mx = absmax_to_float<DT>(mb);
     MxBlk<DT> B = mx_block_setup<DT>(mx, A);
-    if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {                     // the whole wave: straight-line code
+    if (fmt_is_e4m3(A.f) && __builtin_amdgcn_ballot_w64(!(B.fast && B.pow2den)) == 0) {    // e4m3, the whole wave: the scaled converts
+        v.u.x = mx_e4m3_hw_pair<DT>(v.u.x, B.sc, B.mnsc); v.u.y = mx_e4m3_hw_pair<DT>(v.u.y, B.sc, B.mnsc);
+        v.u.z = mx_e4m3_hw_pair<DT>(v.u.z, B.sc, B.mnsc); v.u.w = mx_e4m3_hw_pair<DT>(v.u.w, B.sc, B.mnsc);
+    } else if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {              // the whole wave: straight-line code
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(a[j], B, s_tab));
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(ld16<DT>(v.h, j), B, s_tab));
     } else {
         B.fast = false;                                                  // the general path is right for every block
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem<DT>(a[j], B, A));     // (unrolled: a run-time index would put a[] in scratch)
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem<DT>(ld16<DT>(v.h, j), B, A));     // (unrolled: a run-time index would put v.h[] in scratch)
     }
     if (live) *reinterpret_cast<uint4*>(out + t * 8) = v.u;
     if (live && B.status && A.status) atomicOr(A.status, B.status);
@@ -625,21 +671,36 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
     const int64_t p = t / (hp * A.nblk);
     const int64_t a0 = nb * BS;
     const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    uint32_t raw[BS];
+    uint32_t am = 0u;                                                    // magnitude maxima of the two channels as T bits
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+        raw[b] = (a0 + b < A.axis_len) ? *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post) : 0u;
+        am = pk_absmax<DT>(am, raw[b]);
+    }
+    const float m0 = absmax_to_float<DT>(am & 0xFFFFu), m1 = absmax_to_float<DT>(am >> 16);     // (a NaN element is the maximum: NaN stays NaN)
+    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
+    if (fmt_is_e4m3(A.f) && (BS % 2) == 0 && (A.axis_len % BS) == 0 &&
+        __builtin_amdgcn_ballot_w64(!(B0.fast && B1.fast && B0.pow2den && B1.pow2den)) == 0) {
+        // the scaled converts take two values of ONE block: pair the tokens b, b + 1 of each channel (v_perm), convert, pair back
+#pragma unroll
+        for (int b = 0; b < BS; b += 2) {
+            const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
+            const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, B0.sc, B0.mnsc), q1 = mx_e4m3_hw_pair<DT>(p1, B1.sc, B1.mnsc);
+            *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+        }
+        const int st_ = B0.status | B1.status;
+        if (st_ && A.status) atomicOr(A.status, st_);
+        return;
+    }
     float a0v[BS], a1v[BS];
-    float m0 = 0.f, m1 = 0.f;
-    bool n0 = false, n1 = false;
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         union { uint32_t u; uint16_t h[2]; } w;
-        w.u = (a0 + b < A.axis_len) ? *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post) : 0u;
+        w.u = raw[b];
         a0v[b] = ld16<DT>(w.h, 0); a1v[b] = ld16<DT>(w.h, 1);
-        const float x0 = __builtin_fabsf(a0v[b]), x1 = __builtin_fabsf(a1v[b]);
-        n0 |= (x0 != x0); n1 |= (x1 != x1);
-        m0 = x0 > m0 ? x0 : m0; m1 = x1 > m1 ? x1 : m1;
     }
-    if (n0) m0 = u2f(0x7FC00000u);
-    if (n1) m1 = u2f(0x7FC00000u);
-    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
     if (__builtin_amdgcn_ballot_w64(!(B0.fast && B1.fast)) == 0) {
 #pragma unroll
         for (int b = 0; b < BS; ++b) {
