@@ -587,6 +587,20 @@ template <int DT> MSQ_D float absmax_to_float(uint32_t bits16) {          // T m
     return u2f(bits16 << 16);
 }
 MSQ_D bool fmt_is_e4m3(const Fmt& f) { return f.kind == 0 && f.ebits == 4 && f.mbits == 5; }
+// The ONE magnitude on which the reference's in-dtype arithmetic differs from exact half-away rounding inside the fast path's bounds:
+// the largest T value under the tie between zero and the smallest e4m3 subnormal, |x| = pred_T(2^(se - 10)).  There m = |x| 2^(9 - se)
+// = 1/2 - ulp, and `floor(m + 0.5)` (elemwise_ops.py:59-62) computes m + 0.5 IN T: 1 - ulp/2 is a tie of T's grid under 1 and rounds
+// (to even) to 1.0 -- the element becomes one subnormal step instead of zero (reference-made fixture bf16|tinyh|fp8e4m3_sb4).  Every other
+// m + 0.5 is exact in T or does not cross an integer.  The converts know nothing of it: a wave that holds such a value takes
+// mx_elem_fast instead (one value per block scale and sign: practically never).  T bits of that magnitude:
+template <int DT> MSQ_D uint32_t e4m3_quirk_bits(int sei) {
+    const int k = sei - 10;                                               // the tie is 2^k
+    if (DT == 1) return ((k >= -14) ? (uint32_t)(k + 15) << 10 : 1u << (k + 24)) - 1u;
+    return ((uint32_t)(k + 127) << 7) - 1u;
+}
+template <int DT> MSQ_D uint32_t pk_min_xor(uint32_t acc, uint32_t w, uint32_t cc) {     // min over halfwords of (|w| ^ cc): 0 = that magnitude is present
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(lp_us2_t, acc), __builtin_bit_cast(lp_us2_t, (w & 0x7FFF7FFFu) ^ cc)));
+}
 
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
@@ -639,7 +653,13 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
     }
     const float mx = absmax_to_float<DT>(mb);
     MxBlk<DT> B = mx_block_setup<DT>(mx, A);
-    if (fmt_is_e4m3(A.f) && __builtin_amdgcn_ballot_w64(!(B.fast && B.pow2den)) == 0) {    // e4m3, the whole wave: the scaled converts
+    bool hw = fmt_is_e4m3(A.f) && B.fast && B.pow2den;
+    if (hw) {
+        const uint32_t qb = e4m3_quirk_bits<DT>(B.sei), cc = qb | (qb << 16);
+        const uint32_t tq = pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(0xFFFFFFFFu, v.u.x, cc), v.u.y, cc), v.u.z, cc), v.u.w, cc);
+        hw = (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
+    }
+    if (__builtin_amdgcn_ballot_w64(!hw) == 0) {                         // e4m3, the whole wave: the scaled converts
         v.u.x = mx_e4m3_hw_pair<DT>(v.u.x, B.sc, B.mnsc); v.u.y = mx_e4m3_hw_pair<DT>(v.u.y, B.sc, B.mnsc);
         v.u.z = mx_e4m3_hw_pair<DT>(v.u.z, B.sc, B.mnsc); v.u.w = mx_e4m3_hw_pair<DT>(v.u.w, B.sc, B.mnsc);
     } else if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {              // the whole wave: straight-line code
@@ -680,8 +700,15 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
     }
     const float m0 = absmax_to_float<DT>(am & 0xFFFFu), m1 = absmax_to_float<DT>(am >> 16);     // (a NaN element is the maximum: NaN stays NaN)
     MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
-    if (fmt_is_e4m3(A.f) && (BS % 2) == 0 && (A.axis_len % BS) == 0 &&
-        __builtin_amdgcn_ballot_w64(!(B0.fast && B1.fast && B0.pow2den && B1.pow2den)) == 0) {
+    bool hw = fmt_is_e4m3(A.f) && (BS % 2) == 0 && (A.axis_len % BS) == 0 && B0.fast && B1.fast && B0.pow2den && B1.pow2den;
+    if (hw) {
+        const uint32_t cc = e4m3_quirk_bits<DT>(B0.sei) | (e4m3_quirk_bits<DT>(B1.sei) << 16);
+        uint32_t tq = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) tq = pk_min_xor<DT>(tq, raw[b], cc);
+        hw = (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
+    }
+    if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
         // the scaled converts take two values of ONE block: pair the tokens b, b + 1 of each channel (v_perm), convert, pair back
 #pragma unroll
         for (int b = 0; b < BS; b += 2) {
