@@ -261,6 +261,11 @@ int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int
 /* The GEMM kernel instantiation the same call would launch, as text ("k_qgemm256<6, uint16_t, 16>"): the dispatcher's own decision function,
  * tuning switches (MSQ_GEMM_256 / MSQ_MX_256) included; y_dtype 0 = float32 output, else 16-bit.  For measurement labels (bench.py). */
 int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf, int y_dtype, char* buf, int cap);
+/* Tuning switches without the environment (thread-safe: an atomic per key): key "MSQ_GEMM_256" (-1 = the rules, 0 = k_qgemm3 only, 1 / 2 =
+ * force the 256- / 128-row form of k_qgemm256, 3 = the persistent kernel where its plan applies) or "MSQ_MX_256" (-1, 0, 1, 2 likewise for
+ * k_mxgemm256); value INT_MIN hands the key back to the environment variable of the same name, which is otherwise read per call (for
+ * single-threaded A / B runs).  Returns MSQ_ERR_UNSUPPORTED for an unknown key. */
+int msq_set_tuning(const char* key, int value);
 /* Schedule of the persistent fused GEMM k_qgemm256p (csrc/msq_gemm256p.hip) for a shape -- host arithmetic only, no device needed; for tests
  * and capacity planning.  The T = ceil(M / 256) (N / 256) output tiles are dealt to P resident workgroups (one per CU; cus = CU count,
  * 0 = 256): `full` = T / P whole rounds, and the R = T - full P tiles of the part-filled last round as a stream of R (K / 64) K-steps cut

@@ -52,6 +52,7 @@ _SIGS = {
     "msq_qlinear_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "msq_qlinear_kernel_choice": (C.c_int, [_i64, _i64, _i64, _i32, _i32]),
     "msq_qlinear_kernel_name": (C.c_int, [_i64, _i64, _i64, _i32, _i32, _i32, C.c_char_p, _i32]),
+    "msq_set_tuning": (C.c_int, [C.c_char_p, _i32]),
     "msq_qgemm256p_plan": (C.c_int, [_i64, _i64, _i64, _i32] + [C.POINTER(_i32)] * 4 + [C.POINTER(_i64)]),
     "msq_qgemm256p_segments": (C.c_int, [_i32] * 6 + [C.POINTER(_i32), _i32]),
     "msq_qlinear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),

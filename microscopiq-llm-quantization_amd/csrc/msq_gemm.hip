@@ -1506,7 +1506,24 @@ int msq_launch_qgemm256p(const void* X, const void* ext_plane, const void* code_
 #endif
 // MSQ_GEMM_256 (tuning and A / B, read per call): 0 = k_qgemm3 only, 1 / 2 = force the 256- / 128-row form of k_qgemm256, 3 = force the
 // persistent kernel wherever its plan applies, unset = the rules
-static int q256_forced_env() { const char* e = getenv("MSQ_GEMM_256"); return e ? atoi(e) : -1; }
+// Both switches have a thread-safe form (advisor, round 4: getenv beside another thread's setenv is undefined behaviour): a value set
+// through msq_set_tuning() is held in an atomic and wins; only while none is set is the environment consulted, per call (single-threaded
+// tests and A / B scripts flip it inside one process).
+#include <atomic>
+#include <limits.h>
+static std::atomic<int> g_tune_gemm256{INT_MIN}, g_tune_mx256{INT_MIN};
+static int q256_forced_env() {
+    const int t = g_tune_gemm256.load(std::memory_order_relaxed);
+    if (t != INT_MIN) return t;
+    const char* e = getenv("MSQ_GEMM_256");
+    return e ? atoi(e) : -1;
+}
+extern "C" int msq_set_tuning(const char* key, int value) {
+    if (!key) return MSQ_ERR_BAD_ARG;
+    if (!strcmp(key, "MSQ_GEMM_256")) { g_tune_gemm256.store(value, std::memory_order_relaxed); return MSQ_OK; }
+    if (!strcmp(key, "MSQ_MX_256")) { g_tune_mx256.store(value, std::memory_order_relaxed); return MSQ_OK; }
+    return MSQ_ERR_UNSUPPORTED;
+}
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)
 static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes) {
     int64_t wsb = 0;
@@ -1557,8 +1574,9 @@ static QFamily q_family(int64_t M, int64_t N, int64_t K, bool unified_bf16x, int
 // k_mxgemm256 form for a shape (16 / 8 / 0 = k_mxgemm): mx256_rule and the MSQ_MX_256 switch (1 / 2 force the 256- / 128-row form, 0
 // disables both; read per call -- tests and A / B scripts flip it inside one process; not for concurrent use with setenv)
 static int mx256_family(int64_t M, int64_t N, int wf) {
-    const char* e256 = getenv("MSQ_MX_256");
-    const int forced = e256 ? atoi(e256) : -1;
+    const int t = g_tune_mx256.load(std::memory_order_relaxed);
+    const char* e256 = (t == INT_MIN) ? getenv("MSQ_MX_256") : nullptr;
+    const int forced = (t != INT_MIN) ? t : (e256 ? atoi(e256) : -1);
     const int mf_rule = mx256_rule(M, N, wf);
     return (forced == 2 || (forced < 0 && mf_rule == 8)) ? 8 : ((forced == 1 || (forced != 0 && mf_rule == 16)) ? 16 : 0);
 }

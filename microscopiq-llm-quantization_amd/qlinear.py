@@ -756,20 +756,29 @@ class FusedProjections(nn.Module):
         self._x = self._y = None
         self._ver = -1
         self._left = 0
+        self._last = -1
 
     def slice(self, i, x):
         # the cached result is valid for this very tensor object only (holding the reference keeps its storage from being
         # reused by another tensor) at the same version counter, and for one read per sibling
         # (inference tensors carry no version counter -- `x._version` raises under torch.inference_mode() -- and cannot be
         # written in place outside inference mode: identity alone is a sufficient key for them)
+        #
+        # RESTRICTION (advisor, round 4): an inference tensor CAN be written in place inside torch.inference_mode(), and nothing
+        # on the host sees it -- `q_proj(x); x.mul_(s); k_proj(x)` under inference mode returns k from the old x.  Ordinary
+        # tensors are covered by the version counter.  What is checked for both: every sibling is served at most once per
+        # fused result and in ascending order (q, k, v / gate, up: the order every HF block calls them in); a repeated or
+        # out-of-order call recomputes.  Do not modify the shared input in place between sibling calls under inference mode.
         ver = None if x.is_inference() else x._version
-        if self._x is not x or self._ver != ver or self._left <= 0:
+        if self._x is not x or self._ver != ver or self._left <= 0 or i <= self._last:
             self._y = self.proj(x)
-            self._x, self._ver, self._left = x, ver, len(self.splits)
+            self._x, self._ver, self._left, self._last = x, ver, len(self.splits), -1
         y = self._y[..., self.offsets[i]:self.offsets[i + 1]]
         self._left -= 1
+        self._last = i
         if self._left == 0:
             self._x = self._y = None
+            self._last = -1
         return y
 
 
