@@ -519,10 +519,20 @@ def _kernel_name(P, M, mx):
 
 
 def _gpu_sensors():
-    """Clock / power as far as the box exposes them to an ordinary user (sysfs of the first amdgpu card); {} when nothing is readable."""
+    """Clock / power as far as the box exposes them to an ordinary user: sysfs of the amdgpu card whose PCI address is the one torch reports for
+    cuda:0 (a box shows every card of the node, only one of them is ours); when no address matches, the card drawing the most power.
+    {} when nothing is readable."""
     import glob
-    out = {}
+    want = None
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(0)
+        want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        pass
+    cards = []
     for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        out = {}
         try:
             sclk = open(os.path.join(card, "pp_dpm_sclk")).read()
             cur = [l for l in sclk.splitlines() if l.strip().endswith("*")]
@@ -538,8 +548,15 @@ def _gpu_sensors():
                     pass
         if out:
             out["card"] = card
-            break
-    return out
+            out["pci"] = os.path.basename(os.path.realpath(card))
+            out["matched_cuda0"] = bool(want and out["pci"].lower().startswith(want))
+            cards.append(out)
+    for c in cards:
+        if c["matched_cuda0"]:
+            return c
+    if cards:
+        return max(cards, key=lambda c: c.get("power1_input", c.get("power1_average", 0)))
+    return {}
 
 
 def sustained(step, flops_step, peak, seconds=3.2, chunk=40):
