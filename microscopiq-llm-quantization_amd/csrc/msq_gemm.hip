@@ -1518,10 +1518,12 @@ static int q256_forced_env() {
     const char* e = getenv("MSQ_GEMM_256");
     return e ? atoi(e) : -1;
 }
+extern "C" void msq_set_tuning_lowp_(const char* key, int value);
 extern "C" int msq_set_tuning(const char* key, int value) {
     if (!key) return MSQ_ERR_BAD_ARG;
     if (!strcmp(key, "MSQ_GEMM_256")) { g_tune_gemm256.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_256")) { g_tune_mx256.store(value, std::memory_order_relaxed); return MSQ_OK; }
+    if (!strcmp(key, "MSQ_MX_LOWP_PAIR4")) { msq_set_tuning_lowp_("mx_lowp_pair4", value); return MSQ_OK; }   // 0: one lane per block pair (k_mx_lowp_pair)
     return MSQ_ERR_UNSUPPORTED;
 }
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)

@@ -602,6 +602,29 @@ template <int DT> MSQ_D uint32_t pk_min_xor(uint32_t acc, uint32_t w, uint32_t c
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(lp_us2_t, acc), __builtin_bit_cast(lp_us2_t, (w & 0x7FFF7FFFu) ^ cc)));
 }
 
+// Block quantities of the e4m3 convert path from the T bits of the block maximum, without mx_block_setup's general arithmetic (~150
+// instructions a block; the vectorised kernels run it per LANE: it was most of their instruction count).  ok <=> mx_block_setup would
+// give fast && pow2den with status 0 for this maximum (round to nearest, e4m3):
+//   se0 = floor(R(log2 mx)) (the table rule), se = se0 - emax (an exact small integer in T), |se| inside the scale range;
+//   sc = 2^se exact in T and normal in float32; den = R(sc + 1e-6) == sc (evaluated, not assumed); the three range bounds of
+//   MxBlk::fast with e4m3's min_exp = -6, mbits = 5, emax = 8: se - 9 >= TMINE, se + 10 <= TMAXE, se - 1 >= TMINE + 11; mx finite, != 0.
+// flush_fp32_subnorms never applies (se0 > -127 inside these bounds).  A wave in which any lane says no runs the general set-up.
+template <int DT> MSQ_D bool mx_setup_e4m3_lean(uint32_t mb, const MxLowpArgs& A, const uint8_t* tab, float& sc, float& bound, int& sei) {
+    constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;
+    constexpr uint32_t INFB = (DT == 1) ? 0x7C00u : 0x7F80u;
+    const float mx = absmax_to_float<DT>(mb);
+    const int se = (tab ? floor_log2_tab<DT>(mx, tab) : floor_log2_fast<DT>(mx)) - A.f.emax;
+    const int semax = (1 << (A.scale_bits - 1)) - 1;
+    int lo = TMINE + 12; lo = lo < -semax ? -semax : lo; lo = lo < -126 ? -126 : lo;
+    int hi = TMAXE - 10; hi = hi > semax ? semax : hi;
+    const int sc_e = se < lo ? lo : (se > hi ? hi : se);                 // (keeps the bit pattern below a normal power of two whatever se is)
+    sc = u2f((uint32_t)(sc_e + 127) << 23);
+    bound = 448.f * sc;
+    sei = sc_e;
+    const float den = Rr<DT>(sc + 1e-6f);                                // mx_ops.py:444
+    return mb != 0u && mb < INFB && se >= lo && se <= hi && den == sc;
+}
+
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
@@ -636,12 +659,14 @@ __global__ void __launch_bounds__(256)
 k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A, int64_t nchunks) {
     constexpr int LPB = BS / 8;                                          // lanes per block: 1, 2, 4, 8, 16
     __shared__ uint8_t s_tab[256];
-    floor_log2_tab_init<DT>(s_tab);
-    __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < nchunks;
     union { uint4 u; uint16_t h[8]; } v;
     v.u = live ? *reinterpret_cast<const uint4*>(in + t * 8) : make_uint4(0, 0, 0, 0);
+    // e4m3, round to nearest (kernel-uniform): one exponent look-up per lane -- computed, no table, no barrier in front of the data
+    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0;
+    const uint8_t* tab = e4 ? nullptr : s_tab;
+    if (!e4) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
     // block maximum on the T bit patterns (non-negative T values order like their bits; a NaN's magnitude bits exceed Inf's, so a NaN
     // element IS the maximum and stays one): four packed ops per lane instead of eight converts + compares
     uint32_t am = pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(0u, v.u.x), v.u.y), v.u.z), v.u.w);
@@ -651,20 +676,24 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
         const uint32_t other = (uint32_t)__shfl_xor((int)mb, o, 64);
         mb = other > mb ? other : mb;
     }
+    if (e4) {
+        float sc, bound; int sei;
+        bool hw = mx_setup_e4m3_lean<DT>(mb, A, tab, sc, bound, sei);
+        const uint32_t qb = e4m3_quirk_bits<DT>(sei), cc = qb | (qb << 16);
+        const uint32_t tq = pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(0xFFFFFFFFu, v.u.x, cc), v.u.y, cc), v.u.z, cc), v.u.w, cc);
+        hw = hw && (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {                     // the whole wave: the scaled converts
+            v.u.x = mx_e4m3_hw_pair<DT>(v.u.x, sc, bound); v.u.y = mx_e4m3_hw_pair<DT>(v.u.y, sc, bound);
+            v.u.z = mx_e4m3_hw_pair<DT>(v.u.z, sc, bound); v.u.w = mx_e4m3_hw_pair<DT>(v.u.w, sc, bound);
+            if (live) *reinterpret_cast<uint4*>(out + t * 8) = v.u;
+            return;
+        }
+    }
     const float mx = absmax_to_float<DT>(mb);
     MxBlk<DT> B = mx_block_setup<DT>(mx, A);
-    bool hw = fmt_is_e4m3(A.f) && B.fast && B.pow2den;
-    if (hw) {
-        const uint32_t qb = e4m3_quirk_bits<DT>(B.sei), cc = qb | (qb << 16);
-        const uint32_t tq = pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(pk_min_xor<DT>(0xFFFFFFFFu, v.u.x, cc), v.u.y, cc), v.u.z, cc), v.u.w, cc);
-        hw = (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
-    }
-    if (__builtin_amdgcn_ballot_w64(!hw) == 0) {                         // e4m3, the whole wave: the scaled converts
-        v.u.x = mx_e4m3_hw_pair<DT>(v.u.x, B.sc, B.mnsc); v.u.y = mx_e4m3_hw_pair<DT>(v.u.y, B.sc, B.mnsc);
-        v.u.z = mx_e4m3_hw_pair<DT>(v.u.z, B.sc, B.mnsc); v.u.w = mx_e4m3_hw_pair<DT>(v.u.w, B.sc, B.mnsc);
-    } else if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {              // the whole wave: straight-line code
+    if (__builtin_amdgcn_ballot_w64(!B.fast) == 0) {              // the whole wave: straight-line code
 #pragma unroll
-        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(ld16<DT>(v.h, j), B, s_tab));
+        for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, mx_elem_fast<DT>(ld16<DT>(v.h, j), B, tab));
     } else {
         B.fast = false;                                                  // the general path is right for every block
 #pragma unroll
@@ -680,8 +709,9 @@ template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
     __shared__ uint8_t s_tab[256];
-    floor_log2_tab_init<DT>(s_tab);
-    __syncthreads();
+    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0 && (BS % 2) == 0 && (A.axis_len % BS) == 0;      // kernel-uniform
+    const uint8_t* tab = e4 ? nullptr : s_tab;
+    if (!e4) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
     const int64_t hp = A.post / 2;
     const int64_t total = A.pre * A.nblk * hp;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -698,29 +728,29 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
         raw[b] = (a0 + b < A.axis_len) ? *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post) : 0u;
         am = pk_absmax<DT>(am, raw[b]);
     }
-    const float m0 = absmax_to_float<DT>(am & 0xFFFFu), m1 = absmax_to_float<DT>(am >> 16);     // (a NaN element is the maximum: NaN stays NaN)
-    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
-    bool hw = fmt_is_e4m3(A.f) && (BS % 2) == 0 && (A.axis_len % BS) == 0 && B0.fast && B1.fast && B0.pow2den && B1.pow2den;
-    if (hw) {
-        const uint32_t cc = e4m3_quirk_bits<DT>(B0.sei) | (e4m3_quirk_bits<DT>(B1.sei) << 16);
+    if (e4) {
+        float sc0, sc1, bd0, bd1; int se0, se1;
+        bool hw = mx_setup_e4m3_lean<DT>(am & 0xFFFFu, A, tab, sc0, bd0, se0);
+        hw = mx_setup_e4m3_lean<DT>(am >> 16, A, tab, sc1, bd1, se1) && hw;
+        const uint32_t cc = e4m3_quirk_bits<DT>(se0) | (e4m3_quirk_bits<DT>(se1) << 16);
         uint32_t tq = 0xFFFFFFFFu;
 #pragma unroll
         for (int b = 0; b < BS; ++b) tq = pk_min_xor<DT>(tq, raw[b], cc);
-        hw = (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
-    }
-    if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
-        // the scaled converts take two values of ONE block: pair the tokens b, b + 1 of each channel (v_perm), convert, pair back
+        hw = hw && (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u;
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
+            // the scaled converts take two values of ONE block: pair the tokens b, b + 1 of each channel (v_perm), convert, pair back
 #pragma unroll
-        for (int b = 0; b < BS; b += 2) {
-            const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
-            const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, B0.sc, B0.mnsc), q1 = mx_e4m3_hw_pair<DT>(p1, B1.sc, B1.mnsc);
-            *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
-            *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+            for (int b = 0; b < BS; b += 2) {
+                const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
+                const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, sc0, bd0), q1 = mx_e4m3_hw_pair<DT>(p1, sc1, bd1);
+                *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
+                *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+            }
+            return;
         }
-        const int st_ = B0.status | B1.status;
-        if (st_ && A.status) atomicOr(A.status, st_);
-        return;
     }
+    const float m0 = absmax_to_float<DT>(am & 0xFFFFu), m1 = absmax_to_float<DT>(am >> 16);     // (a NaN element is the maximum: NaN stays NaN)
+    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
     float a0v[BS], a1v[BS];
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
@@ -733,8 +763,8 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
         for (int b = 0; b < BS; ++b) {
             if (a0 + b >= A.axis_len) continue;
             union { uint32_t u; uint16_t h[2]; } w;
-            st16<DT>(w.h, 0, mx_elem_fast<DT>(a0v[b], B0, s_tab));
-            st16<DT>(w.h, 1, mx_elem_fast<DT>(a1v[b], B1, s_tab));
+            st16<DT>(w.h, 0, mx_elem_fast<DT>(a0v[b], B0, tab));
+            st16<DT>(w.h, 1, mx_elem_fast<DT>(a1v[b], B1, tab));
             *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = w.u;
         }
     } else {
@@ -752,7 +782,81 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
     if (st && A.status) atomicOr(A.status, st);
 }
 
+// The same, blocks of 32 along the strided axis with no ragged tail (the K cache of a prefill), cut FOUR ways: a thread block owns one
+// MX block row (32 tokens x 64 channel pairs), wave w its tokens 8 w ... 8 w + 7; the packed magnitude maxima meet in LDS (one dword per
+// lane, one barrier).  k_mx_lowp_pair holds 32 tokens per lane: 127 VGPRs, 4096 waves for a 7B layer cache = ONE round of four waves per
+// SIMD, in which the whole chip reads, then computes, then writes (23 us for 67 MB); eight values per lane give four times the waves at
+// half the registers, and the rounds overlap each other's reads and writes.
+template <int DT>
+__global__ void __launch_bounds__(256)
+k_mx_lowp_pair4(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A, int chunks) {
+    constexpr int BS = 32, TW = 8;
+    __shared__ uint8_t s_tab[256];
+    __shared__ uint32_t s_am[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t bi = blockIdx.x;
+    const int chunk = (int)(bi % chunks);
+    const int64_t r = bi / chunks, nb = r % A.nblk, p = r / A.nblk;
+    const int64_t hp = A.post / 2, cp = (int64_t)chunk * 64 + lane;
+    const bool live = cp < hp;
+    const int64_t base = (p * A.axis_len + nb * BS + w * TW) * A.post + 2 * (live ? cp : 0);
+    uint32_t raw[TW];
+    uint32_t am = 0u;
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+        raw[b] = *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post);
+        am = pk_absmax<DT>(am, raw[b]);
+    }
+    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0;                                     // kernel-uniform
+    const uint8_t* tab = e4 ? nullptr : s_tab;
+    if (!e4) floor_log2_tab_init<DT>(s_tab);
+    s_am[w][lane] = am;
+    __syncthreads();
+    am = pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(s_am[0][lane], s_am[1][lane]), s_am[2][lane]), s_am[3][lane]);
+    if (e4) {
+        float sc0, sc1, bd0, bd1; int se0, se1;
+        bool hw = mx_setup_e4m3_lean<DT>(am & 0xFFFFu, A, tab, sc0, bd0, se0);
+        hw = mx_setup_e4m3_lean<DT>(am >> 16, A, tab, sc1, bd1, se1) && hw;
+        const uint32_t cc = e4m3_quirk_bits<DT>(se0) | (e4m3_quirk_bits<DT>(se1) << 16);
+        uint32_t tq = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < TW; ++b) tq = pk_min_xor<DT>(tq, raw[b], cc);
+        hw = (hw && (tq & 0xFFFFu) != 0u && (tq >> 16) != 0u) || !live;
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
+#pragma unroll
+            for (int b = 0; b < TW; b += 2) {
+                const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
+                const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, sc0, bd0), q1 = mx_e4m3_hw_pair<DT>(p1, sc1, bd1);
+                if (live) {
+                    *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
+                    *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+                }
+            }
+            return;
+        }
+    }
+    const float m0 = absmax_to_float<DT>(am & 0xFFFFu), m1 = absmax_to_float<DT>(am >> 16);     // (a NaN element is the maximum: NaN stays NaN)
+    MxBlk<DT> B0 = mx_block_setup<DT>(m0, A), B1 = mx_block_setup<DT>(m1, A);
+    const bool fastw = __builtin_amdgcn_ballot_w64(!(B0.fast && B1.fast)) == 0;
+    if (!fastw) { B0.fast = false; B1.fast = false; }
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+        union { uint32_t u; uint16_t h[2]; } wi, wo;
+        wi.u = raw[b];
+        const float x0 = ld16<DT>(wi.h, 0), x1 = ld16<DT>(wi.h, 1);
+        if (fastw) { st16<DT>(wo.h, 0, mx_elem_fast<DT>(x0, B0, tab)); st16<DT>(wo.h, 1, mx_elem_fast<DT>(x1, B1, tab)); }
+        else { st16<DT>(wo.h, 0, mx_elem<DT>(x0, B0, A)); st16<DT>(wo.h, 1, mx_elem<DT>(x1, B1, A)); }
+        if (live) *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = wo.u;
+    }
+    const int st = B0.status | B1.status;
+    if (live && w == 0 && st && A.status) atomicOr(A.status, st);
+}
+
 extern "C" void msq_set_error_(const char* msg);
+#include <atomic>
+#include <string.h>
+static std::atomic<int> g_mx_pair4{1};
+extern "C" void msq_set_tuning_lowp_(const char* key, int value) { if (key && !strcmp(key, "mx_lowp_pair4")) g_mx_pair4.store(value); }
 
 // in / out: fp16 (dtype 1) or bf16 (dtype 2) tensors [pre, axis_len, post]; blocks of `block` (8 ... 128) along the axis, the
 // last one zero padded; status_flag (device int, may be NULL) receives MSQ_STATUS_NAN when a shared exponent exceeds the
@@ -775,11 +879,17 @@ extern "C" int msq_quantize_mx_lowp(const void* in, void* out, int dtype, int64_
     const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     const bool vec = post == 1 && (axis_len % block) == 0 && aligned;                    // contiguous axis: 8 values per lane
     const bool pair = !vec && post >= 2 && (post % 2) == 0 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0 && block <= 32;   // strided axis: two channels per lane
+    // ... cut four ways when the axis is whole blocks of 32 (MSQ_TUNE mx_lowp_pair4 = 0 keeps the one-lane-per-block-pair kernel)
+    const int chunks4 = (int)((post / 2 + 63) / 64);
+    const int64_t blocks4 = pre * A.nblk * chunks4;
+    const bool pair4 = pair && block == 32 && (axis_len % 32) == 0 && blocks4 < (int64_t)0x7FFFFFFF && g_mx_pair4.load(std::memory_order_relaxed) != 0;
+    const dim3 grid4((unsigned)(pair4 ? blocks4 : 1));
     const int64_t nchunks = pre * axis_len / 8;
     const int64_t nthreads = vec ? nchunks : (pair ? n / 2 : n);
     const dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
 #define MSQ_MXLP1(BS, DTV)                                                                                              \
         if (vec) hipLaunchKernelGGL((k_mx_lowp_vec<BS, DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, nchunks); \
+        else if (pair4) hipLaunchKernelGGL((k_mx_lowp_pair4<DTV>), grid4, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, chunks4); \
         else if (pair) hipLaunchKernelGGL((k_mx_lowp_pair<(BS <= 32 ? BS : 32), DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
         else hipLaunchKernelGGL((k_mx_lowp<BS, DTV>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A);
 #define MSQ_MXLP(BS)                                                                                                    \

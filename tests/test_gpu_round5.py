@@ -319,3 +319,74 @@ def test_ppl_fixture_shows_one_flipped_code_bit(msq, ppl_default_leg):
     many = bench.ppl_delta_from_env(dev(), "fp4_e2m1", "posit8_es1", 32, paths=("harness_default",), corrupt=corrupt(64))["harness_default"]
     assert many["logits_vs_cpu_reference"]["mean_kl_nats_per_token"] > clean["logits_vs_cpu_reference"]["mean_kl_nats_per_token"]
     assert many["delta"] != clean["delta"]
+
+
+def _eq_bits(a, b):
+    """the same float32 bit patterns (the sign of a zero included), NaN where NaN"""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype):
+    """The e4m3 convert path of the KV-cache MX quantiser decides per block, from the T bits of the block maximum, whether the converts
+    apply (msq_quant_lowp.hip mx_setup_e4m3_lean) -- scales at either end of T's range, the range in which `scale + 1e-6` is no longer the
+    scale, the floor(log2) bump just under powers of two, zero / Inf / NaN blocks must all come out as the reference's in-dtype arithmetic
+    (oracle: msq_oracle_quantize_mx_lowp).  One block maximum per binade of T (plus its bump neighbours), values spread below it; keys
+    layout (blocks along tokens, two channels per lane) and values layout (blocks along the contiguous axis, 8 values per lane)."""
+    from msq import kvcache
+    dn = "f16" if dtype == torch.float16 else "bf16"
+    g = torch.Generator().manual_seed(77)
+    exps = list(range(-26, 17)) if dtype == torch.float16 else list(range(-135, 128, 3)) + [-133, -126, -127, 126, 127]
+    tops = []
+    for e in exps:
+        for mant in (1.0, 1.5, 2.0 - 2.0 ** -9, 2.0 - 2.0 ** -7, 2.0 - 2.0 ** -4):
+            tops.append(mant * 2.0 ** e)
+    tops = torch.tensor(tops, dtype=torch.float64).to(dtype)             # rounding to T: overflow -> inf, underflow -> 0 / subnormals: wanted
+    nb = tops.numel()
+    # values layout: [1, 1, nb, 128] = 4 blocks of 32 per row, each row under one maximum
+    frac = torch.rand(nb, 128, generator=g, dtype=torch.float64) * 2 - 1
+    frac[:, ::32] = 1.0
+    frac[torch.rand(nb, 128, generator=g) < 0.2] *= 2.0 ** -6              # elements deep in the e4m3 subnormal range / under the zero tie
+    V_ = (frac * tops.double()[:, None]).to(dtype)
+    V_[V_ != V_] = 0                                                       # inf * 0 of the overflowed maxima
+    V_ = V_.reshape(1, 1, nb, 128)
+    vq = kvcache.mx_quantize_values(V_.to(dev()), "fp8_e4m3", 32)
+    vo = O.quantize_mx_lowp(V_.float().numpy(), dn, 8, "fp8_e4m3", 3, 32)
+    assert _eq_bits(vq.float().cpu().numpy(), vo), dn
+    # keys layout: [1, 1, 32 * nbk, 128]: channel c of token block b sits under maximum tops[(b * 128 + c) % nb]
+    nbk = (nb + 127) // 128 + 1
+    idx = (torch.arange(nbk)[:, None] * 128 + torch.arange(128)[None, :]) % nb
+    top_k = tops.double()[idx]                                              # [nbk, 128]
+    fk = torch.rand(nbk, 32, 128, generator=g, dtype=torch.float64) * 2 - 1
+    fk[:, 5, :] = -1.0
+    fk[torch.rand(nbk, 32, 128, generator=g) < 0.2] *= 2.0 ** -6
+    K_ = (fk * top_k[:, None, :]).to(dtype)
+    K_[K_ != K_] = 0
+    K_ = K_.reshape(1, 1, nbk * 32, 128)
+    ko = O.quantize_mx_lowp(K_.float().numpy(), dn, 8, "fp8_e4m3", 2, 32)
+    from msq._lib import lib
+    try:
+        for pair4 in (1, 0):                    # k_mx_lowp_pair4 (a block row over four waves, the default) and k_mx_lowp_pair
+            assert lib().msq_set_tuning(b"MSQ_MX_LOWP_PAIR4", pair4) == 0
+            kq = kvcache.mx_quantize_keys(K_.to(dev()), "fp8_e4m3", 32)
+            assert _eq_bits(kq.float().cpu().numpy(), ko), (dn, pair4)
+            # head dims that leave dead lanes (80: 40 channel pairs) and need two 64-pair chunks (160), other element formats
+            for hd, fmt in ((80, "fp8_e4m3"), (160, "fp8_e4m3"), (128, "fp4_e2m1"), (160, "fp6_e3m2"), (80, "int8")):
+                Kh = (torch.randn(2, 3, 64, hd, generator=g) * 3).to(dtype)
+                Kh[0, 0, :32, 1] *= 2.0 ** -12
+                got = kvcache.mx_quantize_keys(Kh.to(dev()), fmt, 32)
+                want = O.quantize_mx_lowp(Kh.float().numpy(), dn, 8, fmt, 2, 32)
+                assert _eq_bits(got.float().cpu().numpy(), want), (dn, pair4, hd, fmt)
+    finally:
+        lib().msq_set_tuning(b"MSQ_MX_LOWP_PAIR4", 1)
+    # NaN and Inf members, and an all-zero block
+    Z = V_.clone().reshape(nb, 128)
+    Z[0, :32] = 0; Z[1, 3] = float("inf"); Z[2, 40] = float("nan"); Z[3, 70] = -float("inf")
+    Z = Z.reshape(1, 1, nb, 128)
+    zq = kvcache.mx_quantize_values(Z.to(dev()), "fp8_e4m3", 32)
+    zo = O.quantize_mx_lowp(Z.float().numpy(), dn, 8, "fp8_e4m3", 3, 32)
+    assert _eq_bits(zq.float().cpu().numpy(), zo), dn
+    zk = kvcache.mx_quantize_keys(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().to(dev()), "fp8_e4m3", 32)
+    zko = O.quantize_mx_lowp(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().float().numpy(), dn, 8, "fp8_e4m3", 2, 32)
+    assert _eq_bits(zk.float().cpu().numpy(), zko), dn
