@@ -423,6 +423,33 @@ int msq_vec_gelu(const float* x, float* out, int64_t n, int first_order, int bit
 int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int64_t n, int bits, int exp_bits,
                 float max_norm, int rmode, int allow_denorm, void* stream);
 
+/* Round 5 -- the activation PRODUCERS in front of the MX Linear, able to hand their result on as the MX-FP8 operand of the scaled-MFMA GEMM
+ * (what MXLinear makes of its input first, linear.py:66-73) in the SAME launch: e4m3 codes [rows * H] row-major + scale bytes [rows * H / 32],
+ * the layout and the bytes of msq_mx_pack_a8 on the producer's output (one shared code path, csrc/msq_mx_pack_core.h) -- the float32
+ * intermediate never reaches memory unless `out` asks for it.
+ *   msq_vec_rmsnorm             replaces mx.RMSNorm's forward (layernorm.py:177 -> RMSNormFunction.forward :98-128): x = Q(x), ms = Q(Q(sum
+ *                               Q(x x)) / H), inv = Q(1 / Q(sqrt(Q(ms + eps)))), out = Q(Q(Q(w) Q(x inv)) + Q(b)); bias == NULL = zeros
+ *                               (Llama's RMSNorm).  Row sum in ATen's order.  H <= 40704.
+ *   msq_vec_rmsnorm_mx_pack_a8  the same + the pack; out may be NULL (packed operand only).  H % 128 == 0, codes 8-byte aligned.
+ *   msq_vec_silu                replaces mx.silu (activations.py:76 -> :420-434): q = Q(x), out = Q(q Q(1 / Q(Q(exp(-q)) + 1))).
+ *   msq_vec_mul                 replaces mx.simd_mul on two tensors of one shape (simd_ops.py:445 -> :154-187): Q(Q(a) Q(b)).
+ *   msq_vec_silu_mul_mx_pack_a8 simd_mul(silu(gate), up) -- the gated-MLP activation -- on rows of I values at row strides ld_gate / ld_up
+ *                               (elements; gate and up may be the halves of one [M, 2 I] projection output), to out [M, I] (may be NULL)
+ *                               and / or packed (codes / scales may both be NULL; then I only needs ld % 4 == 0, I % 8 == 0).  Pack: I % 128 == 0,
+ *                               16-byte aligned buffers.
+ * The exp inside silu is the device's expf (see msq_vec_gelu).  status_flag as msq_mx_pack_a8's. */
+int msq_vec_rmsnorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H, float eps,
+                    int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream);
+int msq_vec_rmsnorm_mx_pack_a8(const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales,
+                               int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
+                               int allow_denorm, int flush_fp32_subnorms, void* stream);
+int msq_vec_silu(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream);
+int msq_vec_mul(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
+                void* stream);
+int msq_vec_silu_mul_mx_pack_a8(const float* gate, const float* up, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
+                                int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode,
+                                int allow_denorm, int flush_fp32_subnorms, void* stream);
+
 /* ---------------------------------------------------------------------------
  * GPTQ column block with MicroScopiQ pruning -- replaces the inner column loop of llm/gptq.py:106-165 (per column:
  * quantize_mx_outlier_hessian on [O, 1], zero the num_outliers least important entries, error feedback to the columns on

@@ -11,7 +11,7 @@ from .quant import (MXQuantizer, Quantizer, quantize, quantize_mx_outlier_hessia
                     quantize_mx_outlier_v1)
 from .qlinear import QuantLinear, RowParallelQuantLinear, make_quant, pack_weight, unpack_weight  # noqa: F401
 from .linear import MXLinear  # noqa: F401
-from .vector_ops import LayerNorm, gelu, simd_add, simd_split  # noqa: F401
+from .vector_ops import LayerNorm, RMSNorm, SiLU, gelu, silu, simd_add, simd_mul, simd_split  # noqa: F401
 from .quant_model import quantize_model  # noqa: F401
 from .matmul import matmul, bmm  # noqa: F401
 

@@ -16,6 +16,7 @@
 
 #include "../../include/msq.h"
 #include "msq_device.h"
+#include "msq_mx_pack_core.h"
 #include "msq_host.h"
 
 using namespace msq;
@@ -23,16 +24,6 @@ using namespace msq;
 extern "C" void msq_set_error_(const char* msg);
 
 namespace {
-
-// shared scale byte of a block (cpp/shared_exp.cuh:14-53 with scale_bits 8): biased max exponent - elem emax,
-// clamped to [0, 254]; 255 (NaN) when the block holds Inf / NaN
-MSQ_D int mx_scale_byte(int max_biased_exp, int elem_emax, int& status) {
-    if (max_biased_exp == 255) { status |= MSQ_STATUS_NAN; return 255; }
-    int e = max_biased_exp - elem_emax;
-    if (e - 127 > 127) { status |= MSQ_STATUS_NAN; return 255; }
-    if (e - 127 < -127) e = 0;
-    return e;
-}
 
 // A wave owns 64 consecutive blocks of 32 floats = one contiguous 8 KiB run: coalesced 16-byte loads, transpose
 // through LDS (row stride 36 words), one block per lane.  FP4: weights, codes scattered into the MFMA tile order;
@@ -287,31 +278,9 @@ k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint
         const float4 v0 = reinterpret_cast<const float4*>(src)[2 * i], v1 = reinterpret_cast<const float4*>(src)[2 * i + 1];
         a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
     }
-    uint32_t mag = 0u;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) { const uint32_t t = f2u(a[b]) & 0x7FFFFFFFu; mag = t > mag ? t : mag; }   // whole magnitude: the Python-path exponent needs the significand
-    {
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-        mag = o1 > mag ? o1 : mag;
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mag, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
-        mag = o2 > mag ? o2 : mag;
-    }
-    const int se = biased_exp_py(mag);
-    int status = 0;
-    const bool fl = (se == 0) && flush;
-    const int sb = mx_scale_byte(se, 8, status);
-    const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
-    const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
     uint32_t cw[2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | 1u), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | 1u);
-        x0 = __builtin_amdgcn_fmed3f(x0, -bound, bound); x1 = __builtin_amdgcn_fmed3f(x1, -bound, bound);   // e4m3 does not saturate
-        v2s_t cur = __builtin_bit_cast(v2s_t, (p & 1) ? cw[p >> 1] : 0u);
-        if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, false);
-        else cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, true);
-        cw[p >> 1] = __builtin_bit_cast(uint32_t, cur);
-    }
+    int sb, status = 0;
+    mx_pack8_e4m3_quad(a, cw, sb, flush, status);                // msq_mx_pack_core.h
     reinterpret_cast<uint2*>(codes)[i] = make_uint2(cw[0], cw[1]);
     if ((threadIdx.x & 3) == 0) scales[i >> 2] = (uint8_t)sb;
     if (status && status_flag) atomicOr(status_flag, status);

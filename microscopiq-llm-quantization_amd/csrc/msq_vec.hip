@@ -17,6 +17,7 @@
 
 #include "../../include/msq.h"
 #include "msq_device.h"
+#include "msq_mx_pack_core.h"
 
 using namespace msq;
 
@@ -305,6 +306,221 @@ k_vec_add(const float* __restrict__ a, const float* __restrict__ b, float* __res
         out[i] = Q(Q(a[i], q) + (b_is_scalar ? bs : Q(b[i], q)), q);                  // simd_ops.py:95-106
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the activation PRODUCERS in front of the MX Linear, each able to hand its result on as the MX-FP8 operand of the scaled-MFMA
+// GEMM (e4m3 codes row-major + one scale byte per 32, the layout of msq_mx_pack_a8) instead of -- or besides -- the float32 tensor:
+//   RMSNorm      layernorm.py:177 -> RMSNormFunction.forward :98-128 (9 rounded ops per element, one row sum in ATen's order)
+//   silu x up    activations.py:76 -> :420-434 (5 rounded ops), simd_mul simd_ops.py:445 -> :154-187 (Q(Q(a) Q(b)))
+// The reference runs ~12 / ~9 eager torch kernels for these and then re-reads the result in MXLinear to quantise it (linear.py:66-73);
+// unfused here it is two launches (producer: 4 B in + 4 B out per element; packer: 4 B in + 1 B out), fused one (4 B in, 1 B out).
+// The pack is msq_mx_pack_core.h's: the bytes are those of msq_mx_pack_a8 on the producer's output.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PackOut { uint8_t* codes; uint8_t* scales; int* status; int flush; };
+
+// one chunk of eight consecutive values of row-major [rows, H] (chunk index i over the whole tensor); the quad's lanes call together
+MSQ_D void pack_chunk(const float (&a)[8], int64_t i, const PackOut& P, int& status) {
+    uint32_t cw[2];
+    int sb;
+    mx_pack8_e4m3_quad(a, cw, sb, P.flush, status);
+    reinterpret_cast<uint2*>(P.codes)[i] = make_uint2(cw[0], cw[1]);
+    if ((i & 3) == 0) P.scales[i >> 2] = (uint8_t)sb;
+}
+
+// any H: one wavefront per row, the row in LDS (as k_vec_layernorm)
+__global__ void __launch_bounds__(64)
+k_vec_rmsnorm(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+              int64_t rows, int64_t H, float eps, VQ q, PackOut P) {
+    extern __shared__ float xs[];
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + r * H;
+    for (int64_t i = lane; i < H; i += 64) xs[i] = Q(xr[i], q);                       // layernorm.py:104
+    __syncthreads();
+    float ms = Q(row_sum_inner8([&](int64_t i) { return Q(xs[i] * xs[i], q); }, H, lane), q);     // :107, vec_reduce_sum
+    ms = Q(ms / (float)H, q);                                                         // vec_div(s, denom)
+    const float mse = Q(ms + eps, q);                                                 // :114
+    const float rms = Q(__builtin_sqrtf(mse), q);                                     // :116
+    const float inv = Q(1.0f / rms, q);                                               // :119
+    __syncthreads();
+    float* orow = out ? out + r * H : nullptr;
+    for (int64_t i = lane; i < H; i += 64) {
+        const float xn = Q(xs[i] * inv, q);                                           // :120
+        const float sc = Q(Q(w[i], q) * xn, q);                                       // :122, :126
+        const float y = Q(sc + (b ? Q(b[i], q) : 0.f), q);                            // :124, :128
+        if (orow) orow[i] = y;
+        xs[i] = y;
+    }
+    if (P.codes) {                                                                    // H % 32 == 0 (checked on the host)
+        __syncthreads();
+        int status = 0;
+        for (int64_t c = lane; c < H / 8; c += 64) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = xs[c * 8 + u];
+            pack_chunk(a, r * (H / 8) + c, P, status);
+        }
+        if (status && P.status) atomicOr(P.status, status);
+    }
+}
+
+// H = 512 G, G <= 16: the register layout of k_vec_layernorm_reg (thread (k, t) owns the addends of its level-0 partial sums).  PACK: the
+// finished row goes through an LDS row buffer into the packer's layout (eight consecutive values per lane, a quad per block).
+template <int FAST, int GP, int PACK>
+__global__ void __launch_bounds__(256)
+k_vec_rmsnorm_reg(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+                  int64_t rows, int H, float eps, VQ q, PackOut P) {
+    __shared__ float part[512];
+    __shared__ float bc[1];
+    __shared__ __attribute__((aligned(16))) float ys[PACK ? GP * 4096 : 4];
+    const int tid = threadIdx.x, k = tid >> 5, t = tid & 31, G = H / 512;
+    float wq[GP][16], bq[GP][16], cur[GP][16], nxt[GP][16];
+    uint32_t wb[GP][16];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi)
+        if (k + 8 * gi < G) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = ((k + 8 * gi) * 16 + j) * 32 + t;
+                const float a = QI<FAST>(w[c], q), d = b ? QI<FAST>(b[c], q) : 0.f;
+                if (FAST) wb[gi][j] = f2u(a) | (f2u(d) >> 16);
+                else { wq[gi][j] = a; bq[gi][j] = d; }
+            }
+        }
+    auto fetch = [&](int64_t r) {
+        const float* xr = x + r * H;
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) nxt[gi][j] = xr[((k + 8 * gi) * 16 + j) * 32 + t];
+            }
+    };
+    auto combine = [&]() -> float {                                // level 1 and the 32 interleave slots, ATen's order (row_sum_inner8)
+        __syncthreads();
+        if (tid < 64) {
+            float p = 0.f;
+            if (tid < 32) { for (int g = 0; g < G; ++g) p += part[g * 32 + tid]; p = 0.f + p; }
+            float p0 = p;
+            for (int kk = 1; kk < 4; ++kk) { const float o = __shfl(p, (tid & 7) + 8 * kk, 64); p0 += o; }
+            float fin = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) fin += u2f(__builtin_amdgcn_readlane(f2u(p0), l));
+            if (tid == 0) bc[0] = fin;
+        }
+        __syncthreads();
+        return bc[0];
+    };
+    int status = 0;
+    if ((int64_t)blockIdx.x < rows) fetch(blockIdx.x);
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[gi][j] = QI<FAST>(nxt[gi][j], q);
+        if (r + gridDim.x < rows) fetch(r + gridDim.x);
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sm += QT<FAST>(cur[gi][j] * cur[gi][j], q);
+                part[(k + 8 * gi) * 32 + t] = sm;
+            }
+        float ms = QT<FAST>(combine(), q);
+        ms = QT<FAST>(ms / (float)H, q);
+        const float mse = QT<FAST>(ms + eps, q);
+        const float rms = QT<FAST>(__builtin_sqrtf(mse), q);
+        const float inv = QT<FAST>(1.0f / rms, q);
+        float* orow = out ? out + r * H : nullptr;
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi)
+            if (k + 8 * gi < G) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float ww = FAST ? u2f(wb[gi][j] & 0xFFFF0000u) : wq[gi][j];
+                    const float bb = FAST ? u2f(wb[gi][j] << 16) : bq[gi][j];
+                    const float y = QO<FAST>(QT<FAST>(ww * QT<FAST>(cur[gi][j] * inv, q), q) + bb, q);
+                    const int c = ((k + 8 * gi) * 16 + j) * 32 + t;
+                    if (orow) orow[c] = y;
+                    if (PACK) ys[c] = y;
+                }
+            }
+        if (PACK) {
+            __syncthreads();
+            for (int c = tid; c < H / 8; c += 256) {
+                const float4 v0 = *reinterpret_cast<const float4*>(ys + c * 8), v1 = *reinterpret_cast<const float4*>(ys + c * 8 + 4);
+                const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                pack_chunk(a, r * (H / 8) + c, P, status);
+            }
+            // (the next row's writes to ys come after its two combine() barriers)
+        }
+    }
+    if (PACK && status && P.status) atomicOr(P.status, status);
+}
+
+template <int FAST>
+MSQ_D float silu_one(float x, const VQ& q) {                      // activations.py:427-434, without the output rounding's zero rule
+    const float qi = QI<FAST>(x, q);
+    float phi = QT<FAST>(expf(-qi), q);                           // vec_exp (vec_use_exp2 off)
+    phi = QT<FAST>(phi + 1.0f, q);
+    if (FAST) phi = QT<FAST>((phi < 8.0e37f) ? __builtin_amdgcn_rcpf(phi) : 1.0f / phi, q);     // (as gelu_one: phi >= 1 has 8 significant bits)
+    else phi = QT<FAST>(1.0f / phi, q);
+    return QO<FAST>(qi * phi, q);
+}
+
+// out = silu(g) (u == nullptr), Q(Q(g) Q(u)) (MODE 1: simd_mul) or simd_mul(silu(g), u) (MODE 2); eight consecutive values per lane, rows of
+// I values at row strides ldg / ldu (gate and up may be the two halves of one [M, 2 I] tensor); out (row stride I) and / or the MX pack.
+template <int FAST, int MODE>
+__global__ void __launch_bounds__(256)
+k_vec_act8(const float* __restrict__ g, const float* __restrict__ u, int64_t ldg, int64_t ldu, float* __restrict__ out, int64_t n8, int I8,
+           VQ q, PackOut P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;                                          // n8 is a multiple of 4 whenever a pack is asked for
+    const int64_t row = i / I8, c8 = i % I8;
+    const float4* gp = reinterpret_cast<const float4*>(g + row * ldg + c8 * 8);
+    const float4 g0 = gp[0], g1 = gp[1];
+    float a[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE != 0) {
+        const float4* up = reinterpret_cast<const float4*>(u + row * ldu + c8 * 8);
+        const float4 u0 = up[0], u1 = up[1];
+        b8[0] = u0.x; b8[1] = u0.y; b8[2] = u0.z; b8[3] = u0.w; b8[4] = u1.x; b8[5] = u1.y; b8[6] = u1.z; b8[7] = u1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (MODE == 0) a[e] = silu_one<FAST>(a[e], q);
+        else if (MODE == 1) a[e] = QO<FAST>(QI<FAST>(a[e], q) * QI<FAST>(b8[e], q), q);
+        else a[e] = QO<FAST>(silu_one<FAST>(a[e], q) * QI<FAST>(b8[e], q), q);       // Q(silu) = silu: vec_quantize of a rounded value
+    }
+    if (out) {
+        float4* op = reinterpret_cast<float4*>(out + i * 8);
+        op[0] = make_float4(a[0], a[1], a[2], a[3]); op[1] = make_float4(a[4], a[5], a[6], a[7]);
+    }
+    if (P.codes) {
+        int status = 0;
+        pack_chunk(a, i, P, status);
+        if (status && P.status) atomicOr(P.status, status);
+    }
+}
+
+// scalar tail / unaligned form of the three element-wise ops (no pack)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_vec_act1(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ out, int64_t n, VQ q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (MODE == 1) { out[i] = Q(Q(g[i], q) * Q(u[i], q), q); continue; }
+        const float qi = Q(g[i], q);
+        float phi = Q(expf(-qi), q);
+        phi = Q(phi + 1.0f, q);
+        phi = Q(1.0f / phi, q);
+        const float s = Q(qi * phi, q);
+        out[i] = (MODE == 0) ? s : Q(s * Q(u[i], q), q);
+    }
+}
+
 }  // namespace
 
 extern "C" void msq_set_error_(const char* msg);
@@ -366,7 +582,7 @@ int msq_vec_layernorm(const float* x, const float* weight, const float* bias, fl
         return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_layernorm: launch failed");
     }
     const size_t lds = (size_t)H * 4;
-    if (lds > 65536) hipFuncSetAttribute((const void*)k_vec_layernorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_vec_layernorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_vec_layernorm, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, x, weight, bias, out, rows, H, eps,
                        VQ{bits, exp_bits, rmode, allow_denorm, max_norm});
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_layernorm: launch failed");
@@ -412,6 +628,105 @@ int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int6
     if (done < n)
         hipLaunchKernelGGL(k_vec_add, dim3(grid1(n - done)), dim3(256), 0, (hipStream_t)stream, a + done, b ? b + done : nullptr, out + done, n - done, b ? 0 : 1, b_scalar, vq);
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_add: launch failed");
+}
+
+
+/* RMSNorm (layernorm.py:98-128) and, with codes / scales given, the MX-FP8 activation pack of its output in the same launch. */
+static int rmsnorm_impl(const char* who, const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales,
+                        int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
+                        int allow_denorm, int flush, void* stream) {
+    if (rows < 0 || H < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: negative size");
+    if (rows * H == 0) return MSQ_OK;
+    (void)who;
+    if (!x || !weight || (!out && !codes)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: null buffer (x, weight and one of out / codes are required)");
+    if ((codes != nullptr) != (scales != nullptr)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm_mx_pack_a8: codes and scales go together");
+    if (codes && (H % 128)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_rmsnorm_mx_pack_a8: H must be a multiple of 128 (the GEMM's K)");
+    if (codes && ((uintptr_t)codes & 7)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_rmsnorm_mx_pack_a8: codes must be 8-byte aligned");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    if (H * 4 > 160 * 1024 - 1024) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_rmsnorm: a row must fit the CU's LDS (H <= 40704)");
+    const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
+    const PackOut P{(uint8_t*)codes, (uint8_t*)scales, status_flag, flush};
+    const hipStream_t st = (hipStream_t)stream;
+    if (H % 512 == 0 && H <= 8192) {
+        const int rpb = rows >= 2048 ? 2 : 1;
+        const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+        const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
+#define MSQ_RMS(FAST, GP) do { if (codes) hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, 1>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P); \
+                               else hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, 0>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P); } while (0)
+        if (H <= 4096) { if (fast) MSQ_RMS(1, 1); else MSQ_RMS(0, 1); }
+        else { if (fast) MSQ_RMS(1, 2); else MSQ_RMS(0, 2); }
+#undef MSQ_RMS
+        return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_rmsnorm: launch failed");
+    }
+    const size_t lds = (size_t)H * 4;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_vec_rmsnorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_vec_rmsnorm, dim3((unsigned)rows), dim3(64), lds, st, x, weight, bias, out, rows, H, eps, vq, P);
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_rmsnorm: launch failed");
+}
+int msq_vec_rmsnorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H, float eps,
+                    int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
+    if (rows * H != 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: null buffer");
+    return rmsnorm_impl("msq_vec_rmsnorm", x, weight, bias, out, nullptr, nullptr, nullptr, rows, H, eps, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+}
+int msq_vec_rmsnorm_mx_pack_a8(const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales, int* status_flag,
+                               int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
+                               int flush_fp32_subnorms, void* stream) {
+    if (rows * H != 0 && (!codes || !scales)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm_mx_pack_a8: null buffer");
+    return rmsnorm_impl("msq_vec_rmsnorm_mx_pack_a8", x, weight, bias, out, codes, scales, status_flag, rows, H, eps, bits, exp_bits, max_norm, rmode,
+                        allow_denorm, flush_fp32_subnorms, stream);
+}
+
+/* mode 0: silu(gate) (activations.py:420-434); 1: simd_mul(gate, up) (simd_ops.py:154-187); 2: simd_mul(silu(gate), up).  Rows of I values at
+ * row strides ld_gate / ld_up (elements); out [M, I] and / or the MX-FP8 pack of the result. */
+static int act_impl(int mode, const float* gate, const float* up, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
+                    int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, int flush,
+                    void* stream) {
+    if (M < 0 || I < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: negative size");
+    if (M * I == 0) return MSQ_OK;
+    if (!gate || (mode != 0 && !up) || (!out && !codes)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: null buffer");
+    if ((codes != nullptr) != (scales != nullptr)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul_mx_pack_a8: codes and scales go together");
+    if (ld_gate < I || (mode != 0 && ld_up < I)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: a row stride is shorter than the row");
+    if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
+    const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
+    const hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)out) & 15) == 0 && (ld_gate % 4) == 0 && (ld_up % 4) == 0 && (I % 8) == 0;
+    if (codes) {
+        if (I % 128) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul_mx_pack_a8: I must be a multiple of 128 (the GEMM's K)");
+        if (!al || ((uintptr_t)codes & 7)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul_mx_pack_a8: buffers must be 16-byte aligned, row strides multiples of 4");
+    }
+    const PackOut P{(uint8_t*)codes, (uint8_t*)scales, status_flag, flush};
+    if (al) {
+        const int64_t n8 = M * I / 8;
+        const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
+        const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
+#define MSQ_ACT(MODE) do { if (fast) hipLaunchKernelGGL((k_vec_act8<1, MODE>), grid, blk, 0, st, gate, up, ld_gate, ld_up, out, n8, (int)(I / 8), vq, P); \
+                           else hipLaunchKernelGGL((k_vec_act8<0, MODE>), grid, blk, 0, st, gate, up, ld_gate, ld_up, out, n8, (int)(I / 8), vq, P); } while (0)
+        if (mode == 0) MSQ_ACT(0); else if (mode == 1) MSQ_ACT(1); else MSQ_ACT(2);
+#undef MSQ_ACT
+    } else {
+        if (ld_gate != I || (mode != 0 && ld_up != I)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul: strided rows need 16-byte aligned buffers and I % 8 == 0");
+        const int64_t n = M * I;
+        if (mode == 0) hipLaunchKernelGGL(k_vec_act1<0>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
+        else if (mode == 1) hipLaunchKernelGGL(k_vec_act1<1>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
+        else hipLaunchKernelGGL(k_vec_act1<2>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
+    }
+    return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_silu_mul: launch failed");
+}
+int msq_vec_silu(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
+    if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu: negative size");
+    if (n > 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu: null buffer");
+    return act_impl(0, x, nullptr, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+}
+int msq_vec_mul(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
+    if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_mul: negative size");
+    if (n > 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_mul: null buffer");
+    return act_impl(1, a, b, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+}
+int msq_vec_silu_mul_mx_pack_a8(const float* gate, const float* up, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
+                                int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
+                                int flush_fp32_subnorms, void* stream) {
+    return act_impl(2, gate, up, ld_gate, ld_up, out, codes, scales, status_flag, M, I, bits, exp_bits, max_norm, rmode, allow_denorm,
+                    flush_fp32_subnorms, stream);
 }
 
 }  // extern "C"

@@ -1097,6 +1097,46 @@ void msq_oracle_vec_add(const float* a, const float* b, float* out, int64_t n, i
     for (int64_t i = 0; i < n; ++i) out[i] = VQ(VQ(a[i], &q) + VQ(b[i], &q), &q);
 }
 
+/* RMSNorm forward, number_system/mx/layernorm.py:98-128 (RMSNormFunction.forward): x = Q(x); x2 = Q(x x); ms = Q(Q(sum x2) / H) (vec_reduce_mean,
+ * vector_ops.py:121-130); rms = Q(sqrt(Q(ms + eps))); inv = Q(1 / rms); x_norm = Q(x inv); out = Q(Q(Q(w) x_norm) + Q(b)). */
+void msq_oracle_vec_rmsnorm(const float* x, const float* w, const float* b, float* out, int64_t rows, int64_t H,
+                            double eps, int bits, int exp_bits, float max_norm, int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    float* t = (float*)malloc(sizeof(float) * H * 2);
+    float* p = t + H;
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int64_t i = 0; i < H; ++i) { t[i] = VQ(x[r * H + i], &q); p[i] = VQ(t[i] * t[i], &q); }   /* :104, :107 */
+        float ms = VQ(sum_inner_v8(p, H), &q);                                      /* vec_reduce_sum */
+        ms = VQ(ms / (float)H, &q);                                                 /* vec_div(s, denom) */
+        const float mse = VQ(ms + (float)eps, &q);                                  /* :114 */
+        const float rms = VQ(sqrtf(mse), &q);                                       /* :116 */
+        const float inv = VQ(1.0f / rms, &q);                                       /* :119 */
+        for (int64_t i = 0; i < H; ++i) {
+            const float xn = VQ(t[i] * inv, &q);                                    /* :120 */
+            const float xs = VQ(VQ(w[i], &q) * xn, &q);                             /* :122, :126 */
+            out[r * H + i] = VQ(xs + VQ(b[i], &q), &q);                             /* :124, :128 */
+        }
+    }
+    free(t);
+}
+/* SiLU forward, activations.py:420-434: q = Q(x); e = Q(exp(-q)); p = Q(e + 1); s = Q(1 / p); out = Q(q s)  (vec_use_exp2 False) */
+void msq_oracle_vec_silu(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    for (int64_t i = 0; i < n; ++i) {
+        const float qi = VQ(x[i], &q);
+        float phi = VQ(expf(-qi), &q);
+        phi = VQ(phi + 1.0f, &q);
+        phi = VQ(1.0f / phi, &q);
+        out[i] = VQ(qi * phi, &q);
+    }
+}
+/* simd_mul, simd_ops.py:154-187 (tensor x tensor): Q(Q(a) Q(b)) */
+void msq_oracle_vec_mul(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm,
+                        int round_mode, int allow_denorm) {
+    const vq_t q = {bits, exp_bits, round_mode, allow_denorm, max_norm};
+    for (int64_t i = 0; i < n; ++i) out[i] = VQ(VQ(a[i], &q) * VQ(b[i], &q), &q);
+}
+
 /* thread count of the OpenMP regions above (0 = all cores); returns the count in effect */
 #ifdef _OPENMP
 #include <omp.h>

@@ -260,6 +260,32 @@ def vec_gelu(x, first_order=False, bits=9, exp_bits=8, max_norm=3.38953138925153
     return out
 
 
+def vec_rmsnorm(x, w, b, eps, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    """mx RMSNorm forward (layernorm.py:98-128) with every op rounded by Q = (bits, exp_bits)."""
+    x = _f32(x); w = _f32(w); b = _f32(b)
+    H = x.shape[-1]
+    out = np.empty_like(x)
+    lib().msq_oracle_vec_rmsnorm(_p(x), _p(w), _p(b), _p(out), C.c_int64(x.size // H), C.c_int64(H), C.c_double(eps),
+                                 *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out
+
+
+def vec_silu(x, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    """mx silu forward (activations.py:420-434)"""
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().msq_oracle_vec_silu(_p(x), _p(out), C.c_int64(x.size), *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out
+
+
+def vec_mul(a, b, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
+    """simd_mul of two tensors of one shape (simd_ops.py:154-187)"""
+    a = _f32(a); b = _f32(b)
+    out = np.empty_like(a)
+    lib().msq_oracle_vec_mul(_p(a), _p(b), _p(out), C.c_int64(a.size), *_vq(bits, exp_bits, max_norm, round, allow_denorm))
+    return out
+
+
 def vec_add(a, b, bits=9, exp_bits=8, max_norm=3.3895313892515355e38, round="nearest", allow_denorm=True):
     a = _f32(a); b = _f32(b)
     out = np.empty_like(a)
