@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
-ROUND_TAG = "r04"
+ROUND_TAG = "r05"
 
 
 def parse_args(argv=None):
@@ -497,7 +497,7 @@ def _clone_packed(P):
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 achievable)
 # sub-objects of the default line's `configs` (BASELINE.json configs 3, 4, 5 and decode) and of `rowparallel`: the --stub path emits
 # the same keys, tests/test_host_logic.py pins them
-CONFIG_KEYS = ("w4a8_mx", "w4a8_mx_plain_fp4", "w6a8_mx_plain_fp6", "w4a8_mxlinear", "kv_quant", "decode_cold", "rowparallel_70b_1gpu", "layer7b_prefill")
+CONFIG_KEYS = ("w4a8_mx", "w4a8_mx_plain_fp4", "w6a8_mx_plain_fp6", "producers", "w4a8_mxlinear", "kv_quant", "decode_cold", "rowparallel_70b_1gpu", "layer7b_prefill")
 ROWPAR_KEYS = ("step_ms", "gemm_ms", "comm_ms", "exposed_comm_ms", "chunks", "comm", "wire_dtype")
 
 
@@ -665,7 +665,35 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
                     "flops": fl, "kernels": "k_mx_pack_a8 + k_mxgemm256", "operand": what, "M": M, "N": N, "K": K,
                     "activations": "fp32 in, MX-FP8 (e4m3, block 32) packed in the step"}
         del P
-    del P_msq
+    # ---- the producers of that activation (round 5): mx.RMSNorm in front of q/k/v / gate/up, silu x up in front of down_proj, handing the MX-FP8
+    # operand straight to the GEMM (msq_vec_rmsnorm_mx_pack_a8 / msq_vec_silu_mul_mx_pack_a8) against producer -> float32 -> msq_mx_pack_a8
+    from msq import vector_ops as V
+    vs = msq.specs.finalize_mx_specs({"w_elem_format": inlier, "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": block, "custom_cuda": True,
+                                      "bfloat": 16})
+    wn = torch.ones(K, device=dev)
+    prod = {}
+    I_ = 11008
+    gu = torch.randn(M, 2 * I_, device=dev)
+    Wd = synth_weight(H, I_, dev, seed=2)
+    P_dn = qlinear.mx_pack_values(quant.outlier_fakequant(Wd, 8, 8, inlier, "fp8_e4m3", 2, -1, block)["out"])
+    del Wd
+    for key, P, n_, k_, unf, fus, byt in (
+            ("rmsnorm_then_qkv_shape_gemm", P_msq, N, K, lambda: V.rms_norm(X, wn, None, 1e-6, vs), lambda: V.rms_norm_mx_pack(X, wn, None, 1e-6, vs), M * K * (4 + 1 + 1 / 32)),
+            ("silu_mul_then_down_proj", P_dn, H, I_, lambda: V.silu_mul(gu[:, :I_], gu[:, I_:], vs), lambda: V.silu_mul(gu[:, :I_], gu[:, I_:], vs, pack=True),
+             M * I_ * (8 + 1 + 1 / 32))):
+        for _ in range(5):
+            qlinear.qlinear_mx_w4a8(fus(), P, None, torch.bfloat16)
+        ms_u = _tgraph([lambda: qlinear.qlinear_mx_w4a8(unf(), P, None, torch.bfloat16)] * 10)
+        ms_f = _tgraph([lambda: qlinear.qlinear_mx_w4a8(fus(), P, None, torch.bfloat16)] * 10)
+        ms_p = _tgraph([fus] * 10)
+        fl_ = 2.0 * M * n_ * k_
+        prod[key] = {"ms_producer_packer_gemm": ms_u, "ms_fused_producer_gemm": ms_f, "speedup": ms_u / ms_f, "ms_fused_producer_alone": ms_p,
+                     "producer_GBps": byt / ms_p / 1e6, "producer_frac_of_hbm": byt / ms_p / 1e6 / HBM_PEAK_GBPS, "producer_bytes": byt,
+                     "tflops_fused_step": fl_ / ms_f / 1e9, "frac_fused_step": fl_ / ms_f / 1e9 / PEAK_FP8_TFLOPS, "M": M, "N": n_, "K": k_}
+    prod["what"] = ("reference ops number_system/mx/layernorm.py:177 (RMSNorm), activations.py:76 (silu), simd_ops.py:445 (simd_mul), bfloat16 rounding after "
+                    "every step; float32 in, MX-FP8 operand out; weight = the exact e4m3 operand of config 3")
+    out["producers"] = prod
+    del P_msq, P_dn, gu
     # ---- config 3 as the reference composes it: MXLinear(w = fp4_e2m1, a = fp8_e4m3, block 32), mx_ops variant (std_dev 5) on BOTH operands
     Pl = qlinear.pack_values(_quantize_mx_outlier_v1(W, 8, 8, inlier, "fp4_e2m1", "max", 5, [1], block))
     f = lambda: qlinear.qlinear_w4a8(X, Pl, None, torch.bfloat16, a_elem_format="fp8_e4m3", a_std_dev=5, a_block_size=block, a_variant=1)

@@ -153,6 +153,9 @@ def test_bench_other_configs_keys_and_rates(bench_line):
     kv = c["kv_quant"]
     for k in ("keys_group_4bit_per_channel_g32", "values_group_4bit_per_token_g32", "keys_mx_fp8_blocks_along_tokens", "values_mx_fp8_blocks_along_head_dim"):
         assert kv[k]["ms"] > 0 and kv[k]["frac"] > 0.1, kv
+    pr = c["producers"]                                        # round 5: fused RMSNorm / silu x up -> MX-FP8 operand in front of the GEMM
+    for k in ("rmsnorm_then_qkv_shape_gemm", "silu_mul_then_down_proj"):
+        assert pr[k]["ms_fused_producer_gemm"] > 0 and pr[k]["speedup"] > 1.02 and pr[k]["producer_frac_of_hbm"] > 0.2, pr[k]
     d = c["decode_cold"]
     assert set(("qkv", "o", "gate_up", "down")) <= set(d) and d["packed_bytes"] > 2.2e8 and d["frac"] > 0.25, d
     assert abs(d["layer_ms"] - sum(d[k]["ms"] for k in ("qkv", "o", "gate_up", "down"))) < 1e-9
