@@ -506,3 +506,50 @@ def test_fused_producers_pack_what_the_unfused_chain_packs(msq, O):
     assert torch.equal(y_a, y_b)
     with pytest.raises(msq._lib.MsqError):
         V.rms_norm_mx_pack(torch.randn(4, 200, device=dev()), torch.ones(200, device=dev()), None, 1e-6, specs)     # H % 128
+
+
+def test_gated_mlp_block_from_mx_modules_matches_the_reference(msq):
+    """A Llama-style gated MLP written against the reference's `mx` module set -- RMSNorm -> MXLinear gate / up -> simd_mul(silu(gate), up) ->
+    MXLinear down -> simd_add(residual, .), w fp4_e2m1 / a fp8_e4m3 / block 32 / bfloat 16 -- with the reference's parameters on its input
+    (tests/golden/vec_ops2.npz `gmlp|*`): every stage against the reference's CPU intermediate.  RMSNorm, simd_mul, simd_add are exact;
+    silu is exact up to the device expf (<= 2 elements); the MXLinears re-round an fp32 GEMM with another summation order to bfloat16
+    (one bf16 ulp on <= 1 % there, as the ResidualMLP test of round 2)."""
+    z = np.load(os.path.join(GOLD, "vec_ops2.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    sp = msq.specs.finalize_mx_specs({"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": 32,
+                                      "bfloat": 16, "custom_cuda": True})
+
+    class GatedMLP(torch.nn.Module):
+        def __init__(self, hidden, inter, mx_specs):
+            super().__init__()
+            self.mx_specs = mx_specs
+            self.norm = msq.RMSNorm(hidden, eps=1e-6, mx_specs=mx_specs)
+            self.gate_proj = msq.MXLinear(hidden, inter, bias=False, mx_specs=mx_specs)
+            self.up_proj = msq.MXLinear(hidden, inter, bias=False, mx_specs=mx_specs)
+            self.down_proj = msq.MXLinear(inter, hidden, bias=False, mx_specs=mx_specs)
+
+        def forward(self, x):
+            x, residual = msq.simd_split(x)
+            h = self.norm(x)
+            a = msq.simd_mul(msq.silu(self.gate_proj(h), mx_specs=self.mx_specs), self.up_proj(h), mx_specs=self.mx_specs)
+            return msq.simd_add(residual, self.down_proj(a), mx_specs=self.mx_specs)
+
+    blk = GatedMLP(128, 384, sp).to(dev())
+    blk.load_state_dict({k[len("gmlp|param|"):]: t(z[k]) for k in z.files if k.startswith("gmlp|param|")})
+    x = t(z["gmlp|x"])
+
+    def close(a, ref, what, frac=0.01):
+        e = np.abs(a.cpu().numpy() - ref)
+        assert (e <= np.abs(ref) * 2.0 ** -7 + 1e-6).all() and (e > 0).mean() <= frac, (what, float(e.max()), float((e > 0).mean()))
+    with torch.no_grad():
+        assert _eq_bits(blk.norm(x).cpu().numpy(), z["gmlp|norm"])
+        close(blk.gate_proj(t(z["gmlp|norm"])), z["gmlp|gate"], "gate")
+        close(blk.up_proj(t(z["gmlp|norm"])), z["gmlp|up"], "up")
+        a = msq.vector_ops.silu_mul(t(z["gmlp|gate"]), t(z["gmlp|up"]), sp)
+        assert (a.cpu().numpy() != z["gmlp|act"]).sum() <= 2
+        close(blk.down_proj(t(z["gmlp|act"])), z["gmlp|down"], "down")
+        assert _eq_bits(msq.simd_add(x, t(z["gmlp|down"]), mx_specs=sp).cpu().numpy(), z["gmlp|y"])
+        y = blk(x).cpu().numpy()
+    e = np.abs(y - z["gmlp|y"])
+    assert (e <= np.abs(z["gmlp|y"]) * 2.0 ** -6 + 1e-6).all(), float(e.max())
+    assert (e > 0).mean() <= 0.05, float((e > 0).mean())
