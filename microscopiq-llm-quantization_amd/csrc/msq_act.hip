@@ -421,6 +421,9 @@ k_act_quant_rows(const float* __restrict__ X, uint16_t* __restrict__ Xq, Outlier
 
 }  // namespace
 
+static msq_host::TuneKey g_act_rows("MSQ_ACT_ROWS");        // 0: statistics + quantiser as two launches (msq_set_tuning / environment, per call)
+extern "C" int msq_set_tuning_act_(const char* key, int value) { return g_act_rows.set_if(key, value); }
+
 extern "C" int64_t msq_act_quant_workspace_bytes(int64_t M, int64_t K, int block, int variant) {
     if (variant != MSQ_VARIANT_MXOPS || M <= 0 || K <= 0 || block <= 0) return 0;
     return 2 * (int64_t)sizeof(float) * M * block;
@@ -460,8 +463,7 @@ static int act_quant_impl(const void* Xv, int x_bf16, void* Xq, int* status_flag
         if (x_bf16 && block == 16) { msq_set_error_("msq_act_quant_bf16_x16: the mx_ops variant on bfloat16 input needs block 32 or 64"); return MSQ_ERR_UNSUPPORTED; }
         // rows of <= 4096 elements, blocks of 32, round-to-nearest: statistics and quantiser in one pass over X (k_act_quant_rows).
         // MSQ_ACT_ROWS=0 (tuning and A / B, read per call) keeps the two launches.
-        const char* er = getenv("MSQ_ACT_ROWS");
-        if (K <= 4096 && block == 32 && rmode == 0 && K / block >= 2 && !(er && atoi(er) == 0)) {
+        if (K <= 4096 && block == 32 && rmode == 0 && K / block >= 2 && g_act_rows.value(1) != 0) {
             const bool hw1 = hw_codec_kind(A.fi) && hw_codec_kind(A.fo);
             const dim3 grid((unsigned)((M + 3) / 4)), blk(256);
             hipStream_t st = (hipStream_t)stream;

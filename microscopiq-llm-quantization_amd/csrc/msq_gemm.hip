@@ -1157,6 +1157,15 @@ static int check_launch2(const char* what) {
     if (e != hipSuccess) { char b[200]; snprintf(b, sizeof(b), "%s: %s", what, hipGetErrorString(e)); return fail2(MSQ_ERR_LAUNCH, b); }
     return MSQ_OK;
 }
+// MSQ_PACK_TWO_PASS (tests / A-B): msq_outlier_pack through the two-pass kernels even where the single-pass one applies; msq_set_tuning or environment
+#include <atomic>
+#include <limits.h>
+static std::atomic<int> g_tune_two_pass{INT_MIN};
+static bool pack_two_pass_forced() {
+    const int t = g_tune_two_pass.load(std::memory_order_relaxed);
+    if (t != INT_MIN) return t != 0;
+    return getenv("MSQ_PACK_TWO_PASS") != nullptr;
+}
 extern "C" void msq_set_error_(const char* msg);
 // tile layout of the packed planes: 1 = 16x16x32 fragments.  (Layout 2 = 32x32x16 fragments was built
 // and measured 8-10 % slower end to end -- the chip holds a lower clock on that MFMA shape -- and removed;
@@ -1294,7 +1303,7 @@ int msq_outlier_pack(const float* W, void* inl_plane, void* out_plane, void* sca
         return rc;
     }
     // single-pass kernel for the common configurations (float/int inliers, nearest rounding, block <= 64) ...
-    if (variant == MSQ_VARIANT_QUANT && getenv("MSQ_PACK_TWO_PASS") == nullptr) {
+    if (variant == MSQ_VARIANT_QUANT && !pack_two_pass_forced()) {
         rc = msq_pack_fused_(W, inl_plane, out_plane, scale_plane, status_flag, N, K, block, inlier_fmt, outlier_fmt,
                              inlier_scale_bits, outlier_scale_bits, std_dev, rmode, flush_fp32_subnorms, ik, ok, stream);
         if (rc != MSQ_ERR_UNSUPPORTED) return rc;
@@ -1519,11 +1528,16 @@ static int q256_forced_env() {
     return e ? atoi(e) : -1;
 }
 extern "C" void msq_set_tuning_lowp_(const char* key, int value);
+extern "C" int msq_set_tuning_act_(const char* key, int value);
+extern "C" int msq_set_tuning_mx_(const char* key, int value);
+extern "C" int msq_set_tuning_vec_(const char* key, int value);
 extern "C" int msq_set_tuning(const char* key, int value) {
     if (!key) return MSQ_ERR_BAD_ARG;
     if (!strcmp(key, "MSQ_GEMM_256")) { g_tune_gemm256.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_256")) { g_tune_mx256.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_LOWP_PAIR4")) { msq_set_tuning_lowp_("mx_lowp_pair4", value); return MSQ_OK; }   // 0: one lane per block pair (k_mx_lowp_pair)
+    if (!strcmp(key, "MSQ_PACK_TWO_PASS")) { g_tune_two_pass.store(value, std::memory_order_relaxed); return MSQ_OK; }
+    if (msq_set_tuning_act_(key, value) || msq_set_tuning_mx_(key, value) || msq_set_tuning_vec_(key, value)) return MSQ_OK;   // MSQ_ACT_ROWS, MSQ_MX_PACK_BLOCK, MSQ_VEC_GENERIC
     return MSQ_ERR_UNSUPPORTED;
 }
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)

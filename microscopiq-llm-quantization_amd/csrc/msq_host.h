@@ -5,6 +5,10 @@
 #include <string.h>
 #include "../../include/msq.h"
 
+#include <atomic>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
 namespace msq_host {
 
 struct FmtInfo { int kind, ebits, mbits, emax; float max_norm, min_norm; };
@@ -69,4 +73,14 @@ inline int format_id(const char* name) {
     return MSQ_ERR_BAD_ARG;
 }
 
+
+// A tuning switch: an atomic that msq_set_tuning() can set (thread-safe, wins), else the environment variable of the same name read per call
+// (single-threaded tests and A / B scripts flip it inside one process).  value(): the override, or atoi(env), or `unset`.
+struct TuneKey {
+    const char* name; std::atomic<int> v{INT_MIN};
+    explicit TuneKey(const char* n) : name(n) {}
+    int value(int unset) const { const int t = v.load(std::memory_order_relaxed); if (t != INT_MIN) return t; const char* e = getenv(name); return e ? atoi(e) : unset; }
+    bool is_set() const { return v.load(std::memory_order_relaxed) != INT_MIN || getenv(name) != nullptr; }
+    bool set_if(const char* key, int value) { if (strcmp(key, name)) return false; v.store(value, std::memory_order_relaxed); return true; }
+};
 }  // namespace msq_host

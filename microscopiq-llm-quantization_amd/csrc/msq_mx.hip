@@ -288,6 +288,9 @@ k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint
 
 }  // namespace
 
+static msq_host::TuneKey g_pack_block("MSQ_MX_PACK_BLOCK");   // != 0: one lane per block (k_mx_pack<0>) instead of the 8-values-per-lane packer
+extern "C" int msq_set_tuning_mx_(const char* key, int value) { return g_pack_block.set_if(key, value); }
+
 extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* status_flag, int64_t M, int64_t K,
                               int flush_fp32_subnorms, void* stream) {
     if (M < 0 || K < 0) { msq_set_error_("msq_mx_pack_a8: negative size"); return MSQ_ERR_BAD_ARG; }
@@ -295,7 +298,7 @@ extern "C" int msq_mx_pack_a8(const float* X, void* codes, void* scales, int* st
     if (K % 128) { msq_set_error_("msq_mx_pack_a8: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
-    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
+    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && g_pack_block.value(0) == 0)
         hipLaunchKernelGGL((k_mx_pack_a8_vec<0>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const void*)X,
                            (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
     else
@@ -371,7 +374,7 @@ extern "C" int msq_mx_pack_a8_bf16(const void* X, void* codes, void* scales, int
     if (K % 128) { msq_set_error_("msq_mx_pack_a8_bf16: K must be a multiple of 128"); return MSQ_ERR_UNSUPPORTED; }
     if (!X || !codes || !scales) { msq_set_error_("msq_mx_pack_a8_bf16: null buffer"); return MSQ_ERR_BAD_ARG; }
     const int64_t nblocks = M * (K / 32);
-    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && !getenv("MSQ_MX_PACK_BLOCK"))
+    if ((((uintptr_t)X | (uintptr_t)codes) & 15) == 0 && g_pack_block.value(0) == 0)
         hipLaunchKernelGGL((k_mx_pack_a8_vec<1>), dim3((unsigned)((nblocks * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                            (uint8_t*)codes, (uint8_t*)scales, nblocks * 4, flush_fp32_subnorms, status_flag);
     else

@@ -18,6 +18,7 @@
 #include "../../include/msq.h"
 #include "msq_device.h"
 #include "msq_mx_pack_core.h"
+#include "msq_host.h"
 
 using namespace msq;
 
@@ -532,9 +533,10 @@ static int vq_check(int bits, int exp_bits, int rmode) {
     return MSQ_OK;
 }
 // MSQ_VEC_GENERIC=1 in the environment sends bfloat16 / nearest through the run-time-parameter kernels too (the parity tests compare the two)
+static msq_host::TuneKey g_vec_generic("MSQ_VEC_GENERIC");
+extern "C" int msq_set_tuning_vec_(const char* key, int value) { return g_vec_generic.set_if(key, value); }
 static bool vq_is_fast(int bits, int exp_bits, int rmode, int allow_denorm) {
-    const char* e = getenv("MSQ_VEC_GENERIC");
-    if (e && e[0] == '1') return false;
+    if (g_vec_generic.value(0) == 1) return false;
     return bits == 9 && exp_bits == 8 && allow_denorm && rmode == 0;
 }
 static int grid1(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g)); }

@@ -542,3 +542,26 @@ def test_persistent_kernel_schedule_covers_every_k_step_once():
                 assert [x[3] for x in l[1:]] == list(range(l[0][4], l[0][5] + 1))
         assert (ws > 0) == bool(tail_blocks) and (not tail_blocks or ws >= 4096 + 262144 * (max(tail_blocks) + 1))
     assert plan(2048, 16384 + 64, 4096)[0] != 0 and plan(2048, 16384, 4096 + 64)[0] != 0 and plan(0, 256, 128)[0] != 0
+
+
+def test_set_tuning_knows_every_switch():
+    """msq_set_tuning (include/msq.h): every A / B switch of the library has an atomic override (no getenv / setenv race for a threaded
+    host); INT_MIN hands a key back to the environment; an unknown key is refused.  Host-only: no device call."""
+    import ctypes
+    from msq._lib import lib
+    L = lib()
+    INT_MIN = -2 ** 31
+    for key in (b"MSQ_GEMM_256", b"MSQ_MX_256", b"MSQ_MX_LOWP_PAIR4", b"MSQ_ACT_ROWS", b"MSQ_MX_PACK_BLOCK", b"MSQ_VEC_GENERIC", b"MSQ_PACK_TWO_PASS"):
+        assert L.msq_set_tuning(key, 1) == 0, key
+        assert L.msq_set_tuning(key, INT_MIN if key != b"MSQ_MX_LOWP_PAIR4" else 1) == 0, key
+    assert L.msq_set_tuning(b"MSQ_NO_SUCH_SWITCH", 1) != 0
+    # the switch reaches the dispatcher: the kernel name of the headline shape under a forced form
+    buf = ctypes.create_string_buffer(128)
+    try:
+        assert L.msq_set_tuning(b"MSQ_GEMM_256", 2) == 0
+        L.msq_qlinear_kernel_name(2048, 16384, 4096, 6, -1, 2, buf, 128)
+        assert b"8>" in buf.value, buf.value
+    finally:
+        L.msq_set_tuning(b"MSQ_GEMM_256", INT_MIN)
+    L.msq_qlinear_kernel_name(2048, 16384, 4096, 6, -1, 2, buf, 128)
+    assert buf.value == b"k_qgemm256<6, uint16_t, 16>", buf.value
