@@ -318,6 +318,29 @@ k_vec_add(const float* __restrict__ a, const float* __restrict__ b, float* __res
 // The pack is msq_mx_pack_core.h's: the bytes are those of msq_mx_pack_a8 on the producer's output.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct PackOut { uint8_t* codes; uint8_t* scales; int* status; int flush; };
+// element i of a float32 (XS 0), bfloat16 (1) or float16 (2) tensor as float (every 16-bit value is a float32 value: the results of casting first)
+template <int XS> MSQ_D float ldx(const void* p, int64_t i) {
+    if (XS == 1) return u2f((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+    if (XS == 2) return (float)reinterpret_cast<const _Float16*>(p)[i];
+    return reinterpret_cast<const float*>(p)[i];
+}
+// eight consecutive elements starting at element index i (16-byte aligned for 16-bit sources, 32-byte pieces for float32)
+template <int XS> MSQ_D void ldx8(const void* p, int64_t i, float (&a)[8]) {
+    if (XS == 0) {
+        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+        const float4 v0 = q[0], v1 = q[1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    } else if (XS == 1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + i);
+        a[0] = u2f(v.x << 16); a[1] = u2f(v.x & 0xFFFF0000u); a[2] = u2f(v.y << 16); a[3] = u2f(v.y & 0xFFFF0000u);
+        a[4] = u2f(v.z << 16); a[5] = u2f(v.z & 0xFFFF0000u); a[6] = u2f(v.w << 16); a[7] = u2f(v.w & 0xFFFF0000u);
+    } else {
+        union { uint4 u; _Float16 h[8]; } r;
+        r.u = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(p) + i);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a[b] = (float)r.h[b];
+    }
+}
 
 // one chunk of eight consecutive values of row-major [rows, H] (chunk index i over the whole tensor); the quad's lanes call together
 MSQ_D void pack_chunk(const float (&a)[8], int64_t i, const PackOut& P, int& status) {
@@ -329,15 +352,15 @@ MSQ_D void pack_chunk(const float (&a)[8], int64_t i, const PackOut& P, int& sta
 }
 
 // any H: one wavefront per row, the row in LDS (as k_vec_layernorm)
+template <int XS>
 __global__ void __launch_bounds__(64)
-k_vec_rmsnorm(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+k_vec_rmsnorm(const void* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
               int64_t rows, int64_t H, float eps, VQ q, PackOut P) {
     extern __shared__ float xs[];
     const int64_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (r >= rows) return;
-    const float* xr = x + r * H;
-    for (int64_t i = lane; i < H; i += 64) xs[i] = Q(xr[i], q);                       // layernorm.py:104
+    for (int64_t i = lane; i < H; i += 64) xs[i] = Q(ldx<XS>(x, r * H + i), q);       // layernorm.py:104
     __syncthreads();
     float ms = Q(row_sum_inner8([&](int64_t i) { return Q(xs[i] * xs[i], q); }, H, lane), q);     // :107, vec_reduce_sum
     ms = Q(ms / (float)H, q);                                                         // vec_div(s, denom)
@@ -368,9 +391,9 @@ k_vec_rmsnorm(const float* __restrict__ x, const float* __restrict__ w, const fl
 
 // H = 512 G, G <= 16: the register layout of k_vec_layernorm_reg (thread (k, t) owns the addends of its level-0 partial sums).  PACK: the
 // finished row goes through an LDS row buffer into the packer's layout (eight consecutive values per lane, a quad per block).
-template <int FAST, int GP, int PACK>
+template <int FAST, int GP, int PACK, int XS>
 __global__ void __launch_bounds__(256)
-k_vec_rmsnorm_reg(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+k_vec_rmsnorm_reg(const void* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
                   int64_t rows, int H, float eps, VQ q, PackOut P) {
     __shared__ float part[512];
     __shared__ float bc[1];
@@ -390,12 +413,11 @@ k_vec_rmsnorm_reg(const float* __restrict__ x, const float* __restrict__ w, cons
             }
         }
     auto fetch = [&](int64_t r) {
-        const float* xr = x + r * H;
 #pragma unroll
         for (int gi = 0; gi < GP; ++gi)
             if (k + 8 * gi < G) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) nxt[gi][j] = xr[((k + 8 * gi) * 16 + j) * 32 + t];
+                for (int j = 0; j < 16; ++j) nxt[gi][j] = ldx<XS>(x, r * H + ((k + 8 * gi) * 16 + j) * 32 + t);
             }
     };
     auto combine = [&]() -> float {                                // level 1 and the 32 interleave slots, ATen's order (row_sum_inner8)
@@ -473,22 +495,17 @@ MSQ_D float silu_one(float x, const VQ& q) {                      // activations
 
 // out = silu(g) (u == nullptr), Q(Q(g) Q(u)) (MODE 1: simd_mul) or simd_mul(silu(g), u) (MODE 2); eight consecutive values per lane, rows of
 // I values at row strides ldg / ldu (gate and up may be the two halves of one [M, 2 I] tensor); out (row stride I) and / or the MX pack.
-template <int FAST, int MODE>
+template <int FAST, int MODE, int XS>
 __global__ void __launch_bounds__(256)
-k_vec_act8(const float* __restrict__ g, const float* __restrict__ u, int64_t ldg, int64_t ldu, float* __restrict__ out, int64_t n8, int I8,
+k_vec_act8(const void* __restrict__ g, const void* __restrict__ u, int64_t ldg, int64_t ldu, float* __restrict__ out, int64_t n8, int I8,
            VQ q, PackOut P) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;                                          // n8 is a multiple of 4 whenever a pack is asked for
     const int64_t row = i / I8, c8 = i % I8;
-    const float4* gp = reinterpret_cast<const float4*>(g + row * ldg + c8 * 8);
-    const float4 g0 = gp[0], g1 = gp[1];
-    float a[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float a[8];
+    ldx8<XS>(g, row * ldg + c8 * 8, a);
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (MODE != 0) {
-        const float4* up = reinterpret_cast<const float4*>(u + row * ldu + c8 * 8);
-        const float4 u0 = up[0], u1 = up[1];
-        b8[0] = u0.x; b8[1] = u0.y; b8[2] = u0.z; b8[3] = u0.w; b8[4] = u1.x; b8[5] = u1.y; b8[6] = u1.z; b8[7] = u1.w;
-    }
+    if (MODE != 0) ldx8<XS>(u, row * ldu + c8 * 8, b8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         if (MODE == 0) a[e] = silu_one<FAST>(a[e], q);
@@ -633,13 +650,14 @@ int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int6
 }
 
 
-/* RMSNorm (layernorm.py:98-128) and, with codes / scales given, the MX-FP8 activation pack of its output in the same launch. */
-static int rmsnorm_impl(const char* who, const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales,
+/* RMSNorm (layernorm.py:98-128) and, with codes / scales given, the MX-FP8 activation pack of its output in the same launch.
+ * x_dtype 0 float32, 1 float16, 2 bfloat16 (the library's dtype codes): 16-bit activations are read as they are. */
+static int rmsnorm_impl(const void* x, int x_dtype, const float* weight, const float* bias, float* out, void* codes, void* scales,
                         int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
                         int allow_denorm, int flush, void* stream) {
     if (rows < 0 || H < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: negative size");
     if (rows * H == 0) return MSQ_OK;
-    (void)who;
+    if (x_dtype < 0 || x_dtype > 2) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: x_dtype must be 0 (float32), 1 (float16) or 2 (bfloat16)");
     if (!x || !weight || (!out && !codes)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: null buffer (x, weight and one of out / codes are required)");
     if ((codes != nullptr) != (scales != nullptr)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm_mx_pack_a8: codes and scales go together");
     if (codes && (H % 128)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_rmsnorm_mx_pack_a8: H must be a multiple of 128 (the GEMM's K)");
@@ -649,85 +667,113 @@ static int rmsnorm_impl(const char* who, const float* x, const float* weight, co
     const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
     const PackOut P{(uint8_t*)codes, (uint8_t*)scales, status_flag, flush};
     const hipStream_t st = (hipStream_t)stream;
+    const int xs = x_dtype == 2 ? 1 : (x_dtype == 1 ? 2 : 0);               // kernel source code: 0 f32, 1 bf16, 2 f16
     if (H % 512 == 0 && H <= 8192) {
         const int rpb = rows >= 2048 ? 2 : 1;
         const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
         const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
-#define MSQ_RMS(FAST, GP) do { if (codes) hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, 1>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P); \
-                               else hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, 0>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P); } while (0)
+#define MSQ_RMS3(FAST, GP, PK, XS) hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, PK, XS>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P)
+#define MSQ_RMS2(FAST, GP, PK) do { if (xs == 0) MSQ_RMS3(FAST, GP, PK, 0); else if (xs == 1) MSQ_RMS3(FAST, GP, PK, 1); else MSQ_RMS3(FAST, GP, PK, 2); } while (0)
+#define MSQ_RMS(FAST, GP) do { if (codes) MSQ_RMS2(FAST, GP, 1); else MSQ_RMS2(FAST, GP, 0); } while (0)
         if (H <= 4096) { if (fast) MSQ_RMS(1, 1); else MSQ_RMS(0, 1); }
         else { if (fast) MSQ_RMS(1, 2); else MSQ_RMS(0, 2); }
 #undef MSQ_RMS
+#undef MSQ_RMS2
+#undef MSQ_RMS3
         return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_rmsnorm: launch failed");
     }
     const size_t lds = (size_t)H * 4;
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_vec_rmsnorm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_vec_rmsnorm, dim3((unsigned)rows), dim3(64), lds, st, x, weight, bias, out, rows, H, eps, vq, P);
+#define MSQ_RMSG(XS) do { if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_vec_rmsnorm<XS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                          hipLaunchKernelGGL(k_vec_rmsnorm<XS>, dim3((unsigned)rows), dim3(64), lds, st, x, weight, bias, out, rows, H, eps, vq, P); } while (0)
+    if (xs == 0) MSQ_RMSG(0); else if (xs == 1) MSQ_RMSG(1); else MSQ_RMSG(2);
+#undef MSQ_RMSG
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_rmsnorm: launch failed");
 }
 int msq_vec_rmsnorm(const float* x, const float* weight, const float* bias, float* out, int64_t rows, int64_t H, float eps,
                     int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
     if (rows * H != 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm: null buffer");
-    return rmsnorm_impl("msq_vec_rmsnorm", x, weight, bias, out, nullptr, nullptr, nullptr, rows, H, eps, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+    return rmsnorm_impl(x, 0, weight, bias, out, nullptr, nullptr, nullptr, rows, H, eps, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
 }
 int msq_vec_rmsnorm_mx_pack_a8(const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales, int* status_flag,
                                int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
                                int flush_fp32_subnorms, void* stream) {
     if (rows * H != 0 && (!codes || !scales)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm_mx_pack_a8: null buffer");
-    return rmsnorm_impl("msq_vec_rmsnorm_mx_pack_a8", x, weight, bias, out, codes, scales, status_flag, rows, H, eps, bits, exp_bits, max_norm, rmode,
+    return rmsnorm_impl(x, 0, weight, bias, out, codes, scales, status_flag, rows, H, eps, bits, exp_bits, max_norm, rmode,
+                        allow_denorm, flush_fp32_subnorms, stream);
+}
+int msq_vec_rmsnorm_mx_pack_a8_x16(const void* x, int x_dtype, const float* weight, const float* bias, float* out, void* codes, void* scales,
+                                   int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
+                                   int allow_denorm, int flush_fp32_subnorms, void* stream) {
+    if (x_dtype != 1 && x_dtype != 2) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_rmsnorm_mx_pack_a8_x16: x_dtype must be 1 (float16) or 2 (bfloat16)");
+    return rmsnorm_impl(x, x_dtype, weight, bias, out, codes, scales, status_flag, rows, H, eps, bits, exp_bits, max_norm, rmode,
                         allow_denorm, flush_fp32_subnorms, stream);
 }
 
 /* mode 0: silu(gate) (activations.py:420-434); 1: simd_mul(gate, up) (simd_ops.py:154-187); 2: simd_mul(silu(gate), up).  Rows of I values at
- * row strides ld_gate / ld_up (elements); out [M, I] and / or the MX-FP8 pack of the result. */
-static int act_impl(int mode, const float* gate, const float* up, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
+ * row strides ld_gate / ld_up (elements); out [M, I] and / or the MX-FP8 pack of the result.  x_dtype as above (gate and up alike). */
+static int act_impl(int mode, const void* gate, const void* up, int x_dtype, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
                     int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, int flush,
                     void* stream) {
     if (M < 0 || I < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: negative size");
     if (M * I == 0) return MSQ_OK;
+    if (x_dtype < 0 || x_dtype > 2) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: x_dtype must be 0 (float32), 1 (float16) or 2 (bfloat16)");
     if (!gate || (mode != 0 && !up) || (!out && !codes)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: null buffer");
     if ((codes != nullptr) != (scales != nullptr)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul_mx_pack_a8: codes and scales go together");
     if (ld_gate < I || (mode != 0 && ld_up < I)) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul: a row stride is shorter than the row");
     if (int rc = vq_check(bits, exp_bits, rmode)) return rc;
     const VQ vq{bits, exp_bits, rmode, allow_denorm, max_norm};
     const hipStream_t st = (hipStream_t)stream;
-    const bool al = (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)out) & 15) == 0 && (ld_gate % 4) == 0 && (ld_up % 4) == 0 && (I % 8) == 0;
+    const int ldm = x_dtype ? 8 : 4;                                        // row strides that keep 16-byte pieces aligned
+    const bool al = (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)out) & 15) == 0 && (ld_gate % ldm) == 0 && (ld_up % ldm) == 0 && (I % 8) == 0;
     if (codes) {
         if (I % 128) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul_mx_pack_a8: I must be a multiple of 128 (the GEMM's K)");
-        if (!al || ((uintptr_t)codes & 7)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul_mx_pack_a8: buffers must be 16-byte aligned, row strides multiples of 4");
+        if (!al || ((uintptr_t)codes & 7)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul_mx_pack_a8: buffers must be 16-byte aligned, row strides multiples of 16 bytes");
     }
     const PackOut P{(uint8_t*)codes, (uint8_t*)scales, status_flag, flush};
+    const int xs = x_dtype == 2 ? 1 : (x_dtype == 1 ? 2 : 0);
     if (al) {
         const int64_t n8 = M * I / 8;
         const dim3 grid((unsigned)((n8 + 255) / 256)), blk(256);
         const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
-#define MSQ_ACT(MODE) do { if (fast) hipLaunchKernelGGL((k_vec_act8<1, MODE>), grid, blk, 0, st, gate, up, ld_gate, ld_up, out, n8, (int)(I / 8), vq, P); \
-                           else hipLaunchKernelGGL((k_vec_act8<0, MODE>), grid, blk, 0, st, gate, up, ld_gate, ld_up, out, n8, (int)(I / 8), vq, P); } while (0)
+#define MSQ_ACT3(FAST, MODE, XS) hipLaunchKernelGGL((k_vec_act8<FAST, MODE, XS>), grid, blk, 0, st, gate, up, ld_gate, ld_up, out, n8, (int)(I / 8), vq, P)
+#define MSQ_ACT2(FAST, MODE) do { if (xs == 0) MSQ_ACT3(FAST, MODE, 0); else if (xs == 1) MSQ_ACT3(FAST, MODE, 1); else MSQ_ACT3(FAST, MODE, 2); } while (0)
+#define MSQ_ACT(MODE) do { if (fast) MSQ_ACT2(1, MODE); else MSQ_ACT2(0, MODE); } while (0)
         if (mode == 0) MSQ_ACT(0); else if (mode == 1) MSQ_ACT(1); else MSQ_ACT(2);
 #undef MSQ_ACT
+#undef MSQ_ACT2
+#undef MSQ_ACT3
     } else {
+        if (x_dtype != 0) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul: 16-bit inputs need 16-byte aligned buffers, I % 8 == 0 and row strides % 8 == 0");
         if (ld_gate != I || (mode != 0 && ld_up != I)) return vfail(MSQ_ERR_UNSUPPORTED, "msq_vec_silu_mul: strided rows need 16-byte aligned buffers and I % 8 == 0");
         const int64_t n = M * I;
-        if (mode == 0) hipLaunchKernelGGL(k_vec_act1<0>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
-        else if (mode == 1) hipLaunchKernelGGL(k_vec_act1<1>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
-        else hipLaunchKernelGGL(k_vec_act1<2>, dim3(grid1(n)), dim3(256), 0, st, gate, up, out, n, vq);
+        const float* g32 = (const float*)gate; const float* u32 = (const float*)up;
+        if (mode == 0) hipLaunchKernelGGL(k_vec_act1<0>, dim3(grid1(n)), dim3(256), 0, st, g32, u32, out, n, vq);
+        else if (mode == 1) hipLaunchKernelGGL(k_vec_act1<1>, dim3(grid1(n)), dim3(256), 0, st, g32, u32, out, n, vq);
+        else hipLaunchKernelGGL(k_vec_act1<2>, dim3(grid1(n)), dim3(256), 0, st, g32, u32, out, n, vq);
     }
     return hipGetLastError() == hipSuccess ? MSQ_OK : vfail(MSQ_ERR_LAUNCH, "msq_vec_silu_mul: launch failed");
 }
 int msq_vec_silu(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
     if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu: negative size");
     if (n > 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu: null buffer");
-    return act_impl(0, x, nullptr, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+    return act_impl(0, x, nullptr, 0, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
 }
 int msq_vec_mul(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream) {
     if (n < 0) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_mul: negative size");
     if (n > 0 && !out) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_mul: null buffer");
-    return act_impl(1, a, b, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
+    return act_impl(1, a, b, 0, n, n, out, nullptr, nullptr, nullptr, n ? 1 : 0, n, bits, exp_bits, max_norm, rmode, allow_denorm, 0, stream);
 }
 int msq_vec_silu_mul_mx_pack_a8(const float* gate, const float* up, int64_t ld_gate, int64_t ld_up, float* out, void* codes, void* scales,
                                 int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
                                 int flush_fp32_subnorms, void* stream) {
-    return act_impl(2, gate, up, ld_gate, ld_up, out, codes, scales, status_flag, M, I, bits, exp_bits, max_norm, rmode, allow_denorm,
+    return act_impl(2, gate, up, 0, ld_gate, ld_up, out, codes, scales, status_flag, M, I, bits, exp_bits, max_norm, rmode, allow_denorm,
+                    flush_fp32_subnorms, stream);
+}
+int msq_vec_silu_mul_mx_pack_a8_x16(const void* gate, const void* up, int x_dtype, int64_t ld_gate, int64_t ld_up, float* out, void* codes,
+                                    void* scales, int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode,
+                                    int allow_denorm, int flush_fp32_subnorms, void* stream) {
+    if (x_dtype != 1 && x_dtype != 2) return vfail(MSQ_ERR_BAD_ARG, "msq_vec_silu_mul_mx_pack_a8_x16: x_dtype must be 1 (float16) or 2 (bfloat16)");
+    return act_impl(2, gate, up, x_dtype, ld_gate, ld_up, out, codes, scales, status_flag, M, I, bits, exp_bits, max_norm, rmode, allow_denorm,
                     flush_fp32_subnorms, stream);
 }
 
