@@ -446,6 +446,14 @@ int msq_vec_rmsnorm(const float* x, const float* weight, const float* bias, floa
 int msq_vec_rmsnorm_mx_pack_a8(const float* x, const float* weight, const float* bias, float* out, void* codes, void* scales,
                                int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
                                int allow_denorm, int flush_fp32_subnorms, void* stream);
+/* ... reading float16 (x_dtype 1) / bfloat16 (2) activations as they are (every 16-bit value is a float32 value: the results of casting first,
+ * without the cast pass); weight / bias stay float32; codes / scales may both be NULL (then `out` is required: the plain producer on a 16-bit input). */
+int msq_vec_rmsnorm_mx_pack_a8_x16(const void* x, int x_dtype, const float* weight, const float* bias, float* out, void* codes, void* scales,
+                                   int* status_flag, int64_t rows, int64_t H, float eps, int bits, int exp_bits, float max_norm, int rmode,
+                                   int allow_denorm, int flush_fp32_subnorms, void* stream);
+int msq_vec_silu_mul_mx_pack_a8_x16(const void* gate, const void* up, int x_dtype, int64_t ld_gate, int64_t ld_up, float* out, void* codes,
+                                    void* scales, int* status_flag, int64_t M, int64_t I, int bits, int exp_bits, float max_norm, int rmode,
+                                    int allow_denorm, int flush_fp32_subnorms, void* stream);   /* row strides % 8 == 0 */
 int msq_vec_silu(const float* x, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm, void* stream);
 int msq_vec_mul(const float* a, const float* b, float* out, int64_t n, int bits, int exp_bits, float max_norm, int rmode, int allow_denorm,
                 void* stream);

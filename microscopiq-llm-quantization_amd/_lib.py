@@ -39,6 +39,8 @@ _SIGS = {
     "msq_vec_add": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_rmsnorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_rmsnorm_mx_pack_a8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "msq_vec_rmsnorm_mx_pack_a8_x16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "msq_vec_silu_mul_mx_pack_a8_x16": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
     "msq_vec_silu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_mul": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "msq_vec_silu_mul_mx_pack_a8": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),

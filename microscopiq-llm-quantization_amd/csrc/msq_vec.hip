@@ -66,6 +66,10 @@ MSQ_D float Qout16(float a) {
 template <int FAST> MSQ_D float QT(float a, const VQ& q) { return FAST ? Qmid16(a) : Q(a, q); }
 template <int FAST> MSQ_D float QI(float a, const VQ& q) { return FAST ? Qin16(a) : Q(a, q); }
 template <int FAST> MSQ_D float QO(float a, const VQ& q) { return FAST ? Qout16(a) : Q(a, q); }
+// a value that enters from a BFLOAT16 tensor under the bfloat16 / nearest rounding is already on the grid: Qin16 would only make a NaN
+// canonical (its payload sits in the upper half: the two-instruction rounding keeps it a NaN) and a -0 a +0 (which no op below tells
+// apart: products and sums with a zero of either sign end in Qout16's +0).  XS: 0 float32, 1 bfloat16, 2 float16 source.
+template <int FAST, int XS> MSQ_D float QIx(float a, const VQ& q) { return (FAST && XS == 1) ? a : QI<FAST>(a, q); }
 
 MSQ_D int ceil_log2_i64(int64_t x) { int l = 0; while (((int64_t)1 << l) < x) ++l; return l; }
 
@@ -441,7 +445,7 @@ k_vec_rmsnorm_reg(const void* __restrict__ x, const float* __restrict__ w, const
 #pragma unroll
         for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) cur[gi][j] = QI<FAST>(nxt[gi][j], q);
+            for (int j = 0; j < 16; ++j) cur[gi][j] = QIx<FAST, XS>(nxt[gi][j], q);
         if (r + gridDim.x < rows) fetch(r + gridDim.x);
 #pragma unroll
         for (int gi = 0; gi < GP; ++gi)
@@ -483,14 +487,22 @@ k_vec_rmsnorm_reg(const void* __restrict__ x, const float* __restrict__ w, const
     if (PACK && status && P.status) atomicOr(P.status, status);
 }
 
-template <int FAST>
-MSQ_D float silu_one(float x, const VQ& q) {                      // activations.py:427-434, without the output rounding's zero rule
-    const float qi = QI<FAST>(x, q);
-    float phi = QT<FAST>(expf(-qi), q);                           // vec_exp (vec_use_exp2 off)
-    phi = QT<FAST>(phi + 1.0f, q);
-    if (FAST) phi = QT<FAST>((phi < 8.0e37f) ? __builtin_amdgcn_rcpf(phi) : 1.0f / phi, q);     // (as gelu_one: phi >= 1 has 8 significant bits)
-    else phi = QT<FAST>(1.0f / phi, q);
-    return QO<FAST>(qi * phi, q);
+// silu in two stages, so that the choice between v_rcp_f32 and the IEEE division is ONE wave-uniform branch per eight values instead of a
+// divergent one per value (the division's expansion + exec juggling was a quarter of the kernel's instructions):
+//   silu_phi: qi = Q(x), phi = Q(Q(exp(-qi)) + 1)            (activations.py:427-429; vec_exp with vec_use_exp2 off)
+//   silu_fin: Q(qi Q(1 / phi))                               (:430-432)
+template <int FAST, int XS>
+MSQ_D float silu_phi(float x, const VQ& q, float& qi) {
+    qi = QIx<FAST, XS>(x, q);
+    const float phi = QT<FAST>(expf(-qi), q);
+    return QT<FAST>(phi + 1.0f, q);
+}
+// RCP: phi >= 1 carries 8 significant bits, so v_rcp_f32's one ulp cannot move the rounded value (as gelu_one); only for phi < 8e37
+// (beyond it the quotient is a float32 subnormal: the IEEE division)
+template <int FAST, bool RCP>
+MSQ_D float silu_fin(float qi, float phi, const VQ& q) {
+    const float s = QT<FAST>(RCP ? __builtin_amdgcn_rcpf(phi) : 1.0f / phi, q);
+    return QO<FAST>(qi * s, q);
 }
 
 // out = silu(g) (u == nullptr), Q(Q(g) Q(u)) (MODE 1: simd_mul) or simd_mul(silu(g), u) (MODE 2); eight consecutive values per lane, rows of
@@ -506,11 +518,25 @@ k_vec_act8(const void* __restrict__ g, const void* __restrict__ u, int64_t ldg, 
     ldx8<XS>(g, row * ldg + c8 * 8, a);
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (MODE != 0) ldx8<XS>(u, row * ldu + c8 * 8, b8);
+    if (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        if (MODE == 0) a[e] = silu_one<FAST>(a[e], q);
-        else if (MODE == 1) a[e] = QO<FAST>(QI<FAST>(a[e], q) * QI<FAST>(b8[e], q), q);
-        else a[e] = QO<FAST>(silu_one<FAST>(a[e], q) * QI<FAST>(b8[e], q), q);       // Q(silu) = silu: vec_quantize of a rounded value
+        for (int e = 0; e < 8; ++e) a[e] = QO<FAST>(QIx<FAST, XS>(a[e], q) * QIx<FAST, XS>(b8[e], q), q);
+    } else {
+        float qi[8], phi[8];
+        bool small = true;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { phi[e] = silu_phi<FAST, XS>(a[e], q, qi[e]); small = small && (phi[e] < 8.0e37f); }
+        if (FAST && __builtin_amdgcn_ballot_w64(!small) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = silu_fin<FAST, true>(qi[e], phi[e], q);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = silu_fin<FAST, false>(qi[e], phi[e], q);
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = QO<FAST>(a[e] * QIx<FAST, XS>(b8[e], q), q);      // Q(silu) = silu: vec_quantize of a rounded value
+        }
     }
     if (out) {
         float4* op = reinterpret_cast<float4*>(out + i * 8);

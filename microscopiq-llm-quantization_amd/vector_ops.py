@@ -125,12 +125,12 @@ def simd_split(in1, mx_specs=None):
 # (`(codes, scales)`, what qlinear.mx_pack_act returns) without the float32 tensor in between.
 # ---------------------------------------------------------------------------------------------------------------------------
 def _rows2d(t, who):
-    """(tensor kept alive, data pointer, row stride in elements, M, I) of a float32 CUDA tensor seen as rows of its last dimension;
+    """(tensor kept alive, data pointer, row stride in elements, M, I) of a float32 / float16 / bfloat16 CUDA tensor seen as rows of its last dimension;
     the rows may sit at a stride (a slice of a wider tensor along the last dimension), the values of a row are contiguous."""
     if not torch.is_tensor(t) or not t.is_cuda:
         raise MsqError("%s needs CUDA/HIP tensors (no CPU fallback)" % who)
     t = t.detach()
-    if t.dtype != torch.float32:
+    if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         t = t.float()
     I = t.shape[-1]
     try:
@@ -154,22 +154,36 @@ def rms_norm(x, weight, bias, eps, mx_specs):
     return out if x.dtype == torch.float32 else out.to(x.dtype)
 
 
+_X16 = {torch.float16: 1, torch.bfloat16: 2}
+
+
 def rms_norm_mx_pack(x, weight, bias, eps, mx_specs, return_out=False, flush_fp32_subnorms=False, check_status=False):
     """RMSNorm and the MX-FP8 (e4m3, block 32, 8-bit scale) pack of its output in one launch: `(codes [M, H] uint8, scales [M, H / 32]
     uint8)` -- the activation operand qlinear.qlinear_mx_w4a8 accepts in place of x (one pack shared by q / k / v or gate / up) --
-    and, with return_out, the float32 output too.  The bytes are those of qlinear.mx_pack_act(rms_norm(x, ...))."""
-    xs = _f32c(x, "RMSNorm")
+    and, with return_out, the float32 output too.  The bytes are those of qlinear.mx_pack_act(rms_norm(x, ...)).  A float16 / bfloat16 x is
+    read as it is (no cast pass; the values of casting first)."""
+    if not torch.is_tensor(x) or not x.is_cuda:
+        raise MsqError("RMSNorm needs CUDA/HIP tensors (no CPU fallback)")
+    xs = x.detach().contiguous() if x.dtype in _X16 else _f32c(x, "RMSNorm")
+    if xs.data_ptr() % 16:
+        xs = xs.clone()
     H = xs.shape[-1]
     M = xs.numel() // H
-    out = torch.empty_like(xs) if return_out else None
+    out = torch.empty(xs.shape, dtype=torch.float32, device=xs.device) if return_out else None
     codes = torch.empty(M, H, dtype=torch.uint8, device=xs.device)
     scales = torch.empty(M, H // 32, dtype=torch.uint8, device=xs.device)
     status = torch.zeros(1, dtype=torch.int32, device=xs.device) if check_status else None
     bits, eb, mn, rm, dn = _rounding(mx_specs)
     b = _f32c(bias, "RMSNorm") if bias is not None else None
-    check(lib().msq_vec_rmsnorm_mx_pack_a8(ptr(xs), ptr(_f32c(weight, "RMSNorm")), ptr(b), ptr(out), ptr(codes), ptr(scales), ptr(status),
-                                           M, H, float(eps), bits, eb, mn, rm, dn, int(bool(flush_fp32_subnorms)),
-                                           current_stream(xs.device)), "msq_vec_rmsnorm_mx_pack_a8")
+    w = _f32c(weight, "RMSNorm")
+    if xs.dtype in _X16:
+        check(lib().msq_vec_rmsnorm_mx_pack_a8_x16(ptr(xs), _X16[xs.dtype], ptr(w), ptr(b), ptr(out), ptr(codes), ptr(scales), ptr(status),
+                                                   M, H, float(eps), bits, eb, mn, rm, dn, int(bool(flush_fp32_subnorms)),
+                                                   current_stream(xs.device)), "msq_vec_rmsnorm_mx_pack_a8_x16")
+    else:
+        check(lib().msq_vec_rmsnorm_mx_pack_a8(ptr(xs), ptr(w), ptr(b), ptr(out), ptr(codes), ptr(scales), ptr(status),
+                                               M, H, float(eps), bits, eb, mn, rm, dn, int(bool(flush_fp32_subnorms)),
+                                               current_stream(xs.device)), "msq_vec_rmsnorm_mx_pack_a8")
     if check_status:
         from .qlinear import _mx_status
         _mx_status(status, "rms_norm_mx_pack")
@@ -263,7 +277,7 @@ def simd_mul(in1, in2, mx_specs=None):
 
 
 def silu_mul(gate, up, mx_specs, pack=False, return_out=None, flush_fp32_subnorms=False, check_status=False):
-    """simd_mul(silu(gate), up) -- the gated-MLP activation -- as one launch.  gate / up: float32 CUDA tensors of one shape, possibly the two
+    """simd_mul(silu(gate), up) -- the gated-MLP activation -- as one launch.  gate / up: float32 (or float16 / bfloat16: read as they are) CUDA tensors of one shape, possibly the two
     halves of one projection output (`gu[..., :I]`, `gu[..., I:]`: read in place at their row stride).  pack=True returns the packed MX-FP8
     operand `(codes, scales)` of the result (the bytes of qlinear.mx_pack_act on it), with return_out=True `((codes, scales), out)`."""
     mx_specs = apply_mx_specs(mx_specs)
@@ -271,6 +285,8 @@ def silu_mul(gate, up, mx_specs, pack=False, return_out=None, flush_fp32_subnorm
         return_out = not pack
     if gate.shape != up.shape:
         raise MsqError("silu_mul: gate and up must have one shape")
+    if gate.dtype != up.dtype:
+        gate, up = gate.float(), up.float()
     gv, gp, ldg, M, I = _rows2d(gate, "silu_mul")
     uv, up_, ldu, _, _ = _rows2d(up, "silu_mul")
     dev = gv.device
@@ -279,8 +295,16 @@ def silu_mul(gate, up, mx_specs, pack=False, return_out=None, flush_fp32_subnorm
     scales = torch.empty(M, I // 32, dtype=torch.uint8, device=dev) if pack else None
     status = torch.zeros(1, dtype=torch.int32, device=dev) if (pack and check_status) else None
     bits, eb, mn, rm, dn = _rounding(mx_specs)
-    check(lib().msq_vec_silu_mul_mx_pack_a8(gp, up_, ldg, ldu, ptr(out), ptr(codes), ptr(scales), ptr(status), M, I, bits, eb, mn, rm, dn,
-                                            int(bool(flush_fp32_subnorms)), current_stream(dev)), "msq_vec_silu_mul_mx_pack_a8")
+    if gv.dtype in _X16:
+        if (gp | up_) % 16 or ldg % 8 or ldu % 8 or I % 8:      # the 16-bit kernel reads 16-byte pieces: fall back to the float32 entry
+            return silu_mul(gate.float(), up.float(), mx_specs, pack=pack, return_out=return_out, flush_fp32_subnorms=flush_fp32_subnorms,
+                            check_status=check_status)
+        check(lib().msq_vec_silu_mul_mx_pack_a8_x16(gp, up_, _X16[gv.dtype], ldg, ldu, ptr(out), ptr(codes), ptr(scales), ptr(status), M, I,
+                                                    bits, eb, mn, rm, dn, int(bool(flush_fp32_subnorms)), current_stream(dev)),
+              "msq_vec_silu_mul_mx_pack_a8_x16")
+    else:
+        check(lib().msq_vec_silu_mul_mx_pack_a8(gp, up_, ldg, ldu, ptr(out), ptr(codes), ptr(scales), ptr(status), M, I, bits, eb, mn, rm, dn,
+                                                int(bool(flush_fp32_subnorms)), current_stream(dev)), "msq_vec_silu_mul_mx_pack_a8")
     if status is not None:
         from .qlinear import _mx_status
         _mx_status(status, "silu_mul")

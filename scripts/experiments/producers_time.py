@@ -35,6 +35,14 @@ a3 = t(lambda: V.simd_mul(V.silu(gate, mx_specs=specs), up, mx_specs=specs))
 b = t(lambda: qlinear.mx_pack_act(y2)); c = t(lambda: V.silu_mul(gate, up, specs, pack=True))
 print("silu x up [%d, %d] f32: producer %.1f us (silu, then simd_mul: %.1f us) + packer %.1f us = %.1f us   | fused %.1f us  (%.0f GB/s of 9 B / element, %.2f of 8 TB/s)   x%.2f" %
       (M, I, a, a3, b, a + b, c, gb(c, M * I * 9.03), gb(c, M * I * 9.03) / 8000, (a + b) / c), flush=True)
+# 16-bit activations read as they are (a bf16 model; the GEMM in front writes bf16): no cast pass, half the bytes in
+xb = x.to(torch.bfloat16); gub = gu.to(torch.bfloat16); gb_, ub_ = gub[:, :I], gub[:, I:]
+c = t(lambda: V.rms_norm_mx_pack(xb, w, None, 1e-6, specs)); u = t(lambda: qlinear.mx_pack_act(V.rms_norm(xb.float(), w, None, 1e-6, specs)))
+print("RMSNorm [%d, %d] bf16:  cast + producer + packer %.1f us | fused, reading bf16 %.1f us  (%.0f GB/s of 3 B / element, %.2f of 8 TB/s)   x%.2f" %
+      (M, H, u, c, gb(c, M * H * 3.03), gb(c, M * H * 3.03) / 8000, u / c), flush=True)
+c = t(lambda: V.silu_mul(gb_, ub_, specs, pack=True)); u = t(lambda: qlinear.mx_pack_act(V.silu_mul(gb_.float(), ub_.float(), specs)))
+print("silu x up [%d, %d] bf16: casts + producer + packer %.1f us | fused, reading bf16 %.1f us  (%.0f GB/s of 5 B / element, %.2f of 8 TB/s)   x%.2f" %
+      (M, I, u, c, gb(c, M * I * 5.03), gb(c, M * I * 5.03) / 8000, u / c), flush=True)
 # steps: producer + GEMM (q/k/v N = 12288 on the RMSNorm output; down_proj N = 4096 on silu x up)
 for name, N, K, unf, fus in (("RMSNorm -> q/k/v", 12288, H, lambda: V.rms_norm(x, w, None, 1e-6, specs), lambda: V.rms_norm_mx_pack(x, w, None, 1e-6, specs)),
                              ("silu x up -> down_proj", 4096, I, lambda: V.silu_mul(gate, up, specs), lambda: V.silu_mul(gate, up, specs, pack=True))):

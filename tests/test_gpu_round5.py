@@ -553,3 +553,30 @@ def test_gated_mlp_block_from_mx_modules_matches_the_reference(msq):
     e = np.abs(y - z["gmlp|y"])
     assert (e <= np.abs(z["gmlp|y"]) * 2.0 ** -6 + 1e-6).all(), float(e.max())
     assert (e > 0).mean() <= 0.05, float((e > 0).mean())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_producers_read_16_bit_activations_as_they_are(msq, dtype):
+    """msq_vec_rmsnorm_mx_pack_a8_x16 / msq_vec_silu_mul_mx_pack_a8_x16: a float16 / bfloat16 activation goes in without a cast pass and gives
+    the bytes (and, when asked for, the float32 output) of the float32 entry on x.float() -- every 16-bit value is a float32 value; register
+    and generic RMSNorm kernels, contiguous and strided gate / up halves, a strided view that is not 16-byte aligned (falls back)."""
+    from msq import vector_ops as V
+    specs = msq.specs.finalize_mx_specs({"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": 32,
+                                         "custom_cuda": True, "bfloat": 16})
+    g = torch.Generator(device=dev()).manual_seed(31)
+    for H in (384, 4096, 8192):
+        x = (torch.randn(37, H, device=dev(), generator=g) * 4).to(dtype)
+        x[0, :3] = torch.tensor([0.0, -0.0, 6e-8], device=dev()).to(dtype)
+        w = torch.randn(H, device=dev(), generator=g) * 0.3 + 1
+        (c0, s0), y0 = V.rms_norm_mx_pack(x.float(), w, None, 1e-5, specs, return_out=True)
+        (c1, s1), y1 = V.rms_norm_mx_pack(x, w, None, 1e-5, specs, return_out=True)
+        assert torch.equal(c0, c1) and torch.equal(s0, s1) and _eq_bits(y0.cpu().numpy(), y1.cpu().numpy()), H
+    for (M, I) in ((9, 256), (40, 11008)):
+        gu = (torch.randn(M, 2 * I, device=dev(), generator=g) * 3).to(dtype)
+        for gate, up in ((gu[:, :I], gu[:, I:]), (gu[:, :I].contiguous(), gu[:, I:].contiguous())):
+            (c0, s0), y0 = V.silu_mul(gate.float(), up.float(), specs, pack=True, return_out=True)
+            (c1, s1), y1 = V.silu_mul(gate, up, specs, pack=True, return_out=True)
+            assert torch.equal(c0, c1) and torch.equal(s0, s1) and _eq_bits(y0.cpu().numpy(), y1.cpu().numpy()), (M, I)
+    odd = (torch.randn(8, 2 * 256 + 4, device=dev(), generator=g)).to(dtype)
+    ga, ub = odd[:, 2:258], odd[:, 258:514]                      # 4-byte aligned views: the wrapper takes the float32 entry
+    assert _eq_bits(V.silu_mul(ga, ub, specs).cpu().numpy(), V.silu_mul(ga.float(), ub.float(), specs).cpu().numpy())
