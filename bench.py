@@ -686,10 +686,13 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
         ms_u = _tgraph([lambda: qlinear.qlinear_mx_w4a8(unf(), P, None, torch.bfloat16)] * 10)
         ms_f = _tgraph([lambda: qlinear.qlinear_mx_w4a8(fus(), P, None, torch.bfloat16)] * 10)
         ms_p = _tgraph([fus] * 10)
+        pk_ = fus()
+        ms_g = _tgraph([lambda: qlinear.qlinear_mx_w4a8(pk_, P, None, torch.bfloat16)] * 10)      # the GEMM on an operand that is already packed
         fl_ = 2.0 * M * n_ * k_
         prod[key] = {"ms_producer_packer_gemm": ms_u, "ms_fused_producer_gemm": ms_f, "speedup": ms_u / ms_f, "ms_fused_producer_alone": ms_p,
                      "producer_GBps": byt / ms_p / 1e6, "producer_frac_of_hbm": byt / ms_p / 1e6 / HBM_PEAK_GBPS, "producer_bytes": byt,
-                     "tflops_fused_step": fl_ / ms_f / 1e9, "frac_fused_step": fl_ / ms_f / 1e9 / PEAK_FP8_TFLOPS, "M": M, "N": n_, "K": k_}
+                     "tflops_fused_step": fl_ / ms_f / 1e9, "frac_fused_step": fl_ / ms_f / 1e9 / PEAK_FP8_TFLOPS,
+                     "ms_gemm_on_packed_operand": ms_g, "frac_gemm_on_packed_operand": fl_ / ms_g / 1e9 / PEAK_FP8_TFLOPS, "M": M, "N": n_, "K": k_}
     prod["what"] = ("reference ops number_system/mx/layernorm.py:177 (RMSNorm), activations.py:76 (silu), simd_ops.py:445 (simd_mul), bfloat16 rounding after "
                     "every step; float32 in, MX-FP8 operand out; weight = the exact e4m3 operand of config 3")
     out["producers"] = prod
