@@ -518,6 +518,23 @@ def _kernel_name(P, M, mx):
         return "k_qgemm"
 
 
+class _no_gc:
+    """A timed region without the cycle collector, as `timeit` runs its loops: after the perplexity leg this process holds millions of Python
+    objects (transformers, the model), a generation-2 pass takes ~30 ms, and a host that sits in it while the GPU drains its queue shows up as
+    GPU time -- the row-parallel leg measured 1.9-5.0 ms per step for 0.75 ms of work (round 5, scripts/experiments/rp_stall.py)."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *a):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 def _gpu_sensors():
     """Clock / power as far as the box exposes them to an ordinary user: sysfs of the amdgpu card whose PCI address is the one torch reports for
     cuda:0 (a box shows every card of the node, only one of them is ours); when no address matches, the card drawing the most power.
@@ -569,18 +586,19 @@ def sustained(step, flops_step, peak, seconds=3.2, chunk=40):
     ev = torch.cuda.Event(enable_timing=True); ev.record(); evs.append(ev)
     n = 0
     sens_mid = {}
-    while True:
-        for _ in range(chunk):
-            step()
-        n += 1
-        ev = torch.cuda.Event(enable_timing=True); ev.record(); evs.append(ev)
-        if n % 8 == 0:
-            ev.synchronize()                                 # keep the launch queue short: the host clock then tracks the device
-            if time.perf_counter() - t0 >= seconds:
-                break
-            if not sens_mid and time.perf_counter() - t0 >= seconds / 2:
-                sens_mid = _gpu_sensors()
-    torch.cuda.synchronize()
+    with _no_gc():
+        while True:
+            for _ in range(chunk):
+                step()
+            n += 1
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); evs.append(ev)
+            if n % 8 == 0:
+                ev.synchronize()                                 # keep the launch queue short: the host clock then tracks the device
+                if time.perf_counter() - t0 >= seconds:
+                    break
+                if not sens_mid and time.perf_counter() - t0 >= seconds / 2:
+                    sens_mid = _gpu_sensors()
+        torch.cuda.synchronize()
     ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
     tot = sum(ms)
     acc, k = 0.0, len(ms)
@@ -786,16 +804,25 @@ def rowparallel_measure(rp, X, M, dev, group_on, world, comm):
     nt = 20
     evs = []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # a caller-owned output buffer, as a serving loop has: with a fresh tensor per call the caching allocator cannot hand back the block an async
+    # collective still holds an event on, the host (20 calls ahead of the GPU) gets a new hipMalloc -- an implicit device synchronisation --
+    # every few calls, and the "step" measured is the allocator's (round 5: 0.75 ms of GPU work per step read as 1.9-5.0 ms)
+    yout = torch.empty(X.reshape(-1, X.shape[-1]).shape[0], rp.shard.out_features, dtype=rp.reduce_dtype, device=dev)
+    _rp = rp
+    rp = lambda x, gemm_events=None: _rp(x, gemm_events=gemm_events, out=yout)
+    rp.comm_only = lambda M_, dt_, dev_: _rp.comm_only(M_, dt_, dev_, buf=yout if dt_ == yout.dtype else None)
+    rp.chunks_for = _rp.chunks_for
     for _ in range(5):
         rp(X)
     if group_on:
         dist.barrier()
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(nt):
-        rp(X, gemm_events=evs)
-    e1.record()
-    torch.cuda.synchronize()
+    with _no_gc():
+        e0.record()
+        for _ in range(nt):
+            rp(X, gemm_events=evs)
+        e1.record()
+        torch.cuda.synchronize()
     step_ms = e0.elapsed_time(e1) / nt
     gemm_ms = sum(a.elapsed_time(b) for a, b in evs) / nt
     comm_ms = None
@@ -804,11 +831,12 @@ def rowparallel_measure(rp, X, M, dev, group_on, world, comm):
             rp.comm_only(M, torch.bfloat16, dev)
         dist.barrier()
         torch.cuda.synchronize()
-        e0.record()
-        for _ in range(nt):
-            rp.comm_only(M, torch.bfloat16, dev)
-        e1.record()
-        torch.cuda.synchronize()
+        with _no_gc():
+            e0.record()
+            for _ in range(nt):
+                rp.comm_only(M, torch.bfloat16, dev)
+            e1.record()
+            torch.cuda.synchronize()
         comm_ms = e0.elapsed_time(e1) / nt
     r = {"step_ms": step_ms, "gemm_ms": gemm_ms, "comm_ms": comm_ms, "exposed_comm_ms": max(0.0, step_ms - gemm_ms),
          "chunks": rp.chunks_for(M), "comm": comm, "wire_dtype": "bf16",
@@ -1226,15 +1254,16 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    with _no_gc():
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream (torch's current stream = the stream handed to the C ABI)
     if world > 1:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
@@ -1267,7 +1296,13 @@ def main(argv=None):
             rp2 = qlinear.RowParallelQuantLinear(qlinear.QuantLinear.from_packed(Pr, None, out_dtype=torch.bfloat16), world, rank, None,
                                                  comm=args.comm, chunks=args.chunks, reduce_dtype=torch.bfloat16, single_rank_collectives=src)
             Xr = torch.randn(M, 28672 // world, device=dev).to(torch.bfloat16)
-            rowpar_times = rowparallel_measure(rp2, Xr, M, dev, True, world, args.comm)
+            if os.environ.get("MSQ_RP_PROFILE"):                  # debugging aid: where the host time of the leg goes
+                import cProfile, pstats, io
+                pr_ = cProfile.Profile(); pr_.enable()
+                rowpar_times = rowparallel_measure(rp2, Xr, M, dev, True, world, args.comm)
+                pr_.disable(); sio = io.StringIO(); pstats.Stats(pr_, stream=sio).sort_stats("cumulative").print_stats(25); sys.stderr.write(sio.getvalue())
+            else:
+                rowpar_times = rowparallel_measure(rp2, Xr, M, dev, True, world, args.comm)
             fr = 2.0 * M * 8192 * 28672
             sm = rowpar_times.get("max_over_ranks", rowpar_times)["step_ms"]
             rowpar_times.update({"workload": "Llama-2-70B down_proj [8192 x 28672], K split over %d GPUs, M = %d" % (world, M), "flops": fr,

@@ -900,6 +900,7 @@ class RowParallelQuantLinear(nn.Module):
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.comm, self.chunks, self.reduce_dtype = comm, int(chunks), reduce_dtype
         self.single_rank_collectives = bool(single_rank_collectives)   # run the collectives with one rank too (profiling on one GPU)
+        self._parts = {}                      # reduce-scatter pieces, kept across calls (see forward)
 
     @staticmethod
     def shard_bounds(in_features, world_size, rank, block_size, multiple=64):
@@ -955,18 +956,22 @@ class RowParallelQuantLinear(nn.Module):
         rows = (((M + nch - 1) // nch) + 127) // 128 * 128
         return [(r0, min(M, r0 + rows)) for r0 in range(0, M, rows)]
 
-    def comm_only(self, M, dtype=None, device=None):
-        """The collectives of one forward on an [M, N] buffer, without the GEMMs (bench.py: what the wire alone costs)."""
+    def comm_only(self, M, dtype=None, device=None, buf=None):
+        """The collectives of one forward on an [M, N] buffer, without the GEMMs (bench.py: what the wire alone costs).  ``buf``: a caller-owned
+        [M, N] buffer to run them on (zero-filled here), see forward's ``out``."""
         import torch.distributed as dist
         N, G, pg = self.shard.out_features, self.world_size, self.process_group
         dev = device if device is not None else next(self.shard.buffers()).device
-        y = torch.zeros(M, N, dtype=dtype or self.reduce_dtype, device=dev)
+        y = buf.zero_() if buf is not None else torch.zeros(M, N, dtype=dtype or self.reduce_dtype, device=dev)
         use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
         pending = []
         for r0, r1 in self.chunk_bounds(M):
             yc = y[r0:r1]
             if use_rs and (r1 - r0) % G == 0:
-                part = torch.empty((r1 - r0) // G, N, dtype=y.dtype, device=dev)
+                key = (r0, r1, N, y.dtype, y.device)
+                part = self._parts.get(key)
+                if part is None:
+                    part = self._parts[key] = torch.empty((r1 - r0) // G, N, dtype=y.dtype, device=dev)
                 pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
                 pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
             else:
@@ -975,15 +980,24 @@ class RowParallelQuantLinear(nn.Module):
             h.wait()
         return y
 
-    def forward(self, x_local, gemm_events=None):
+    def forward(self, x_local, gemm_events=None, out=None):
         """x_local: [..., K/G] (this rank's slice of the activations) -> the full sum [..., N] in ``reduce_dtype``.
         ``gemm_events``: a list that receives one (start, end) event pair per GEMM chunk, recorded on the compute stream
-        (bench.py: GEMM time against the step time = the communication that is NOT hidden)."""
+        (bench.py: GEMM time against the step time = the communication that is NOT hidden).
+        ``out``: a caller-owned [M, N] buffer of ``reduce_dtype`` for the result.  A serving loop should pass one: every tensor an async
+        collective touches is held back by the caching allocator until the communication stream's event has been SEEN complete, so a host
+        that runs ahead of the GPU gets a fresh hipMalloc (an implicit device synchronisation, tens of ms) every few calls instead of the
+        block it just freed.  The reduce-scatter pieces are kept by the module for the same reason."""
         import torch.distributed as dist
         lead = tuple(x_local.shape[:-1])
         x2 = x_local.reshape(-1, x_local.shape[-1])
         M, N, G = x2.shape[0], self.shard.out_features, self.world_size
-        y = torch.empty(M, N, dtype=self.reduce_dtype, device=x2.device)
+        if out is not None:
+            if tuple(out.shape) != (M, N) or out.dtype != self.reduce_dtype or out.device != x2.device or not out.is_contiguous():
+                raise MsqError("RowParallelQuantLinear: out must be a contiguous [%d, %d] %s tensor on %s" % (M, N, self.reduce_dtype, x2.device))
+            y = out
+        else:
+            y = torch.empty(M, N, dtype=self.reduce_dtype, device=x2.device)
         direct = isinstance(self.shard, (QuantLinear, MXLinearW4A8)) and getattr(self.shard, "out_dtype", None) == self.reduce_dtype
 
         def partial(r0, r1):                     # the shard's GEMM on rows [r0, r1), written into y[r0:r1]
@@ -1000,7 +1014,7 @@ class RowParallelQuantLinear(nn.Module):
 
         if G == 1 and not self.single_rank_collectives:
             partial(0, M)
-            return y.reshape(*lead, N)
+            return y.reshape(*lead, N)       # (y is `out` when one was given)
         pg = self.process_group
         use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
         pending = []
@@ -1008,7 +1022,11 @@ class RowParallelQuantLinear(nn.Module):
             partial(r0, r1)
             yc = y[r0:r1]
             if use_rs and (r1 - r0) % G == 0:
-                part = torch.empty((r1 - r0) // G, N, dtype=self.reduce_dtype, device=y.device)
+                # (kept across calls: written and read on the communication stream only, in order; the caller's stream waits below)
+                key = (r0, r1, N, self.reduce_dtype, y.device)
+                part = self._parts.get(key)
+                if part is None:
+                    part = self._parts[key] = torch.empty((r1 - r0) // G, N, dtype=self.reduce_dtype, device=y.device)
                 pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
                 pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
             else:

@@ -365,9 +365,8 @@ def test_default_bench_line_rowparallel_leg_on_a_single_rank_rccl_group(msq):
     assert len(seen) == 1 and seen[0]["backend"] == "nccl" and seen[0]["rccl"]
     r = d["rowparallel"]
     assert set(bench.ROWPAR_KEYS) <= set(r) and r["chunks"] == 2 and r["comm"] == "rs_ag" and r["scaling"] == "strong"
-    # (rate floor: a functional check.  The two M = 1024 chunks take the 128-row form with exactly one block per CU; RCCL's kernels on the
-    # other stream hold a few CUs, the grid then needs a second round: 366-560 TFLOP/s by run, 780 us for the two chunks alone)
-    assert r["gemm_ms"] > 0 and r["comm_ms"] > 0 and r["step_ms"] >= 0.98 * r["gemm_ms"] and r["tflops_whole_job"] > 250
+    # (round 5: 1.9-5.0 ms per step were Python's cycle collector stalling the host mid-loop; timed loops now run without it: ~0.92 ms at 2 chunks)
+    assert r["gemm_ms"] > 0 and r["comm_ms"] > 0 and r["step_ms"] >= 0.98 * r["gemm_ms"] and r["tflops_whole_job"] > 650
 
 
 # ----------------------------------------------------------------------------------------------------------------------
