@@ -13,4 +13,6 @@ scripts/pmc_gpu.sh ${R}_posit > $O/${R}_pmc_posit.txt 2>&1
 scripts/pmc_gpu.sh ${R}_fp8 --outlier fp8_e4m3 > $O/${R}_pmc_fp8.txt 2>&1
 scripts/round_profiles.sh $R > /dev/null 2>&1
 scripts/experiments/pmc_one.sh act1 k_act_quant_rows > $O/${R}_pmc_act_quant_v1.txt 2>&1
+python3 scripts/experiments/producers_time.py 2> /dev/null > $O/${R}_producers_run.txt
+python3 scripts/experiments/kv_mx_time.py 2> /dev/null > $O/${R}_kv_mx_run.txt
 cat $O/gpu_tests.txt
