@@ -181,8 +181,8 @@ MSQ_D void store_half_tile(const f32x4_t (&acc)[8][4], char* wsm, __amdgpu_buffe
     }
 }
 
-// one work segment of a block: K-steps [kt0, kt1) of tile `tile`; role 0 = writes Y, 1 = tail piece (leaves a partial tile in slot
-// `blockIdx`), 2 = head piece (adds the slots of blocks peer0 .. peer1, then writes Y)
+// one work segment of a block: K-steps [kt0, kt1) of tile `tile`; role 0 = writes Y, 1 = producer piece (leaves a partial tile in slot
+// `blockIdx`), 2 = owner's piece (adds the slots of blocks peer0 .. peer1 -- all below its own index --, then writes Y)
 struct Seg { int tile, kt0, kt1, role, peer0, peer1; };
 
 // Host and device share this arithmetic (msq_qgemm256p_segments below lists a block's segments for the tests).  P blocks, `full` whole rounds, R stream-K tiles of KT
@@ -206,19 +206,25 @@ __host__ __device__ inline Seg seg_get(int i, int b, int P, int full, int R, int
         lenB = u1 - u0 - lenA;
         nsk = 1 + (lenB > 0 ? 1 : 0);
     }
-    // order: the tail piece (if the run starts inside a tile) FIRST, the whole tiles, the piece that starts a tile LAST -- the partial
-    // tile a head piece needs was then written a whole round of tiles earlier by its neighbour
-    const int nfirst = (nsk > 0 && ka0 > 0) ? 1 : 0;
+    // A run covers the END of one stream-K tile (piece A) and / or the BEGINNING of the next (piece B).  The block that holds a tile's LAST
+    // K-steps owns it: it waits for the partial tiles of the blocks that hold the tile's earlier K-steps -- LOWER block indices only, so the
+    // wait never depends on a block that has not been dispatched yet (workgroups start in index order): no co-residency assumption.  A
+    // producer piece is the FIRST thing its block does (nothing it waits for), the whole tiles follow, the owner's piece comes LAST: the
+    // partial tiles it needs were written a whole round of tiles earlier.
+    const bool hasB = lenB > 0;
+    const bool Aends = (nsk > 0) && (ka0 + lenA == KT);
+    const bool Aprod = (nsk > 0) && !Aends;                      // A stops inside its tile: a producer (then there is no piece B)
+    const int nfirst = (hasB || Aprod) ? 1 : 0;
     if (i >= nfirst && i < nfirst + full) { s.tile = b + (i - nfirst) * P; s.kt0 = 0; s.kt1 = KT; s.role = 0; s.peer0 = 0; s.peer1 = -1; return s; }
-    const bool pieceA = (i < nfirst) || (nfirst == 0);           // (a run that starts on a tile boundary has one piece: A)
-    if (pieceA) { s.tile = full * P + sA; s.kt0 = ka0; s.kt1 = ka0 + lenA; }
-    else { s.tile = full * P + sA + 1; s.kt0 = 0; s.kt1 = lenB; }
     s.peer0 = 0; s.peer1 = -1;
-    if (s.kt0 > 0) s.role = 1;
-    else if (s.kt1 < KT) {
-        // the head piece ends where this block's run ends; the rest of the tile lies in the following blocks' runs
-        s.role = 2; s.peer0 = b + 1; s.peer1 = ((s.tile - full * P + 1) * KT - 1) / q;
-    } else s.role = 0;
+    if (i < nfirst && hasB) {                                    // the beginning of the next tile: producer (a whole tile when q >= KT)
+        s.tile = full * P + sA + 1; s.kt0 = 0; s.kt1 = lenB; s.role = (lenB == KT) ? 0 : 1;
+        return s;
+    }
+    s.tile = full * P + sA; s.kt0 = ka0; s.kt1 = ka0 + lenA;
+    if (Aprod) s.role = 1;
+    else if (ka0 > 0) { s.role = 2; s.peer0 = (sA * KT) / q; s.peer1 = b - 1; }     // owner: the blocks whose runs hold K-steps [0, ka0) of this tile
+    else s.role = 0;
     return s;
 }
 

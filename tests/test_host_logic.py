@@ -497,9 +497,11 @@ def test_kernel_choice_rule_for_llama_shapes():
 def test_persistent_kernel_schedule_covers_every_k_step_once():
     """msq_qgemm256p_plan / msq_qgemm256p_segments (host logic, the same arithmetic the device runs, csrc/msq_gemm256p.hip): for the
     Llama-2-7B projections (llm/llama.py:226-256 shapes), ragged and tiny shapes and other CU counts -- every (tile, K-step) belongs to
-    exactly one segment of one block; segments are whole pairs of K-steps; a tile that is cut has ONE head piece (K-step 0 onward, role 2)
-    whose peer list names, in block order, exactly the blocks that hold its other pieces (role 1), and a tail piece is always the FIRST
-    segment of its block (so no block waits for a block that waits); the workspace covers one slot per block that can hold a tail piece."""
+    exactly one segment of one block; segments are whole pairs of K-steps; a tile that is cut has ONE owner's piece (the one that holds its
+    LAST K-steps, role 2) whose peer list names, in block order, exactly the blocks that hold its other pieces (role 1) -- ALL of them
+    below the owner's own index (workgroups start in index order: the wait never depends on a block that has not been dispatched; no
+    co-residency assumption) --, a producer piece is always the FIRST segment of its block and an owner's piece the LAST (so no block waits
+    for a block that waits); the workspace covers one slot per block that can hold a producer piece."""
     import msq
     L = msq._lib.lib()
 
@@ -530,16 +532,18 @@ def test_persistent_kernel_schedule_covers_every_k_step_once():
                     cover[(t, k)] = b
                 pieces.setdefault(t, []).append((k0, k1, role, b, p0, p1))
                 if role == 1:
-                    assert i == 0 and k0 > 0
+                    assert i == 0 and k1 < KT
                     tail_blocks.add(b)
+                if role == 2:
+                    assert i == n - 1 and k0 > 0 and k1 == KT and 0 <= p0 <= p1 < b
         assert len(cover) == T * KT
         for t, l in pieces.items():
             l.sort()
             if len(l) == 1:
                 assert l[0][:3] == (0, KT, 0)
             else:
-                assert l[0][0] == 0 and l[0][2] == 2 and all(x[2] == 1 for x in l[1:])
-                assert [x[3] for x in l[1:]] == list(range(l[0][4], l[0][5] + 1))
+                assert l[0][0] == 0 and l[-1][2] == 2 and all(x[2] == 1 for x in l[:-1])
+                assert [x[3] for x in l[:-1]] == list(range(l[-1][4], l[-1][5] + 1)) and all(x[3] < l[-1][3] for x in l[:-1])
         assert (ws > 0) == bool(tail_blocks) and (not tail_blocks or ws >= 4096 + 262144 * (max(tail_blocks) + 1))
     assert plan(2048, 16384 + 64, 4096)[0] != 0 and plan(2048, 16384, 4096 + 64)[0] != 0 and plan(0, 256, 128)[0] != 0
 
