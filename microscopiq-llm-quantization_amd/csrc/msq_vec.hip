@@ -33,6 +33,15 @@ struct VQ { int bits, ebits, rmode, dn; float max_norm; };
 MSQ_D float Qbf(float a, int drop, int rmode) {
     const uint32_t u = f2u(a);
     if ((u & 0x7F800000u) == 0x7F800000u) return a;
+    if (rmode == 1) {
+        // Truncation is the one mode in which the PYTHON path's private exponent shows (elemwise_ops.py:139-140: floor(torch.log2(|a|)) in
+        // float32): for the K largest floats below a power of two 2^u it is u, one binade high (msq_device.h ilog2f_torch), the value is
+        // scaled by 2^-u instead of 2^-(u-1) and loses one more mantissa bit -- (2^(m-1) - 1) / 2^(m-1) 2^u instead of the float below 2^u
+        // on the grid.  Nearest / even round such a value to 2^u either way.  The reference's CPU outputs hold this
+        // (tests/golden/vec_rmsnorm_modes.npz: `b - tiny` under floor); the native codec (quant_bits, msq_vec_round's force_codec) does not.
+        const uint32_t E = (u >> 23) & 0xFFu;
+        if (E != 0u && E < 254u && ilog2f_torch(u2f(u & 0x7FFFFFFFu)) + 127 > (int)E) drop += 1;
+    }
     const uint32_t mag = u & 0x7FFFFFFFu, half = 1u << (drop - 1);
     const uint32_t add = (rmode == 0) ? half : ((rmode == 2) ? (half - 1u + ((mag >> drop) & 1u)) : 0u);
     const uint32_t r = (mag + add) & ~((1u << drop) - 1u);

@@ -84,6 +84,11 @@ for case in range(cases):
     y = V.rms_norm(x.to(dev), w.to(dev), None if b is None else b.to(dev), eps, specs).cpu().numpy()
     yo = O.vec_rmsnorm(x.numpy(), w.numpy(), np.zeros(H, np.float32) if b is None else b.numpy(), eps, bits, 8, mn, rd)
     ok = eq_bits(y, yo)
+    why = []
+    if not ok:
+        dm = np.ascontiguousarray(y).view(np.uint32) != np.ascontiguousarray(yo).view(np.uint32)
+        i = tuple(np.argwhere(dm)[0])
+        why.append("rmsnorm: %d values differ, first %r vs oracle %r (x %r)" % (int(dm.sum()), float(y[i]), float(yo[i]), float(x[i])))
     if H % 128 == 0 and rd == "nearest":
         c0, s0 = qlinear.mx_pack_act(torch.from_numpy(y).to(dev))
         c1, s1 = V.rms_norm_mx_pack(x.to(dev), w.to(dev), None if b is None else b.to(dev), eps, specs)
@@ -102,7 +107,11 @@ for case in range(cases):
     silu_off += nd
     ok = ok and nd <= 3
     mm = V.simd_mul(gate.to(dev), up.to(dev), mx_specs=specs).cpu().numpy()
-    ok = ok and eq_bits(mm, O.vec_mul(gate.contiguous().numpy(), up.contiguous().numpy(), bits, 8, mn, rd))
+    mmo = O.vec_mul(gate.contiguous().numpy(), up.contiguous().numpy(), bits, 8, mn, rd)
+    if not eq_bits(mm, mmo):
+        i = tuple(np.argwhere(mm.view(np.uint32) != mmo.view(np.uint32))[0])
+        why.append("simd_mul: %r x %r -> %r vs oracle %r" % (float(gate[i]), float(up[i]), float(mm[i]), float(mmo[i])))
+        ok = False
     if I % 128 == 0 and rd == "nearest":
         gud = gu.to(dev)
         c0, s0 = qlinear.mx_pack_act(torch.from_numpy(m).to(dev))
@@ -110,7 +119,7 @@ for case in range(cases):
         ok = ok and torch.equal(c0, c1) and torch.equal(s0, s1)
     if not ok:
         bad_p += 1
-        print("PRODUCER FAIL bfloat", bf, rd, "H", H, "rows", rows, "I", I, "M", M, "silu diffs", nd, flush=True)
+        print("PRODUCER FAIL bfloat", bf, rd, "H", H, "rows", rows, "I", I, "M", M, "silu diffs", nd, why, flush=True)
 print("producer cases", cases, "failures", bad_p, "silu x up elements off by the device expf:", silu_off, flush=True)
 print("TOTAL failures", bad + bad_p)
 sys.exit(1 if bad + bad_p else 0)

@@ -852,4 +852,15 @@ def test_vector_rounding_fast_path_equals_codec(msq):
                 msq._lib.check(L.msq_vec_round(msq._lib.ptr(x), msq._lib.ptr(out), x.numel(), m, 8, mn, rm, 1, force,
                                                msq._lib.current_stream(dev())), "msq_vec_round")
             same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            if rm == 1:
+                # round 5: under truncation the vector ops follow the reference's PYTHON path, whose private exponent floor(torch.log2(|x|))
+                # is one high for the K largest floats below a power of two (one more mantissa bit goes); the native codec keeps the
+                # exponent field.  Those inputs are checked against the oracle in tests/test_gpu_round5.py; everything else is equal.
+                ax = x.abs().cpu()
+                fin = torch.isfinite(ax) & (ax >= 2.0 ** -126)
+                lg = torch.floor(torch.log2(torch.where(fin, ax, torch.ones_like(ax))))
+                ef = ((ax.view(torch.int32) >> 23) & 0xFF).float() - 127.0
+                bump = (fin & (lg > ef)).to(same.device)
+                assert int(bump.sum()) > 0
+                same = same | bump
             assert bool(same.all()), (bfloat, rm, int((~same).sum()))

@@ -580,3 +580,37 @@ def test_fused_producers_read_16_bit_activations_as_they_are(msq, dtype):
     odd = (torch.randn(8, 2 * 256 + 4, device=dev(), generator=g)).to(dtype)
     ga, ub = odd[:, 2:258], odd[:, 258:514]                      # 4-byte aligned views: the wrapper takes the float32 entry
     assert _eq_bits(V.silu_mul(ga, ub, specs).cpu().numpy(), V.silu_mul(ga.float(), ub.float(), specs).cpu().numpy())
+
+
+def test_vector_rounding_under_truncation_follows_the_python_path(msq, O):
+    """quantize_elemwise_op with round="floor" (elemwise_ops.py:139-140, :47-78): the private exponent is floor(torch.log2(|x|)) in float32,
+    one binade high for the K largest floats below a power of two, and truncation then drops one more mantissa bit.  (a) the rounding of the
+    vector ops (msq_vec_round, bfloat16 / 12 / 10, all three modes) against the oracle's Python-path core on the 55 k probes of
+    tests/golden/log2_f32.npz (the 128 largest floats below every power of two, both signs); (b) RMSNorm and simd_add against fixtures made by
+    the reference itself (tests/golden/vec_rmsnorm_modes.npz, make_golden_vec_modes.py: bfloat12 / 16, floor / nearest, inputs scaled 2^-30 ..
+    2^30, eps 1e-6 / 1e-12 -- `b - tiny` under floor lands on exactly those floats)."""
+    from msq import vector_ops as V
+    L = msq._lib.lib()
+    z = np.load(os.path.join(GOLD, "log2_f32.npz"))
+    xs = z["bits"].astype(np.uint32).view(np.float32)
+    # (not the 44 largest floats: there torch.log2 says 128, the Python path scales by 2^128 = inf and returns NaN in every mode; the
+    # library returns +-inf on overflow, as the reference's native kernel does)
+    xs = xs[np.isfinite(xs) & (xs > 0) & (xs < 3.4e38)]
+    x = np.concatenate([xs, -xs]).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev())
+    for bfloat in (16, 12, 10):
+        m = bfloat - 7
+        mn = 2.0 ** 127 * (2 ** (m - 1) - 1) / 2 ** (m - 2)
+        for rm, rd in ((0, "nearest"), (1, "floor"), (2, "even")):
+            out = torch.empty_like(xt)
+            msq._lib.check(L.msq_vec_round(msq._lib.ptr(xt), msq._lib.ptr(out), xt.numel(), m, 8, mn, rm, 1, 0, msq._lib.current_stream(dev())), "msq_vec_round")
+            want = O.quantize_elemwise_core(x, m, 8, mn, rd, False, True)
+            assert _eq(out.cpu().numpy(), want), (bfloat, rd, int((out.cpu().numpy() != want).sum()))
+    zz = np.load(os.path.join(GOLD, "vec_rmsnorm_modes.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    for k in sorted(set(f.rsplit("|", 1)[0] for f in zz.files)):
+        bf, rd, H, sc, eps = k.split("|")
+        specs = msq.specs.finalize_mx_specs({"w_elem_format": "fp4_e2m1", "a_elem_format": "fp8_e4m3", "scale_bits": 8, "block_size": 32,
+                                             "custom_cuda": True, "bfloat": int(bf), "round": rd})
+        y = V.rms_norm(t(zz[k + "|x"]), t(zz[k + "|w"]), t(zz[k + "|b"]), float(eps), specs).cpu().numpy()
+        assert _eq(y, zz[k + "|y"]), (k, int((y != zz[k + "|y"]).sum()))
