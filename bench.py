@@ -523,10 +523,14 @@ class _no_gc:
     objects (transformers, the model), a generation-2 pass takes ~30 ms, and a host that sits in it while the GPU drains its queue shows up as
     GPU time -- the row-parallel leg measured 1.9-5.0 ms per step for 0.75 ms of work (round 5, scripts/experiments/rp_stall.py)."""
 
+    def __init__(self, collect=False):
+        self.collect = collect                  # a collection takes tens of ms with the GPU idle: do it BEFORE the warm-up, never between it and the timed loop
+
     def __enter__(self):
         import gc
         self.was = gc.isenabled()
-        gc.collect()
+        if self.collect:
+            gc.collect()
         gc.disable()
 
     def __exit__(self, *a):
@@ -587,7 +591,7 @@ def sustained(step, flops_step, peak, seconds=3.2, chunk=40):
     n = 0
     sens_mid = {}
     skip = set()
-    with _no_gc():
+    with _no_gc(collect=True):                   # (starts from idle anyway: the first chunk is the re-ramp, the figure is the last second)
         while True:
             for _ in range(chunk):
                 step()
@@ -612,7 +616,7 @@ def sustained(step, flops_step, peak, seconds=3.2, chunk=40):
     return {"seconds": tot / 1e3, "launches": len(ms) * chunk, "chunk": chunk,
             "tflops_last_second": tf(acc, last_n), "frac": tf(acc, last_n) / peak,
             "tflops_first_chunk": tf(ms[0], 1), "tflops_whole": tf(tot, len(ms)),
-            "tflops_min_chunk": tf(max(ms), 1), "tflops_max_chunk": tf(min(ms), 1),
+            "tflops_min_chunk": tf(max(ms[1:] or ms), 1), "tflops_max_chunk": tf(min(ms), 1),     # (min: without the first chunk, the re-ramp from idle)
             "sensors_mid_run": sens_mid, "sensors_after": _gpu_sensors(),
             "what": "back-to-back launches of the headline step after the timed region; rate of the last >= 1 s of them"}
 
@@ -814,6 +818,8 @@ def rowparallel_measure(rp, X, M, dev, group_on, world, comm):
     rp = lambda x, gemm_events=None: _rp(x, gemm_events=gemm_events, out=yout)
     rp.comm_only = lambda M_, dt_, dev_: _rp.comm_only(M_, dt_, dev_, buf=yout if dt_ == yout.dtype else None)
     rp.chunks_for = _rp.chunks_for
+    import gc
+    gc.collect()
     for _ in range(5):
         rp(X)
     if group_on:
@@ -1249,6 +1255,8 @@ def main(argv=None):
     # Round 5: a count is the wrong unit -- some boxes of the pool need ~40 ms out of idle (the first 40-launch chunk of `sustained` after the
     # CPU legs: 231 TFLOP/s), 100 launches of this kernel are 18 ms, and the timed region then began inside the ramp (value 0.550 beside a
     # sustained 0.595 on such a box).  Launch until RAMP_S seconds of device time have passed (at least 100 launches), synchronising every 50.
+    import gc
+    gc.collect()                                # (the timed loop below runs with the collector off; the pass it would want happens here)
     RAMP, RAMP_S = 0, 0.4
     t_r = time.perf_counter()
     while RAMP < 100 or time.perf_counter() - t_r < RAMP_S:
