@@ -475,11 +475,12 @@ def _tgraph(fns, reps=10):
         g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
+    with _no_gc():
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps / len(fns)
 
 
