@@ -458,7 +458,7 @@ def ppl_delta_from_env(dev, fi, fo, bs, paths=("bf16",), corrupt=None):
 
 def _tgraph(fns, reps=10):
     """Device time per call in ms: the calls of `fns` captured into ONE HIP graph on a side stream, `reps` replays timed with HIP
-    events (no Python / ctypes launch floor between the kernels)."""
+    events (no Python / ctypes launch floor between the kernels); the median replay."""
     import torch
     torch.cuda.synchronize()        # nothing of the caller's warm-up loop runs beside the side stream's first calls (two streams entering
                                     # hipBLASLt at once stalled the whole device in layer7b_prefill: every later synchronize hung)
@@ -474,14 +474,17 @@ def _tgraph(fns, reps=10):
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one event pair per replay, the MEDIAN replay: a single stall of the stream (round 5: one replay of the decode probe took 70 ms for no
+    # reason the trace shows; the mean of three called `down` 1.0 ms) must not become the figure
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     with _no_gc():
-        e0.record()
-        for _ in range(reps):
+        evs[0].record()
+        for i in range(reps):
             g.replay()
-        e1.record()
+            evs[i + 1].record()
         torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps / len(fns)
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(reps))
+    return per[len(per) // 2] / len(fns)
 
 
 def _clone_packed(P):
