@@ -635,7 +635,8 @@ def layer7b_prefill(dev, M=2048, inlier="fp4_e2m1", block=32):
     shapes = (("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008))
     X = {k_: torch.randn(M, k_, device=dev).to(torch.bfloat16) for k_ in (4096, 11008)}
     res = {"M": M, "projections": {}}
-    tot = {"posit8_es1": 0.0, "fp8_e4m3": 0.0, "hipblaslt_bf16_unpacked": 0.0}
+    tot = {"posit8_es1": 0.0, "fp8_e4m3": 0.0, "hipblaslt_bf16_unpacked": 0.0, "mx_e4m3_operand": 0.0, "mx_fp4": 0.0}
+    from msq import quant
     fl_layer = 0.0
     for name, n_, k_ in shapes:
         W = synth_weight(n_, k_, dev, seed=3)
@@ -653,7 +654,18 @@ def layer7b_prefill(dev, M=2048, inlier="fp4_e2m1", block=32):
             if fo == "fp8_e4m3":
                 dense = qlinear.unpack_weight(P, torch.bfloat16)
             del P
-        del W
+        # the same projection on the MX matrix path (scaled MFMA, activations already packed by their producer, 5.004): the MicroScopiQ weight as
+        # one exact e4m3 operand, and plain MX-FP4; priced on the fp8 peak
+        xp = qlinear.mx_pack_act(X[k_])
+        for key, Pm in (("mx_e4m3_operand", qlinear.mx_pack_values(quant.outlier_fakequant(W, 8, 8, inlier, "fp8_e4m3", 2, -1, block)["out"])),
+                        ("mx_fp4", qlinear.mx_pack_weight(W, w_fmt="e2m1"))):
+            for _ in range(10):
+                qlinear.qlinear_mx_w4a8(xp, Pm, None, torch.bfloat16)
+            ms = _tgraph([lambda Pm=Pm: qlinear.qlinear_mx_w4a8(xp, Pm, None, torch.bfloat16)] * 10)
+            row[key] = {"ms": ms, "tflops": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_FP8_TFLOPS, "peak": PEAK_FP8_TFLOPS}
+            tot[key] += ms
+            del Pm
+        del W, xp
         for _ in range(20):
             X[k_] @ dense.t()
         ms = _tgraph([lambda: X[k_] @ dense.t()] * 10)
@@ -661,7 +673,8 @@ def layer7b_prefill(dev, M=2048, inlier="fp4_e2m1", block=32):
         tot["hipblaslt_bf16_unpacked"] += ms
         del dense
         res["projections"][name] = row
-    res["layer"] = {k: {"ms": v, "tflops": fl_layer / v / 1e9, "frac": fl_layer / v / 1e9 / PEAK_BF16_TFLOPS} for k, v in tot.items()}
+    res["layer"] = {k: {"ms": v, "tflops": fl_layer / v / 1e9, "frac": fl_layer / v / 1e9 / (PEAK_FP8_TFLOPS if k.startswith("mx_") else PEAK_BF16_TFLOPS)}
+                    for k, v in tot.items()}
     res["flops_per_layer"] = fl_layer
     res["peak"] = PEAK_BF16_TFLOPS
     res["bound"] = "mfma"

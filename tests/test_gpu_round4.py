@@ -176,13 +176,14 @@ def test_bench_line_names_its_kernel_sustains_and_carries_the_true_7b_layer(benc
     lp = bench_line["configs"]["layer7b_prefill"]
     pr = lp["projections"]
     assert set(pr) == {"qkv", "o", "gate_up", "down"} and lp["M"] == 2048
-    for key in ("posit8_es1", "fp8_e4m3", "hipblaslt_bf16_unpacked"):
+    for key in ("posit8_es1", "fp8_e4m3", "hipblaslt_bf16_unpacked", "mx_e4m3_operand", "mx_fp4"):
         assert abs(lp["layer"][key]["ms"] - sum(pr[n][key]["ms"] for n in pr)) < 1e-9
         assert abs(lp["layer"][key]["tflops"] - lp["flops_per_layer"] / lp["layer"][key]["ms"] / 1e9) < 1e-6
     assert abs(lp["flops_per_layer"] - 2.0 * 2048 * (12288 * 4096 + 4096 * 4096 + 22016 * 4096 + 4096 * 11008)) < 1
     for n in pr:
         for fo in ("posit8_es1", "fp8_e4m3"):
             assert pr[n][fo]["frac"] > 0.3 and pr[n][fo]["kernel"].startswith("k_qgemm"), (n, fo, pr[n][fo])
+        assert pr[n]["mx_fp4"]["ms"] < pr[n]["posit8_es1"]["ms"] and pr[n]["mx_e4m3_operand"]["frac"] > 0.2, (n, pr[n])      # the MX matrix path (fp8 peak)
 
 
 def test_bench_line_ppl_and_cpu_baseline_parity(bench_line):
