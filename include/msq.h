@@ -267,7 +267,7 @@ int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int m
  * single-threaded A / B runs).  "MSQ_MX_LOWP_PAIR4" (1 default / 0): msq_quantize_mx_lowp on a strided axis of whole 32-blocks through
  * k_mx_lowp_pair4 (a block row cut over four waves) or k_mx_lowp_pair.  The other test / A-B switches likewise (override, else the environment per
  * call): "MSQ_ACT_ROWS" (0: the mx_ops activation quantiser as two launches), "MSQ_MX_PACK_BLOCK" (1: one lane per block in msq_mx_pack_a8),
- * "MSQ_VEC_GENERIC" (1: the vector ops through the run-time-parameter rounding), "MSQ_PACK_TWO_PASS" (1: msq_outlier_pack in two passes).
+ * "MSQ_VEC_GENERIC" (1: the vector ops through the run-time-parameter rounding), "MSQ_RMS_RPB" (rows per block of the register RMSNorm kernel), "MSQ_PACK_TWO_PASS" (1: msq_outlier_pack in two passes).
  * Returns MSQ_ERR_UNSUPPORTED for an unknown key. */
 int msq_set_tuning(const char* key, int value);
 /* Schedule of the persistent fused GEMM k_qgemm256p (csrc/msq_gemm256p.hip) for a shape -- host arithmetic only, no device needed; for tests

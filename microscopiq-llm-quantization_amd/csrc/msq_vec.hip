@@ -586,7 +586,8 @@ static int vq_check(int bits, int exp_bits, int rmode) {
 }
 // MSQ_VEC_GENERIC=1 in the environment sends bfloat16 / nearest through the run-time-parameter kernels too (the parity tests compare the two)
 static msq_host::TuneKey g_vec_generic("MSQ_VEC_GENERIC");
-extern "C" int msq_set_tuning_vec_(const char* key, int value) { return g_vec_generic.set_if(key, value); }
+static msq_host::TuneKey g_rms_rpb("MSQ_RMS_RPB");          // rows per block of the register RMSNorm kernel (tuning)
+extern "C" int msq_set_tuning_vec_(const char* key, int value) { return g_vec_generic.set_if(key, value) || g_rms_rpb.set_if(key, value); }
 static bool vq_is_fast(int bits, int exp_bits, int rmode, int allow_denorm) {
     if (g_vec_generic.value(0) == 1) return false;
     return bits == 9 && exp_bits == 8 && allow_denorm && rmode == 0;
@@ -704,7 +705,8 @@ static int rmsnorm_impl(const void* x, int x_dtype, const float* weight, const f
     const hipStream_t st = (hipStream_t)stream;
     const int xs = x_dtype == 2 ? 1 : (x_dtype == 1 ? 2 : 0);               // kernel source code: 0 f32, 1 bf16, 2 f16
     if (H % 512 == 0 && H <= 8192) {
-        const int rpb = rows >= 2048 ? 2 : 1;
+        int rpb = rows >= 8192 ? 4 : (rows >= 2048 ? 2 : 1);      // rows per block, measured (scripts/experiments/rms_rpb.py): M 2048: 13.5 / 13.3 / 14.5 / 15.6 us for 1 / 2 / 3 / 4; M 8192: 42.2 / 36.9 / 36.7 / 35.7
+        { const int t = g_rms_rpb.value(0); if (t > 0) rpb = t; }
         const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
         const bool fast = vq_is_fast(bits, exp_bits, rmode, allow_denorm);
 #define MSQ_RMS3(FAST, GP, PK, XS) hipLaunchKernelGGL((k_vec_rmsnorm_reg<FAST, GP, PK, XS>), dim3(grid), dim3(256), 0, st, x, weight, bias, out, rows, (int)H, eps, vq, P)
