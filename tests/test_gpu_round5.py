@@ -471,6 +471,15 @@ def test_fused_producers_pack_what_the_unfused_chain_packs(msq, O):
                 c2, s2 = V.rms_norm_mx_pack(x, w, bias, 1e-6, specs)
                 assert torch.equal(c0, c1) and torch.equal(s0, s1) and torch.equal(c0, c2) and torch.equal(s0, s2), (H, rows, bias is None)
                 assert _eq_bits(y.cpu().numpy(), y1.cpu().numpy()), (H, rows)
+    # many rows: two and four rows per block (rows >= 2048 / 8192), against the oracle as well
+    for rows in (2051, 8195):
+        x = torch.randn(rows, 1024, device=dev(), generator=g) * 2
+        w = torch.randn(1024, device=dev(), generator=g) * 0.3 + 1
+        y = V.rms_norm(x, w, None, 1e-6, specs)
+        assert _eq_bits(y.cpu().numpy(), O.vec_rmsnorm(x.cpu().numpy(), w.cpu().numpy(), np.zeros(1024, np.float32), 1e-6, 9, 8, _bf_max_norm(16), "nearest")), rows
+        c0, s0 = qlinear.mx_pack_act(y)
+        c1, s1 = V.rms_norm_mx_pack(x, w, None, 1e-6, specs)
+        assert torch.equal(c0, c1) and torch.equal(s0, s1), rows
     for (M, I) in ((5, 128), (64, 1408), (33, 11008)):
         gu = torch.randn(M, 2 * I, device=dev(), generator=g) * 2.5
         gu[0, :4] = torch.tensor([0.0, -0.0, 90.0, -104.0], device=dev())
