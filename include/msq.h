@@ -427,7 +427,8 @@ int msq_vec_add(const float* a, const float* b, float b_scalar, float* out, int6
                 float max_norm, int rmode, int allow_denorm, void* stream);
 
 /* Round 5 -- the activation PRODUCERS in front of the MX Linear, able to hand their result on as the MX-FP8 operand of the scaled-MFMA GEMM
- * (what MXLinear makes of its input first, linear.py:66-73) in the SAME launch: e4m3 codes [rows * H] row-major + scale bytes [rows * H / 32],
+ * (plain MX quantisation of the activation along the last axis, quantize_mx_op mx_ops.py:460-490 with a_elem_format fp8_e4m3 -- the operand of
+ * msq_qlinear_mx_w4a8 / _w8a8 / _w6a8; the reference's own MXLinear applies its outlier variant there, linear.py:66-73: msq_act_quant_bf16) in the SAME launch: e4m3 codes [rows * H] row-major + scale bytes [rows * H / 32],
  * the layout and the bytes of msq_mx_pack_a8 on the producer's output (one shared code path, csrc/msq_mx_pack_core.h) -- the float32
  * intermediate never reaches memory unless `out` asks for it.
  *   msq_vec_rmsnorm             replaces mx.RMSNorm's forward (layernorm.py:177 -> RMSNormFunction.forward :98-128): x = Q(x), ms = Q(Q(sum

@@ -326,7 +326,7 @@ k_vec_add(const float* __restrict__ a, const float* __restrict__ b, float* __res
 // GEMM (e4m3 codes row-major + one scale byte per 32, the layout of msq_mx_pack_a8) instead of -- or besides -- the float32 tensor:
 //   RMSNorm      layernorm.py:177 -> RMSNormFunction.forward :98-128 (9 rounded ops per element, one row sum in ATen's order)
 //   silu x up    activations.py:76 -> :420-434 (5 rounded ops), simd_mul simd_ops.py:445 -> :154-187 (Q(Q(a) Q(b)))
-// The reference runs ~12 / ~9 eager torch kernels for these and then re-reads the result in MXLinear to quantise it (linear.py:66-73);
+// The reference runs ~12 / ~9 eager torch kernels for these and then re-reads the result in the Linear to quantise it (quantize_mx_op, mx_ops.py:460-490);
 // unfused here it is two launches (producer: 4 B in + 4 B out per element; packer: 4 B in + 1 B out), fused one (4 B in, 1 B out).
 // The pack is msq_mx_pack_core.h's: the bytes are those of msq_mx_pack_a8 on the producer's output.
 // ---------------------------------------------------------------------------------------------------------------------------
