@@ -52,6 +52,7 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
 #pragma unroll
     for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
     uint32_t ui = 0u, uo = 0u;
+    bool quirky = false;
 #pragma unroll
     for (int b = 0; b < BS; b += 2) {
         bool m[2];
@@ -70,11 +71,13 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
             m[j] = (a[b + j] < lo) || (a[b + j] > hi);
             if (v1) mkw[(b + j) >> 5] |= (m[j] ? 1u : 0u) << ((b + j) & 31);
             const uint32_t t = f2u(a[b + j]) & 0x7FFFFFFFu;
+            quirky |= mantissa_all_ones(t);
             ti[j] = m[j] ? 0u : t; to[j] = m[j] ? t : 0u;
         }
         ui = max(ui, max(ti[0], ti[1])); uo = max(uo, max(to[0], to[1]));
     }
     if (max(ui, uo) >= 0x7F800000u) return false;                      // NaN / Inf element (a NaN compares false: unmasked)
+    if (quirky) return false;                                          // could be pred(half the smallest step): msq_device.h half_away_quirk_bits
     const float mx_in = u2f(ui), mx_o = u2f(uo);
     float se_in = shared_exp_of_max(mx_in);
     if (A.flush && !(se_in > -127.f)) return false;

@@ -96,6 +96,34 @@ MSQ_HD float round_mantissa(float a, int rmode) {
     return s * (__builtin_floorf(m + 0.5f) - tie);
 }
 
+// ---------------------------------------------------------------------------
+// The one magnitude on which the reference's "nearest" is not round-half-away.  elemwise_ops.py:64-65 rounds with
+// floor(|x| + 0.5) IN float32 on the value scaled to the integer grid.  Below the grid's first step that sum is inexact for
+// exactly one input: |x| = pred(0.5) -- 0.5 + (0.5 - 2^-25) = 1 - 2^-25 is a tie of the float32 grid under 1 and rounds
+// (to even) to 1.0 -- so the reference returns the grid's SMALLEST step where true rounding gives 0 (`even`, :66-72, takes
+// the same sum).  In unscaled terms: |x| = pred(h), h = half the smallest subnormal of the element format x the block scale.
+// The reference's native kernel (cpp/quantize.cuh:88-149, integer rounding) does not have it.  The arithmetic codecs here
+// (quant_core_sat, quant_core_fast) reproduce it by construction; the bit / hardware-convert codecs call these helpers.
+// Found in round 6 by planted maxima one ulp under a power of two meeting a block scale set by a larger neighbour
+// (tests/test_gpu_a9_quantize_mx.py); ~1e-8 of Gaussian float32 weights.
+// ---------------------------------------------------------------------------
+// bit pattern of pred(2^t) (t = exponent of HALF the smallest step, after scaling); 0xFFFFFFFF when 2^t is not a float
+MSQ_HD uint32_t half_away_quirk_bits(int t) {
+    if (t >= -126 && t <= 127) return ((uint32_t)(t + 127) << 23) - 1u;
+    if (t >= -148) return (1u << (t + 149)) - 1u;
+    return 0xFFFFFFFFu;
+}
+// input for a round-to-nearest-EVEN convert that yields the reference's result: an exact tie becomes "just above the tie"
+// (| 1: ties and grid points of the <= 8-bit grids have >= 15 trailing zero mantissa bits, nothing else moves across one),
+// the quirk magnitude becomes "just above h" (+ 2 ulps)
+MSQ_HD float sticky_half_away(float a, uint32_t quirk_bits) {
+    const uint32_t u = f2u(a);
+    return u2f(((u & 0x7FFFFFFFu) == quirk_bits) ? u + 2u : (u | 1u));
+}
+// conservative block-level test for the fast paths that fall back to the arithmetic codec: some element has an all-ones
+// mantissa (every pred(2^t) has); 32 x 2^-23 of the blocks
+MSQ_HD bool mantissa_all_ones(uint32_t bits) { return (bits & 0x7FFFFFu) == 0x7FFFFFu; }
+
 MSQ_HD float quant_core_sat(float a, int bits, int ebits, float max_norm, int rmode) {
     float out;
     const float up = pow2i(bits - 2);

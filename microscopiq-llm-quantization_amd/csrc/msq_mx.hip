@@ -105,14 +105,20 @@ k_mx_pack(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* _
     const float s_op = AF6 ? 1.0f : u2f((uint32_t)sb << 23);    // the converts read the exponent field only
     const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
     uint32_t cw[FP4 ? 4 : 8];
+    // the reference's floor(|x| + 0.5) in float32 (msq_device.h half_away_quirk_bits): half the smallest step of the grid x the scale
+    // (e2m1: 2^-2, e4m3: 2^-10; the fp6 grids are met after the exact scaling: e3m2 2^-5, e2m3 2^-4)
+    const uint32_t qb = VAL ? 0xFFFFFFFFu : half_away_quirk_bits(AF6 ? (AF6 == 3 ? -5 : -4) : sb - 127 - (FP4 ? 2 : 10));
 #pragma unroll
     for (int p = 0; p < BS / 2; ++p) {
         typedef short v2s_t __attribute__((ext_vector_type(2)));
-        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | (VAL ? 0u : 1u)), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | (VAL ? 0u : 1u));
+        float x0 = fl ? 0.f : (VAL ? a[2 * p] : sticky_half_away(a[2 * p], qb)), x1 = fl ? 0.f : (VAL ? a[2 * p + 1] : sticky_half_away(a[2 * p + 1], qb));
         if (AF6) {                                               // fp6 value of a / 2^(sb - 127) (arithmetic codec), then an exact convert
             const int sh = 127 - (sb == 255 ? 127 : sb);
-            x0 = fl ? 0.f : quant_bits(__builtin_ldexpf(a[2 * p], sh), AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
-            x1 = fl ? 0.f : quant_bits(__builtin_ldexpf(a[2 * p + 1], sh), AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
+            const float y0 = __builtin_ldexpf(a[2 * p], sh), y1 = __builtin_ldexpf(a[2 * p + 1], sh);
+            x0 = fl ? 0.f : quant_bits(y0, AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
+            x1 = fl ? 0.f : quant_bits(y1, AF6 == 3 ? 4 : 5, AF6, AF6 == 3 ? 28.0f : 7.5f, 0, true, true);
+            if (!fl && (f2u(y0) & 0x7FFFFFFFu) == qb) x0 = __builtin_copysignf(AF6 == 3 ? 0.0625f : 0.125f, y0);
+            if (!fl && (f2u(y1) & 0x7FFFFFFFu) == qb) x1 = __builtin_copysignf(AF6 == 3 ? 0.0625f : 0.125f, y1);
         }
         if (FP4) {
             uint32_t w = (p & 3) ? cw[p >> 2] : 0u;
@@ -236,7 +242,10 @@ k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t
 #pragma unroll
         for (int b = 0; b < BS; ++b) {
             const float si = fl ? 0.f : __builtin_ldexpf(a[b], 127 - sb);               // a / 2^(sb - 127), exact
-            const uint32_t cd = fp6_code<EB>(quant_bits(si, MBITS, EB, MAXN, 0, true, true));
+            float q = quant_bits(si, MBITS, EB, MAXN, 0, true, true);
+            // the reference's floor(|x| + 0.5) in float32 (msq_device.h half_away_quirk_bits): pred(half the smallest step) -> one step
+            if ((f2u(si) & 0x7FFFFFFFu) == half_away_quirk_bits(EB == 3 ? -5 : -4)) q = __builtin_copysignf(EB == 3 ? 0.0625f : 0.125f, si);
+            const uint32_t cd = fp6_code<EB>(q);
             const int bit = 6 * b;
             w[bit >> 5] |= cd << (bit & 31);
             if ((bit & 31) > 26) w[(bit >> 5) + 1] |= cd >> (32 - (bit & 31));

@@ -36,9 +36,10 @@ MSQ_D void mx_pack8_e4m3_quad(const float (&a)[8], uint32_t (&cw)[2], int& sb, i
     sb = mx_scale_byte(se, 8, status);
     const float s_op = u2f((uint32_t)sb << 23);                 // the converts read the exponent field only
     const float bound = __builtin_ldexpf(448.f, sb - 127);       // e4m3 max_norm x scale (exact)
+    const uint32_t qb = half_away_quirk_bits(sb - 127 - 10);     // e4m3: smallest subnormal 2^-9, half of it 2^-10, x the block scale
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        float x0 = fl ? 0.f : u2f(f2u(a[2 * p]) | 1u), x1 = fl ? 0.f : u2f(f2u(a[2 * p + 1]) | 1u);
+        float x0 = fl ? 0.f : sticky_half_away(a[2 * p], qb), x1 = fl ? 0.f : sticky_half_away(a[2 * p + 1], qb);
         x0 = __builtin_amdgcn_fmed3f(x0, -bound, bound); x1 = __builtin_amdgcn_fmed3f(x1, -bound, bound);   // e4m3 does not saturate
         v2s_t cur = __builtin_bit_cast(v2s_t, (p & 1) ? cw[p >> 1] : 0u);
         if ((p & 1) == 0) cur = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(cur, x0, x1, s_op, false);

@@ -309,6 +309,7 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
     for (int w = 0; w < (BS + 31) / 32; ++w) mkw[w] = 0u;
     float mx_in = 0.f, mx_o = 0.f;
     bool nonfinite = false;
+    bool quirky = false;            // an element that could be pred(half the smallest step): the converts round it to 0, the reference does not
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
         if (A.variant != 0) {
@@ -320,6 +321,7 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
         mkw[b >> 5] |= (m ? 1u : 0u) << (b & 31);
         const float t = __builtin_fabsf(a[b]);
         nonfinite |= ((f2u(a[b]) & 0x7F800000u) == 0x7F800000u);
+        if (RM == 0 && !EMIT && HW != 0) quirky |= mantissa_all_ones(f2u(a[b]));
         mx_in = (!m && t > mx_in) ? t : mx_in;
         mx_o = (m && t > mx_o) ? t : mx_o;
     }
@@ -355,7 +357,7 @@ MSQ_D int outlier_block_fast(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
         // a block without (non-zero) outliers never uses the outlier scale: every masked element is +-0 and comes
         // out as +0 on either route, so its se_out (-127 with 8 scale bits in variant 1) must not force the slow path
         const bool no_out = (mx_o == 0.f);
-        const bool safe = !nonfinite && !fl && status == 0 && se_in >= -60.f && se_in <= 60.f &&
+        const bool safe = !nonfinite && !quirky && !fl && status == 0 && se_in >= -60.f && se_in <= 60.f &&
                           (no_out || (se_out >= -60.f && se_out <= 60.f));
         if (safe) {
             const int ei = (int)se_in, eo = no_out ? 0 : (int)se_out - (int)se_in;

@@ -103,10 +103,17 @@ MSQ_D float mx_shared_scale(int shared_exp, int scale_bits, float elem_max_norm)
 // exponent of one element for the block maximum: the exponent field (the reference's native kernels, cpp/shared_exp.cuh) or, with pyexp,
 // what its Python path gets from floor(torch.log2(.)) (msq_device.h biased_exp_py); and the element codec: the native bit codec, or --
 // Python path under truncation only, where the private exponent of elemwise_ops.py:139-144 decides the grid -- the arithmetic one
-MSQ_D int mx_exp_of(uint32_t bits, int pyexp) { return pyexp ? biased_exp_py(bits) : (int)((bits >> 23) & 0xFF); }
-MSQ_D float mx_elem(float si, int mbits, int ebits, float max_norm, int rmode, int pyexp) {
-    if (pyexp && rmode == 1) return quant_core_sat(si, mbits, ebits, max_norm, rmode);
-    return quant_bits(si, mbits, ebits, max_norm, rmode, true, true);
+// PY is a template parameter like EPS: as a run-time argument (round 5) it put both codecs into every kernel and the
+// register tile of k_mx_tile_cols4 into scratch (272 / 528 bytes per lane, 2.5-2.9x slower); `make check-resources` gates it
+template <bool PY> MSQ_D int mx_exp_of(uint32_t bits) { return PY ? biased_exp_py(bits) : (int)((bits >> 23) & 0xFF); }
+template <bool PY> MSQ_D float mx_elem(float si, int mbits, int ebits, float max_norm, int rmode) {
+    if (PY && rmode == 1) return quant_core_sat(si, mbits, ebits, max_norm, rmode);
+    const float q = quant_bits(si, mbits, ebits, max_norm, rmode, true, true);
+    if (PY) {                                                    // the Python path's floor(|x| + 0.5) in float32: msq_device.h half_away_quirk_bits
+        const int t = (ebits ? 2 - (1 << (ebits - 1)) : 0) - mbits + 1;
+        if ((f2u(si) & 0x7FFFFFFFu) == half_away_quirk_bits(t)) return __builtin_copysignf(pow2i(t + 1), si);
+    }
+    return q;
 }
 
 // quantize_mx with precomputed max values (replaces cpp/mx.cuh:15-53)
@@ -134,30 +141,31 @@ k_mx_maxvals(const float* __restrict__ in, float* __restrict__ out, const float*
 //             max biased exponent by a DPP/shuffle butterfly inside the wave.
 // EPS: the divisor of the reference's PYTHON path, `2**shared_exp + 1e-6` in fp32 (mx_ops.py:444; custom_cuda = False) --
 // the native path the entry replaces divides by the scale itself (cpp/mx.cuh:132).
-template <int TS, bool EPS = false>
+template <int TS, bool EPS = false, bool PY = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_inner(const float* __restrict__ in, float* __restrict__ out, int64_t total, int scale_bits,
-                int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
+                int ebits, int mbits, float max_norm, int flush, int rmode) {
     // axis_len % TS == 0, TS power of two <= 64: element i belongs to tile i / TS
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float v = (i < total) ? in[i] : 0.f;
-    int se = mx_exp_of(f2u(v), pyexp);
+    uint32_t um = f2u(v) & 0x7FFFFFFFu;
 #pragma unroll
     for (int m = TS / 2; m > 0; m >>= 1) {
-        const int o = __shfl_xor(se, m, 64);
-        se = o > se ? o : se;
+        const uint32_t o = (uint32_t)__shfl_xor((int)um, m, 64);
+        um = o > um ? o : um;
     }
+    const int se = mx_exp_of<PY>(um);
     const bool fl = (se == 0) && flush;
     const float scale = mx_shared_scale(se, scale_bits, max_norm);
     const float si = fl ? 0.f : v / (EPS ? scale + 1e-6f : scale);
-    if (i < total) out[i] = mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
+    if (i < total) out[i] = mx_elem<PY>(si, mbits, ebits, max_norm, rmode) * scale;
 }
 
-template <bool EPS = false>
+template <bool EPS = false, bool PY = false>
 __global__ void __launch_bounds__(256)
 k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len,
                   int64_t post, int tile, int64_t ntiles, int scale_bits, int ebits, int mbits,
-                  float max_norm, int flush, int rmode, int pyexp) {
+                  float max_norm, int flush, int rmode) {
     const int64_t total = pre * ntiles * post;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -167,16 +175,17 @@ k_mx_tile_generic(const float* __restrict__ in, float* __restrict__ out, int64_t
         const int64_t a0 = ti * tile;
         int64_t a1 = a0 + tile; a1 = a1 > axis_len ? axis_len : a1;
         const int64_t base = (p * axis_len) * post + q;
-        int se = 0;
+        uint32_t um = 0;
         for (int64_t a = a0; a < a1; ++a) {
-            const int e = mx_exp_of(f2u(in[base + a * post]), pyexp);
-            se = e > se ? e : se;
+            const uint32_t u = f2u(in[base + a * post]) & 0x7FFFFFFFu;
+            um = u > um ? u : um;
         }
+        const int se = mx_exp_of<PY>(um);
         const bool fl = (se == 0) && flush;
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         for (int64_t a = a0; a < a1; ++a) {
             const float si = fl ? 0.f : in[base + a * post] / (EPS ? scale + 1e-6f : scale);
-            out[base + a * post] = mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
+            out[base + a * post] = mx_elem<PY>(si, mbits, ebits, max_norm, rmode) * scale;
         }
     }
 }
@@ -192,47 +201,48 @@ MSQ_D float mx_scale_recip(float scale) {
     return e == 254 ? u2f(1u << 22) : u2f((uint32_t)(254 - e) << 23);
 }
 
-template <bool EPS>
-MSQ_D float mx_apply(float v, float scale, float rs, bool fl, int mbits, int ebits, float max_norm, int rmode, int pyexp) {
+template <bool EPS, bool PY>
+MSQ_D float mx_apply(float v, float scale, float rs, bool fl, int mbits, int ebits, float max_norm, int rmode) {
     const float si = fl ? 0.f : (EPS ? v / (scale + 1e-6f) : v * rs);
-    return mx_elem(si, mbits, ebits, max_norm, rmode, pyexp) * scale;
+    return mx_elem<PY>(si, mbits, ebits, max_norm, rmode) * scale;
 }
 
 // tile innermost (post == 1), TS in {4, 8, 16, 32, 64}: TS / 4 neighbouring lanes share a tile
-template <int TS, bool EPS>
+template <int TS, bool EPS, bool PY>
 __global__ void __launch_bounds__(256)
 k_mx_tile_inner4(const float* __restrict__ in, float* __restrict__ out, int64_t nvec, int scale_bits,
-                 int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
+                 int ebits, int mbits, float max_norm, int flush, int rmode) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < nvec; b += stride) {
         const int64_t i = b + threadIdx.x;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nvec) v = reinterpret_cast<const float4*>(in)[i];
-        const int m01 = max(mx_exp_of(f2u(v.x), pyexp), mx_exp_of(f2u(v.y), pyexp));
-        const int m23 = max(mx_exp_of(f2u(v.z), pyexp), mx_exp_of(f2u(v.w), pyexp));
-        int se = max(m01, m23);
+        const uint32_t m01 = max(f2u(v.x) & 0x7FFFFFFFu, f2u(v.y) & 0x7FFFFFFFu);
+        const uint32_t m23 = max(f2u(v.z) & 0x7FFFFFFFu, f2u(v.w) & 0x7FFFFFFFu);
+        uint32_t um = max(m01, m23);
 #pragma unroll
         for (int m = TS / 8; m > 0; m >>= 1) {
-            const int o = __shfl_xor(se, m, 64);
-            se = o > se ? o : se;
+            const uint32_t o = (uint32_t)__shfl_xor((int)um, m, 64);
+            um = o > um ? o : um;
         }
+        const int se = mx_exp_of<PY>(um);                         // monotone in |bits|: the rule once, on the maximum
         const bool fl = (se == 0) && flush;
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         const float rs = mx_scale_recip(scale);
-        v.x = mx_apply<EPS>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
-        v.y = mx_apply<EPS>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
-        v.z = mx_apply<EPS>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
-        v.w = mx_apply<EPS>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode, pyexp);
+        v.x = mx_apply<EPS, PY>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.y = mx_apply<EPS, PY>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.z = mx_apply<EPS, PY>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.w = mx_apply<EPS, PY>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
         if (i < nvec) reinterpret_cast<float4*>(out)[i] = v;
     }
 }
 
 // tile along an outer axis (post % 4 == 0, tile <= TILE): one lane per (tile, 4 neighbouring columns); the TILE x 4
 // values stay in registers between the exponent scan and the quantisation, every access is a coalesced 16-byte one
-template <int TILE, bool EPS>
+template <int TILE, bool EPS, bool PY>
 __global__ void __launch_bounds__(256)
 k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t pre, int64_t axis_len, int64_t post4,
-                int tile, int64_t ntiles, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode, int pyexp) {
+                int tile, int64_t ntiles, int scale_bits, int ebits, int mbits, float max_norm, int flush, int rmode) {
     const int64_t total = pre * ntiles * post4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -244,25 +254,43 @@ k_mx_tile_cols4(const float* __restrict__ in, float* __restrict__ out, int64_t p
     const float4* src = reinterpret_cast<const float4*>(in) + (p * axis_len + a0) * post4 + q;
     float4* dst = reinterpret_cast<float4*>(out) + (p * axis_len + a0) * post4 + q;
     float4 r[TILE];
-    int ex = 0, ey = 0, ez = 0, ew = 0;
+    // the exponent rule (field, or the Python path's floor(log2)) is monotone in |bits|: one unsigned maximum per element,
+    // the rule once per column (inside the unrolled loop its rare log2f branch x 4 x TILE kept hipcc from unrolling at all)
+    uint32_t ux = 0, uy = 0, uz = 0, uw = 0;
 #pragma unroll
     for (int j = 0; j < TILE; ++j) {
         r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < rows) r[j] = src[(int64_t)j * post4];
-        ex = max(ex, mx_exp_of(f2u(r[j].x), pyexp)); ey = max(ey, mx_exp_of(f2u(r[j].y), pyexp));
-        ez = max(ez, mx_exp_of(f2u(r[j].z), pyexp)); ew = max(ew, mx_exp_of(f2u(r[j].w), pyexp));
+        ux = max(ux, f2u(r[j].x) & 0x7FFFFFFFu); uy = max(uy, f2u(r[j].y) & 0x7FFFFFFFu);
+        uz = max(uz, f2u(r[j].z) & 0x7FFFFFFFu); uw = max(uw, f2u(r[j].w) & 0x7FFFFFFFu);
     }
+    const int ex = mx_exp_of<PY>(ux), ey = mx_exp_of<PY>(uy), ez = mx_exp_of<PY>(uz), ew = mx_exp_of<PY>(uw);
     const float sx = mx_shared_scale(ex, scale_bits, max_norm), sy = mx_shared_scale(ey, scale_bits, max_norm);
     const float sz = mx_shared_scale(ez, scale_bits, max_norm), sw = mx_shared_scale(ew, scale_bits, max_norm);
     const float rx = mx_scale_recip(sx), ry = mx_scale_recip(sy), rz = mx_scale_recip(sz), rw = mx_scale_recip(sw);
     const bool fx = (ex == 0) && flush, fy = (ey == 0) && flush, fz = (ez == 0) && flush, fw = (ew == 0) && flush;
+    if (PY && rmode == 1) {
+        // Python path under truncation: the arithmetic codec (log2f per element).  Kept OUT of the unrolled register-tile
+        // loop -- with both codecs in its body hipcc gave up unrolling and put r[] into scratch -- and fed from the
+        // (L2-resident) source again: the rare configuration pays a second read, the common one keeps its registers.
+        for (int j = 0; j < rows; ++j) {
+            const float4 v = src[(int64_t)j * post4];
+            float4 o;
+            o.x = quant_core_sat(fx ? 0.f : (EPS ? v.x / (sx + 1e-6f) : v.x * rx), mbits, ebits, max_norm, 1) * sx;
+            o.y = quant_core_sat(fy ? 0.f : (EPS ? v.y / (sy + 1e-6f) : v.y * ry), mbits, ebits, max_norm, 1) * sy;
+            o.z = quant_core_sat(fz ? 0.f : (EPS ? v.z / (sz + 1e-6f) : v.z * rz), mbits, ebits, max_norm, 1) * sz;
+            o.w = quant_core_sat(fw ? 0.f : (EPS ? v.w / (sw + 1e-6f) : v.w * rw), mbits, ebits, max_norm, 1) * sw;
+            dst[(int64_t)j * post4] = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TILE; ++j) {
         float4 o;
-        o.x = mx_apply<EPS>(r[j].x, sx, rx, fx, mbits, ebits, max_norm, rmode, pyexp);
-        o.y = mx_apply<EPS>(r[j].y, sy, ry, fy, mbits, ebits, max_norm, rmode, pyexp);
-        o.z = mx_apply<EPS>(r[j].z, sz, rz, fz, mbits, ebits, max_norm, rmode, pyexp);
-        o.w = mx_apply<EPS>(r[j].w, sw, rw, fw, mbits, ebits, max_norm, rmode, pyexp);
+        o.x = mx_apply<EPS, PY>(r[j].x, sx, rx, fx, mbits, ebits, max_norm, rmode);
+        o.y = mx_apply<EPS, PY>(r[j].y, sy, ry, fy, mbits, ebits, max_norm, rmode);
+        o.z = mx_apply<EPS, PY>(r[j].z, sz, rz, fz, mbits, ebits, max_norm, rmode);
+        o.w = mx_apply<EPS, PY>(r[j].w, sw, rw, fw, mbits, ebits, max_norm, rmode);
         if (j < rows) dst[(int64_t)j * post4] = o;
     }
 }
@@ -280,10 +308,10 @@ k_mx_maxvals_rows4(const float* __restrict__ in, float* __restrict__ out, const 
         const float scale = mx_shared_scale(se, scale_bits, max_norm);
         const float rs = mx_scale_recip(scale);
         float4 v = reinterpret_cast<const float4*>(in)[i];
-        v.x = mx_apply<false>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
-        v.y = mx_apply<false>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
-        v.z = mx_apply<false>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
-        v.w = mx_apply<false>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode, 0);
+        v.x = mx_apply<false, false>(v.x, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.y = mx_apply<false, false>(v.y, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.z = mx_apply<false, false>(v.z, scale, rs, fl, mbits, ebits, max_norm, rmode);
+        v.w = mx_apply<false, false>(v.w, scale, rs, fl, mbits, ebits, max_norm, rmode);
         reinterpret_cast<float4*>(out)[i] = v;
     }
 }
@@ -591,10 +619,10 @@ static void launch_elemwise_16(const void* in, void* out, int64_t n, int bits, i
                            (T*)out + done, n - done, bits, ebits, max_norm, rmode, saturate, allow_denorm);
 }
 
-template <bool EPS>
+template <bool EPS, bool PY>
 static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                              int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
-                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream, int pyexp) {
+                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
     if (pre < 0 || axis_len < 0 || post < 0) return fail(MSQ_ERR_BAD_ARG, "msq_quantize_mx_by_tile: negative size");
     const int64_t total = pre * axis_len * post;
     if (total == 0) return MSQ_OK;
@@ -607,8 +635,8 @@ static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t a
     if (post == 1 && pow2 && tile_size >= 4 && tile_size <= 64 && axis_len % tile_size == 0 && al16) {
         const int64_t nvec = total / 4;
         const int g = grid_for(nvec, 256, 2048 * 4);
-#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner4<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, nvec, \
-                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp); break;
+#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner4<TS, EPS, PY>), dim3(g), dim3(256), 0, st, in, out, nvec, \
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
         switch (tile_size) { MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
 #undef MSQ_TI
     } else if (post > 1 && post % 4 == 0 && tile_size <= 32 && al16 && pre * ((axis_len + tile_size - 1) / tile_size) * (post / 4) < (int64_t)0x7FFFFFFF * 256) {
@@ -616,22 +644,22 @@ static int launch_mx_by_tile(const float* in, float* out, int64_t pre, int64_t a
         const int64_t nthreads = pre * ntiles * (post / 4);
         const unsigned g = (unsigned)((nthreads + 255) / 256);
         if (tile_size <= 16)
-            hipLaunchKernelGGL((k_mx_tile_cols4<16, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
-                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
+            hipLaunchKernelGGL((k_mx_tile_cols4<16, EPS, PY>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
         else
-            hipLaunchKernelGGL((k_mx_tile_cols4<32, EPS>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
-                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
+            hipLaunchKernelGGL((k_mx_tile_cols4<32, EPS, PY>), dim3(g), dim3(256), 0, st, in, out, pre, axis_len, post / 4, tile_size,
+                               ntiles, scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode);
     } else if (post == 1 && pow2 && tile_size <= 64 && axis_len % tile_size == 0) {
         const int g = grid_for(total, 256);
-#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner<TS, EPS>), dim3(g), dim3(256), 0, st, in, out, total, \
-                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode, pyexp); break;
+#define MSQ_TI(TS) case TS: hipLaunchKernelGGL((k_mx_tile_inner<TS, EPS, PY>), dim3(g), dim3(256), 0, st, in, out, total, \
+                        scale_bits, elem_ebits, elem_mbits, elem_max_norm, flush_fp32_subnorms, rmode); break;
         switch (tile_size) { MSQ_TI(1) MSQ_TI(2) MSQ_TI(4) MSQ_TI(8) MSQ_TI(16) MSQ_TI(32) MSQ_TI(64) }
 #undef MSQ_TI
     } else {
         const int64_t ntiles = (axis_len + tile_size - 1) / tile_size;
-        hipLaunchKernelGGL(k_mx_tile_generic<EPS>, dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_mx_tile_generic<EPS, PY>), dim3(grid_for(pre * ntiles * post, 256, 16384)), dim3(256), 0, st,
                            in, out, pre, axis_len, post, tile_size, ntiles, scale_bits, elem_ebits, elem_mbits,
-                           elem_max_norm, flush_fp32_subnorms, rmode, pyexp);
+                           elem_max_norm, flush_fp32_subnorms, rmode);
     }
     return check_launch("msq_quantize_mx_by_tile");
 }
@@ -709,25 +737,25 @@ int msq_quantize_mx(const float* in, float* out, const float* max_values, int64_
 int msq_quantize_mx_by_tile(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                             int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                             float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
-    return launch_mx_by_tile<false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                    elem_max_norm, flush_fp32_subnorms, rmode, stream, 0);
+    return launch_mx_by_tile<false, false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                           elem_max_norm, flush_fp32_subnorms, rmode, stream);
 }
 
 int msq_quantize_mx_by_tile_py(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                                int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                                float elem_max_norm, int flush_fp32_subnorms, int rmode, void* stream) {
-    return launch_mx_by_tile<true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                   elem_max_norm, flush_fp32_subnorms, rmode, stream, 1);
+    return launch_mx_by_tile<true, true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
+                                         elem_max_norm, flush_fp32_subnorms, rmode, stream);
 }
 
 int msq_quantize_mx_by_tile_ex(const float* in, float* out, int64_t pre, int64_t axis_len, int64_t post,
                                int tile_size, int scale_bits, int elem_ebits, int elem_mbits,
                                float elem_max_norm, int flush_fp32_subnorms, int rmode, int py_divisor, int py_exponent, void* stream) {
-    if (py_divisor)
-        return launch_mx_by_tile<true>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                       elem_max_norm, flush_fp32_subnorms, rmode, stream, py_exponent ? 1 : 0);
-    return launch_mx_by_tile<false>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits,
-                                    elem_max_norm, flush_fp32_subnorms, rmode, stream, py_exponent ? 1 : 0);
+#define MSQ_MXT(E, P) launch_mx_by_tile<E, P>(in, out, pre, axis_len, post, tile_size, scale_bits, elem_ebits, elem_mbits, \
+                                             elem_max_norm, flush_fp32_subnorms, rmode, stream)
+    if (py_divisor) return py_exponent ? MSQ_MXT(true, true) : MSQ_MXT(true, false);
+    return py_exponent ? MSQ_MXT(false, true) : MSQ_MXT(false, false);
+#undef MSQ_MXT
 }
 
 int msq_reduce_sum_inner(const float* in, float* out, int64_t outer, int64_t inner, void* stream) {

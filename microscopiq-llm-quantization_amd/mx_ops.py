@@ -1,9 +1,16 @@
 """MX block quantisation -- the surface of number_system/mx/mx_ops.py (_quantize_mx :332,
 quantize_mx_op :460, _quantize_mx_outlier_v1 :210, quantize_mx_outlier_op :492), on the GPU.
 
-``_quantize_mx`` follows the upstream OCP-MX / native-kernel semantics (cpp/mx.cuh), i.e.
-WITHOUT the `+1e-6` that the reference added at mx_ops.py:444 (a reference defect that
-breaks three of its own KATs)."""
+``_quantize_mx`` selects its arithmetic from the ``custom_cuda`` flag, as the reference does:
+
+* ``custom_cuda=True``  -> the reference's NATIVE kernel (cpp/mx.cuh:107-170, cpp/shared_exp.cuh:14-53): shared exponent = the
+  exponent FIELD of the block maximum, divisor = the scale.  This is what the upstream KATs pin.
+* ``custom_cuda=False`` -> the reference's PYTHON path (mx_ops.py:332-457): shared exponent = ``floor(torch.log2(max))`` (one
+  higher for the up to 88 largest floats under a power of two), under ``round="floor"`` the private exponents too.  Its
+  divisor ``2**e + 1e-6`` (mx_ops.py:444, a reference defect that breaks three of its own KATs) is NOT
+  applied unless ``with reference_python_divisor():`` is active -- inside it the result is the reference's CPU output bit
+  for bit; outside it is "the Python path without the defect", which is also what the MX GEMM operand packers encode
+  (msq_mx_pack_*: pinned by the GEMM tests against ``oracle.quantize_mx``)."""
 import torch
 
 from . import funcs
@@ -13,11 +20,9 @@ from .quant import VARIANT_MXOPS, outlier_fakequant
 from .specs import mx_assert_test
 
 
-# The reference's `_quantize_mx` has two arithmetic variants: its native kernel divides by the shared scale
-# (cpp/mx.cuh:132, custom_cuda=True), its Python path by `scale + 1e-6` (mx_ops.py:444, custom_cuda=False), which moves
-# every tie of the scaled element down (3 % of bfloat16-rounded activations in fp6).  The native variant is the default
-# here whatever the flag says (it is what the MX-native GEMM operands encode and what the upstream KATs pin);
-# `with reference_python_divisor():` selects the Python variant, bit for bit.
+# The divisor of the Python path: `scale + 1e-6` (mx_ops.py:444) moves every tie of the scaled element down (3 % of
+# bfloat16-rounded activations in fp6).  Off by default (see the module docstring); `with reference_python_divisor():` turns
+# it on for custom_cuda=False calls, bit for bit the reference's CPU result.  custom_cuda=True never takes it (cpp/mx.cuh:132).
 _PY_DIVISOR = [False]
 
 
@@ -40,7 +45,8 @@ _LOWP_BLOCKS = (8, 16, 32, 64, 128)
 
 def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None, block_size=0, round="nearest",
                  flush_fp32_subnorms=False, custom_cuda=False, compute_dtype="input"):
-    """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile.
+    """mx_ops.py:332-457; single-axis, executed by msq_quantize_mx_by_tile_ex.  ``custom_cuda`` picks the reference's native
+    kernel arithmetic (True) or its Python path (False) -- module docstring.
 
     fp16 / bf16 tensors (``compute_dtype="input"``, the default): one launch of msq_quantize_mx_lowp, which computes IN the
     tensor dtype op by op -- what the reference does with a half tensor (its native kernel is float32 only, so the Python path
@@ -83,7 +89,7 @@ def _quantize_mx(A, scale_bits, elem_format, shared_exp_method="max", axes=None,
         return out
     y = funcs.quantize_mx_by_tile_func_cuda(x.float() if x.dtype != torch.float32 else x, scale_bits, ebits, mbits,
                                             max_norm, tile, axis, flush_fp32_subnorms, int(RoundingMode[round]),
-                                            python_divisor=_PY_DIVISOR[0], python_exponent=True)   # this IS the Python path (mx_ops.py:332-457)
+                                            python_divisor=_PY_DIVISOR[0] and not custom_cuda, python_exponent=not custom_cuda)
     return y if A.dtype == torch.float32 else y.to(A.dtype)
 
 
