@@ -257,6 +257,8 @@ int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 #define MSQ_KERNEL_T256    2
 #define MSQ_KERNEL_T128    3
 #define MSQ_KERNEL_PERSISTENT 4   /* k_qgemm256p: persistent 256-row blocks, stream-K over the part-filled last round (MSQ_GEMM_256=3) */
+#define MSQ_KERNEL_STREAMK 5      /* k_qgemm_sk (round 6): 32 < M <= 256 on wide projections -- one strip (or strip pair) per block, K cut over the block's
+                                   * waves, partial tiles summed in LDS in a fixed order: no split-K planes, one launch (MSQ_GEMM_SK=0 disables, 1-3 force a form) */
 int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int mx_wf);
 /* The GEMM kernel instantiation the same call would launch, as text ("k_qgemm256<6, uint16_t, 16>"): the dispatcher's own decision function,
  * tuning switches (MSQ_GEMM_256 / MSQ_MX_256) included; y_dtype 0 = float32 output, else 16-bit.  For measurement labels (bench.py). */

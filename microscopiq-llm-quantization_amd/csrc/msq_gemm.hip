@@ -1483,7 +1483,7 @@ static int pick_kc(int64_t N, int64_t K) {
 static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes);
 int64_t msq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || (N % BN) || (K % BK)) return 0;
-    if (use_gemv(M, N, K)) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }
+    if (use_gemv(M, N, K)) { const int kc = pick_kc(N, K); return (((K / BK + kc - 1) / kc + 3) / 4) * M * N * 4; }   // (k_qgemm_sk needs none; sized for the rule's fall-backs all the same)
     const int ks = pick_ksplit(M, N, K);
     int64_t w = ks > 1 ? (int64_t)ks * M * N * 4 : 0, wp = 0;
     if (qp_rule(M, N, K, &wp) && wp > w) w = wp;                 // flag words + partial-tile slots of the persistent kernel's stream-K round
@@ -1520,7 +1520,15 @@ int msq_launch_qgemm256p(const void* X, const void* ext_plane, const void* code_
 // tests and A / B scripts flip it inside one process).
 #include <atomic>
 #include <limits.h>
-static std::atomic<int> g_tune_gemm256{INT_MIN}, g_tune_mx256{INT_MIN};
+static std::atomic<int> g_tune_gemm256{INT_MIN}, g_tune_mx256{INT_MIN}, g_tune_sk{INT_MIN};
+// MSQ_GEMM_SK (tuning and A / B, read per call like MSQ_GEMM_256): 0 = never k_qgemm_sk, 1 / 2 / 3 = force its form (msq_gemm_stream.hip:
+// 64-row / 128-row strips, 128 x 128 blocks) wherever the kernel applies, unset = sk_rule()
+static int sk_forced_env() {
+    const int t = g_tune_sk.load(std::memory_order_relaxed);
+    if (t != INT_MIN) return t;
+    const char* e = getenv("MSQ_GEMM_SK");
+    return e ? atoi(e) : -1;
+}
 static int q256_forced_env() {
     const int t = g_tune_gemm256.load(std::memory_order_relaxed);
     if (t != INT_MIN) return t;
@@ -1535,10 +1543,30 @@ extern "C" int msq_set_tuning(const char* key, int value) {
     if (!key) return MSQ_ERR_BAD_ARG;
     if (!strcmp(key, "MSQ_GEMM_256")) { g_tune_gemm256.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_256")) { g_tune_mx256.store(value, std::memory_order_relaxed); return MSQ_OK; }
+    if (!strcmp(key, "MSQ_GEMM_SK")) { g_tune_sk.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_LOWP_PAIR4")) { msq_set_tuning_lowp_("mx_lowp_pair4", value); return MSQ_OK; }   // 0: one lane per block pair (k_mx_lowp_pair)
     if (!strcmp(key, "MSQ_PACK_TWO_PASS")) { g_tune_two_pass.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (msq_set_tuning_act_(key, value) || msq_set_tuning_mx_(key, value) || msq_set_tuning_vec_(key, value)) return MSQ_OK;   // MSQ_ACT_ROWS, MSQ_MX_PACK_BLOCK, MSQ_VEC_GENERIC
     return MSQ_ERR_UNSUPPORTED;
+}
+// k_qgemm_sk (msq_gemm_stream.hip): K cut over the waves INSIDE a block, partial tiles summed in LDS -- form 1 / 2 / 3, 0 = not for this shape
+extern "C" int msq_qgemm_sk_form(int64_t M, int64_t N, int64_t K, int form);
+extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
+                                   int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int form, void* stream);
+// The rule (also behind msq_qlinear_kernel_choice): the regime between the decode kernels and the prefill grids -- more than 32 rows, and a
+// grid of (row blocks) x (strips or strip pairs) that fills at least three quarters of the CUs in ONE round, which the 128 / 256-row
+// blocks of the prefill kernels cannot do without split-K planes.  Measured: profiles/r06_midm_forms.txt.
+static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x) {
+    if (!unified_bf16x) return 0;
+    const int forced = sk_forced_env();
+    if (forced == 0) return 0;
+    if (forced > 0) return msq_qgemm_sk_form(M, N, K, forced);
+    if (M <= 32 || M > 256) return 0;
+    const int form = msq_qgemm_sk_form(M, N, K, 0);
+    if (!form) return 0;
+    const int64_t bm = form == 1 ? 64 : 128, bn = form == 3 ? 128 : 64;
+    const int64_t blocks = ((M + bm - 1) / bm) * (N / bn);
+    return (blocks >= 192 && blocks <= 288) ? form : 0;
 }
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)
 static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes) {
@@ -1619,6 +1647,11 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     hipStream_t st0 = (hipStream_t)stream;
     const int y16 = (y_dtype == 1) ? 1 : 0;                       // fp16 output: the 16-bit kernels with the half conversion
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
+    if (const int skf = sk_rule(M, N, K, unified && !x_f16)) {
+        const int e = msq_launch_qgemm_sk(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, skf, stream);
+        if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(K cut inside the block, k_qgemm_sk form %d): %s", skf, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
+        return MSQ_OK;
+    }
     if (use_gemv(M, N, K)) {
         const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
         const int kcd = unified ? direct_kc(M, N, K) : 0;                // > 0: one block of 16 waves covers all of K
@@ -2157,8 +2190,9 @@ int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int
         return mf == 16 ? MSQ_KERNEL_T256 : (mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128);
     }
     if (K % BK) return -1;
-    if (use_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
     const bool unified = out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X;
+    if (sk_rule(M, N, K, unified)) return MSQ_KERNEL_STREAMK;
+    if (use_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
     const QFamily f = q_family(M, N, K, unified, out_kind, msq_qlinear_workspace_bytes(M, N, K));
     return f.persistent ? MSQ_KERNEL_PERSISTENT : (f.mf == 16 ? MSQ_KERNEL_T256 : (f.mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128));
 }
@@ -2174,7 +2208,11 @@ int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int m
         else snprintf(buf, cap, "k_mxgemm256<%s, %d, %d>", yt, mx_wf, fam == MSQ_KERNEL_T256 ? 16 : 8);
         return MSQ_OK;
     }
-    if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_qgemv_u / k_qgemv<out kind %d>", out_kind);
+    if (fam == MSQ_KERNEL_STREAMK) {
+        const int f = sk_rule(M, N, K, true);
+        snprintf(buf, cap, "k_qgemm_sk<%d, %s, %d, %d, %d>", out_kind, yt, f == 1 ? 4 : 8, f == 3 ? 2 : 1, f == 1 ? 8 : (f == 2 ? 4 : 2));
+    }
+    else if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_qgemv_u / k_qgemv<out kind %d>", out_kind);
     else if (fam == MSQ_KERNEL_GEMM128) snprintf(buf, cap, "k_qgemm3<out kind %d, %s>", out_kind, yt);
     else if (fam == MSQ_KERNEL_PERSISTENT) snprintf(buf, cap, "k_qgemm256p<%d, %s>", out_kind, yt);
     else snprintf(buf, cap, "k_qgemm256<%d, %s, %d>", out_kind, yt, fam == MSQ_KERNEL_T256 ? 16 : 8);
