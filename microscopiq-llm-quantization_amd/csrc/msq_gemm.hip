@@ -1553,20 +1553,26 @@ extern "C" int msq_set_tuning(const char* key, int value) {
 extern "C" int msq_qgemm_sk_form(int64_t M, int64_t N, int64_t K, int form);
 extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
                                    int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int form, void* stream);
-// The rule (also behind msq_qlinear_kernel_choice): the regime between the decode kernels and the prefill grids -- more than 32 rows, and a
-// grid of (row blocks) x (strips or strip pairs) that fills at least three quarters of the CUs in ONE round, which the 128 / 256-row
-// blocks of the prefill kernels cannot do without split-K planes.  Measured: profiles/r06_midm_forms.txt.
+// The rule (also behind msq_qlinear_kernel_choice), from profiles/r06_midm_forms.txt (HIP-graph device times, posit / fp8 outliers, the Llama-2-7B
+// projections, 16384 x 4096 and 8192 x 8192).  What bounds the kernel is the ~70 GB/s at which ONE CU pulls bytes out of L2 (MI355X_MICROARCH.md,
+// "Indexed rows"): a block re-reads its M activation rows over all of K next to its strip of packed weights -- (2 M + 74) K bytes -- so it wins
+// where that is less than what split-K planes cost: up to 64 rows on every projection with K <= 8192 (48-64 rows: 12288 x 4096 24.7 -> 16.9 us,
+// 16384 x 4096 28.4 -> 18.9, 22016 x 4096 36.5 -> 30.3, 4096 x 4096 16.2 -> 12.3, 8192 x 8192 26.2 -> 23.7; 4096 x 11008 loses: 22.1 -> 27.9), up
+// to 128 rows on the one-round grids of 128-row strips (12288: 27.3 -> 21.6, 16384: 30.8 -> 24.3; 22016 ties and keeps the split-K GEMM) and,
+// as two 64-row blocks per strip, on the 4096 x 4096 projections (21.9 -> 13.3).  Beyond 128 rows the 128 x 128 form only ties (256 x 16384 x 4096:
+// 42.1 -> 40.2): forced forms only.
 static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x) {
     if (!unified_bf16x) return 0;
     const int forced = sk_forced_env();
     if (forced == 0) return 0;
     if (forced > 0) return msq_qgemm_sk_form(M, N, K, forced);
-    if (M <= 32 || M > 256) return 0;
-    const int form = msq_qgemm_sk_form(M, N, K, 0);
-    if (!form) return 0;
-    const int64_t bm = form == 1 ? 64 : 128, bn = form == 3 ? 128 : 64;
-    const int64_t blocks = ((M + bm - 1) / bm) * (N / bn);
-    return (blocks >= 192 && blocks <= 288) ? form : 0;
+    if (M <= 32 || M > 128) return 0;
+    const int64_t strips = N / TILE_N, KT = K / BK;
+    int form = 0;
+    if (M <= 64) form = (strips >= 64 && strips <= 352 && KT <= 128) ? 1 : 0;
+    else if (strips >= 192 && strips <= 288) form = 2;
+    else if (strips >= 64 && strips <= 128 && KT <= 64) form = 1;
+    return form ? msq_qgemm_sk_form(M, N, K, form) : 0;
 }
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)
 static bool qp_rule(int64_t M, int64_t N, int64_t K, int64_t* ws_bytes) {
@@ -2210,7 +2216,8 @@ int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int m
     }
     if (fam == MSQ_KERNEL_STREAMK) {
         const int f = sk_rule(M, N, K, true);
-        snprintf(buf, cap, "k_qgemm_sk<%d, %s, %d, %d, %d>", out_kind, yt, f == 1 ? 4 : 8, f == 3 ? 2 : 1, f == 1 ? 8 : (f == 2 ? 4 : 2));
+        snprintf(buf, cap, "k_qgemm_sk<%d, %s, %d, %d, %d, %d>", out_kind, yt, (f == 1 || f == 5) ? 4 : 8, (f == 3 || f == 5) ? 2 : 1,
+                 (f == 1 || f == 4) ? 8 : ((f == 2 || f == 5) ? 4 : 2), f == 4 ? 1 : ((f == 3 || f == 5) ? 3 : 2));
     }
     else if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_qgemv_u / k_qgemv<out kind %d>", out_kind);
     else if (fam == MSQ_KERNEL_GEMM128) snprintf(buf, cap, "k_qgemm3<out kind %d, %s>", out_kind, yt);

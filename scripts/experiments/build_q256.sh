@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../../microscopiq-llm-quantization_amd/csrc"
 OUT=../../scripts/experiments/abl; mkdir -p $OUT
 TAG=${STEM#msq_}; TAG=${TAG/gemm256/q256}
 OBJS=""
-for o in msq_quant msq_quant_lowp msq_quant_hw msq_pack_emit msq_pack_twopass msq_pack_unified msq_act msq_mx msq_kv msq_vec msq_gptq msq_gemm msq_gemm256 msq_mxgemm256; do
+for o in msq_quant msq_quant_lowp msq_quant_hw msq_pack_emit msq_pack_twopass msq_pack_unified msq_act msq_mx msq_kv msq_vec msq_gptq msq_gemm msq_gemm256 msq_gemm256p msq_mxgemm256 msq_gemm_stream; do
   [ "$o" = "$STEM" ] || OBJS="$OBJS $o.o"
 done
 while [ $# -ge 2 ]; do

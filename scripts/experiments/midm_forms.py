@@ -28,13 +28,37 @@ for shp in sys.argv[2:]:
     W = torch.randn(N, K, device=dev) * 0.02; W[torch.rand(N, K, device=dev) < 0.005] *= 16
     X = torch.randn(M, K, device=dev).to(torch.bfloat16)
     r = []
+    ncopy = int(os.environ.get("MIDM_COPIES", "1"))       # > 1: the graph walks `ncopy` copies of the packed weight (cold: 5 x 78 MB > the 256 MB Infinity Cache)
     for fo in ("posit8_es1", "fp8_e4m3"):
         P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout="unified")
         try:
-            us = min(tg(lambda: qlinear.qlinear(X, P, None, torch.bfloat16)) for _ in range(2))
+            if ncopy > 1:
+                import copy
+                Ps = [P]
+                for _ in range(ncopy - 1):
+                    Q = copy.copy(P); Q.out = P.out.clone(); Q.scl = P.scl.clone(); Q.inl = P.inl.clone() if P.inl is not None else None
+                    Ps.append(Q)
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for Q in Ps: qlinear.qlinear(X, Q, None, torch.bfloat16)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        for _ in range(2):
+                            for Q in Ps: qlinear.qlinear(X, Q, None, torch.bfloat16)
+                for _ in range(3): g.replay()
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): g.replay()
+                e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / 10 / (2 * ncopy) * 1e3
+                del Ps
+            else:
+                us = min(tg(lambda: qlinear.qlinear(X, P, None, torch.bfloat16)) for _ in range(2))
             r.append("%6.1f" % us)
         except Exception as e:
-            r.append("  fail")
+            r.append("  fail " + str(e)[:80])
     if os.environ.get("MIDM_BLAS"):
         Wb = qlinear.unpack_weight(P).to(torch.bfloat16)
         r.append("hipBLASLt %6.1f" % min(tg(lambda: torch.nn.functional.linear(X, Wb)) for _ in range(2)))

@@ -24,11 +24,12 @@ def _case(O, M, N, K, fo, seed):
 @pytest.mark.parametrize("form,M,N,K", [
     (1, 33, 256, 64 * 8), (1, 64, 512, 64 * 16), (1, 50, 256, 64 * 3), (1, 64, 768, 64 * 11), (1, 130, 256, 64 * 9),
     (2, 65, 256, 64 * 4), (2, 128, 512, 64 * 12), (2, 100, 256, 64 * 5), (2, 128, 256, 64 * 1), (2, 300, 512, 64 * 7),
-    (3, 129, 256, 64 * 2), (3, 256, 512, 64 * 8), (3, 200, 256, 64 * 6), (3, 512, 768, 64 * 4), (3, 700, 2048, 64 * 10)])
+    (3, 129, 256, 64 * 2), (3, 256, 512, 64 * 8), (3, 200, 256, 64 * 6), (3, 512, 768, 64 * 4), (3, 700, 2048, 64 * 10),
+    (4, 65, 256, 64 * 8), (4, 128, 512, 64 * 19), (4, 100, 256, 64 * 3), (4, 128, 256, 64 * 1), (4, 300, 2048, 64 * 9)])
 @pytest.mark.parametrize("fo", ["posit8_es1", "fp8_e4m3"])
 def test_forced_forms_against_the_oracle(msq, O, form, M, N, K, fo, monkeypatch):
     """Each form FORCED (MSQ_GEMM_SK = 1: 64-row strip, eight waves; 2: 128-row strip, four waves; 3: 128 x 128 block, two k-groups of two
-    waves) against O.linear on the ORACLE's fake-quant weight: K of 1 ... 16 tiles (fewer tiles than waves, tile counts that are not multiples
+    waves; 4: 128-row strip, eight waves with one activation buffer each and a two-phase reduction) against O.linear on the ORACLE's fake-quant weight: K of 1 ... 16 tiles (fewer tiles than waves, tile counts that are not multiples
     of the ring of three, an odd count per wave), ragged M (the last row block clamps its loads and masks its stores), several row blocks,
     panel counts that are and are not multiples of 8 (both block orders); bias, float32 / bfloat16 / float16 outputs (one sum, rounded
     once); 20 launches bit-identical."""
@@ -51,14 +52,15 @@ def test_forced_forms_against_the_oracle(msq, O, form, M, N, K, fo, monkeypatch)
     monkeypatch.delenv("MSQ_GEMM_SK")
 
 
-@pytest.mark.parametrize("M", [48, 64, 96, 128, 192, 256])
+@pytest.mark.parametrize("M", [48, 64, 96, 128])
 def test_default_rule_takes_the_kernel_on_wide_projections(msq, O, M):
     """The library's own rule (no switch) on a 12288-wide projection (the fused q/k/v of Llama-2-7B: 192 strips) with a short K: kernel choice 5
-    (MSQ_KERNEL_STREAMK), no workspace needed, result against the oracle.  M <= 32 keeps the decode kernels, M > 256 the prefill ones."""
+    (MSQ_KERNEL_STREAMK), no workspace needed, result against the oracle.  M <= 32 keeps the decode kernels, M > 128 the prefill ones."""
     N, K = 12288, 256
     L = msq._lib.lib()
     assert L.msq_qlinear_kernel_choice(M, N, K, 6, -1) == 5
-    assert L.msq_qlinear_kernel_choice(32, N, K, 6, -1) == 0 and L.msq_qlinear_kernel_choice(1024, N, K, 6, -1) != 5
+    assert L.msq_qlinear_kernel_choice(32, N, K, 6, -1) == 0 and L.msq_qlinear_kernel_choice(129, N, K, 6, -1) != 5
+    assert L.msq_qlinear_kernel_choice(64, 4096, 11008, 6, -1) != 5 and L.msq_qlinear_kernel_choice(128, 4096, 4096, 6, -1) == 5
     buf = ctypes.create_string_buffer(128)
     assert L.msq_qlinear_kernel_name(M, N, K, 6, -1, 2, buf, 128) == 0 and buf.value.decode().startswith("k_qgemm_sk<6, uint16_t")
     W, X, bias, ref = _case(O, M, N, K, "posit8_es1", 7 + M)
