@@ -1555,12 +1555,12 @@ extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const v
                                    int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int form, void* stream);
 // The rule (also behind msq_qlinear_kernel_choice), from profiles/r06_midm_forms.txt (HIP-graph device times, posit / fp8 outliers, the Llama-2-7B
 // projections, 16384 x 4096 and 8192 x 8192).  What bounds the kernel is the ~70 GB/s at which ONE CU pulls bytes out of L2 (MI355X_MICROARCH.md,
-// "Indexed rows"): a block re-reads its M activation rows over all of K next to its strip of packed weights -- (2 M + 74) K bytes -- so it wins
-// where that is less than what split-K planes cost: up to 64 rows on every projection with K <= 8192 (48-64 rows: 12288 x 4096 24.7 -> 16.9 us,
-// 16384 x 4096 28.4 -> 18.9, 22016 x 4096 36.5 -> 30.3, 4096 x 4096 16.2 -> 12.3, 8192 x 8192 26.2 -> 23.7; 4096 x 11008 loses: 22.1 -> 27.9), up
-// to 128 rows on the one-round grids of 128-row strips (12288: 27.3 -> 21.6, 16384: 30.8 -> 24.3; 22016 ties and keeps the split-K GEMM) and,
-// as two 64-row blocks per strip, on the 4096 x 4096 projections (21.9 -> 13.3).  Beyond 128 rows the 128 x 128 form only ties (256 x 16384 x 4096:
-// 42.1 -> 40.2): forced forms only.
+// "Indexed rows" / "ring-gemm"): a block re-reads its activation rows over all of K next to its strip of packed weights -- (2 rows + 74) K bytes --
+// so it wins where that is less than what split-K planes cost: 64-row blocks (form 1) up to M = 64 on every projection with K <= 8192 (48-64 rows:
+// 12288 x 4096 24.2 -> 17.8 us, 16384 x 4096 28.9 -> 22.0, 22016 x 4096 36.6 -> 31.9, 4096 x 4096 16.5 -> 14.2, 8192 x 8192 26.8 -> 25.2; 4096 x 11008
+// loses: 22.1 -> 27.9) and, as two row blocks per strip, up to M = 128 on the 4096 x 4096 projections (21.5 -> 14.4).  The 128-row forms (2, 4)
+// and the 128 / 64 x 128 blocks (3, 5) tie with or lose to the split-K GEMM once their activation ring is filled in an architecturally
+// ordered way: forced forms only.
 static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x) {
     if (!unified_bf16x) return 0;
     const int forced = sk_forced_env();
@@ -1570,7 +1570,6 @@ static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x) {
     const int64_t strips = N / TILE_N, KT = K / BK;
     int form = 0;
     if (M <= 64) form = (strips >= 64 && strips <= 352 && KT <= 128) ? 1 : 0;
-    else if (strips >= 192 && strips <= 288) form = 2;
     else if (strips >= 64 && strips <= 128 && KT <= 64) form = 1;
     return form ? msq_qgemm_sk_form(M, N, K, form) : 0;
 }

@@ -16,9 +16,9 @@
 //   * packed planes: the same planes and tile order as every other kernel (nothing is re-packed), through buffer descriptors with SGPR
 //     offsets, three tiles (six half-step sets) in flight per wave;
 //   * activation tile of a K-tile (16 MF rows x 64 k, bf16): LDS-DMA into the group's own ring (XOR-swizzled 16-byte chunks, conflict-free
-//     fragment reads), staged two tiles ahead.  WN = 1: the ring is private to the wave -- NO block barrier in the K-loop, the wave's own
-//     vmcnt orders its DMA against its reads, two buffers; WN = 2: the two waves of a group share the tile, one barrier per tile, three
-//     buffers;
+//     fragment reads), staged two tiles ahead.  WN = 1: the ring is private to the wave (two buffers, restaged behind the wave's own last read);
+//     WN = 2: the two waves of a group share the tile (three buffers).  One counted vmcnt + block barrier per tile in every form: nothing else
+//     orders LDS-DMA data for a ds_read, not even inside one wave;
 //   * the per-wave stream is k_qgemm3's half-step (4 MFMAs per activation fragment, one quarter of the NEXT half-step's weight fragments
 //     converted behind them: v_cvt_scalef32_pk_bf16_fp8 + the extension-bit rotate / and-or).
 // Forms (launcher; the dispatcher's sk_rule picks 1 and 2): 1 = MF 4, WN 1, KG 8 (64 rows, eight waves, one strip); 2 = MF 8, WN 1, KG 4 (128 rows,
@@ -171,6 +171,23 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (void __attribute__((address_space(3)))*)(smem_g + buf * A_TILE + (wn * PPW + p) * 1024),
                                                      16, aoff[p], koff, 0, 0);
     };
+    // REG: the private two-buffer ring is filled through REGISTERS (buffer_load_b128 -> ds_write_b128 into the same lane-linear image): LDS
+    // writes and reads of one wave execute in order, the compiler's own vmcnt / lgkmcnt waits order everything, no barrier and no lockstep in
+    // the K-loop -- with LDS-DMA every tile needs a block barrier (see below), and eight waves that wait for each other's loads at every tile
+    // lose what the cut of K bought (64 rows, 16384 x 4096: 18.9 -> 21.9 us; 128 rows, 12288 x 4096: 21.6 -> 27.5).  The loads of tile i + 2 are
+    // issued at the end of tile i IN FRONT of the packed loads (vmcnt is in-order: behind them they would wait for the whole ring) and written
+    // to LDS at the end of tile i + 1.
+    constexpr bool REG = (WN == 1 && NB == 2 && !(MSQ_SK_ABL & 16));
+    u32x4_t xs[REG ? PPW : 1];
+    auto xload = [&](int i) {
+        const uint32_t koff = (uint32_t)kt_of(i) * (BK * 2);
+#pragma unroll
+        for (int p = 0; p < (REG ? PPW : 0); ++p) xs[p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[p], koff, 0));
+    };
+    auto xwrite = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < (REG ? PPW : 0); ++p) *reinterpret_cast<u32x4_t*>(smem_g + buf * A_TILE + p * 1024 + lane16) = xs[p];
+    };
     const int sw = (c >> 1) & 7;
     const int rd0 = c * 128 + (((0 + g) ^ sw) << 4);
     const int rd1 = c * 128 + (((4 + g) ^ sw) << 4);
@@ -186,16 +203,24 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     constexpr int RING = (MSQ_SK_RING > 0) ? MSQ_SK_RING : ((MF <= 4) ? 4 : 3);
     TileSet<OUT_KIND> sA, sB, sC, sD;
     u32x4_t wfA[4], wfB[4];
-    stage(0, 0);
-    if (NB > 1) stage(1, 1);
+    if (REG) xload(0);
+    else { stage(0, 0); if (NB > 1) stage(1, 1); }
     load_set(sA, 0);
     load_set(sB, 1);
     load_set(sC, 2);
     if (RING == 4) load_set(sD, 3);
     __builtin_amdgcn_s_waitcnt(0);
-    if (WN > 1) __builtin_amdgcn_s_barrier();
+    if (REG) { xwrite(0); xload(1); }
+    else __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int q = 0; q < 8; ++q) convert_quarter<IN_KIND, OUT_KIND>(wfA, sA.h0, sA.sc, 0, q);
+    // LDS-DMA data is ordered for a ds_read ONLY by the issuing wave's counted vmcnt followed by a barrier the reader has passed
+    // (cdna_hip_programming.md section 5, "Read a staged buffer one phase AFTER the wait that retires it") -- also when issuer and reader are the
+    // same wave: the first build of the private-ring forms read right behind its own vmcnt and returned rare wrong tiles once the ring was one
+    // buffer deep (round 6, tests/test_gpu_n2_gemm_midm.py form 4).  So every tile ends with the wait AND a block barrier, and every wave runs
+    // the same number of tiles (the block's maximum): a wave whose tiles have run out keeps staging / loading (clamped to its last tile: the
+    // vmcnt arithmetic stays the same) and skips the arithmetic.
+    const int nt_all = REG ? nt : sgpr((KT + KG - 1) / KG);
 
     // One tile of the wave.  In flight at its end, oldest first (vmcnt counts in issue order): [the loads of tile i + 2 (previous tile),]
     // the DMA pieces of tile i + 2, the loads of tile i + 3 -- everything older (the DMA pieces of tile i + 1) has landed.
@@ -210,40 +235,51 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
         const char* abase = smem_g + buf * A_TILE;                                                                 \
         const int buf2 = (NB <= 2) ? buf : ((buf == 0) ? 2 : buf - 1);          /* (buf + 2) % 3 */                \
         if (NB == 3) { stage((I) + 2, buf2); __builtin_amdgcn_sched_barrier(0); }                                  \
-        sk_half_step<OUT_KIND, MF>(acc, wfA, wfB, CUR.h1, CUR.sc, 1, abase + rd0);                                 \
-        keep_live(NXT.h0); keep_live4(NXT.sc);     /* hipcc's vmcnt wait for tile i + 1's planes lands here */      \
-        sk_half_step<OUT_KIND, MF>(acc, wfB, wfA, NXT.h0, NXT.sc, 0, abase + rd1);                                 \
-        if (NB <= 2) { __builtin_amdgcn_s_waitcnt(0xC07F); stage((I) + NB, buf2); __builtin_amdgcn_sched_barrier(0); }   /* lgkmcnt(0): this wave's reads of the buffer are done */ \
-        load_set(CUR, (I) + RING);                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));                                \
-        if (WN > 1) __builtin_amdgcn_s_barrier();                                                                  \
+        if (REG || (I) < nt) {                                                                                     \
+            sk_half_step<OUT_KIND, MF>(acc, wfA, wfB, CUR.h1, CUR.sc, 1, abase + rd0);                             \
+            keep_live(NXT.h0); keep_live4(NXT.sc);     /* hipcc's vmcnt wait for tile i + 1's planes lands here */  \
+            sk_half_step<OUT_KIND, MF>(acc, wfB, wfA, NXT.h0, NXT.sc, 0, abase + rd1);                             \
+        }                                                                                                          \
+        if (REG) {                                                                                                 \
+            xwrite(buf ^ 1);                       /* tile i + 1 (requested a tile ago) into the buffer tile i - 1 was read from */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            xload((I) + 2);                        /* in front of the packed loads: in-order vmcnt */              \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            load_set(CUR, (I) + RING);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } else {                                                                                                   \
+            if (NB <= 2) { __builtin_amdgcn_s_waitcnt(0xC07F); stage((I) + NB, buf2); __builtin_amdgcn_sched_barrier(0); }   /* lgkmcnt(0): this wave's reads of the buffer are done */ \
+            load_set(CUR, (I) + RING);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));                            \
+            __builtin_amdgcn_s_barrier();                                                                          \
+        }                                                                                                          \
         buf = (buf + 1 == NB) ? 0 : buf + 1;                                                                       \
     }
     if constexpr (RING == 3) {
         int i = 0;
-        for (; i + 2 < nt; i += 3) {
+        for (; i + 2 < nt_all; i += 3) {
             SK_TILE(i, sA, sB)
             SK_TILE(i + 1, sB, sC)
             SK_TILE(i + 2, sC, sA)
         }
-        if (i < nt) {
+        if (i < nt_all) {
             SK_TILE(i, sA, sB)
-            if (i + 1 < nt) SK_TILE(i + 1, sB, sC)
+            if (i + 1 < nt_all) SK_TILE(i + 1, sB, sC)
         }
     } else {
         int i = 0;
-        for (; i + 3 < nt; i += 4) {
+        for (; i + 3 < nt_all; i += 4) {
             SK_TILE(i, sA, sB)
             SK_TILE(i + 1, sB, sC)
             SK_TILE(i + 2, sC, sD)
             SK_TILE(i + 3, sD, sA)
         }
-        if (i < nt) {
+        if (i < nt_all) {
             SK_TILE(i, sA, sB)
-            if (i + 1 < nt) {
+            if (i + 1 < nt_all) {
                 SK_TILE(i + 1, sB, sC)
-                if (i + 2 < nt) SK_TILE(i + 2, sC, sD)
+                if (i + 2 < nt_all) SK_TILE(i + 2, sC, sD)
             }
         }
     }

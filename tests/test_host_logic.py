@@ -485,7 +485,7 @@ def test_kernel_choice_rule_for_llama_shapes():
     assert [ch(2048, N, K, U8X) for N, K in layer] == [T128, T128, T256, T128]
     assert [ch(4096, N, K, U8) for N, K in layer] == [T256, T256, T128, T256]
     SK = 5                                                                                    # round 6: K cut inside the block (k_qgemm_sk)
-    assert [ch(128, N, K, U8X) for N, K in layer] == [SK, SK, G128, G128]                     # one-round strip grids; gate / up ties, K = 11008 loses
+    assert [ch(128, N, K, U8X) for N, K in layer] == [G128, SK, G128, G128]                   # two 64-row blocks per strip on the 4096 x 4096 projection only
     assert [ch(64, N, K, U8X) for N, K in layer] == [SK, SK, SK, G128] and [ch(33, N, K, U8) for N, K in layer] == [SK, SK, SK, G128]
     assert [ch(129, N, K, U8X) for N, K in layer] == [G128, G128, T128, G128] and ch(128, 16384, 4096, 2) == G128   # beyond 128 rows / two-plane layouts: as before
     assert ch(512, 22016, 4096, U8X) == T256 and ch(512, 22016, 4096, U8) == T256             # part-filled single round: M <= 512
