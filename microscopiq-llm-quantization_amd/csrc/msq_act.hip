@@ -77,7 +77,7 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
         ui = max(ui, max(ti[0], ti[1])); uo = max(uo, max(to[0], to[1]));
     }
     if (max(ui, uo) >= 0x7F800000u) return false;                      // NaN / Inf element (a NaN compares false: unmasked)
-    if (quirky) return false;                                          // could be pred(half the smallest step): msq_device.h half_away_quirk_bits
+
     const float mx_in = u2f(ui), mx_o = u2f(uo);
     float se_in = shared_exp_of_max(mx_in);
     if (A.flush && !(se_in > -127.f)) return false;
@@ -92,6 +92,12 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
     const float s_in = u2f((uint32_t)(ei + 127) << 23), s_eff = u2f((uint32_t)(eo + 127) << 23);
     const float b_in = A.fi.max_norm * s_in, b_out = A.fo.max_norm * s_eff;
     uint32_t dropped = 0u;
+    // The converts round half away from zero exactly; the reference's float32 `floor(|x| + 0.5)` does not for ONE magnitude per grid (msq_device.h
+    // half_away_quirk_bits): |x| = pred(half the smallest step) comes back as one step.  A block that holds an all-ones mantissa (every such
+    // magnitude has one; ~1 block in 260 000 of Gaussian data) runs the same loop with the exact per-element fix-up -- NOT the general routine:
+    // one wave in it stretched this 19 us kernel by 8 us (round 6, profiles/r06_act_quirk_ab.txt).
+    const int hexp_i = ei + (A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0) - A.fi.mbits + 1;      // exponent of half the smallest inlier step x the block scale
+    const int hexp_o = (ei + eo) + (A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0) - A.fo.mbits + 1;
 #pragma unroll
     for (int b = 0; b < BS; b += 2) {
         const float x0 = u2f(f2u(a[b]) | 1u), x1 = u2f(f2u(a[b + 1]) | 1u);
@@ -104,6 +110,21 @@ MSQ_D bool act_block_lean(const float (&a)[BS], uint32_t (&h)[BS / 2], const Out
         const uint32_t r0 = f2u((m0 ? vo0 : vi0) + 0.0f), r1 = f2u((m1 ? vo1 : vi1) + 0.0f);
         dropped |= r0 | r1;
         h[b >> 1] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);           // (r0 >> 16) | (r1 & 0xFFFF0000)
+    }
+    if (quirky) {                                                          // the fix-up pass: compares only, patches the packed halves in place
+        const uint32_t qi = half_away_quirk_bits(hexp_i), qo = half_away_quirk_bits(hexp_o);
+        const uint32_t fi_ = f2u(pow2i(hexp_i + 1)) >> 16, fo_ = f2u(pow2i(hexp_o + 1)) >> 16;     // one step, as bf16 bits
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            bool m;
+            if (v1) m = (mkw[b >> 5] >> (b & 31)) & 1u;
+            else m = (a[b] < lo) || (a[b] > hi);
+            const uint32_t u = f2u(a[b]);
+            if ((u & 0x7FFFFFFFu) == (m ? qo : qi)) {
+                const uint32_t f = ((u >> 16) & 0x8000u) | (m ? fo_ : fi_);
+                h[b >> 1] = (b & 1) ? ((h[b >> 1] & 0x0000FFFFu) | (f << 16)) : ((h[b >> 1] & 0xFFFF0000u) | f);
+            }
+        }
     }
     if (dropped & 0xFFFFu) status |= MSQ_STATUS_INEXACT;                   // no NaN can reach this point
     return true;

@@ -1652,6 +1652,10 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     hipStream_t st0 = (hipStream_t)stream;
     const int y16 = (y_dtype == 1) ? 1 : 0;                       // fp16 output: the 16-bit kernels with the half conversion
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
+    // fp16 activations are converted inside the decode kernels only: where the bf16 call takes k_qgemm_sk the caller casts (one kernel, one
+    // summation order for both activation dtypes: tests/test_gpu_round3.py::test_decode_kernels_take_fp16_activations)
+    if (x_f16 && sk_rule(M, N, K, unified))
+        return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_f16x: this shape runs k_qgemm_sk, which reads bf16 activations: cast them to bf16");
     if (const int skf = sk_rule(M, N, K, unified && !x_f16)) {
         const int e = msq_launch_qgemm_sk(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, skf, stream);
         if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(K cut inside the block, k_qgemm_sk form %d): %s", skf, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }

@@ -17,8 +17,19 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
 
+import time
+
+RAMP_S = 0.25      # the chip needs a few hundred ms of back-to-back work to leave its idle clocks (round 6: the act quantiser read 27 us in the
+                   # first process of a box and 19-20 us in every later one with 10-30 warm-up launches; bench.py ramps by time for the same reason)
+
+
 def t(fn, n=20, warm=30):
-    # the first few dozen launches after an idle phase run at lower clocks: warm up first
+    # the first launches after an idle phase run at lower clocks: warm up by TIME, then by count
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < RAMP_S:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -41,9 +52,11 @@ def tg(fn, reps=10, n=20):
         with torch.cuda.graph(g, stream=st):
             for _ in range(reps):
                 fn()
-    for _ in range(5):
-        g.replay()
-    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < RAMP_S:
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
@@ -103,10 +116,12 @@ def sec_gemm():
             for layout in ("planes", "unified"):
                 P = qlinear.pack_weight(W, 8, 8, "fp4_e2m1", fo, 2, 32, layout=layout)
                 Wu = qlinear.unpack_weight(P, torch.bfloat16)
-                for M in (1, 16, 64, 128, 512, 2048, 8192):
+                for M in (1, 16, 64, 128, 256, 512, 2048, 8192):
                     X = torch.randn(M, K, device=dev).to(torch.bfloat16)
                     ms = t(lambda: qlinear.qlinear(X, P))
                     line = f"N{N:5d} K{K:5d} {fo:11s} {layout:8s} M{M:5d}: {ms*1e3:7.1f} us {2*M*N*K/ms/1e9:7.1f} TF  packed stream {P.nbytes/ms/1e6:5.0f} GB/s"
+                    if layout == "unified" and M <= 512:      # device time without the Python / launch floor (round 6)
+                        line += f" | device (graph) {tg(lambda: qlinear.qlinear(X, P))*1e3:6.1f} us"
                     if layout == "planes" and fo == "fp8_e4m3":
                         ms2 = t(lambda: X @ Wu.t())
                         line += f" | hipBLASLt bf16 {ms2*1e3:7.1f} us {2*M*N*K/ms2/1e9:7.1f} TF"

@@ -1,7 +1,8 @@
 import os, sys, warnings
 os.environ["PYTHONDONTWRITEBYTECODE"] = "1"; sys.dont_write_bytecode = True; warnings.filterwarnings("ignore")
 import numpy as np, torch
-sys.path.insert(0, "/root/repo/tests/golden"); sys.path.insert(0, "/root/repo")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import make_golden as MG
 scratch, quant, mx_ops, elemwise_ops, formats, linear, specs, posit_mod = MG._import_reference()
 from mx import RMSNorm
@@ -26,4 +27,4 @@ for bf, rd in ((12, "floor"), (16, "floor"), (12, "nearest")):
                 out[k + "|x"], out[k + "|w"], out[k + "|b"], out[k + "|y"] = x.numpy(), w.numpy(), b.numpy(), y
                 if d: print("oracle != reference", k, d)
 print("cases with oracle != reference:", nbad)
-np.savez_compressed("/root/repo/tests/golden/vec_rmsnorm_modes.npz", **out)
+np.savez_compressed(os.path.join(HERE, "vec_rmsnorm_modes.npz"), **out)      # beside itself, like every other generator
