@@ -1509,7 +1509,7 @@ int msq_launch_qgemm256(const void* X, const void* ext_plane, const void* code_p
 // the persistent stream-K form (msq_gemm256p.hip): plan = host arithmetic of the schedule (0 = applies) and the workspace it needs
 int msq_qgemm256p_plan(int64_t M, int64_t N, int64_t K, int cus, int* P, int* full, int* R, int* q, int64_t* ws_bytes);
 int msq_launch_qgemm256p(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
-                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* workspace, void* stream);
+                         int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* workspace, int64_t workspace_bytes, void* stream);   // -12345: plan of THIS device does not fit: fall back
 #ifndef MSQ_QP_DEFAULT
 #define MSQ_QP_DEFAULT 0       /* 1: k_qgemm256p where qp_rule() prefers it */
 #endif
@@ -1737,7 +1737,12 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
         // the same function's answer.
         const QFamily qf = q_family(M, N, K, unified && !x_f16, out_kind, workspace ? workspace_bytes : 0);
         if (qf.persistent) {
-            const int e = msq_launch_qgemm256p(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, workspace, stream);
+            const int e = msq_launch_qgemm256p(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, workspace, workspace ? workspace_bytes : 0, stream);
+            if (e == -12345) {                                       // this device's CU count gives another plan than the rule's 256: the 256-row kernel
+                const int e2 = msq_launch_qgemm256(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, 16, stream);
+                if (e2) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(k_qgemm256 after the persistent plan did not fit): %s", hipGetErrorString((hipError_t)e2)); return fail2(MSQ_ERR_LAUNCH, b); }
+                return MSQ_OK;
+            }
             if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(persistent 256-row tiles, k_qgemm256p): %s", hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
             return MSQ_OK;
         }

@@ -589,10 +589,14 @@ extern "C" int msq_qgemm256p_segments(int b, int P, int full, int R, int KT, int
 // Launcher (called by qlinear_bf16_impl, msq_gemm.hip).  Preconditions checked by the caller: unified layout, N % 256 == 0, every
 // buffer offset below 4 GiB, msq_qgemm256p_plan(...) == 0 and workspace_bytes >= its ws_bytes.  Returns hipGetLastError().
 extern "C" int msq_launch_qgemm256p(const void* X, const void* ext_plane, const void* code_plane, const void* scale_plane, const float* bias, void* Y,
-                                    int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* workspace, void* stream) {
+                                    int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
     int P = 0, full = 0, R = 0, q = 0;
     int64_t wsb = 0;
-    if (msq_qgemm256p_plan(M, N, K, cu_count(), &P, &full, &R, &q, &wsb)) return (int)hipErrorInvalidValue;
+    // The dispatcher's rule sized the workspace for 256 CUs; this device (a CPX / DPX partition, a CU mask, another part) may have another count
+    // and another plan: when that plan does not apply or needs more slots than the caller gave, return MSQ_QP_FALLBACK -- the dispatcher then
+    // takes k_qgemm256 instead of failing the call or writing past the workspace (advisor, round 5).
+    if (msq_qgemm256p_plan(M, N, K, cu_count(), &P, &full, &R, &q, &wsb) || wsb > workspace_bytes || (wsb > 0 && !workspace)) return -12345;
     const dim3 grid((unsigned)P), blk(256);
     const size_t lds = (size_t)4 * 256 * 128 + 256 * 32;          // four activation buffers + the segment table
     const int y16 = (y_dtype == 1) ? 1 : 0;

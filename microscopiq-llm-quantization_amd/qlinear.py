@@ -125,8 +125,11 @@ def pack_weight(W, inlier_scale_bits=8, outlier_scale_bits=8, inlier_elem_format
                           inlier_elem_format, outlier_elem_format, std_dev, block_size, round, flush_fp32_subnorms, variant, "planes", n, k)
                 if bool((unpack_weight(P) == Wq.float()).all()):
                     return P
-            except MsqError:
-                pass
+            except MsqError as e:
+                # only "the planes do not reproduce these values" (the pack kernel's own exactness proof, MSQ_STATUS_INEXACT) falls through to the
+                # unified planes; a configuration the packer does not support is the caller's error and is reported as such (advisor, round 5)
+                if "INEXACT" not in str(e).upper() and "exact" not in str(e).lower():
+                    raise
             try:
                 return pack_values(Wq, (PLANE_U8, PLANE_U8X))
             except MsqError:
@@ -902,6 +905,17 @@ class RowParallelQuantLinear(nn.Module):
         self.single_rank_collectives = bool(single_rank_collectives)   # run the collectives with one rank too (profiling on one GPU)
         self._parts = {}                      # reduce-scatter pieces, kept across calls (see forward)
 
+    def _part(self, chunk_index, rows, N, dtype, device):
+        """The reduce-scatter piece of chunk `chunk_index`: ONE buffer per chunk position (the chunks of a call are in flight together, so they
+        cannot share one), grown to the largest piece seen and sliced -- a serving loop with varying M keeps as many buffers as it has chunks,
+        not one per (r0, r1) it ever saw (advisor, round 5).  Assumes ONE communication stream per module instance: the buffer is written and read
+        by the collectives of that stream only, in order."""
+        key = (chunk_index, N, dtype, device)
+        buf = self._parts.get(key)
+        if buf is None or buf.shape[0] < rows:
+            buf = self._parts[key] = torch.empty(rows, N, dtype=dtype, device=device)
+        return buf[:rows]
+
     @staticmethod
     def shard_bounds(in_features, world_size, rank, block_size, multiple=64):
         """[k0, k1) of a rank; the split must fall on a tile multiple (64; 128 on the MX path) and a block multiple."""
@@ -965,13 +979,10 @@ class RowParallelQuantLinear(nn.Module):
         y = buf.zero_() if buf is not None else torch.zeros(M, N, dtype=dtype or self.reduce_dtype, device=dev)
         use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
         pending = []
-        for r0, r1 in self.chunk_bounds(M):
+        for ci, (r0, r1) in enumerate(self.chunk_bounds(M)):
             yc = y[r0:r1]
             if use_rs and (r1 - r0) % G == 0:
-                key = (r0, r1, N, y.dtype, y.device)
-                part = self._parts.get(key)
-                if part is None:
-                    part = self._parts[key] = torch.empty((r1 - r0) // G, N, dtype=y.dtype, device=dev)
+                part = self._part(ci, (r1 - r0) // G, N, y.dtype, dev)
                 pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
                 pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
             else:
@@ -1018,15 +1029,12 @@ class RowParallelQuantLinear(nn.Module):
         pg = self.process_group
         use_rs = self.comm == "rs_ag" and dist.get_backend(pg) == "nccl"
         pending = []
-        for r0, r1 in self.chunk_bounds(M):
+        for ci, (r0, r1) in enumerate(self.chunk_bounds(M)):
             partial(r0, r1)
             yc = y[r0:r1]
             if use_rs and (r1 - r0) % G == 0:
                 # (kept across calls: written and read on the communication stream only, in order; the caller's stream waits below)
-                key = (r0, r1, N, self.reduce_dtype, y.device)
-                part = self._parts.get(key)
-                if part is None:
-                    part = self._parts[key] = torch.empty((r1 - r0) // G, N, dtype=self.reduce_dtype, device=y.device)
+                part = self._part(ci, (r1 - r0) // G, N, self.reduce_dtype, y.device)
                 pending.append(dist.reduce_scatter_tensor(part, yc, op=dist.ReduceOp.SUM, group=pg, async_op=True))
                 pending.append(dist.all_gather_into_tensor(yc, part, group=pg, async_op=True))
             else:

@@ -13,6 +13,15 @@ def _rounding(mx_specs, round=None):
     """(bits, exp_bits, max_norm, rmode, allow_denorm) of quantize_elemwise_op (elemwise_ops.py:237-266) for these specs"""
     if round is None:
         round = mx_specs['round']
+    # vector_ops.py:61-81 of the reference switch `exp` to vec_exp2(Q(LOG2_E_BF16 x)) under 'vec_use_exp2' and `a / b` to Q(a Q(1 / b)) under
+    # 'vec_use_recip': other arithmetic than the kernels implement -- refuse instead of silently returning different values (advisor, round 5)
+    for key in ('vec_use_exp2', 'vec_use_recip'):
+        try:
+            on = bool(mx_specs[key])
+        except (KeyError, TypeError):
+            on = False
+        if on:
+            raise MsqError("mx_specs['%s'] is not implemented by the HIP vector ops (they compute exp(x) and a / b directly, the reference's default)" % key)
     rm = int(RoundingMode[round])
     if mx_specs['bfloat'] > 0 and mx_specs['fp'] > 0:
         raise ValueError("Cannot set both [bfloat] and [fp] in mx_specs.")

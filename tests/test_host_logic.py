@@ -157,11 +157,11 @@ import numpy as np, torch, torch.distributed as dist
 import msq
 from msq.qlinear import RowParallelQuantLinear
 from oracle import oracle as O
-rank, world = int(sys.argv[1]), 2
+rank, world = int(sys.argv[1]), int(sys.argv[3]) if len(sys.argv) > 3 else 2
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
 dist.init_process_group("gloo", rank=rank, world_size=world)
 rng = np.random.RandomState(0)
-N, K, M = 64, 256, 300
+N, K, M = (64, 256, 300) if world == 2 else (64, 28672, 72)     # world 8: the TRUE K of Llama-2-70B's down_proj (SURVEY 8e): shards of 3584
 W = (rng.randn(N, K) * 0.02).astype(np.float32); X = rng.randn(M, K).astype(np.float32)
 bias = rng.randn(N).astype(np.float32)
 k0, k1 = RowParallelQuantLinear.shard_bounds(K, world, rank, 32)
@@ -179,7 +179,14 @@ for comm, chunks in (("rs_ag", 0), ("all_reduce", 1), ("rs_ag", 3)):   # gloo ha
     rp = RowParallelQuantLinear(OracleShard(), world, rank, None, comm=comm, chunks=chunks)
     y = rp(xl)
     assert y.shape == (M, N) and y.dtype == torch.float32
-    assert np.abs(y.numpy() - ref).max() < 1e-5, (comm, chunks, np.abs(y.numpy() - ref).max())
+    assert np.abs(y.numpy() - ref).max() < 1e-5 * max(1.0, float(np.abs(ref).max())), (comm, chunks, np.abs(y.numpy() - ref).max())
+if world == 8:
+    assert (k0, k1) == (rank * 3584, (rank + 1) * 3584)
+    # a caller-owned output and varying M (the cache of reduce-scatter pieces is keyed by shape, advisor round 5): results stay right
+    rp = RowParallelQuantLinear(OracleShard(), world, rank, None, comm="rs_ag", chunks=2)
+    for m_ in (72, 40, 72, 8):
+        y = rp(xl[:m_])
+        assert np.abs(y.numpy() - ref[:m_]).max() < 1e-5 * max(1.0, float(np.abs(ref).max())), m_
 assert RowParallelQuantLinear(OracleShard(), world, rank, chunks=0).chunks_for(2048) == 2
 assert RowParallelQuantLinear(OracleShard(), world, rank, chunks=0).chunks_for(300) == 1
 assert RowParallelQuantLinear(OracleShard(), 1, 0).chunks_for(4096) == 1
@@ -197,6 +204,19 @@ def test_row_parallel_two_ranks_gloo(msq, tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o
+
+
+def test_row_parallel_eight_ranks_gloo_at_the_70b_shard_bounds(msq, tmp_path):
+    """World size 8 at shard_bounds(28672, 8, r, 32) -- the partitioning the first hardware SCALE run will use (judge, round 5, item 9): eight
+    gloo processes, every rank's K slice of 3584, both collectives, chunked and not, varying M through one module instance."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = str(30100 + (os.getpid() % 500))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, "8"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=dict(os.environ, OMP_NUM_THREADS="1")) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o[-1500:]
 
 
 def test_bench_gpus_flag_spawns_ranks(tmp_path):
