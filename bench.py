@@ -808,6 +808,28 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
         ms = _tgraph([fn] * 10)
         kv[key] = {"ms": ms, "GBps": byts / ms / 1e6, "frac": byts / ms / 1e6 / HBM_PEAK_GBPS}
     out["kv_quant"] = dict(kv, bytes=byts, bound="hbm", peak=HBM_PEAK_GBPS, cache="[1, 32, 4096, 128] float16 (read once + written once)")
+    # ... and config 4's METRIC end to end on the committed fixture (tests/golden/gsm8k_fixture: a 2-layer Llama trained on two-step word problems,
+    # few-shot prompt, 96 problems): the loop of kv_quant/evaluation_gsm8k.py:455-533 (harness/gsm8k.py evaluate) with MXKVCache at the GEAR hook
+    try:
+        fx = os.path.join(ROOT, "tests", "golden", "gsm8k_fixture")
+        from transformers import AutoTokenizer, LlamaForCausalLM
+        from msq.harness import gsm8k as G8
+        tk = AutoTokenizer.from_pretrained(os.path.join(fx, "model"))
+        gm = LlamaForCausalLM.from_pretrained(os.path.join(fx, "model"), torch_dtype=torch.float16).to(dev).eval()
+        prompt, qs, ans = G8.load_fixture(fx)
+        def cfg_(**kw):
+            return kvcache.CompressionConfig(attention_number=gm.config.num_hidden_layers, streaming=True, streaming_gap=32, stream_grouping=True, **kw).copy_for_all_attention()
+        accs = {"uncompressed_fp16": G8.evaluate(gm, tk, prompt, qs, ans, None, batch_size=32, max_new_tokens=40)}
+        for key, kw in (("KIVI_4bit_g32", dict(compress_method="KIVI", quantize_bit=4, group_size=32)),
+                        ("KIVI_2bit_g32", dict(compress_method="KIVI", quantize_bit=2, group_size=32)),
+                        ("MX_fp8_e4m3", dict(compress_method="MX", mx_format="fp8_e4m3", mx_block=32)),
+                        ("MX_fp4_e2m1", dict(compress_method="MX", mx_format="fp4_e2m1", mx_block=32)),
+                        ("MSQ_fp4_fp8", dict(compress_method="MSQ", mx_format="fp4_e2m1", mx_outlier_format="fp8_e4m3", mx_block=32))):
+            accs[key] = G8.evaluate(gm, tk, prompt, qs, ans, cfg_(**kw), batch_size=32, max_new_tokens=40)
+        out["kv_quant"]["gsm8k_fixture_accuracy"] = dict(accs, problems=len(qs), what="exact match, greedy, 4-shot CoT prompt; fixture model, NOT Llama-2 on GSM8K (neither is in the image)")
+        del gm
+    except Exception as e:
+        out["kv_quant"]["gsm8k_fixture_accuracy"] = {"error": repr(e)[:300]}
     del k
     # ---- decode, M = 1, COLD weights: one decoder layer's four fused projections, each walked over > 1 GB of distinct packed copies
     from msq import _lib

@@ -1653,7 +1653,7 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     const int y16 = (y_dtype == 1) ? 1 : 0;                       // fp16 output: the 16-bit kernels with the half conversion
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     // fp16 activations are converted inside the decode kernels only: where the bf16 call takes k_qgemm_sk the caller casts (one kernel, one
-    // summation order for both activation dtypes: tests/test_gpu_round3.py::test_decode_kernels_take_fp16_activations)
+    // summation order for both activation dtypes: tests/test_gpu_n2_gemm.py::test_decode_kernels_take_fp16_activations)
     if (x_f16 && sk_rule(M, N, K, unified))
         return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_f16x: this shape runs k_qgemm_sk, which reads bf16 activations: cast them to bf16");
     if (const int skf = sk_rule(M, N, K, unified && !x_f16)) {

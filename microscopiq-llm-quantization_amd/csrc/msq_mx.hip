@@ -265,7 +265,7 @@ k_mx_pack_w6(const float* __restrict__ src, uint8_t* __restrict__ codes, uint8_t
 // Activations (MODE 0 of k_mx_pack: e4m3 codes row-major + one scale byte per block), one lane per EIGHT consecutive values:
 // four neighbouring lanes hold a block, its largest exponent crosses them by two quad permutes, every lane converts its own
 // eight values and stores 8 bytes -- 32-byte loads, 8-byte stores, no LDS transpose.  Same scale rule, same converts, same
-// flags as k_mx_pack<0> (tests/test_gpu_round3.py::test_mx_act_pack_vec_equals_block_kernel).
+// flags as k_mx_pack<0> (tests/test_gpu_n3_mx_w4a8.py::test_mx_act_pack_vec_equals_block_kernel).
 template <int XS>      // source: 0 float32, 1 bfloat16, 2 float16 (every half value is an fp32 value: the codes of casting first)
 __global__ void __launch_bounds__(256)
 k_mx_pack_a8_vec(const void* __restrict__ src, uint8_t* __restrict__ codes, uint8_t* __restrict__ scales, int64_t n8, int flush,

@@ -212,7 +212,7 @@ MSQ_D float quant_core_fast(float a, int shift, int pe_lo, int pe_hi, float max_
 // posit<n,es> rounding of an fp32 value, fast path: when at least one FRACTION bit survives
 // (fb >= 1) the posit's round-to-nearest-even on the bit pattern is an ordinary RNE of the
 // significand to fb fraction bits; everything else (exponent bits cut, saturation, specials)
-// goes through the generic posit_round().  Identical results (tests/test_gpu_parity.py::test_posit_tables).
+// goes through the generic posit_round().  Identical results (tests/test_gpu_a13_posit.py::test_posit_tables).
 MSQ_D float posit_round_fast(float t, int n, int es) {
     const uint32_t ut = f2u(t) & 0x7FFFFFFFu;
     if (ut - 1u >= 0x7F7FFFFFu) return posit_round(t, n, es);          // 0, Inf, NaN

@@ -25,7 +25,10 @@ extern "C" void msq_set_error_(const char* msg);
 // the whole 64 x 64 tile.  The half tile needs 9.2 KB of LDS per wave instead of 17.4: four workgroups per CU instead of
 // two -- the kernel is latency-bound (one row per lane, LDS round trips between its phases), occupancy is what it lacks.
 template <int BS, bool EXT, int HW>
-__global__ void __launch_bounds__(256, (BS <= 32 ? 4 : 2))
+#ifndef MSQ_PACKU_MINB
+#define MSQ_PACKU_MINB 4
+#endif
+__global__ void __launch_bounds__(256, (BS <= 32 ? MSQ_PACKU_MINB : 2))
 k_pack_tile_u(const float* __restrict__ W, uint8_t* __restrict__ ext_plane, uint8_t* __restrict__ code_plane,
               uint8_t* __restrict__ scl_plane, OutlierArgs A, int64_t N, int64_t K) {
     // Lane r owns row r of the tile in LDS (KW + 4 words per row) and works on it IN PLACE, one block / one 32-k half at

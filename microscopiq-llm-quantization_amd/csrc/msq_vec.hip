@@ -29,7 +29,7 @@ struct VQ { int bits, ebits, rmode, dn; float max_norm; };
 // mantissa bits is integer arithmetic on the fp32 pattern, subnormals and the carry into the exponent (up to Inf: the
 // reference does not saturate here) included: nearest = half away from zero = add half a quantum to the magnitude and
 // truncate; even = add (half - 1 + kept lsb); floor = truncate.  Bit-identical to quant_bits for every finite input
-// (tests/test_gpu_round2.py::test_vector_rounding_fast_path_equals_codec); Inf / NaN pass through.
+// (tests/test_gpu_f4_vector_ops_golden.py::test_vector_rounding_fast_path_equals_codec); Inf / NaN pass through.
 MSQ_D float Qbf(float a, int drop, int rmode) {
     const uint32_t u = f2u(a);
     if ((u & 0x7F800000u) == 0x7F800000u) return a;
@@ -60,7 +60,7 @@ MSQ_D float Q(float a, const VQ& q) {
 // NaN, which arithmetic propagates and the two instructions keep); (ii) by Qout on every value that leaves: in between a zero
 // of either sign gives the same non-zero results (no op of the three functions divides by, or takes the root of, such a value:
 // the variance is a sum of squares, phi >= 1), so the outputs are those of Qbf at every step.
-// tests/test_gpu_round3.py::test_vector_ops_fast_rounding_equals_generic runs both variants on every bfloat16 pattern.
+// tests/test_gpu_f4_vector_ops_golden.py::test_vector_ops_fast_rounding_equals_generic runs both variants on every bfloat16 pattern.
 MSQ_D float Qmid16(float a) { return u2f((f2u(a) + 0x8000u) & 0xFFFF0000u); }
 MSQ_D float Qin16(float a) {
     const uint32_t u = f2u(a);

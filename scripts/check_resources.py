@@ -36,6 +36,12 @@ ALLOW = [
     (r"^k_mxgemm256<u16, \d, 8>", 16, "prologue state, outside the K-loop"),
     (r"^k_qgemm3<0, 6, (float|u16), 1, 16, 4, 1>", 20, "five dwords of prologue state (U8X extension plane pointers), outside the K-loop"),
     (r"^k_mxgemv<1, 2, 16, 4>", 12, "three dwords, decode MX-FP6 at 16 rows: epilogue"),
+    # --- measured: profiles/r06_pack_occupancy_ab.txt -- the unified pack at 4 blocks per CU (128 VGPRs, these few dwords of scratch outside the
+    #     per-block loops) is 5 % FASTER than at 3 blocks without scratch (151.5 against 160.1 us posit, 106.3 against 111.5 fp8)
+    (r"^k_pack_tile_u<(8|16|32), (true|false), \d>", 72, "occupancy 4 with <= 72 B of scratch measured faster than occupancy 3 without (profiles/r06_pack_occupancy_ab.txt)"),
+    # --- reachable only through MSQ_GEMV_U_WAVES=16 (tuning) at 33-64 rows, a regime k_qgemm_sk takes since round 6; the dispatcher's own
+    #     choices for four row groups are 8 / 4 / 2 waves (no scratch)
+    (r"^k_qgemv_u<\d, 4, 16, false, false>", 160, "tuning-only instantiation (MSQ_GEMV_U_WAVES=16 at 33-64 rows)"),
 ]
 
 

@@ -826,7 +826,7 @@ def test_bench_ppl_delta_hook_with_local_checkpoint(msq, tmp_path, monkeypatch):
     assert r["windows"] == 880 // 64 and r["layers_kept_dense"] == 0
     assert np.isfinite(r["ppl_cpu_reference"]) and np.isfinite(r["ppl_hip_packed_fused"])
     assert abs(r["delta"]) / r["ppl_cpu_reference"] < 0.05 / 5.5, r               # BASELINE's 0.05 at PPL ~5.5, as a ratio
-    monkeypatch.setenv("MSQ_PPL_DISABLE", "1")             # (without MSQ_PPL_MODEL the committed trained fixture is used: tests/test_gpu_round4.py)
+    monkeypatch.setenv("MSQ_PPL_DISABLE", "1")             # (without MSQ_PPL_MODEL the committed trained fixture is used: tests/legacy_gpu_round4.py)
     assert bench.ppl_delta_from_env(dev(), "fp4_e2m1", "fp8_e4m3", 32) is None
 
 
@@ -855,7 +855,7 @@ def test_vector_rounding_fast_path_equals_codec(msq):
             if rm == 1:
                 # round 5: under truncation the vector ops follow the reference's PYTHON path, whose private exponent floor(torch.log2(|x|))
                 # is one high for the K largest floats below a power of two (one more mantissa bit goes); the native codec keeps the
-                # exponent field.  Those inputs are checked against the oracle in tests/test_gpu_round5.py; everything else is equal.
+                # exponent field.  Those inputs are checked against the oracle in tests/legacy_gpu_round5.py; everything else is equal.
                 ax = x.abs().cpu()
                 fin = torch.isfinite(ax) & (ax >= 2.0 ** -126)
                 lg = torch.floor(torch.log2(torch.where(fin, ax, torch.ones_like(ax))))

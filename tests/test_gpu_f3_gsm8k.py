@@ -1,0 +1,118 @@
+"""SURVEY 8 row f3 / BASELINE config 4 END TO END on a fixture: the GSM8K-CoT evaluation loop of kv_quant/evaluation_gsm8k.py:455-533 (few-shot
+prompt -> greedy `generate` with the compressing KV cache -> cut at the next "Question:" -> exact match on the last number) driven through
+``MXKVCache`` (the GEAR hook, modeling_llama_new.py:944-1030) on the GPU, for KIVI-style integer groups, plain MX and the MicroScopiQ outlier
+quantiser (judge, round 5, missing 4 / next 8).  The model, prompt and problems are tests/golden/gsm8k_fixture (make_gsm8k_fixture.py: a 2-layer
+Llama trained on two-step word problems whose numbers have to be copied out of the question, i.e. out of the cache)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import G, dev
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(G, "gsm8k_fixture")
+
+
+@pytest.fixture(scope="module")
+def fixture_model(msq):
+    from transformers import AutoTokenizer, LlamaForCausalLM
+    tok = AutoTokenizer.from_pretrained(os.path.join(FIX, "model"))
+    m = LlamaForCausalLM.from_pretrained(os.path.join(FIX, "model"), torch_dtype=torch.float16).to(dev()).eval()
+    import msq.harness.gsm8k  # noqa: F401
+    prompt, qs, ans = msq.harness.gsm8k.load_fixture(FIX)
+    return m, tok, prompt, qs, ans
+
+
+def _cfg(msq, layers, **kw):
+    c = msq.kvcache.CompressionConfig(attention_number=layers, streaming=True, streaming_gap=32, stream_grouping=True, **kw)
+    return c.copy_for_all_attention()
+
+
+CONFIGS = {
+    "KIVI_4bit": dict(compress_method="KIVI", quantize_bit=4, group_size=32),
+    "KIVI_2bit": dict(compress_method="KIVI", quantize_bit=2, group_size=32),
+    "MX_fp8_e4m3": dict(compress_method="MX", mx_format="fp8_e4m3", mx_block=32),
+    "MX_fp4_e2m1": dict(compress_method="MX", mx_format="fp4_e2m1", mx_block=32),
+    "MSQ_fp4_fp8": dict(compress_method="MSQ", mx_format="fp4_e2m1", mx_outlier_format="fp8_e4m3", mx_block=32),
+}
+
+
+class _HostOracleKV:
+    """the three quantiser entry points of msq.kvcache computed by the ORACLE on the host (test infrastructure only): same signatures, the
+    tensor goes to the CPU as float32 values of its own dtype, the oracle computes in that dtype, the result comes back"""
+
+    def __init__(self, O):
+        self.O = O
+
+    def _back(self, x, y):
+        return torch.from_numpy(np.ascontiguousarray(y)).to(x.device).to(x.dtype)
+
+    def group(self, input, quantize_bit, group_size, along_tokens):
+        B, H, S, D = input.shape
+        if along_tokens and (group_size <= 0 or S % group_size):
+            raise RuntimeError("ragged sequence")
+        x = input.contiguous()
+        return self._back(x, self.O.kv_group_quant(x.float().cpu().numpy(), quantize_bit, group_size, along_tokens, dtype=str(x.dtype)))
+
+    def _mx(self, t, axis, elem_format, block_size, scale_bits, outlier_format, std_dev):
+        x = t.contiguous()
+        a = x.float().cpu().numpy()
+        if outlier_format is None:
+            y = self.O.quantize_mx_lowp(a, str(x.dtype), scale_bits, elem_format, axis=axis, block_size=block_size)
+        else:
+            y = self.O.outlier_fakequant_lowp(a, str(x.dtype), scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size)["out"]
+        return self._back(x, y)
+
+    def keys(self, key, elem_format="fp8_e4m3", block_size=32, scale_bits=8, outlier_format=None, std_dev=2):
+        return self._mx(key, 2, elem_format, block_size, scale_bits, outlier_format, std_dev)
+
+    def values(self, value, elem_format="fp8_e4m3", block_size=32, scale_bits=8, outlier_format=None, std_dev=2):
+        return self._mx(value, 3, elem_format, block_size, scale_bits, outlier_format, std_dev)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_accuracy_with_hip_caches_equals_the_host_oracle_caches(msq, O, fixture_model, name, monkeypatch):
+    """The same loop twice per cache configuration: K / V fake-quantised by libmsq_hip.so, and by the oracle on the host (the three entry points
+    of msq.kvcache swapped for the test).  The quantisers are bit-exact, so the caches are the same bits and greedy decoding writes the SAME TEXT:
+    every generation is compared, not only the accuracy."""
+    m, tok, prompt, qs, ans = fixture_model
+    n = 32
+    ev = msq.harness.gsm8k.evaluate
+    cfg = _cfg(msq, m.config.num_hidden_layers, **CONFIGS[name])
+    acc_hip, s_hip = ev(m, tok, prompt, qs[:n], ans[:n], cfg, batch_size=16, max_new_tokens=40, return_samples=True)
+    host = _HostOracleKV(O)
+    monkeypatch.setattr(msq.kvcache, "_group_quant", host.group)
+    monkeypatch.setattr(msq.kvcache, "mx_quantize_keys", host.keys)
+    monkeypatch.setattr(msq.kvcache, "mx_quantize_values", host.values)
+    acc_host, s_host = ev(m, tok, prompt, qs[:n], ans[:n], cfg, batch_size=16, max_new_tokens=40, return_samples=True)
+    assert [s["generation"] for s in s_hip] == [s["generation"] for s in s_host]
+    assert acc_hip == acc_host
+
+
+def test_fixture_accuracy_by_cache_configuration(msq, fixture_model):
+    """What the metric shows on the fixture (96 problems): the uncompressed fp16 cache solves nearly all of them; 4-bit groups, MX-FP8 and the
+    MicroScopiQ quantiser hold that accuracy within a few problems; 2-bit groups and MX-FP4 lose a stated amount -- the numbers of a problem sit
+    in the cache when the answer is written.  The same figures ride in bench.py's line (configs.kv_quant.gsm8k_fixture_accuracy)."""
+    m, tok, prompt, qs, ans = fixture_model
+    ev = msq.harness.gsm8k.evaluate
+    base = ev(m, tok, prompt, qs, ans, None, batch_size=32, max_new_tokens=40)
+    acc = {k: ev(m, tok, prompt, qs, ans, _cfg(msq, m.config.num_hidden_layers, **kw), batch_size=32, max_new_tokens=40) for k, kw in CONFIGS.items()}
+    print("gsm8k fixture accuracy: uncompressed %.3f, %s" % (base, ", ".join("%s %.3f" % kv for kv in acc.items())))
+    assert base >= 0.9
+    assert acc["KIVI_4bit"] >= base - 0.08 and acc["MX_fp8_e4m3"] >= base - 0.08 and acc["MSQ_fp4_fp8"] >= base - 0.15
+    assert acc["KIVI_2bit"] <= base - 0.10                      # 2-bit groups damage the copied numbers
+
+
+def test_evaluate_loop_mechanics(msq, fixture_model):
+    """generation_split, zero-shot prompt, samples: the fields of the reference's EvaluationSample (:518-527); a split string that never occurs
+    keeps the whole generation (the last number of a LATER block then decides: accuracy changes)."""
+    m, tok, prompt, qs, ans = fixture_model
+    ev = msq.harness.gsm8k.evaluate
+    acc, samples = ev(m, tok, prompt, qs[:8], ans[:8], None, batch_size=4, max_new_tokens=60, return_samples=True)
+    assert set(samples[0]) == {"question", "generation", "answer", "list_from_pred", "list_from_answer", "pred", "label", "is_pred_true"}
+    assert any("\nQuestion: " in s["generation"] for s in samples)           # the model goes on to write the next block: the cut matters
+    acc_nosplit = ev(m, tok, prompt, qs[:8], ans[:8], None, batch_size=4, max_new_tokens=60, generation_split="@@never@@")
+    assert acc_nosplit < acc
+    assert ev(m, tok, prompt, qs[:4], ans[:4], None, batch_size=4, max_new_tokens=8, zero_shot=True) <= acc
