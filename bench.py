@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (MI355X_MICROARCH.md); the fp4 x fp8 scaled MFMA issues at the fp8 rate
-ROUND_TAG = "r05"
+ROUND_TAG = "r06"
 
 
 def parse_args(argv=None):

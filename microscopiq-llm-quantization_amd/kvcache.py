@@ -55,20 +55,32 @@ def fake_groupwise_channel_asymmetric_quantization_new(input, quantize_bit, grou
     return _group_quant(input, quantize_bit, group_size, True)
 
 
+def _msq_f32(t, scale_bits, elem_format, outlier_format, std_dev, axis, block_size):
+    """The MicroScopiQ quantiser on a cache tensor, computed in FLOAT32 and cast back to the cache dtype.  Not in the cache's own half
+    precision: utils/quant.py:489-492 tests the SIGNED values against bounds derived from |A|, so a block whose values are all negative -- a
+    key channel with a consistent sign, common in a KV cache -- is flagged outlier as a whole; its inlier part is all zero, e_in clamps to -20
+    (:207-211), the outliers enter their own domain as o 2^-20, and e_out = floor(log2(max)) - 8 lands near -25: 2^-25 is zero in fp16, the
+    division gives Inf / NaN and the reference's NaN assert (:225-250) fires.  Found by running config 4's loop end to end (round 6: every
+    generation with the fp16 cache came back empty).  In float32 the same block quantises to its fp8 outlier values."""
+    if t.dtype == torch.float32:
+        return outlier_fakequant(t, scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size)["out"]
+    return outlier_fakequant(t.float(), scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size)["out"].to(t.dtype)
+
+
 def mx_quantize_keys(key, elem_format="fp8_e4m3", block_size=32, scale_bits=8, outlier_format=None, std_dev=2):
     """K cache [B, H, S, D]: MX blocks of `block_size` consecutive TOKENS of one channel (per-channel grouping, the
     axis KIVI quantises keys along).  ``outlier_format`` set -> MicroScopiQ inlier / outlier quantiser instead of plain
     MX.  S need not be a multiple of the block: the last block is zero padded like every MX tensor (utils/quant.py:563-583)."""
     if outlier_format is None:
         return _quantize_mx(key, scale_bits, elem_format, axes=[2], block_size=block_size)
-    return outlier_fakequant(key, scale_bits, scale_bits, elem_format, outlier_format, std_dev, 2, block_size)["out"]
+    return _msq_f32(key, scale_bits, elem_format, outlier_format, std_dev, 2, block_size)
 
 
 def mx_quantize_values(value, elem_format="fp8_e4m3", block_size=32, scale_bits=8, outlier_format=None, std_dev=2):
     """V cache [B, H, S, D]: MX blocks along head_dim of one token (per-token grouping)."""
     if outlier_format is None:
         return _quantize_mx(value, scale_bits, elem_format, axes=[3], block_size=block_size)
-    return outlier_fakequant(value, scale_bits, scale_bits, elem_format, outlier_format, std_dev, 3, block_size)["out"]
+    return _msq_f32(value, scale_bits, elem_format, outlier_format, std_dev, 3, block_size)
 
 
 class CompressionConfig(dict):
