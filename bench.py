@@ -698,7 +698,7 @@ def m_sweep(dev, H=4096, inlier="fp4_e2m1", block=32, Ms=(16, 64, 128, 256, 512,
         P = qlinear.pack_weight(W, 8, 8, inlier, "posit8_es1", 2, block, layout="unified")
         del W
         dense = qlinear.unpack_weight(P, torch.bfloat16)
-        wbytes = float(P.nbytes())
+        wbytes = float(P.nbytes)
         rows = {}
         Ps = [P] + ([_clone_packed(P) for _ in range(cold_copies)] if name == "headline_4HxH" else [])
         for M in Ms:

@@ -41,6 +41,9 @@
 #ifndef MSQ_Q256_RT
 #define MSQ_Q256_RT 4          /* row tiles per XCD super-tile (see the block order in the kernel) */
 #endif
+#ifndef MSQ_Q128_SOLO_DEFAULT
+#define MSQ_Q128_SOLO_DEFAULT 0
+#endif
 #ifndef MSQ_Q256_PF
 #define MSQ_Q256_PF 2          /* activation-fragment reads in flight ahead of the MFMA group that consumes them (ring of 4) */
 #endif
@@ -326,7 +329,14 @@ extern "C" int msq_launch_qgemm256(const void* X, const void* ext_plane, const v
     const int bm = 16 * mf;
     const int MT = (int)((M + bm - 1) / bm), NTB = (int)(N / 256);
     const dim3 grid((unsigned)(MT * NTB)), blk(256);
-    const size_t lds = (size_t)4 * bm * 128;                     // four activation buffers (>= the epilogue's 4 x 8 KiB slices)
+    size_t lds = (size_t)4 * bm * 128;                           // four activation buffers (>= the epilogue's 4 x 8 KiB slices)
+    // 128-row blocks on a grid of at most one block per CU: ask for more LDS than half a CU has, so that the dispatcher cannot put two of them
+    // on one CU while another CU idles (MSQ_Q128_SOLO: 0 never, 1 always, unset = the measured rule)
+    {
+        static const int solo_env = [] { const char* e = getenv("MSQ_Q128_SOLO"); return e ? atoi(e) : -1; }();
+        const bool solo = mf == 8 && (solo_env == 1 || (solo_env < 0 && MSQ_Q128_SOLO_DEFAULT && (int64_t)MT * NTB <= 256));
+        if (solo) lds = 84 * 1024;
+    }
     const int y16 = (y_dtype == 1) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
 #define Q256_LAUNCH(OK, YT, MFV)                                                                                       \
