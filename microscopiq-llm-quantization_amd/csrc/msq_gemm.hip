@@ -1561,16 +1561,19 @@ extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const v
 // loses: 22.1 -> 27.9) and, as two row blocks per strip, up to M = 128 on the 4096 x 4096 projections (21.5 -> 14.4).  The 128-row forms (2, 4)
 // and the 128 / 64 x 128 blocks (3, 5) tie with or lose to the split-K GEMM once their activation ring is filled in an architecturally
 // ordered way: forced forms only.
-static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x) {
+// Round 6, late: form 6 (128 x 128 blocks, eight waves) on one-round grids of 129-256 rows with posit outliers: 16384 x 4096 44.2 -> 40.1 us,
+// 12288 x 4096 40.2 -> 36.7 (fp8 outliers tie: the split-K GEMM keeps them); it loses on two-round grids (22016, 8192 x 8192) and short N.
+static int sk_rule(int64_t M, int64_t N, int64_t K, bool unified_bf16x, int out_kind = MSQ_PLANE_U8) {
     if (!unified_bf16x) return 0;
     const int forced = sk_forced_env();
     if (forced == 0) return 0;
     if (forced > 0) return msq_qgemm_sk_form(M, N, K, forced);
-    if (M <= 32 || M > 128) return 0;
+    if (M <= 32 || M > 256) return 0;
     const int64_t strips = N / TILE_N, KT = K / BK;
     int form = 0;
     if (M <= 64) form = (strips >= 64 && strips <= 352 && KT <= 128) ? 1 : 0;
-    else if (strips >= 64 && strips <= 128 && KT <= 64) form = 1;
+    else if (M <= 128) form = (strips >= 64 && strips <= 128 && KT <= 64) ? 1 : 0;
+    else if (out_kind == MSQ_PLANE_U8X && KT <= 64 && strips >= 192 && strips <= 288) form = 6;     // 2 row blocks x strips / 2 = 192 ... 288 blocks
     return form ? msq_qgemm_sk_form(M, N, K, form) : 0;
 }
 // persistent kernel for this shape?  (M > 64: the decode kernels come first)
@@ -1654,9 +1657,9 @@ static int qlinear_bf16_impl(const void* X, const void* inl_plane, const void* o
     const int groups0 = unified ? 16 : (block < 32 ? 64 : 16);
     // fp16 activations are converted inside the decode kernels only: where the bf16 call takes k_qgemm_sk the caller casts (one kernel, one
     // summation order for both activation dtypes: tests/test_gpu_n2_gemm.py::test_decode_kernels_take_fp16_activations)
-    if (x_f16 && sk_rule(M, N, K, unified))
+    if (x_f16 && sk_rule(M, N, K, unified, out_kind))
         return fail2(MSQ_ERR_UNSUPPORTED, "msq_qlinear_f16x: this shape runs k_qgemm_sk, which reads bf16 activations: cast them to bf16");
-    if (const int skf = sk_rule(M, N, K, unified && !x_f16)) {
+    if (const int skf = sk_rule(M, N, K, unified && !x_f16, out_kind)) {
         const int e = msq_launch_qgemm_sk(X, inl_plane, out_plane, scale_plane, bias, Y, y_dtype, M, N, K, out_kind, groups0, skf, stream);
         if (e) { char b[200]; snprintf(b, sizeof(b), "msq_qlinear_bf16(K cut inside the block, k_qgemm_sk form %d): %s", skf, hipGetErrorString((hipError_t)e)); return fail2(MSQ_ERR_LAUNCH, b); }
         return MSQ_OK;
@@ -2205,7 +2208,7 @@ int msq_qlinear_kernel_choice(int64_t M, int64_t N, int64_t K, int out_kind, int
     }
     if (K % BK) return -1;
     const bool unified = out_kind == MSQ_PLANE_U8 || out_kind == MSQ_PLANE_U8X;
-    if (sk_rule(M, N, K, unified)) return MSQ_KERNEL_STREAMK;
+    if (sk_rule(M, N, K, unified, out_kind)) return MSQ_KERNEL_STREAMK;
     if (use_gemv(M, N, K)) return MSQ_KERNEL_DECODE;
     const QFamily f = q_family(M, N, K, unified, out_kind, msq_qlinear_workspace_bytes(M, N, K));
     return f.persistent ? MSQ_KERNEL_PERSISTENT : (f.mf == 16 ? MSQ_KERNEL_T256 : (f.mf == 8 ? MSQ_KERNEL_T128 : MSQ_KERNEL_GEMM128));
@@ -2223,9 +2226,9 @@ int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int m
         return MSQ_OK;
     }
     if (fam == MSQ_KERNEL_STREAMK) {
-        const int f = sk_rule(M, N, K, true);
-        snprintf(buf, cap, "k_qgemm_sk<%d, %s, %d, %d, %d, %d>", out_kind, yt, (f == 1 || f == 5) ? 4 : 8, (f == 3 || f == 5) ? 2 : 1,
-                 (f == 1 || f == 4) ? 8 : ((f == 2 || f == 5) ? 4 : 2), f == 4 ? 1 : ((f == 3 || f == 5) ? 3 : 2));
+        const int f = sk_rule(M, N, K, true, out_kind);
+        snprintf(buf, cap, "k_qgemm_sk<%d, %s, %d, %d, %d, %d>", out_kind, yt, (f == 1 || f == 5) ? 4 : 8, (f == 3 || f == 5 || f == 6) ? 2 : 1,
+                 (f == 1 || f == 4) ? 8 : ((f == 2 || f == 5 || f == 6) ? 4 : 2), f == 4 ? 1 : ((f == 3 || f == 5) ? 3 : 2));
     }
     else if (fam == MSQ_KERNEL_DECODE) snprintf(buf, cap, "k_qgemv_u / k_qgemv<out kind %d>", out_kind);
     else if (fam == MSQ_KERNEL_GEMM128) snprintf(buf, cap, "k_qgemm3<out kind %d, %s>", out_kind, yt);

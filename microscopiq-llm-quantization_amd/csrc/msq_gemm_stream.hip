@@ -93,7 +93,11 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     constexpr int IN_KIND = MSQ_PLANE_NONE;
     // NB = activation buffers per k-group: 3 with WN > 1 (shared tile, one barrier per tile); WN = 1 (private ring): 2, or 1 where eight
     // waves of 128 rows leave no room for more (the tile is re-staged behind its last read and awaited at once: the SIMD's other wave covers it)
-    static_assert((WN == 1 && (NB == 1 || NB == 2)) || (WN > 1 && NB == 3), "activation ring");
+    static_assert((WN == 1 && (NB == 1 || NB == 2)) || (WN > 1 && (NB == 3 || NB == 2)), "activation ring");
+    // WN > 1 with TWO buffers (form 6: eight waves on 128 x 128 blocks -- three buffers of 16 KiB for four k-groups do not fit): the tile's ONE
+    // barrier does double duty -- every wave of the group has finished reading buffer b AND tile i + 1 (staged right behind the previous barrier,
+    // awaited in front of this one) is visible -- and tile i + 2 is staged into b right behind it.
+    constexpr bool LATE = (WN > 1 && NB == 2);
     constexpr int BM = 16 * MF;                                  // block rows
     constexpr int A_TILE = BM * BK * 2;                          // bytes of one activation tile
     constexpr int PPW = BM / 8 / WN;                             // 1 KiB staging pieces (8 rows) per wave and tile
@@ -228,7 +232,7 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
     //   WN = 2 (ring of three, one barrier per tile): tile i + 2 goes into the buffer tile i - 1 was read from, at the top of the tile.
     //   WN = 1, ONE buffer: tile i + 1 is staged into the only buffer behind the last read of tile i and awaited right away (only the loads of
     //   tile i + RING are younger)
-    constexpr int N_WAIT = (NB == 1) ? SET_LOADS : SET_LOADS + ((MSQ_SK_ABL & 1) ? 0 : PPW) + SET_LOADS;
+    constexpr int N_WAIT = (NB == 1 || LATE) ? SET_LOADS : SET_LOADS + ((MSQ_SK_ABL & 1) ? 0 : PPW) + SET_LOADS;
     int buf = 0;
 #define SK_TILE(I, CUR, NXT)                                                                                       \
     {                                                                                                              \
@@ -244,6 +248,13 @@ k_qgemm_sk(const uint16_t* __restrict__ X, const uint8_t* __restrict__ ext_plane
             xwrite(buf ^ 1);                       /* tile i + 1 (requested a tile ago) into the buffer tile i - 1 was read from */ \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             xload((I) + 2);                        /* in front of the packed loads: in-order vmcnt */              \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            load_set(CUR, (I) + RING);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } else if (LATE) {                                                                                         \
+            __builtin_amdgcn_s_waitcnt(0x0070 | (N_WAIT & 15) | ((N_WAIT >> 4) << 14));     /* vmcnt(N_WAIT) lgkmcnt(0): tile i + 1 has landed, this wave's reads are done */ \
+            __builtin_amdgcn_s_barrier();                                                                          \
+            stage((I) + 2, buf2);                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
             load_set(CUR, (I) + RING);                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -372,14 +383,15 @@ inline void attr_done_s(DevOnceS& o) {
 }  // namespace
 
 // Shape of the block for M rows (0 = the kernel does not apply): form 1 = MF 4, WN 1, KG 8; 2 = MF 8, WN 1, KG 4; 3 = MF 8, WN 2, KG 2;
-// 4 = MF 8, WN 1, KG 8 with ONE activation buffer per wave (eight waves of 128 rows: two per SIMD); 5 = MF 4, WN 2, KG 4 (64 x 128 blocks).
+// 4 = MF 8, WN 1, KG 8 with ONE activation buffer per wave (eight waves of 128 rows: two per SIMD); 5 = MF 4, WN 2, KG 4 (64 x 128 blocks);
+// 6 = MF 8, WN 2, KG 4 (128 x 128 blocks, EIGHT waves, two activation buffers per k-group, two-phase reduction).
 // `form` > 0 forces (tests, A / B).  Preconditions checked by the caller: unified layout, bf16 activations, K % 64 == 0, N % 256 == 0.
 extern "C" int msq_qgemm_sk_form(int64_t M, int64_t N, int64_t K, int form) {
     if (form <= 0) form = (M <= 64) ? 1 : ((M <= 128) ? 2 : 3);
     const int64_t KT = K / 64;
     if (form == 3 && ((KT & 1) || (N % 128))) return 0;
-    if (form == 5 && ((KT & 3) || (N % 128))) return 0;
-    if (form < 1 || form > 5 || KT < 1) return 0;
+    if ((form == 5 || form == 6) && ((KT & 3) || (N % 128))) return 0;
+    if (form < 1 || form > 6 || KT < 1) return 0;
     return form;
 }
 
@@ -387,8 +399,9 @@ extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const v
                                    int y_dtype, int64_t M, int64_t N, int64_t K, int out_kind, int scl_groups, int form, void* stream) {
     form = msq_qgemm_sk_form(M, N, K, form);
     if (!form) return (int)hipErrorInvalidValue;
-    const int mf = (form == 1 || form == 5) ? 4 : 8, wn = (form == 3 || form == 5) ? 2 : 1, kg = (form == 1 || form == 4) ? 8 : ((form == 2 || form == 5) ? 4 : 2);
-    const int bm = 16 * mf, nb = (form == 4) ? 1 : ((wn == 1) ? 2 : 3);
+    const int mf = (form == 1 || form == 5) ? 4 : 8, wn = (form == 3 || form == 5 || form == 6) ? 2 : 1,
+              kg = (form == 1 || form == 4) ? 8 : ((form == 2 || form == 5 || form == 6) ? 4 : 2);
+    const int bm = 16 * mf, nb = (form == 4) ? 1 : ((wn == 1 || form == 6) ? 2 : 3);
     const int MT = (int)((M + bm - 1) / bm), NTB = (int)(N / (64 * wn));
     const dim3 grid((unsigned)(MT * NTB)), blk((unsigned)(64 * wn * kg));
     size_t ring = (size_t)kg * nb * bm * 128, redb = (size_t)wn * kg * mf * 4 * 1024;
@@ -403,7 +416,7 @@ extern "C" int msq_launch_qgemm_sk(const void* X, const void* ext_plane, const v
                             (const uint8_t*)scale_plane, bias, (YT*)Y, (int)M, (int)N, (int)K, scl_groups, y16); } while (0)
 #define SK_FORM(OK, YT) do { if (form == 1) SK_LAUNCH(OK, YT, 4, 1, 8, 2); else if (form == 2) SK_LAUNCH(OK, YT, 8, 1, 4, 2); \
                              else if (form == 3) SK_LAUNCH(OK, YT, 8, 2, 2, 3); else if (form == 4) SK_LAUNCH(OK, YT, 8, 1, 8, 1); \
-                             else SK_LAUNCH(OK, YT, 4, 2, 4, 3); } while (0)
+                             else if (form == 5) SK_LAUNCH(OK, YT, 4, 2, 4, 3); else SK_LAUNCH(OK, YT, 8, 2, 4, 2); } while (0)
     if (out_kind == MSQ_PLANE_U8) { if (y_dtype == 0) SK_FORM(MSQ_PLANE_U8, float); else SK_FORM(MSQ_PLANE_U8, uint16_t); }
     else { if (y_dtype == 0) SK_FORM(MSQ_PLANE_U8X, float); else SK_FORM(MSQ_PLANE_U8X, uint16_t); }
 #undef SK_FORM

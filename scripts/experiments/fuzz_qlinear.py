@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 L = msq._lib.lib()
-NAMES = {0: "decode", 1: "gemm128", 2: "t256", 3: "t128"}
+NAMES = {0: "decode", 1: "gemm128", 2: "t256", 3: "t128", 4: "persistent", 5: "streamk(sk)"}
 bad = 0
 seen = {}
 for case in range(cases):

@@ -25,11 +25,13 @@ def _case(O, M, N, K, fo, seed):
     (1, 33, 256, 64 * 8), (1, 64, 512, 64 * 16), (1, 50, 256, 64 * 3), (1, 64, 768, 64 * 11), (1, 130, 256, 64 * 9),
     (2, 65, 256, 64 * 4), (2, 128, 512, 64 * 12), (2, 100, 256, 64 * 5), (2, 128, 256, 64 * 1), (2, 300, 512, 64 * 7),
     (3, 129, 256, 64 * 2), (3, 256, 512, 64 * 8), (3, 200, 256, 64 * 6), (3, 512, 768, 64 * 4), (3, 700, 2048, 64 * 10),
-    (4, 65, 256, 64 * 8), (4, 128, 512, 64 * 19), (4, 100, 256, 64 * 3), (4, 128, 256, 64 * 1), (4, 300, 2048, 64 * 9)])
+    (4, 65, 256, 64 * 8), (4, 128, 512, 64 * 19), (4, 100, 256, 64 * 3), (4, 128, 256, 64 * 1), (4, 300, 2048, 64 * 9),
+    (5, 64, 256, 64 * 4), (5, 200, 768, 64 * 12), (6, 129, 256, 64 * 4), (6, 256, 512, 64 * 8), (6, 200, 256, 64 * 12), (6, 700, 2048, 64 * 20)])
 @pytest.mark.parametrize("fo", ["posit8_es1", "fp8_e4m3"])
 def test_forced_forms_against_the_oracle(msq, O, form, M, N, K, fo, monkeypatch):
     """Each form FORCED (MSQ_GEMM_SK = 1: 64-row strip, eight waves; 2: 128-row strip, four waves; 3: 128 x 128 block, two k-groups of two
-    waves; 4: 128-row strip, eight waves with one activation buffer each and a two-phase reduction) against O.linear on the ORACLE's fake-quant weight: K of 1 ... 16 tiles (fewer tiles than waves, tile counts that are not multiples
+    waves; 4: 128-row strip, eight waves with one activation buffer each and a two-phase reduction; 5: 64 x 128 blocks; 6: 128 x 128 blocks with
+    EIGHT waves, two activation buffers per k-group, one barrier per tile that retires the reads of a buffer and publishes the next tile) against O.linear on the ORACLE's fake-quant weight: K of 1 ... 16 tiles (fewer tiles than waves, tile counts that are not multiples
     of the ring of three, an odd count per wave), ragged M (the last row block clamps its loads and masks its stores), several row blocks,
     panel counts that are and are not multiples of 8 (both block orders); bias, float32 / bfloat16 / float16 outputs (one sum, rounded
     once); 20 launches bit-identical."""
@@ -78,7 +80,8 @@ def test_tuning_switch_through_the_abi(msq):
     assert L.msq_set_tuning(b"MSQ_GEMM_SK", -(2 ** 31)) == 0      # INT_MIN: back to the environment / the rule
 
 
-@pytest.mark.parametrize("form,M,N,K", [(1, 64, 2048, 64 * 19), (2, 128, 2048, 64 * 19), (4, 128, 2048, 64 * 19), (4, 128, 512, 64 * 19), (3, 256, 2048, 64 * 18)])
+@pytest.mark.parametrize("form,M,N,K", [(1, 64, 2048, 64 * 19), (2, 128, 2048, 64 * 19), (4, 128, 2048, 64 * 19), (4, 128, 512, 64 * 19), (3, 256, 2048, 64 * 18),
+                                           (6, 256, 2048, 64 * 20)])
 def test_forms_repeat_bit_for_bit_beside_a_copy_stream(msq, O, form, M, N, K):
     """The activation tiles reach LDS by LDS-DMA; their reads are ordered by the issuing wave's counted vmcnt AND a block barrier (nothing else
     orders them -- the first build of the private-ring forms read right behind the wave's own vmcnt and form 4, one buffer deep, returned wrong

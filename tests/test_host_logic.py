@@ -507,7 +507,8 @@ def test_kernel_choice_rule_for_llama_shapes():
     SK = 5                                                                                    # round 6: K cut inside the block (k_qgemm_sk)
     assert [ch(128, N, K, U8X) for N, K in layer] == [G128, SK, G128, G128]                   # two 64-row blocks per strip on the 4096 x 4096 projection only
     assert [ch(64, N, K, U8X) for N, K in layer] == [SK, SK, SK, G128] and [ch(33, N, K, U8) for N, K in layer] == [SK, SK, SK, G128]
-    assert [ch(129, N, K, U8X) for N, K in layer] == [G128, G128, T128, G128] and ch(128, 16384, 4096, 2) == G128   # beyond 128 rows / two-plane layouts: as before
+    assert [ch(129, N, K, U8X) for N, K in layer] == [SK, G128, T128, G128] and [ch(256, N, K, U8) for N, K in layer] == [G128, G128, T128, G128]   # 129-256 rows: 128 x 128 blocks on one-round grids, posit outliers only
+    assert ch(256, 16384, 4096, U8X) == SK and ch(257, 16384, 4096, U8X) != SK and ch(128, 16384, 4096, 2) == G128   # two-plane layouts: as before
     assert ch(512, 22016, 4096, U8X) == T256 and ch(512, 22016, 4096, U8) == T256             # part-filled single round: M <= 512
     assert ch(768, 12288, 4096, U8X) == T256 and ch(768, 12288, 4096, U8) == G128             # ... beyond: posit only
     assert ch(2048, 16384, 4096, 2) == G128                                                   # two-plane layouts (MSQ-T1) stay on k_qgemm3
