@@ -593,3 +593,36 @@ def test_set_tuning_knows_every_switch():
         L.msq_set_tuning(b"MSQ_GEMM_256", INT_MIN)
     L.msq_qlinear_kernel_name(2048, 16384, 4096, 6, -1, 2, buf, 128)
     assert buf.value == b"k_qgemm256<6, uint16_t, 16>", buf.value
+
+
+def test_isa_of_the_mid_m_kernel_keeps_its_accumulators_in_place(tmp_path):
+    """k_qgemm_sk (csrc/msq_gemm_stream.hip) compiled to gfx950 assembly (no GPU needed): no instantiation touches scratch, and the 128-row forms
+    -- whose MFMAs are tied inline-asm statements on AGPRs because hipcc left to itself shuttled 448 v_accvgpr copies through the K-loop -- contain
+    no v_accvgpr copy inside any loop (backward branch): the accumulators are written by the zero initialisation in front of the K-loop and read by
+    the hand-over to LDS behind it."""
+    import re
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(ROOT, "microscopiq-llm-quantization_amd", "csrc", "msq_gemm_stream.hip")
+    out = str(tmp_path / "sk.s")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "--cuda-device-only", "-S", src, "-o", out],
+                          stderr=subprocess.DEVNULL)
+    s = open(out).read()
+    names = re.findall(r"^(_ZN\S*k_qgemm_sk\S*):", s, re.M)
+    assert len(names) >= 24                                              # 6 forms x 2 layouts x 2 output types
+    for nm in names:
+        i = s.index("\n" + nm + ":"); j = s.index("s_endpgm", i)
+        body = s[i:j]
+        assert "scratch_" not in body, nm
+        mf = int(re.search(r"k_qgemm_skILi\dE\wLi(\d+)E", nm).group(1))
+        if mf == 8:
+            # loops = backward branches; no accumulator copy inside any of them
+            lines = body.split("\n")
+            labels = {m.group(1): k for k, l in enumerate(lines) for m in [re.match(r"^(\.LBB\S+):", l)] if m}
+            for k, l in enumerate(lines):
+                m = re.search(r"s_cbranch\S+\s+(\.LBB\S+)", l)
+                if m and m.group(1) in labels and labels[m.group(1)] < k:
+                    assert not any("v_accvgpr" in x for x in lines[labels[m.group(1)]:k]), nm
+            assert body.count("v_accvgpr_write") >= 128, nm               # (the zero initialisation; LDS stores read the AGPRs directly)
+        assert body.count("v_mfma_f32_16x16x32") >= 64, nm
