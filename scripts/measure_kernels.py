@@ -33,12 +33,16 @@ def t(fn, n=20, warm=30):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    best = None
+    for _ in range(3):          # eager calls of 10-30 us kernels are bound by the host: a hiccup there only ever ADDS time -- the best of three loops
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) / n
+        best = dt if best is None or dt < best else best
+    return best
 
 
 def tg(fn, reps=10, n=20):
