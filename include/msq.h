@@ -154,7 +154,9 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
  *   e_in / e_out  float [pre,nblk,post] clamped shared exponents (NaN kept)
  *   num_outliers  int8 [ceil(nblk/block)*post] (utils/quant.py:66; needs pre == 1)
  *   status_flag   int (device): MSQ_STATUS_* bits OR-ed in
- *   workspace     device scratch of msq_outlier_workspace_bytes() bytes (variant 1 only, else NULL)
+ *   workspace     device scratch of msq_outlier_workspace_bytes() bytes: variant 1 needs it; variant 0 uses it for fp16 / bf16 tensors
+ *                 computed in their dtype (MSQ_DTYPE_*_NATIVE: the list of waves the packed kernels hand back to the op-by-op kernel,
+ *                 csrc/msq_quant_lowp.hip) -- NULL there runs the op-by-op kernel alone: same results, a third of the speed
  * in/out dtype: 0 = f32 (bit-exact vs the reference); 2 = bf16 tensors (read as f32 values, computed in f32, one
  *   round-to-nearest-even on the way out: the same bits as upcasting, running dtype 0 and casting back), built for
  *   round-to-nearest with float / int inlier formats, variant 0; 1 = f16 and the remaining combinations return
@@ -269,7 +271,8 @@ int msq_qlinear_kernel_name(int64_t M, int64_t N, int64_t K, int out_kind, int m
  * single-threaded A / B runs).  "MSQ_MX_LOWP_PAIR4" (1 default / 0): msq_quantize_mx_lowp on a strided axis of whole 32-blocks through
  * k_mx_lowp_pair4 (a block row cut over four waves) or k_mx_lowp_pair.  The other test / A-B switches likewise (override, else the environment per
  * call): "MSQ_ACT_ROWS" (0: the mx_ops activation quantiser as two launches), "MSQ_MX_PACK_BLOCK" (1: one lane per block in msq_mx_pack_a8),
- * "MSQ_VEC_GENERIC" (1: the vector ops through the run-time-parameter rounding), "MSQ_RMS_RPB" (rows per block of the register RMSNorm kernel), "MSQ_PACK_TWO_PASS" (1: msq_outlier_pack in two passes).
+ * "MSQ_VEC_GENERIC" (1: the vector ops through the run-time-parameter rounding), "MSQ_RMS_RPB" (rows per block of the register RMSNorm kernel), "MSQ_PACK_TWO_PASS" (1: msq_outlier_pack in two passes),
+ * "MSQ_OUTLIER_LOWP_PK" (0: msq_outlier_fakequant in the tensor dtype through k_outlier_lowp only, not the packed kernels).
  * Returns MSQ_ERR_UNSUPPORTED for an unknown key. */
 int msq_set_tuning(const char* key, int value);
 /* Schedule of the persistent fused GEMM k_qgemm256p (csrc/msq_gemm256p.hip) for a shape -- host arithmetic only, no device needed; for tests

@@ -1545,6 +1545,7 @@ extern "C" int msq_set_tuning(const char* key, int value) {
     if (!strcmp(key, "MSQ_MX_256")) { g_tune_mx256.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_GEMM_SK")) { g_tune_sk.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (!strcmp(key, "MSQ_MX_LOWP_PAIR4")) { msq_set_tuning_lowp_("mx_lowp_pair4", value); return MSQ_OK; }   // 0: one lane per block pair (k_mx_lowp_pair)
+    if (!strcmp(key, "MSQ_OUTLIER_LOWP_PK")) { msq_set_tuning_lowp_("outlier_lowp_pk", value); return MSQ_OK; }   // 0: the op-by-op in-dtype fake-quant kernel only
     if (!strcmp(key, "MSQ_PACK_TWO_PASS")) { g_tune_two_pass.store(value, std::memory_order_relaxed); return MSQ_OK; }
     if (msq_set_tuning_act_(key, value) || msq_set_tuning_mx_(key, value) || msq_set_tuning_vec_(key, value)) return MSQ_OK;   // MSQ_ACT_ROWS, MSQ_MX_PACK_BLOCK, MSQ_VEC_GENERIC
     return MSQ_ERR_UNSUPPORTED;

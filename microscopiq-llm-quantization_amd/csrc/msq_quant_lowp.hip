@@ -307,15 +307,10 @@ MSQ_D int outlier_block_lowp(float (&a)[BS], uint32_t (&mkw)[(BS + 31) / 32], fl
 
 // lane <-> (p, nb, q), q fastest.  post > 1: each of the BS row accesses of a wave is one contiguous 128-byte segment;
 // post == 1: every lane walks its own contiguous block (the cache lines are shared by neighbouring lanes).
+// the work of lane `t` (one block); every lane of a wave calls it with consecutive t (the transposition slice is the wave's)
 template <int BS, int DT>
-__global__ void __launch_bounds__(256)
-k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A) {
-    __shared__ uint8_t l2tab[256];                          // bump allowance of floor(R(log2 .)) by biased exponent (fast path)
-    __shared__ __attribute__((aligned(16))) char xsm[(BS % 8 == 0) ? 4 * 64 * (BS * 2 + 16) : 16];   // one transposition slice per wave
-    floor_log2_tab_init<DT>(l2tab);
-    __syncthreads();
+MSQ_D void outlier_lowp_lane(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, const OutlierArgs& A, int64_t t, const uint8_t* l2tab, char* xsm) {
     const int64_t total = A.pre * A.nblk * A.post;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int64_t q = t % A.post;
     const int64_t nb = (t / A.post) % A.nblk;
@@ -417,6 +412,31 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
     if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
     if (status && A.status) atomicOr(A.status, status);
+}
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A) {
+    __shared__ uint8_t l2tab[256];                          // bump allowance of floor(R(log2 .)) by biased exponent (fast path)
+    __shared__ __attribute__((aligned(16))) char xsm[(BS % 8 == 0) ? 4 * 64 * (BS * 2 + 16) : 16];   // one transposition slice per wave
+    floor_log2_tab_init<DT>(l2tab);
+    __syncthreads();
+    outlier_lowp_lane<BS, DT>(in, out, A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, l2tab, xsm);
+}
+// The waves the packed kernels below could not take (their list: ws[0] = count, ws[8 ...] = first lane of each, in this kernel's lane
+// numbering): a fixed grid walks the list, one entry per wave and trip.
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws) {
+    __shared__ uint8_t l2tab[256];
+    __shared__ __attribute__((aligned(16))) char xsm[4 * 64 * (BS * 2 + 16)];
+    const int64_t count = ws[0];
+    if (count == 0) return;
+    floor_log2_tab_init<DT>(l2tab);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += nw)
+        outlier_lowp_lane<BS, DT>(in, out, A, ws[8 + i] + lane, l2tab, xsm);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -852,11 +872,440 @@ k_mx_lowp_pair4(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxL
     if (live && w == 0 && st && A.status) atomicOr(A.status, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The MicroScopiQ fake-quant on PACKED half values (round 6): two T values of one block per dword, the statistics in float32
+// with a proof of the rounding, the element step through the gfx950 scaled converts.  k_outlier_lowp above spends ~70 vector
+// instructions per element (VALU bound, 0.2 of the HBM rate); this form ~20.  Same results, bit for bit -- the goldens
+// (tests/golden/outlier_lowp.npz) and the oracle pin it, and tests/test_gpu_a6_lowp_packed.py holds it against the op-by-op
+// kernel above on adversarial inputs.  What makes it legal:
+//  * mask: x < lo or x > hi on packed values -- fp16: the sign of the correctly rounded differences x - lo, hi - x (v_pk_add_f16;
+//    fp16 denormals are kept, so a difference of unequal values never rounds to zero); bf16: saturating differences of the
+//    order-preserving integer keys of the bit patterns.  Both are wrong only for a zero against a zero bound of the other sign:
+//    blocks whose bound is +-0 (or NaN) are not taken here.
+//  * std: the reference's value is R_T((float) double Welford).  Here: sd' = sqrt(sum (|x| - c)^2 / n) in float32 with c = the
+//    fp32 mean already summed in ATen's order; |sd' - sd| <= n / 8 + 4 float32 ulps (four fma chains of n / 4, the rounding of each
+//    difference, the square root, and the term n (mean - c)^2 that the shifted centre leaves out, negligible once
+//    sd' >= n 2^-12 c).  When sd' lies further than that from every rounding boundary of T, R_T(sd') is the reference's value;
+//    the lanes where it does not (one block in ~400 for fp16, ~3000 for bf16) run the double two-pass form.
+//  * the element step: inside the exponent bounds checked per block every scaling of utils/quant.py:214-258 is exact in T (or
+//    is the one correctly rounded product the reference also forms: fp16 outliers, v_pk_mul_f16), and the codec
+//    (elemwise_ops.py:84-174, nearest) is "half away from zero on the format's grid, subnormals kept, saturating" except on ONE
+//    magnitude per side (pred_T of half the smallest step: DESIGN.md 5.002).  The converts round to nearest even; with the lowest
+//    significand bit of the source set no input is a tie and nothing else changes sides (T has >= 3 more significand bits than the
+//    grids, and the bounds keep T's own spacing four times finer than the smallest step).  Magnitudes only go through the
+//    converts; the sign comes back where the result is not zero (the reference's final `inl + o` turns every -0 into +0).
+//    The excepted magnitude sits in the bulk of a weight block (a quarter to a half of the inlier maximum: every other wave holds
+//    one), so it is lifted over the tie on its way into the convert (pk_lift) rather than sent elsewhere.
+//    A wave with a block outside the bounds takes outlier_block_lowp.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short lp_s2_t __attribute__((ext_vector_type(2)));
+MSQ_D uint32_t pk_max_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(lp_us2_t, a), __builtin_bit_cast(lp_us2_t, b))); }
+MSQ_D uint32_t pk_min_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(lp_us2_t, a), __builtin_bit_cast(lp_us2_t, b))); }
+MSQ_D uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(lp_us2_t, a), __builtin_bit_cast(lp_us2_t, b))); }
+MSQ_D uint32_t pk_subsat_i16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(lp_s2_t, a), __builtin_bit_cast(lp_s2_t, b))); }
+MSQ_D uint32_t pk_add_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (lp_us2_t)(__builtin_bit_cast(lp_us2_t, a) + __builtin_bit_cast(lp_us2_t, b))); }
+MSQ_D uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (lp_us2_t)(__builtin_bit_cast(lp_us2_t, a) * __builtin_bit_cast(lp_us2_t, b))); }
+MSQ_D uint32_t pk_sign_fill(uint32_t a) { const lp_s2_t f = {15, 15}; return __builtin_bit_cast(uint32_t, (lp_s2_t)(__builtin_bit_cast(lp_s2_t, a) >> f)); }   // 0xFFFF where bit 15 is set
+MSQ_D uint32_t dup16(uint32_t h) { return h | (h << 16); }                  // h <= 0xFFFF
+template <int DT> MSQ_D uint32_t t_bits(float v) {                       // bit pattern of a float that IS a T value
+    if (DT == 1) return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v);
+    return f2u(v) >> 16;
+}
+template <int DT> MSQ_D uint32_t pow2_bits(int k) {                      // T bits of 2^k (fp16: subnormals included, k >= -24)
+    if (DT == 1) return (k >= -14) ? (uint32_t)(k + 15) << 10 : 1u << ((k + 24) & 31);
+    return (uint32_t)(k + 127) << 7;
+}
+MSQ_D float pow2f(int k) { return u2f((uint32_t)(k + 127) << 23); }      // -126 <= k <= 127
+
+// quantise-dequantise two T magnitudes of one block on the grid K (1 e4m3, 2 e5m2, 3 e2m1; lowest significand bit set by the caller):
+// round(m / sf) on the grid, times sb.  bound = T bits of max_norm * sf (the fp8 converts do not saturate)
+#ifndef MSQ_LOWP_FP4_CLAMP
+#define MSQ_LOWP_FP4_CLAMP 0          // the e2m1 converts saturate by themselves (as their float32-source forms do in msq_outlier_core.h)
+#endif
+template <int DT, int K> MSQ_D uint32_t hw_mag_pair(uint32_t m, float sf, float sb, uint32_t bound) {
+    if (K != 3 || MSQ_LOWP_FP4_CLAMP) m = pk_min_u16(m, bound);
+    // (the converts write one byte / one half of their destination and keep the rest: the source register itself serves -- the part
+    //  that is read back is the part just written)
+    if (DT == 1) {
+        const lp_h2_t x = __builtin_bit_cast(lp_h2_t, m);
+        if (K == 3) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(__builtin_amdgcn_cvt_scalef32_pk_fp4_f16(m, x, sf, 0), sb, 0));
+        lp_v2s_t c = __builtin_bit_cast(lp_v2s_t, m);
+        if (K == 1) { c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, x, sf, false); return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(uint32_t, c), sb, false)); }
+        c = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(c, x, sf, false);
+        return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(__builtin_bit_cast(uint32_t, c), sb, false));
+    } else {
+        const lp_b2_t x = __builtin_bit_cast(lp_b2_t, m);
+        if (K == 3) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(__builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(m, x, sf, 0), sb, 0));
+        lp_v2s_t c = __builtin_bit_cast(lp_v2s_t, m);
+        if (K == 1) { c = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(c, x, sf, false); return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(__builtin_bit_cast(uint32_t, c), sb, false)); }
+        c = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(c, x, sf, false);
+        return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(__builtin_bit_cast(uint32_t, c), sb, false));
+    }
+}
+
+// fp16 outliers: x 2^e_in is often an fp16 SUBNORMAL (e4m3 spans 17 binades: 2^e_out sits near 2^-18 for a weight block), where the
+// lowest bit of the half is worth a whole step of the grid and cannot serve as the sticky bit.  The pair goes to float32 (exact), takes
+// the bit there, and enters the float32-source convert; the way back is the f16 convert as before.  m: clamped, the excepted magnitude
+// already lifted
+template <int K> MSQ_D uint32_t hw_mag_pair_f32src(uint32_t m, float s) {
+    const lp_h2_t h = __builtin_bit_cast(lp_h2_t, m);
+    const float x0 = u2f(f2u((float)h[0]) | 1u), x1 = u2f(f2u((float)h[1]) | 1u);
+    if (K == 3) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(__builtin_amdgcn_cvt_scalef32_pk_fp4_f32(m, x0, x1, s, 0), s, 0));
+    lp_v2s_t c = __builtin_bit_cast(lp_v2s_t, m);
+    if (K == 1) { c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c, x0, x1, s, false); return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(uint32_t, c), s, false)); }
+    c = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(c, x0, x1, s, false);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(__builtin_bit_cast(uint32_t, c), s, false));
+}
+
+// The excepted magnitude of a side, q = pred_T(first tie) (its lowest bit is set), becomes "just above the tie" on its way into the
+// convert: |x| == q -> q + 2 ulps.  (|x| == q - 1 -> q, which the converts round down like q - 1; everything else: |x| | 1.)
+// q = 0xFFFF where the side has none.
+MSQ_D uint32_t pk_lift(uint32_t a, uint32_t q) { return pk_add_u16(a, pk_subsat_u16(0x00020002u, a ^ q)) | 0x00010001u; }
+// T bits (both halves) of pred_T(2^k), or 0xFFFF: an fp16 SUBNORMAL pred (k <= -14) is further below the tie than half an ulp of
+// 1/2 -- its spacing is 2^-24, not 2^(k - 11) --, R(m + 0.5) stays below 1 and there is no exception
+template <int DT> MSQ_D uint32_t pk_excepted(int k) {
+    if (DT == 1) return (k >= -13) ? dup16(((uint32_t)(k + 15) << 10) - 1u) : 0xFFFFFFFFu;
+    return dup16(((uint32_t)(k + 127) << 7) - 1u);
+}
+
+// The element loop of one block.  e_in / e_out: the block's two scale exponents; tie_i / tie_o: exponent of the first tie (half the
+// smallest step) of the inlier grid in x's domain, of the outlier grid in the domain of x 2^e_in.
+template <int BS, int DT, int KI, int KO>
+MSQ_D void pk_codec_loop(const uint32_t (&pw)[BS / 2], const uint32_t (&mk)[BS / 2], uint32_t (&res)[BS / 2], const OutlierArgs& A, int ei, int eo,
+                         int tie_i, int tie_o) {
+    const float s_in = pow2f(ei);
+    // fp16: outliers are rounded into the domain of x 2^e_in first (:216, v_pk_mul_f16 -- a real rounding where the product is an
+    // fp16 subnormal), converted with 2^e_out, and leave through R(. / 2^e_in) (:258).  bf16: x 2^e_in is exact (or far below the first
+    // tie), so ONE scale 2^(e_out - e_in) takes x to the outlier grid and back
+    const float s_out = (DT == 1) ? pow2f(eo) : pow2f(eo - ei);
+    const uint32_t b_out = dup16(t_bits<DT>(A.fo.max_norm * s_out));
+    const uint32_t q_in = pk_excepted<DT>(tie_i), q_out = pk_excepted<DT>((DT == 1) ? tie_o : tie_o - ei);
+    const uint32_t b_in = (KI == 4) ? 0u : dup16(t_bits<DT>(A.fi.max_norm * s_in));
+    // int2 inliers: |x| >= step / 2 ? step : 0 -- and the excepted magnitude, one ulp below step / 2, joins the upper side
+    const uint32_t h_in = (KI == 4) ? dup16(pow2_bits<DT>(ei - 1)) - ((q_in != 0xFFFFFFFFu) ? 0x00020002u : 0x00010001u) : 0u;
+    const uint32_t st_in = (KI == 4) ? dup16(pow2_bits<DT>(ei)) : 0u;
+    const uint32_t m_dn = dup16((uint32_t)(ei + 15) << 10), m_up = dup16((uint32_t)(15 - ei) << 10);       // fp16 only: |e_in| <= 14
+#pragma unroll
+    for (int j = 0; j < BS / 2; ++j) {
+        const uint32_t w = pw[j], a = w & 0x7FFF7FFFu, m = mk[j];
+        uint32_t ri, ro;
+        if (DT == 1) {
+            if (KI == 4) ri = pk_mul_u16(pk_min_u16(pk_subsat_u16(a, h_in), 0x00010001u), st_in);
+            else ri = hw_mag_pair<DT, KI>(pk_lift(a, q_in), s_in, s_in, b_in);
+            const uint32_t t1 = __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, a) * __builtin_bit_cast(lp_h2_t, m_dn)));
+            uint32_t tl = pk_add_u16(t1, pk_subsat_u16(0x00020002u, t1 ^ q_out));
+            if (KO != 3 || MSQ_LOWP_FP4_CLAMP) tl = pk_min_u16(tl, b_out);
+            const uint32_t q = hw_mag_pair_f32src<KO>(tl, s_out);
+            ro = __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, q) * __builtin_bit_cast(lp_h2_t, m_up)));
+        } else {
+            // one lift serves both converts: each element uses the result of its own side only
+            const uint32_t in = pk_lift(a, (q_out & m) | (q_in & ~m));
+            if (KI == 4) ri = pk_mul_u16(pk_min_u16(pk_subsat_u16(a, h_in), 0x00010001u), st_in);
+            else ri = hw_mag_pair<DT, KI>(in, s_in, s_in, b_in);
+            ro = hw_mag_pair<DT, KO>(in, s_out, s_out, b_out);
+        }
+        const uint32_t rm = (ro & m) | (ri & ~m);
+        // the sign where the magnitude is not zero (rm <= 0x7FFF: rm + 0x7FFF has bit 15 set iff rm != 0)
+        res[j] = ((pk_add_u16(rm, 0x7FFF7FFFu) & w) & 0x80008000u) | rm;
+    }
+}
+
+// floor(R(log2 max)) - emax and the clamp of utils/quant.py:207-211 / :237-242 on integers: the exponent is an integer in
+// [-133, 127] and emax <= 15, so the reference's float chain (every step rounded to T) is exact.  mb: T bits of the block maximum
+// (finite); a zero maximum: fp16 R(2^-126) = 0 -> log2 = -inf -> the lower clamp; bf16 keeps 2^-126.  false: the exponent exceeds
+// the scale range (the reference stores NaN)
+template <int DT> MSQ_D bool scale_exp_int(uint32_t mb, float mx, int emax, int sb, const uint8_t* tab, int& se) {
+    const int lim = (1 << (sb - 1)) - 1, neg = (-lim < -20) ? -20 : -lim;
+    int e = floor_log2_tab<DT>(mx, tab) - emax;
+    e = (mb == 0u) ? ((DT == 1) ? -100000 : -126 - emax) : e;
+    se = (e < -lim) ? neg : e;
+    return e <= lim;
+}
+
+// one block: pw[] = the BS values, two per dword in axis order.  Returns true when res[] / mk[] (0xFFFF per outlier) / the
+// two exponents are the block's result; false: nothing is, the caller runs outlier_block_lowp.  Straight-line apart from the
+// (divergent, rare) double-precision std.
+#ifdef MSQ_LOWP_WHY
+__device__ unsigned long long g_lowp_why[16];
+extern "C" void msq_lowp_why_(unsigned long long* out16, int reset) {
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lowp_why), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_lowp_why), z, sizeof(z)); }
+}
+#define MSQ_WHY(cond, slot) do { if (!(cond)) atomicAdd(&g_lowp_why[slot], 1ull); } while (0)
+#else
+#define MSQ_WHY(cond, slot) do { } while (0)
+#endif
+template <int BS, int DT>
+MSQ_D bool outlier_block_pk(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2], uint32_t (&mk)[BS / 2], float& se_in_o, float& se_out_o,
+                            const OutlierArgs& A, int order, const uint8_t* l2tab, int kin, int kout) {
+    bool ok = true;
+    float lo, hi;
+    {
+        float ab[BS];
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j) {
+            const uint32_t a = pw[j] & 0x7FFF7FFFu;
+            if (DT == 1) { const lp_h2_t h = __builtin_bit_cast(lp_h2_t, a); ab[2 * j] = (float)h[0]; ab[2 * j + 1] = (float)h[1]; }
+            else { ab[2 * j] = u2f(a << 16); ab[2 * j + 1] = u2f(a & 0xFFFF0000u); }
+        }
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        const float c = s * (1.0f / (float)BS);                         // exact: BS is a power of two
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+        for (int b = 0; b < BS; b += 4) {
+            const float d0 = ab[b] - c, d1 = ab[b + 1] - c, d2 = ab[b + 2] - c, d3 = ab[b + 3] - c;
+            q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1); q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
+        }
+        const float var = ((q0 + q1) + (q2 + q3)) * (1.0f / (float)BS);
+        float sdp = __builtin_amdgcn_sqrtf(var);                        // v_sqrt_f32: 1 ulp (inside the margin below)
+        constexpr int DROP = (DT == 1) ? 13 : 16;
+        constexpr uint32_t MARG = BS / 8 + 7, HALF = 1u << (DROP - 1);
+        const uint32_t fr = f2u(sdp) & ((1u << DROP) - 1u);
+        const uint32_t dist = fr > HALF ? fr - HALF : HALF - fr;
+        const float sdmin = (DT == 1) ? 6.103515625e-05f : 8.8817841970012523e-16f, sdmax = (DT == 1) ? 60000.f : 1.125899906842624e15f;
+        const bool std_ok = dist > MARG && sdp >= sdmin && sdp <= sdmax && sdp >= (float)BS * 0.000244140625f * c;
+#ifndef MSQ_LOWP_NOSTD64
+        if (__builtin_amdgcn_ballot_w64(!std_ok) != 0ull) {
+            if (!std_ok) sdp = std_twopass_checked<BS>(ab, 0);
+        }
+#endif
+        const float mean = Rr<DT>(c);                                   // utils/quant.py:477
+        const float sd = Rr<DT>(sdp);                                   // :478
+        const float ks = Rr<DT>(A.k * sd);
+        lo = Rr<DT>(mean - ks); hi = Rr<DT>(mean + ks);                 // :489-490
+    }
+    ok = ok && lo == lo && hi == hi;
+    MSQ_WHY(lo == lo && hi == hi, 0);
+    // ---- mask and the two masked maxima, on the bit patterns
+    uint32_t mi = 0u, mo = 0u;
+    {
+        // a zero bound against a zero of the other sign: x < +-0 and x > +-0 are false for both zeros.  fp16: (-0) - (+0) = -0 would say
+        // "below" -- the lower bound becomes -0 (x - (-0) = x + 0 >= +0 for both zeros), the upper one +0; bf16: the key of -0 is -1, of +0
+        // is 0 -- "below zero" is key < -1, "above zero" is key > 0
+        const uint32_t lob = dup16((lo == 0.f) ? 0x8000u : t_bits<DT>(lo)), hib = dup16((hi == 0.f) ? 0u : t_bits<DT>(hi));
+        const uint32_t lok = lob ^ (pk_sign_fill(lob) & 0x7FFF7FFFu), hik = hib ^ (pk_sign_fill(hib) & 0x7FFF7FFFu);
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j) {
+            const uint32_t w = pw[j];
+            uint32_t sg;
+            if (DT == 1) {
+                const lp_h2_t x = __builtin_bit_cast(lp_h2_t, w);
+                sg = __builtin_bit_cast(uint32_t, (lp_h2_t)(x - __builtin_bit_cast(lp_h2_t, lob))) | __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, hib) - x));
+            } else {
+                const uint32_t key = w ^ (pk_sign_fill(w) & 0x7FFF7FFFu);
+                sg = pk_subsat_i16(key, lok) | pk_subsat_i16(hik, key);
+            }
+            const uint32_t m = pk_sign_fill(sg);                        // :492
+            mk[j] = m;
+            mo = pk_max_u16(mo, w & 0x7FFF7FFFu & m);
+            mi = pk_max_u16(mi, w & 0x7FFF7FFFu & ~m);
+        }
+    }
+    const uint32_t mib = (mi & 0xFFFFu) > (mi >> 16) ? (mi & 0xFFFFu) : (mi >> 16), mob = (mo & 0xFFFFu) > (mo >> 16) ? (mo & 0xFFFFu) : (mo >> 16);
+    constexpr uint32_t INFB = (DT == 1) ? 0x7C00u : 0x7F80u;
+    ok = ok && mib < INFB && mob < INFB;
+    MSQ_WHY(mib < INFB && mob < INFB, 1);
+    // ---- the two shared exponents (:196-211, :229-242)
+    // e_in: fp16 multiplies by 2^e_in and 2^-e_in as halves (normal for |e| <= 14).  e_out: the reference's R(2^e_out) must BE 2^e_out --
+    // below 2^-24 it is 0 in fp16 and every outlier of the block becomes NaN (x / 0), which is the op-by-op kernel's business
+    constexpr int ELO = (DT == 1) ? -14 : -50, EHI = (DT == 1) ? 14 : 50, EOLO = (DT == 1) ? -24 : -50, EOHI = (DT == 1) ? 14 : 50;
+    int ei, eo;
+    ok = scale_exp_int<DT>(mib, absmax_to_float<DT>(mib), A.fi.emax, A.in_sb, l2tab, ei) && ok;
+    se_in_o = (float)ei;
+    MSQ_WHY(ok, 2);
+    MSQ_WHY(ei >= ELO, 3); MSQ_WHY(ei <= EHI, 4);
+    ok = ok && ei >= ELO && ei <= EHI;
+    ei = ok ? ei : 0;
+    const float mx_out = Rr<DT>(__builtin_ldexpf(absmax_to_float<DT>(mob), ei));   // max over the block of R(o sc_in) (:216): monotone maps
+    // a block without (non-zero) outliers never uses the outlier scale: every masked element is +-0 and comes out as +0
+    const bool no_out = mob == 0u;
+    const bool eo_ok = scale_exp_int<DT>(t_bits<DT>(mx_out), mx_out, A.fo.emax, A.out_sb, l2tab, eo);
+    se_out_o = (float)eo;
+    MSQ_WHY(eo_ok, 5); MSQ_WHY(no_out || eo >= EOLO, 6); MSQ_WHY(no_out || eo <= EOHI, 7);
+    ok = ok && eo_ok && (no_out || (eo >= EOLO && eo <= EOHI));
+    eo = (ok && !no_out) ? eo : 0;
+    // ---- bounds (see the header): first tie, top binade and the raw tie of either side
+    const int mine_i = A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0, mine_o = A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0;
+    const int rawt_i = mine_i - A.fi.mbits + 1, rawt_o = mine_o - A.fo.mbits + 1;
+    const int tie_i = ei + rawt_i, tie_o = eo + rawt_o;                 // inliers: in x's domain; outliers: in the domain of x 2^e_in
+    if (DT == 1) {
+        // inliers enter their convert as halves: fp16's own spacing (2^-24) must be four times finer than the first tie; outliers enter
+        // theirs as float32 and need no such bound
+        ok = ok && tie_i >= -22 && ei + A.fi.emax + 1 <= 15 && (ei <= 0 || rawt_i >= -13)
+                && eo + A.fo.emax + 1 <= 15 && (eo <= 0 || rawt_o >= -13)
+                && eo + A.fo.emax >= -22;                               // the clamp bound max_norm 2^e_out is an fp16 value (1.75 2^k: k >= -22)
+        // nothing overflows fp16 on its way into either element domain: |t| < 2^(emax + 2) there (the exponent rule lifts by one at
+        // most; a clamped exponent only makes t smaller) -- only e5m2 (emax 15) can get past 65504
+        // -- nor does R(2^pe) of the largest private exponent (the rule may lift it to 16: Inf in fp16, NaN results in the reference)
+        if (A.fi.emax + 2 > 15) { const float ti = Rr<DT>(__builtin_ldexpf(absmax_to_float<DT>(mib), -ei)); ok = ok && ti < 3.0e38f && (ti == 0.f || floor_log2_tab<DT>(ti, l2tab) <= 15); }
+        if (A.fo.emax + 2 > 15) { const float to = Rr<DT>(__builtin_ldexpf(mx_out, -eo)); ok = ok && to < 3.0e38f && (to == 0.f || floor_log2_tab<DT>(to, l2tab) <= 15); }
+    }
+    if (DT == 1) { MSQ_WHY(tie_i >= -22, 8); MSQ_WHY(ei + A.fi.emax + 1 <= 15, 9); MSQ_WHY(ei <= 0 || rawt_i >= -13, 10);
+                   MSQ_WHY(eo + A.fo.emax + 1 <= 15, 11); MSQ_WHY(eo <= 0 || rawt_o >= -13, 12); MSQ_WHY(eo + A.fo.emax >= -22, 13); }
+    MSQ_WHY(ok, 14); MSQ_WHY(false, 15);
+    const int combo = kin * 4 + kout;
+    if (combo == 4 * 4 + 3) pk_codec_loop<BS, DT, 4, 3>(pw, mk, res, A, ei, eo, tie_i, tie_o);          // int2 / fp4: the harness default
+    else if (combo == 3 * 4 + 1) pk_codec_loop<BS, DT, 3, 1>(pw, mk, res, A, ei, eo, tie_i, tie_o);     // e2m1 / e4m3
+    else if (combo == 3 * 4 + 3) pk_codec_loop<BS, DT, 3, 3>(pw, mk, res, A, ei, eo, tie_i, tie_o);
+    else if (combo == 3 * 4 + 2) pk_codec_loop<BS, DT, 3, 2>(pw, mk, res, A, ei, eo, tie_i, tie_o);
+    else pk_codec_loop<BS, DT, 1, 1>(pw, mk, res, A, ei, eo, tie_i, tie_o);                             // e4m3 / e4m3 (the launcher admits these five)
+    return ok;
+}
+
+// Blocks along the contiguous axis (post == 1, whole blocks, 16-byte aligned): one lane per block; the 64 blocks of a wave are one
+// contiguous run that crosses to the lanes through the wave's LDS slice, as in k_outlier_lowp.  A wave with a block outside the packed
+// form's bounds writes nothing and puts itself on the list for k_outlier_lowp_list (keeping that path's ~250 registers out of this kernel:
+// inlined as a branch it halved the occupancy and cost a factor of three).
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
+    __shared__ uint8_t l2tab[256];
+    constexpr int CH = BS / 8, ROWB = BS * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char xsm[4 * 64 * ROWB];
+    floor_log2_tab_init<DT>(l2tab);
+    __syncthreads();
+    const int64_t total = A.pre * A.nblk;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_t0 = t - lane;
+    if (wave_t0 >= total) return;
+    const bool live = t < total, full = wave_t0 + 64 <= total;
+    char* const wsl = xsm + wv * (64 * ROWB);
+    const int64_t wave_base = wave_t0 * BS;
+    uint32_t pw[BS / 2];
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = c * 64 + lane;
+            *reinterpret_cast<uint4*>(wsl + (j / CH) * ROWB + (j % CH) * 16) = *reinterpret_cast<const uint4*>(in + wave_base + (int64_t)j * 8);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(wsl + lane * ROWB + c * 16);
+            pw[4 * c] = u.x; pw[4 * c + 1] = u.y; pw[4 * c + 2] = u.z; pw[4 * c + 3] = u.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint4 u = live ? *reinterpret_cast<const uint4*>(in + t * BS + c * 8) : make_uint4(0, 0, 0, 0);
+            pw[4 * c] = u.x; pw[4 * c + 1] = u.y; pw[4 * c + 2] = u.z; pw[4 * c + 3] = u.w;
+        }
+    }
+    uint32_t res[BS / 2], mk[BS / 2];
+    float se_in, se_out;
+    const bool ok = outlier_block_pk<BS, DT>(pw, res, mk, se_in, se_out, A, 1, l2tab, kin, kout) || !live;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+        if (lane == 0) ws[8 + atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull)] = wave_t0;
+        return;
+    }
+    if (full) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<uint4*>(wsl + lane * ROWB + c * 16) = make_uint4(res[4 * c], res[4 * c + 1], res[4 * c + 2], res[4 * c + 3]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = c * 64 + lane;
+            *reinterpret_cast<uint4*>(out + wave_base + (int64_t)j * 8) = *reinterpret_cast<const uint4*>(wsl + (j / CH) * ROWB + (j % CH) * 16);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<uint4*>(out + t * BS + c * 8) = make_uint4(res[4 * c], res[4 * c + 1], res[4 * c + 2], res[4 * c + 3]);
+    }
+    if (!live) return;
+    if (A.mask) {
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j)
+            *reinterpret_cast<uint16_t*>(A.mask + t * BS + 2 * j) = (uint16_t)((mk[j] & 1u) | ((mk[j] >> 8) & 0x100u));
+    }
+    if (A.e_in) A.e_in[t] = se_in;
+    if (A.e_out) A.e_out[t] = se_out;
+}
+
+// Blocks along a strided axis (post even, whole blocks, 4-byte aligned): one lane per PAIR of neighbouring columns -- a wave moves
+// 256 contiguous bytes per row --, the rows b, b + 1 of each column paired into one dword (v_perm) for the packed arithmetic.
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
+    __shared__ uint8_t l2tab[256];
+    floor_log2_tab_init<DT>(l2tab);
+    __syncthreads();
+    const int64_t hp = A.post / 2;
+    const int64_t total = A.pre * A.nblk * hp;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (t - lane >= total) return;
+    const bool live = t < total;
+    const int64_t tt = live ? t : t - lane;                              // (the wave's first lane is live)
+    const int64_t q = (tt % hp) * 2;
+    const int64_t nb = (tt / hp) % A.nblk;
+    const int64_t p = tt / (hp * A.nblk);
+    const int64_t base = (p * A.axis_len + nb * BS) * A.post + q;
+    uint32_t p0[BS / 2], p1[BS / 2];
+    // (lanes past the end re-read lane 0's columns and store nothing: no per-load branches)
+    const uint16_t* src = in + base;
+#pragma unroll
+    for (int j = 0; j < BS / 2; ++j) {
+        const uint32_t r0 = *reinterpret_cast<const uint32_t*>(src);
+        const uint32_t r1 = *reinterpret_cast<const uint32_t*>(src + A.post);
+        src += 2 * A.post;
+        p0[j] = __builtin_amdgcn_perm(r1, r0, 0x05040100u);
+        p1[j] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+    }
+    // ATen's order of the block sums (see outlier_lowp_lane): the same for both columns of a pair (the limits are even)
+    const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
+    const int order = (q < lim) ? 0 : 2;
+    uint32_t r0[BS / 2], r1[BS / 2], m0[BS / 2], m1[BS / 2];
+    float si0, so0, si1, so1;
+    const bool ok0 = outlier_block_pk<BS, DT>(p0, r0, m0, si0, so0, A, order, l2tab, kin, kout);
+    const bool ok1 = outlier_block_pk<BS, DT>(p1, r1, m1, si1, so1, A, order, l2tab, kin, kout);
+    if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1)) != 0ull) {
+        // this wave's columns are the lanes 2 (t - lane) ... + 127 of k_outlier_lowp's numbering: two of its waves
+        if (lane == 0) {
+            const unsigned long long i = atomicAdd(reinterpret_cast<unsigned long long*>(ws), 2ull);
+            ws[8 + i] = 2 * (t - lane); ws[8 + i + 1] = 2 * (t - lane) + 64;
+        }
+        return;
+    }
+    if (!live) return;
+    uint16_t* dst = out + base;
+#pragma unroll
+    for (int j = 0; j < BS / 2; ++j) {
+        *reinterpret_cast<uint32_t*>(dst) = __builtin_amdgcn_perm(r1[j], r0[j], 0x05040100u);
+        *reinterpret_cast<uint32_t*>(dst + A.post) = __builtin_amdgcn_perm(r1[j], r0[j], 0x07060302u);
+        dst += 2 * A.post;
+    }
+    if (A.mask) {
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j) {
+            *reinterpret_cast<uint16_t*>(A.mask + base + (int64_t)(2 * j) * A.post) = (uint16_t)((m0[j] & 1u) | ((m1[j] & 1u) << 8));
+            *reinterpret_cast<uint16_t*>(A.mask + base + (int64_t)(2 * j + 1) * A.post) = (uint16_t)(((m0[j] >> 16) & 1u) | (((m1[j] >> 16) & 1u) << 8));
+        }
+    }
+    const int64_t eidx = (p * A.nblk + nb) * A.post + q;
+    if (A.e_in) { A.e_in[eidx] = si0; A.e_in[eidx + 1] = si1; }
+    if (A.e_out) { A.e_out[eidx] = so0; A.e_out[eidx + 1] = so1; }
+}
+
 extern "C" void msq_set_error_(const char* msg);
 #include <atomic>
 #include <string.h>
 static std::atomic<int> g_mx_pair4{1};
-extern "C" void msq_set_tuning_lowp_(const char* key, int value) { if (key && !strcmp(key, "mx_lowp_pair4")) g_mx_pair4.store(value); }
+static std::atomic<int> g_outlier_pk{1};
+extern "C" void msq_set_tuning_lowp_(const char* key, int value) {
+    if (key && !strcmp(key, "mx_lowp_pair4")) g_mx_pair4.store(value);
+    if (key && !strcmp(key, "outlier_lowp_pk")) g_outlier_pk.store(value);
+}
 
 // in / out: fp16 (dtype 1) or bf16 (dtype 2) tensors [pre, axis_len, post]; blocks of `block` (8 ... 128) along the axis, the
 // last one zero padded; status_flag (device int, may be NULL) receives MSQ_STATUS_NAN when a shared exponent exceeds the
@@ -911,12 +1360,43 @@ __global__ void __launch_bounds__(256) k_floor_log2_lowp(const float* __restrict
 }
 
 // called from msq_outlier_fakequant (msq_quant.hip) for dtype MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE
-extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* stream) {
+// bytes of the list of handed-back waves: a 64-byte head (the count) + one 8-byte entry per wave of k_outlier_lowp's lane numbering
+extern "C" int64_t msq_outlier_lowp_ws_bytes_(int64_t pre, int64_t axis_len, int64_t post, int block) {
+    if (block != 16 && block != 32) return 0;
+    const int64_t lanes = pre * ((axis_len + block - 1) / block) * post;
+    return 64 + 8 * ((lanes + 63) / 64 + 2);
+}
+extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* ws, int64_t ws_bytes, void* stream) {
     const OutlierArgs& A = *(const OutlierArgs*)args;
     const int64_t n = A.pre * A.nblk * A.post;
     int64_t g = (n + 255) / 256; if (g < 1) g = 1;
     const dim3 grid((unsigned)g), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    // the packed form: round to nearest, the format pairs with a hardware codec, whole blocks of 16 / 32, aligned tensors, and a
+    // workspace for the list of waves it hands back (msq_outlier_workspace_bytes)
+    const int kin = hw_codec_kind(A.fi), kout = hw_codec_kind(A.fo), combo = kin * 4 + kout;
+    const bool pk_fmt = A.rmode == 0 && !A.flush && (combo == 4 * 4 + 3 || combo == 3 * 4 + 1 || combo == 3 * 4 + 3 || combo == 3 * 4 + 2 || combo == 1 * 4 + 1);
+    const uintptr_t al = (uintptr_t)in | (uintptr_t)out | (uintptr_t)A.mask;
+    if (pk_fmt && (block == 16 || block == 32) && (A.axis_len % block) == 0 && g_outlier_pk.load(std::memory_order_relaxed) != 0 &&
+        ws && ws_bytes >= msq_outlier_lowp_ws_bytes_(A.pre, A.axis_len, A.post, block) && ((uintptr_t)ws & 7) == 0) {
+        const bool contig = A.post == 1 && (al & 15) == 0;
+        const bool strided = A.post >= 2 && (A.post % 2) == 0 && (al & 3) == 0;
+        if (contig || strided) {
+            const int64_t lanes = contig ? A.pre * A.nblk : A.pre * A.nblk * (A.post / 2);
+            const dim3 gp((unsigned)((lanes + 255) / 256));
+            int64_t gl = (n + 255) / 256; if (gl > 512) gl = 512;
+            const dim3 glist((unsigned)gl);
+            if (hipMemsetAsync(ws, 0, 64, st) != hipSuccess) return 1;
+#define MSQ_LPK(BS, DTV)                                                                                               \
+            if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
+            else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
+            hipLaunchKernelGGL((k_outlier_lowp_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws);
+            if (block == 16) { if (dt == 1) { MSQ_LPK(16, 1) } else { MSQ_LPK(16, 2) } }
+            else { if (dt == 1) { MSQ_LPK(32, 1) } else { MSQ_LPK(32, 2) } }
+#undef MSQ_LPK
+            return 1;
+        }
+    }
 #define MSQ_LP(BS)                                                                                                     \
     case BS:                                                                                                           \
         if (dt == 1) hipLaunchKernelGGL((k_outlier_lowp<BS, 1>), grid, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A); \
