@@ -422,8 +422,74 @@ k_outlier_lowp(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, Outl
     __syncthreads();
     outlier_lowp_lane<BS, DT>(in, out, A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, l2tab, xsm);
 }
-// The waves the packed kernels below could not take (their list: ws[0] = count, ws[8 ...] = first lane of each, in this kernel's lane
-// numbering): a fixed grid walks the list, one entry per wave and trip.
+// NaN-keeping maximum over the BS lanes of a block (the sequential `t > mx || t != t ? t : mx` ends on NaN iff one member is NaN)
+template <int BS> MSQ_D float group_max_nan(float t) {
+#pragma unroll
+    for (int o = 1; o < BS; o <<= 1) {
+        const float u = __shfl_xor(t, o, 64);
+        t = (u > t || u != u) ? u : t;
+    }
+    return t;
+}
+// The op-by-op path of outlier_block_lowp with ONE ELEMENT per lane (the BS lanes of a block are neighbours inside a wave; every lane holds
+// the whole block for the statistics, which it computes redundantly).  A handed-back wave is one instruction stream of ~250 instructions per
+// element whatever the number of lanes that need it: a lane per block walks BS elements of it (~30 us for a few entries, longer than the
+// packed kernel itself), a lane per element one.  blk[]: the block's BS values; x = blk[i], this lane's.
+template <int BS, int DT>
+MSQ_D float outlier_elem_lowp(const float (&blk)[BS], float x, bool& mask, float& se_in_o, float& se_out_o, int& status, const OutlierArgs& A, int order) {
+    float lo, hi;
+    {
+        float ab[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) ab[b] = __builtin_fabsf(blk[b]);
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        const float mean = Rr<DT>(s / (float)BS);                       // utils/quant.py:477
+        const float sd = Rr<DT>(std_twopass_checked<BS>(ab, 0));        // :478
+        const float ks = Rr<DT>(A.k * sd);
+        lo = Rr<DT>(mean - ks); hi = Rr<DT>(mean + ks);                 // :489-490
+    }
+    const bool m = (x < lo) || (x > hi);                                // :492
+    mask = m;
+    const float mf = m ? 1.f : 0.f;
+    float inl = x * (1.0f - mf);                                        // :192
+    float a = x * mf;                                                   // :193
+    const float mx_in = group_max_nan<BS>(__builtin_fabsf(inl));
+    float se_in = shared_exp_lowp<DT>(mx_in);                           // :196-198
+    const bool fl = A.flush && !(se_in > -127.f);
+    se_in = Rr<DT>(se_in - (float)A.fi.emax);                           // :207
+    se_in = clamp_scale_exp(se_in, A.in_sb, 0);                         // :208-211
+    const float sc_in = pow2_lowp<DT>(se_in);
+    const Div d_in = make_div(sc_in);
+    float v = inl;
+    if (fl) v = v * 0.f;
+    v = Rr<DT>(divp(v, d_in));                                          // :214
+    a = Rr<DT>(a * sc_in);                                              // :216
+    v = core_lowp<DT>(v, A.fi, A.rmode);                                // :218-221
+    v = Rr<DT>(v * sc_in);                                              // :224
+    if (v != v || a != a) status |= MSQ_STATUS_NAN;                     // :225-226
+    const float mx_out = group_max_nan<BS>(__builtin_fabsf(a));
+    float se_out = shared_exp_lowp<DT>(mx_out);                         // :229-231
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    se_out = Rr<DT>(se_out - (float)A.fo.emax);                         // :237
+    se_out = clamp_scale_exp(se_out, A.out_sb, 0);                      // :239-242
+    if (se_out != se_out) status |= MSQ_STATUS_NAN;
+    const float sc_out = pow2_lowp<DT>(se_out);
+    const Div d_out = make_div(sc_out);
+    float o = Rr<DT>(divp(a, d_out));                                   // :247
+    if (o != o) status |= MSQ_STATUS_NAN;                               // :250
+    o = core_lowp<DT>(o, A.fo, A.rmode);                                // :252-255
+    o = Rr<DT>(divp(Rr<DT>(o * sc_out), d_in));                         // :258
+    se_in_o = se_in; se_out_o = se_out;
+    return Rr<DT>(v + o);                                               // :262
+}
+
+// The waves the packed kernels below could not take (their list: ws[0] = count, ws[8 ...] = first lane of each, in k_outlier_lowp's lane
+// numbering).  A short list (the usual case: a few blocks without inliers per tensor) is done one element per lane -- a thread block takes
+// 256 / BS of an entry's 64 blocks per trip; a long one (a tensor outside the packed form's bounds altogether) one block per lane, as
+// k_outlier_lowp would have: the redundant statistics of the first form cost throughput, the second costs latency.
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws) {
@@ -431,6 +497,42 @@ k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
     __shared__ __attribute__((aligned(16))) char xsm[4 * 64 * (BS * 2 + 16)];
     const int64_t count = ws[0];
     if (count == 0) return;
+    const int64_t total = A.pre * A.nblk * A.post;
+    if (count * 16 <= (total + 63) / 64) {
+        constexpr int BPT = 256 / BS, TRIPS = 64 / BPT;                 // blocks per trip; trips per entry
+        uint16_t* const sx = reinterpret_cast<uint16_t*>(xsm);
+        const int lb = threadIdx.x / BS, i = threadIdx.x % BS;
+        for (int64_t w = blockIdx.x; w < count * TRIPS; w += gridDim.x) {
+            const int64_t t = ws[8 + w / TRIPS] + (w % TRIPS) * BPT + lb;
+            const bool live = t < total;
+            const int64_t tt = live ? t : 0;
+            const int64_t q = tt % A.post, nb = (tt / A.post) % A.nblk, p = tt / (A.post * A.nblk);
+            const int64_t at = ((p * A.axis_len + nb * BS + i) * A.post) + q;
+            __syncthreads();
+            sx[threadIdx.x] = in[at];
+            __syncthreads();
+            float blk[BS];
+#pragma unroll
+            for (int b = 0; b < BS; ++b) blk[b] = ld16<DT>(sx, lb * BS + b);
+            int order = 1;                                           // reduced dim contiguous
+            if (A.post > 1) {
+                const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
+                order = (q < lim) ? 0 : 2;
+            }
+            bool m; float se_in, se_out; int status = 0;
+            const float r = outlier_elem_lowp<BS, DT>(blk, ld16<DT>(sx, threadIdx.x), m, se_in, se_out, status, A, order);
+            if (live) {
+                st16<DT>(out, at, r);
+                if (A.mask) A.mask[at] = (uint8_t)m;
+                if (i == 0) {
+                    if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
+                    if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
+                }
+                if (status && A.status) atomicOr(A.status, status);
+            }
+        }
+        return;
+    }
     floor_log2_tab_init<DT>(l2tab);
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -994,9 +1096,14 @@ MSQ_D void pk_codec_loop(const uint32_t (&pw)[BS / 2], const uint32_t (&mk)[BS /
             if (KI == 4) ri = pk_mul_u16(pk_min_u16(pk_subsat_u16(a, h_in), 0x00010001u), st_in);
             else ri = hw_mag_pair<DT, KI>(pk_lift(a, q_in), s_in, s_in, b_in);
             const uint32_t t1 = __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, a) * __builtin_bit_cast(lp_h2_t, m_dn)));
-            uint32_t tl = pk_add_u16(t1, pk_subsat_u16(0x00020002u, t1 ^ q_out));
-            if (KO != 3 || MSQ_LOWP_FP4_CLAMP) tl = pk_min_u16(tl, b_out);
-            const uint32_t q = hw_mag_pair_f32src<KO>(tl, s_out);
+            uint32_t q;
+            if (KO == 3) {
+                // e2m1 spans four binades: with the first tie at 2^-22 or above (checked per block) the half's own spacing is fine enough
+                q = hw_mag_pair<DT, KO>(pk_lift(t1, q_out), s_out, s_out, b_out);
+            } else {
+                const uint32_t tl = pk_min_u16(pk_add_u16(t1, pk_subsat_u16(0x00020002u, t1 ^ q_out)), b_out);
+                q = hw_mag_pair_f32src<KO>(tl, s_out);
+            }
             ro = __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, q) * __builtin_bit_cast(lp_h2_t, m_up)));
         } else {
             // one lift serves both converts: each element uses the result of its own side only
@@ -1006,8 +1113,14 @@ MSQ_D void pk_codec_loop(const uint32_t (&pw)[BS / 2], const uint32_t (&mk)[BS /
             ro = hw_mag_pair<DT, KO>(in, s_out, s_out, b_out);
         }
         const uint32_t rm = (ro & m) | (ri & ~m);
-        // the sign where the magnitude is not zero (rm <= 0x7FFF: rm + 0x7FFF has bit 15 set iff rm != 0)
-        res[j] = ((pk_add_u16(rm, 0x7FFF7FFFu) & w) & 0x80008000u) | rm;
+        if (DT == 1) {
+            // the sign: rm * (+-1) + 0 -- a zero comes out as +0 whatever its factor's sign (v_pk_fma_f16; exact)
+            const lp_h2_t z = {(_Float16)0.f, (_Float16)0.f};
+            res[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(lp_h2_t, rm), __builtin_bit_cast(lp_h2_t, (w & 0x80008000u) | 0x3C003C00u), z));
+        } else {
+            // the sign where the magnitude is not zero (rm <= 0x7FFF: rm + 0x7FFF has bit 15 set iff rm != 0)
+            res[j] = ((pk_add_u16(rm, 0x7FFF7FFFu) & w) & 0x80008000u) | rm;
+        }
     }
 }
 
@@ -1063,7 +1176,9 @@ MSQ_D bool outlier_block_pk(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2
         const float var = ((q0 + q1) + (q2 + q3)) * (1.0f / (float)BS);
         float sdp = __builtin_amdgcn_sqrtf(var);                        // v_sqrt_f32: 1 ulp (inside the margin below)
         constexpr int DROP = (DT == 1) ? 13 : 16;
-        constexpr uint32_t MARG = BS / 8 + 7, HALF = 1u << (DROP - 1);
+        // |sd' - (float) sd_double| <= (BS / 8 + 2.5) [four fma chains of BS / 4, two adds, the rounded differences, half of it through the root]
+        // + 1 [v_sqrt_f32] + 0.5 [the double's own rounding to float] ulps; one more for good measure
+        constexpr uint32_t MARG = BS / 8 + 5, HALF = 1u << (DROP - 1);
         const uint32_t fr = f2u(sdp) & ((1u << DROP) - 1u);
         const uint32_t dist = fr > HALF ? fr - HALF : HALF - fr;
         const float sdmin = (DT == 1) ? 6.103515625e-05f : 8.8817841970012523e-16f, sdmax = (DT == 1) ? 60000.f : 1.125899906842624e15f;
@@ -1137,7 +1252,8 @@ MSQ_D bool outlier_block_pk(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2
         // theirs as float32 and need no such bound
         ok = ok && tie_i >= -22 && ei + A.fi.emax + 1 <= 15 && (ei <= 0 || rawt_i >= -13)
                 && eo + A.fo.emax + 1 <= 15 && (eo <= 0 || rawt_o >= -13)
-                && eo + A.fo.emax >= -22;                               // the clamp bound max_norm 2^e_out is an fp16 value (1.75 2^k: k >= -22)
+                && eo + A.fo.emax >= -22                                // the clamp bound max_norm 2^e_out is an fp16 value (1.75 2^k: k >= -22)
+                && (kout != 3 || tie_o >= -22);                         // e2m1 outliers enter as halves too (pk_codec_loop)
         // nothing overflows fp16 on its way into either element domain: |t| < 2^(emax + 2) there (the exponent rule lifts by one at
         // most; a clamped exponent only makes t smaller) -- only e5m2 (emax 15) can get past 65504
         // -- nor does R(2^pe) of the largest private exponent (the rule may lift it to 16: Inf in fp16, NaN results in the reference)

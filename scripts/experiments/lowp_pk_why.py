@@ -13,7 +13,7 @@ buf = (ctypes.c_ulonglong * 16)()
 g = torch.Generator(device=F.dev).manual_seed(7)
 for dt in (torch.float16, torch.bfloat16):
     for kind in sys.argv[1:] or ["weights", "ties", "scales", "sparse", "negative", "subnormal"]:
-        W = F.make(kind, (2048, 1024), dt, g)
+        W = F.make(kind, tuple(int(v) for v in os.environ.get("WHY_SHAPE", "2048,1024").split(",")), dt, g)
         for fi, fo in (("int2", "fp4"), ("fp4_e2m1", "fp8_e4m3")):
             for axis, bs in ((0, 16), (-1, 32)):
                 L.msq_lowp_why_(buf, 1)
