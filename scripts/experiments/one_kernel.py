@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch one side kernel a few times (for rocprofv3 --pmc passes).  Usage: python3 scripts/experiments/one_kernel.py layernorm|gelu|kv16|kv32|act0|act1|pack_posit|lowp16|kvmx_keys|kvmx_values|rms_pack|silu_pack"""
+"""Launch one side kernel a few times (for rocprofv3 --pmc passes).  Usage: python3 scripts/experiments/one_kernel.py layernorm|gelu|kv16|kv32|act0|act1|pack_posit|lowp16|lowp16_h|lowpbf_h|kvmx_keys|kvmx_values|rms_pack|silu_pack"""
 import os
 import sys
 
@@ -25,6 +25,8 @@ fn = None if what.startswith(("sk", "gemm3_")) else {"layernorm": lambda: vector
       "act0": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 2, 32, "nearest", False, 0),
       "act1": lambda: qlinear.act_quant(X, 8, 8, "fp8_e4m3", "fp8_e4m3", 5, 32, "nearest", False, 1),
       "lowp16": lambda: msq.quant.outlier_fakequant(W16, 8, 8, "fp4_e2m1", "fp8_e4m3", 2, -1, 32),
+      "lowp16_h": lambda: msq.quant.outlier_fakequant(W16, 8, 8, "int2", "fp4", 2, 0, 16),               # the harness call (llm/llama.py:229-253)
+      "lowpbf_h": lambda: msq.quant.outlier_fakequant(W.to(torch.bfloat16), 8, 8, "int2", "fp4", 2, 0, 16),
       "pack_posit": lambda: qlinear.pack_weight(W, 8, 8, "fp4_e2m1", "posit8_es1", 2, 32, layout="unified"), "gemv_gateup": None,
       # round 5: KV-cache MX-FP8 keys / values in fp16, the fused producers
       "kvmx_keys": lambda: kvcache.mx_quantize_keys(C16, "fp8_e4m3", 32), "kvmx_values": lambda: kvcache.mx_quantize_values(C16, "fp8_e4m3", 32),
