@@ -501,7 +501,8 @@ def _clone_packed(P):
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 achievable)
 # sub-objects of the default line's `configs` (BASELINE.json configs 3, 4, 5 and decode) and of `rowparallel`: the --stub path emits
 # the same keys, tests/test_host_logic.py pins them
-CONFIG_KEYS = ("w4a8_mx", "w4a8_mx_plain_fp4", "w6a8_mx_plain_fp6", "producers", "w4a8_mxlinear", "kv_quant", "decode_cold", "rowparallel_70b_1gpu", "m_sweep", "layer7b_prefill")
+CONFIG_KEYS = ("w4a8_mx", "w4a8_mx_plain_fp4", "w6a8_mx_plain_fp6", "producers", "w4a8_mxlinear", "kv_quant", "rtn_fakequant_in_dtype", "decode_cold", "rowparallel_70b_1gpu", "m_sweep",
+               "layer7b_prefill")
 ROWPAR_KEYS = ("step_ms", "gemm_ms", "comm_ms", "exposed_comm_ms", "chunks", "comm", "wire_dtype")
 
 
@@ -808,6 +809,27 @@ def other_configs(dev, M=2048, H=4096, inlier="fp4_e2m1", block=32):
         ms = _tgraph([fn] * 10)
         kv[key] = {"ms": ms, "GBps": byts / ms / 1e6, "frac": byts / ms / 1e6 / HBM_PEAK_GBPS}
     out["kv_quant"] = dict(kv, bytes=byts, bound="hbm", peak=HBM_PEAK_GBPS, cache="[1, 32, 4096, 128] float16 (read once + written once)")
+    # ---- the RTN harness's own call (llm/llama.py:229-253): quantize_mx_outlier_v1 on the checkpoint IN its dtype, W[4H, H]; the packed kernels of
+    # DESIGN.md 5.005 (k_outlier_lowp_pk / _pk2).  Algorithmic bytes: the tensor read once + written once
+    rtn = {}
+    Wr = synth_weight(N, K, dev, seed=0)
+    for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        Wh = Wr.to(dt)
+        for nm, fi_, fo_, ax_, bs_ in (("int2_fp4_b16_out_features", "int2", "fp4", 0, 16), ("fp4_fp8e4m3_b32_in_features", inlier, "fp8_e4m3", -1, block)):
+            fn = lambda Wh=Wh, fi_=fi_, fo_=fo_, ax_=ax_, bs_=bs_: quant.outlier_fakequant(Wh, 8, 8, fi_, fo_, 2, ax_, bs_)
+            keep, quant.CHECK_NAN = quant.CHECK_NAN, False                 # (the status read-back is a host sync: not inside a graph)
+            try:
+                for _ in range(10):
+                    fn()
+                ms = _tgraph([fn] * 10)
+            finally:
+                quant.CHECK_NAN = keep
+            by = 2.0 * Wh.numel() * 2
+            rtn[dn + "_" + nm] = {"ms": ms, "GBps": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBPS}
+        del Wh
+    del Wr
+    out["rtn_fakequant_in_dtype"] = dict(rtn, bytes=2.0 * N * K * 2, bound="hbm (kernels: issue-bound, 28-32 VALU per weight)", peak=HBM_PEAK_GBPS, N=N, K=K,
+                                         what="utils/quant.py:147-266 computed in the checkpoint dtype, every op rounded as ATen's CPU half kernels do; bit-exact vs the reference")
     # ... and config 4's METRIC end to end on the committed fixture (tests/golden/gsm8k_fixture: a 2-layer Llama trained on two-step word problems,
     # few-shot prompt, 96 problems): the loop of kv_quant/evaluation_gsm8k.py:455-533 (harness/gsm8k.py evaluate) with MXKVCache at the GEAR hook
     try:

@@ -153,6 +153,9 @@ def test_bench_other_configs_keys_and_rates(bench_line):
     kv = c["kv_quant"]
     for k in ("keys_group_4bit_per_channel_g32", "values_group_4bit_per_token_g32", "keys_mx_fp8_blocks_along_tokens", "values_mx_fp8_blocks_along_head_dim"):
         assert kv[k]["ms"] > 0 and kv[k]["frac"] > 0.1, kv
+    rt = c["rtn_fakequant_in_dtype"]                           # round 6: the harness's fake-quant in the checkpoint dtype on the packed kernels (5.005)
+    for k in ("fp16_int2_fp4_b16_out_features", "fp16_fp4_fp8e4m3_b32_in_features", "bf16_int2_fp4_b16_out_features", "bf16_fp4_fp8e4m3_b32_in_features"):
+        assert rt[k]["ms"] > 0 and rt[k]["frac"] >= 0.35 and abs(rt[k]["GBps"] - rt["bytes"] / rt[k]["ms"] / 1e6) < 1e-6, rt   # the review's bar: 0.35 of HBM
     pr = c["producers"]                                        # round 5: fused RMSNorm / silu x up -> MX-FP8 operand in front of the GEMM
     for k in ("rmsnorm_then_qkv_shape_gemm", "silu_mul_then_down_proj"):
         assert pr[k]["ms_fused_producer_gemm"] > 0 and pr[k]["speedup"] > 1.02 and pr[k]["producer_frac_of_hbm"] > 0.2, pr[k]
