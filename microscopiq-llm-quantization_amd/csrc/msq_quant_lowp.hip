@@ -1478,7 +1478,7 @@ __global__ void __launch_bounds__(256) k_floor_log2_lowp(const float* __restrict
 // called from msq_outlier_fakequant (msq_quant.hip) for dtype MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE
 // bytes of the list of handed-back waves: a 64-byte head (the count) + one 8-byte entry per wave of k_outlier_lowp's lane numbering
 extern "C" int64_t msq_outlier_lowp_ws_bytes_(int64_t pre, int64_t axis_len, int64_t post, int block) {
-    if (block != 16 && block != 32) return 0;
+    if (block != 8 && block != 16 && block != 32 && block != 64) return 0;
     const int64_t lanes = pre * ((axis_len + block - 1) / block) * post;
     return 64 + 8 * ((lanes + 63) / 64 + 2);
 }
@@ -1488,12 +1488,12 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
     int64_t g = (n + 255) / 256; if (g < 1) g = 1;
     const dim3 grid((unsigned)g), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    // the packed form: round to nearest, the format pairs with a hardware codec, whole blocks of 16 / 32, aligned tensors, and a
+    // the packed form: round to nearest, the format pairs with a hardware codec, whole blocks of 8 ... 64, aligned tensors, and a
     // workspace for the list of waves it hands back (msq_outlier_workspace_bytes)
     const int kin = hw_codec_kind(A.fi), kout = hw_codec_kind(A.fo), combo = kin * 4 + kout;
     const bool pk_fmt = A.rmode == 0 && !A.flush && (combo == 4 * 4 + 3 || combo == 3 * 4 + 1 || combo == 3 * 4 + 3 || combo == 3 * 4 + 2 || combo == 1 * 4 + 1);
     const uintptr_t al = (uintptr_t)in | (uintptr_t)out | (uintptr_t)A.mask;
-    if (pk_fmt && (block == 16 || block == 32) && (A.axis_len % block) == 0 && g_outlier_pk.load(std::memory_order_relaxed) != 0 &&
+    if (pk_fmt && (block == 8 || block == 16 || block == 32 || block == 64) && (A.axis_len % block) == 0 && g_outlier_pk.load(std::memory_order_relaxed) != 0 &&
         ws && ws_bytes >= msq_outlier_lowp_ws_bytes_(A.pre, A.axis_len, A.post, block) && ((uintptr_t)ws & 7) == 0) {
         const bool contig = A.post == 1 && (al & 15) == 0;
         const bool strided = A.post >= 2 && (A.post % 2) == 0 && (al & 3) == 0;
@@ -1507,8 +1507,10 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
             if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
             else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
             hipLaunchKernelGGL((k_outlier_lowp_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws);
-            if (block == 16) { if (dt == 1) { MSQ_LPK(16, 1) } else { MSQ_LPK(16, 2) } }
-            else { if (dt == 1) { MSQ_LPK(32, 1) } else { MSQ_LPK(32, 2) } }
+            if (block == 8) { if (dt == 1) { MSQ_LPK(8, 1) } else { MSQ_LPK(8, 2) } }
+            else if (block == 16) { if (dt == 1) { MSQ_LPK(16, 1) } else { MSQ_LPK(16, 2) } }
+            else if (block == 32) { if (dt == 1) { MSQ_LPK(32, 1) } else { MSQ_LPK(32, 2) } }
+            else { if (dt == 1) { MSQ_LPK(64, 1) } else { MSQ_LPK(64, 2) } }
 #undef MSQ_LPK
             return 1;
         }

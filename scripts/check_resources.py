@@ -18,6 +18,7 @@ ALLOW = [
     #     configuration use 16 or 32, which live in registers); never a measured configuration
     (r"^k_outlier_(contig|strided)<(64|128)[,>]", 1600, "block 64 / 128 fall-back, fp32"),
     (r"^k_outlier_lowp<(64|128)[,>]", 1600, "block 64 / 128 fall-back, in-dtype fp16 / bf16"),
+    (r"^k_outlier_lowp_list<64[,>]", 600, "the same op-by-op path behind the packed kernels (blocks of 64: the waves they hand back)"),
     (r"^k_mx_lowp<(64|128)[,>]", 600, "block 64 / 128 fall-back, plain MX in-dtype"),
     (r"^k_act_quant<64[,>]", 300, "block 64 fall-back of the mx_ops activation quantiser (configs use 32)"),
     (r"^k_gptq_block<64>", 300, "GPTQ column solver at quant block 64 (harness: 16, BASELINE: 32)"),

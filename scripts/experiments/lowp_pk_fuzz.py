@@ -129,7 +129,9 @@ def main():
                         continue
                     W = make(kind, shape, dt, g)
                     for fi, fo in COMBOS:
-                        for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16)):
+                        for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16), (0, 8), (-1, 8), (0, 64), (-1, 64)):
+                            if W.shape[axis] % bs:
+                                continue
                             for sd, sb in ((2.0, 8), (3.0, 8), (1.0, 4)):
                                 a = run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:], kind))
                                 b = run(W, fi, fo, sd, axis, bs, sb, 0)

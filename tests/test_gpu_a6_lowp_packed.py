@@ -67,7 +67,7 @@ def test_packed_kernels_without_workspace_fall_back(msq):
 
 def test_packed_vs_op_by_op_adversarial(msq):
     """The generator of scripts/experiments/lowp_pk_fuzz.py, one round on the two small shapes: every kind of input, five format pairs, both axes,
-    blocks of 16 and 32, three (std_dev, scale bits) settings, both dtypes -- and every kind is partly ON the packed path (a comparison of the
+    blocks of 8 / 16 / 32 / 64, three (std_dev, scale bits) settings, both dtypes -- and every kind is partly ON the packed path (a comparison of the
     op-by-op kernel with itself proves nothing)."""
     F = _fuzz()
     F.HANDED.clear()
@@ -79,7 +79,9 @@ def test_packed_vs_op_by_op_adversarial(msq):
             for shape in ((256, 512), (96, 160)):
                 W = F.make(kind, shape, dt, g)
                 for fi, fo in F.COMBOS:
-                    for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16)):
+                    for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16), (0, 8), (-1, 8), (0, 64), (-1, 64)):
+                        if W.shape[axis] % bs:
+                            continue
                         for sd, sb in ((2.0, 8), (3.0, 8), (1.0, 4)):
                             a = F.run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:], kind))
                             b = F.run(W, fi, fo, sd, axis, bs, sb, 0)
@@ -87,7 +89,7 @@ def test_packed_vs_op_by_op_adversarial(msq):
                             assert torch.equal(a["mask"], b["mask"]) and F.same(a["e_in"], b["e_in"]) and F.same(a["e_out"], b["e_out"]), (dt, kind, shape, fi, fo, axis, bs)
                             assert a["status"] == b["status"], (dt, kind, shape, fi, fo, axis, bs, sd, sb)
                             n += 1
-    assert n == 2 * len(kinds) * 2 * 5 * 4 * 3
+    assert n == 2 * len(kinds) * (8 + 6) * 5 * 3          # [256, 512]: all eight (axis, block) settings; [96, 160]: 64 does not divide either axis
     for (dn, kind), (h, w) in F.HANDED.items():
         assert h < w, (dn, kind, h, w)                     # some waves of every kind stayed on the packed path
     for dn in ("float16", "bfloat16"):
@@ -107,7 +109,7 @@ def test_goldens_that_run_on_the_packed_kernels(msq):
     for key, m in sorted(meta.items()):
         dn, tname, cname = key.split("|")
         isb, osb, fi, fo, sd, axes, bs, rnd = m["cfg"]
-        if "assert" in m or rnd != "nearest" or (fi, fo) not in pairs or bs not in (16, 32) or isb != osb:
+        if "assert" in m or rnd != "nearest" or (fi, fo) not in pairs or bs not in (8, 16, 32, 64) or isb != osb:
             continue
         bits = torch.from_numpy(z[f"in|{dn}|{tname}"].astype(np.int16))
         A = bits.view(torch.float16 if dn == "f16" else torch.bfloat16).to(dev())
