@@ -126,3 +126,33 @@ def test_goldens_that_run_on_the_packed_kernels(msq):
         taken += 1
         whole += int(h == 0)
     assert taken >= 40 and whole >= 20, (taken, whole)
+
+
+def test_packed_kernels_on_tensors_with_leading_and_trailing_dims(msq):
+    """[pre, axis, post] with pre > 1 and post > 1 (the KV-cache shape [B, H, T, D] quantised along T or D; a stacked-expert weight): the strided
+    kernel walks (p, block, column pair), the contiguous one p * nblk blocks; partial last waves on both; odd post (no column pairs) and a ragged
+    axis take the op-by-op kernel."""
+    F = _fuzz()
+    g = torch.Generator(device=dev()).manual_seed(3)
+    keep, msq.quant.CHECK_NAN = msq.quant.CHECK_NAN, False        # (compare the tensors themselves: the reference's NaN blocks included)
+    try:
+        _nd_cases(msq, F, g)
+    finally:
+        msq.quant.CHECK_NAN = keep
+
+
+def _nd_cases(msq, F, g):
+    for dt in (torch.float16, torch.bfloat16):
+        for shape in ((6, 64, 40), (3, 5, 96, 32), (2, 32, 7), (4, 40, 64)):
+            W = (torch.randn(*shape, generator=g, device=dev()) * 0.05).to(dt)
+            for axis in range(1, len(shape)):
+                for bs in (16, 32):
+                    for fi, fo in (("int2", "fp4"), ("fp4_e2m1", "fp8_e4m3")):
+                        a = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, axis, bs, want_mask=True, want_exps=True)
+                        assert msq._lib.lib().msq_set_tuning(b"MSQ_OUTLIER_LOWP_PK", 0) == 0
+                        try:
+                            b = msq.quant.outlier_fakequant(W, 8, 8, fi, fo, 2, axis, bs, want_mask=True, want_exps=True)
+                        finally:
+                            msq._lib.lib().msq_set_tuning(b"MSQ_OUTLIER_LOWP_PK", 1)
+                        assert F.same(a["out"], b["out"]) and torch.equal(a["mask"], b["mask"]), (dt, shape, axis, bs, fi)
+                        assert F.same(a["e_in"], b["e_in"]) and F.same(a["e_out"], b["e_out"]), (dt, shape, axis, bs, fi)
