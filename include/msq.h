@@ -157,9 +157,9 @@ int msq_reduce_max_inner(const float* in, float* out, int64_t outer, int64_t inn
  *   workspace     device scratch of msq_outlier_workspace_bytes() bytes: variant 1 needs it; variant 0 uses it for fp16 / bf16 tensors
  *                 computed in their dtype (MSQ_DTYPE_*_NATIVE: the list of waves the packed kernels hand back to the op-by-op kernel,
  *                 csrc/msq_quant_lowp.hip) -- NULL there runs the op-by-op kernel alone: same results, a third of the speed
- * in/out dtype: 0 = f32 (bit-exact vs the reference); 2 = bf16 tensors (read as f32 values, computed in f32, one
+ * in/out dtype: 0 = f32 (bit-exact vs the reference); 1 = fp16 / 2 = bf16 tensors (read as f32 values, computed in f32, one
  *   round-to-nearest-even on the way out: the same bits as upcasting, running dtype 0 and casting back), built for
- *   round-to-nearest with float / int inlier formats, variant 0; 1 = f16 and the remaining combinations return
+ *   round-to-nearest with float / int inlier formats, variant 0; the remaining combinations return
  *   MSQ_ERR_UNSUPPORTED (the Python shim upcasts).
  *   MSQ_DTYPE_F16_NATIVE / MSQ_DTYPE_BF16_NATIVE = fp16 / bf16 tensors COMPUTED IN THAT DTYPE: every torch op of
  *   utils/quant.py:147-266 rounded back to the tensor dtype as ATen's CPU half kernels do -- what the reference's RTN

@@ -20,6 +20,25 @@ template <> struct IO<bf16io_t> {
     static MSQ_D void st(bf16io_t* p, int64_t i, float v) { p[i].v = __builtin_bit_cast(uint16_t, (__bf16)v); }
 };
 
+// float16 tensors: likewise (every fp16 is an fp32 value); written with v_cvt_f16_f32 = torch's .to(float16): nearest even, subnormals kept,
+// overflow to Inf.  Same result as upcast -> compute -> downcast, without the two cast passes (the MicroScopiQ KV cache runs this: kvcache.py)
+struct f16io_t { uint16_t v; };
+template <> struct IO<f16io_t> {
+    static MSQ_D float ld(const f16io_t* p, int64_t i) { return (float)__builtin_bit_cast(_Float16, p[i].v); }
+    static MSQ_D void st(f16io_t* p, int64_t i, float v) { p[i].v = __builtin_bit_cast(uint16_t, (_Float16)v); }
+};
+// two values of a dword of a 16-bit tensor (low half first), and back
+template <typename T> MSQ_D void unpack2(uint32_t w, float& lo, float& hi) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16io_t)) {
+        lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+    } else { lo = u2f(w << 16); hi = u2f(w & 0xFFFF0000u); }
+}
+template <typename T> MSQ_D uint32_t pack2(float lo, float hi) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16io_t))
+        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
+    else return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+}
+
 template <int BS>
 MSQ_D void outlier_side_outputs(const OutlierArgs& A, const uint32_t (&mkw)[(BS + 31) / 32], float se_in,
                                 float se_out, int status, int64_t p, int64_t nb, int64_t q) {
@@ -76,6 +95,57 @@ k_outlier_strided(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) 
     outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, q);
 }
 
+// --- layout A for 16-bit tensors with an even contiguous extent (the K cache: blocks of BS tokens of one channel, post = head_dim): one lane
+// per PAIR of neighbouring columns, 4-byte accesses -- a wave moves 256 contiguous bytes per row instead of 128, half as many memory
+// instructions per byte.  The two columns are two blocks, quantised one after the other; the results wait in the dwords they came from.
+// Worth 2-4 % only (fp16 keys [1, 32, 4096, 128], fp4 + fp8 outliers: 48.7 -> 46.6 us; bf16 W[16384,4096] blocks of 32 along out_features
+// 161.9 -> 158.4 us): these launches are one round of waves whose length is a lane's serial walk through its blocks, not memory instructions.
+template <int BS, typename T, int FAST>
+__global__ void __launch_bounds__(256)
+k_outlier_strided_pair(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
+    static_assert(sizeof(T) == 2, "16-bit tensors");
+    const int64_t hp = A.post / 2;
+    const int64_t total = A.pre * A.nblk * hp;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t q = (t % hp) * 2;
+    const int64_t nb = (t / hp) % A.nblk;
+    const int64_t p = t / (hp * A.nblk);
+    const int64_t a0 = nb * BS;
+    const int64_t base = (p * A.axis_len + a0) * A.post + q;
+    const uint16_t* in16 = reinterpret_cast<const uint16_t*>(in);
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+    uint32_t raw[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+        raw[b] = (a0 + b < A.axis_len) ? *reinterpret_cast<const uint32_t*>(in16 + base + (int64_t)b * A.post) : 0u;   // zero padding, :563-583
+    const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;     // (even: both columns on the same side)
+    const int order = (q < lim) ? 0 : 2;
+#pragma unroll
+    for (int col = 0; col < 2; ++col) {
+        float a[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) { float lo, hi; unpack2<T>(raw[b], lo, hi); a[b] = col ? hi : lo; }
+        uint32_t mkw[(BS + 31) / 32];
+        float se_in, se_out;
+        const float* vm = A.vmean ? A.vmean + (p * BS) * A.post + q + col : nullptr;
+        const float* vs = A.vstd ? A.vstd + (p * BS) * A.post + q + col : nullptr;
+        int status;
+        if (FAST == 3) status = outlier_block_fast<BS, 0, false, 1>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+        else status = outlier_block_fast<BS, 0, false, 2>(a, mkw, se_in, se_out, A, order, vm, vs, A.post);
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            const uint32_t h = pack2<T>(a[b], 0.f) & 0xFFFFu;
+            raw[b] = col ? ((raw[b] & 0x0000FFFFu) | (h << 16)) : ((raw[b] & 0xFFFF0000u) | h);
+            if (A.mask && a0 + b < A.axis_len) A.mask[base + (int64_t)b * A.post + col] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+        outlier_side_outputs<BS>(A, mkw, se_in, se_out, status, p, nb, q + col);
+    }
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+        if (a0 + b < A.axis_len) *reinterpret_cast<uint32_t*>(out16 + base + (int64_t)b * A.post) = raw[b];
+}
+
 // --- layout B: post == 1 (block contiguous).  A wave owns 64 consecutive blocks.
 // When axis_len % BS == 0 they are one contiguous run of 64*BS floats: the wave
 // streams it with 16-byte coalesced accesses and transposes through LDS (row stride
@@ -98,15 +168,17 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
     const int64_t base = p * A.axis_len + a0;
     float* tl = tile[wv];
     if (fast) {
-        if constexpr (sizeof(T) == 2) {                           // 8 bf16 per 16-byte load
+        if constexpr (sizeof(T) == 2) {                           // 8 bf16 / fp16 per 16-byte load
             const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(in) + g0 * BS);
 #pragma unroll
             for (int t = 0; t < BS / 8; ++t) {
                 const int f = lane + 64 * t;
                 const int row = f / (BS / 8), c8 = f % (BS / 8);
                 const uint4 v = src[f];
-                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8) = make_float4(u2f(v.x << 16), u2f(v.x & 0xFFFF0000u), u2f(v.y << 16), u2f(v.y & 0xFFFF0000u));
-                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4) = make_float4(u2f(v.z << 16), u2f(v.z & 0xFFFF0000u), u2f(v.w << 16), u2f(v.w & 0xFFFF0000u));
+                float4 x, y;
+                unpack2<T>(v.x, x.x, x.y); unpack2<T>(v.y, x.z, x.w); unpack2<T>(v.z, y.x, y.y); unpack2<T>(v.w, y.z, y.w);
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8) = x;
+                *reinterpret_cast<float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4) = y;
             }
         } else {
         const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + g0 * BS);
@@ -158,9 +230,7 @@ k_outlier_contig(const T* __restrict__ in, T* __restrict__ out, OutlierArgs A) {
                 const int row = f / (BS / 8), c8 = f % (BS / 8);
                 const float4 x = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c8 * 8);
                 const float4 y = *reinterpret_cast<const float4*>(tl + row * LDS_STRIDE + c8 * 8 + 4);
-                auto pk = [](float lo, float hi) -> uint32_t {
-                    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16); };
-                dst[f] = make_uint4(pk(x.x, x.y), pk(x.z, x.w), pk(y.x, y.y), pk(y.z, y.w));
+                dst[f] = make_uint4(pack2<T>(x.x, x.y), pack2<T>(x.z, x.w), pack2<T>(y.x, y.y), pack2<T>(y.z, y.w));
             }
         } else {
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + g0 * BS);
@@ -192,6 +262,17 @@ static inline bool launch_outlier_variant(const void* in, void* out, const Outli
     const int64_t nthreads = A.pre * A.nblk * A.post;
     int64_t g = (nthreads + 255) / 256; if (g < 1) g = 1;
     const dim3 grid((unsigned)g), blk(256);
+    if constexpr (sizeof(T) == 2 && (FAST == 3 || FAST == 4)) {
+        if (A.post >= 2 && (A.post % 2) == 0 && block <= 32 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0) {
+            const dim3 gp((unsigned)((nthreads / 2 + 255) / 256));
+            switch (block) {
+                case 8: hipLaunchKernelGGL((k_outlier_strided_pair<8, T, FAST>), gp, blk, 0, st, (const T*)in, (T*)out, A); return true;
+                case 16: hipLaunchKernelGGL((k_outlier_strided_pair<16, T, FAST>), gp, blk, 0, st, (const T*)in, (T*)out, A); return true;
+                case 32: hipLaunchKernelGGL((k_outlier_strided_pair<32, T, FAST>), gp, blk, 0, st, (const T*)in, (T*)out, A); return true;
+                default: break;
+            }
+        }
+    }
 #define MSQ_OL(BS)                                                                                          \
     case BS:                                                                                                \
         if (A.post == 1) hipLaunchKernelGGL((k_outlier_contig<BS, T, FAST>), grid, blk, 0, st, (const T*)in, (T*)out, A);  \

@@ -571,11 +571,11 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
 extern "C" int64_t msq_outlier_lowp_ws_bytes_(int64_t pre, int64_t axis_len, int64_t post, int block);
 extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream);
 
-// dtype 2 (bf16 tensors) is built for round-to-nearest with float / int inliers (the hardware-convert variants and
+// dtype 1 / 2 (fp16 / bf16 tensors, computed in fp32) is built for round-to-nearest with float / int inliers (the hardware-convert variants and
 // the nearest-specialised arithmetic one); everything else is f32 only (the host shim upcasts)
 static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, hipStream_t st, int dtype = 0) {
     bool ok;
-    if (dtype != 0 && !(dtype == 2 && A.fi.kind == 0 && A.rmode == 0))
+    if (dtype != 0 && !((dtype == 1 || dtype == 2) && A.fi.kind == 0 && A.rmode == 0))
         return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: this dtype / format / rounding combination is f32 only; the host shim upcasts");
     if (A.fi.kind == 0) {                                      // float/int inliers; outliers float/int or posit
         if (A.rmode == 0) {
@@ -583,6 +583,7 @@ static int launch_outlier(const void* in, void* out, OutlierArgs& A, int block, 
             if (ih && oh) return msq_launch_outlier_hw_(in, out, &A, block, 1, dtype, (void*)st);            // both through the converts
             if (ih && A.fo.kind == 1) return msq_launch_outlier_hw_(in, out, &A, block, 2, dtype, (void*)st); // inliers only, posit outliers
             if (dtype == 2) ok = launch_outlier_variant<1, bf16io_t>(in, out, A, block, st);
+            else if (dtype == 1) ok = launch_outlier_variant<1, f16io_t>(in, out, A, block, st);
             else ok = launch_outlier_variant<1>(in, out, A, block, st);
         } else ok = launch_outlier_variant<2>(in, out, A, block, st);
     } else ok = launch_outlier_variant<0>(in, out, A, block, st);   // posit inliers: generic maths
@@ -867,8 +868,8 @@ int msq_outlier_fakequant(const void* in, void* out, uint8_t* mask, float* e_in,
             return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: block size must be 8, 16, 32, 64 or 128");
         return check_launch("msq_outlier_fakequant(native half)");
     }
-    if (dtype == 0 || dtype == 2) rc = launch_outlier(in, out, A, block, st, dtype);
-    else return fail(MSQ_ERR_UNSUPPORTED, "msq_outlier_fakequant: dtype 1 (f16 computed in f32) is not built; use MSQ_DTYPE_F16_NATIVE or upcast");
+    if (dtype == 0 || dtype == 1 || dtype == 2) rc = launch_outlier(in, out, A, block, st, dtype);
+    else return fail(MSQ_ERR_BAD_ARG, "msq_outlier_fakequant: dtype must be 0 (f32), 1 (f16), 2 (bf16) or MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE");
     if (rc) return rc;
     return check_launch("msq_outlier_fakequant");
 }

@@ -15,10 +15,12 @@ using namespace msq;
 extern "C" void msq_set_error_(const char* msg);
 
 // mode 1: inliers and outliers through the converts; mode 2: inliers through the converts, posit outliers
-// dtype 0 = f32, 2 = bf16 tensors
+// dtype 0 = f32, 1 = fp16 tensors, 2 = bf16 tensors (both computed in fp32)
 extern "C" int msq_launch_outlier_hw_(const void* in, void* out, const OutlierArgs* A, int block, int mode, int dtype, void* stream) {
     bool ok;
-    if (dtype == 2) ok = (mode == 1) ? launch_outlier_variant<3, bf16io_t>(in, out, *A, block, (hipStream_t)stream)
+    if (dtype == 1) ok = (mode == 1) ? launch_outlier_variant<3, f16io_t>(in, out, *A, block, (hipStream_t)stream)
+                                     : launch_outlier_variant<4, f16io_t>(in, out, *A, block, (hipStream_t)stream);
+    else if (dtype == 2) ok = (mode == 1) ? launch_outlier_variant<3, bf16io_t>(in, out, *A, block, (hipStream_t)stream)
                                      : launch_outlier_variant<4, bf16io_t>(in, out, *A, block, (hipStream_t)stream);
     else ok = (mode == 1) ? launch_outlier_variant<3>(in, out, *A, block, (hipStream_t)stream)
                           : launch_outlier_variant<4>(in, out, *A, block, (hipStream_t)stream);

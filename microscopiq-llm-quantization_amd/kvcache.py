@@ -62,9 +62,8 @@ def _msq_f32(t, scale_bits, elem_format, outlier_format, std_dev, axis, block_si
     (:207-211), the outliers enter their own domain as o 2^-20, and e_out = floor(log2(max)) - 8 lands near -25: 2^-25 is zero in fp16, the
     division gives Inf / NaN and the reference's NaN assert (:225-250) fires.  Found by running config 4's loop end to end (round 6: every
     generation with the fp16 cache came back empty).  In float32 the same block quantises to its fp8 outlier values."""
-    if t.dtype == torch.float32:
-        return outlier_fakequant(t, scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size)["out"]
-    return outlier_fakequant(t.float(), scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size)["out"].to(t.dtype)
+    # (fp16 / bf16 caches are read and written as they are by the float32 kernels: no cast passes, the bits of upcast -> quantise -> downcast)
+    return outlier_fakequant(t, scale_bits, scale_bits, elem_format, outlier_format, std_dev, axis, block_size, compute_dtype="float32")["out"]
 
 
 def mx_quantize_keys(key, elem_format="fp8_e4m3", block_size=32, scale_bits=8, outlier_format=None, std_dev=2):

@@ -72,10 +72,10 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
     native_half = (compute_dtype == "input" and x.dtype in (torch.float16, torch.bfloat16) and variant == VARIANT_QUANT
                    and not want_num_outliers and not str(inlier_elem_format).startswith("posit")
                    and not str(outlier_elem_format).startswith("posit"))
-    # bf16 tensors go through natively (read as fp32 values, computed in fp32, one RNE rounding on the way out:
-    # the same result as the upcast / downcast shim) where the kernels are built for it: round-to-nearest with
-    # float / int inliers, quant.py variant; everything else (fp16, other rounding modes, posit inliers) is upcast
-    native_bf16 = (x.dtype == torch.bfloat16 and round == "nearest" and variant == VARIANT_QUANT
+    # bf16 / fp16 tensors computed in fp32 go through natively (read as fp32 values, one RNE rounding on the way out: the same
+    # result as the upcast / downcast shim) where the kernels are built for it: round-to-nearest with float / int inliers,
+    # quant.py variant; everything else (other rounding modes, posit inliers) is upcast
+    native_bf16 = (x.dtype in (torch.bfloat16, torch.float16) and not native_half and round == "nearest" and variant == VARIANT_QUANT
                    and not str(inlier_elem_format).startswith("posit"))
     if x.dtype != torch.float32 and not native_bf16 and not native_half:
         x = x.float()
@@ -100,7 +100,7 @@ def outlier_fakequant(A, inlier_scale_bits, outlier_scale_bits, inlier_elem_form
     if native_half:
         dtype_code = 0x11 if x.dtype == torch.float16 else 0x12      # MSQ_DTYPE_F16_NATIVE / MSQ_DTYPE_BF16_NATIVE
     else:
-        dtype_code = 2 if native_bf16 else 0
+        dtype_code = (1 if x.dtype == torch.float16 else 2) if native_bf16 else 0
     wsb = L.msq_outlier_workspace_bytes(pre, axis_len, post, blk, variant)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb > 0 else None
     check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), ptr(n_out), ptr(status),

@@ -246,6 +246,12 @@ def sec_kv():
             print(f"{str(dt)[6:]:8s} {bits} bit: per-channel g32 {mc*1e3:6.1f} us {b/mc/1e6:5.0f} GB/s | per-token g32 {mt*1e3:6.1f} us {b/mt/1e6:5.0f} GB/s | per-token g4096 {mw*1e3:6.1f} us {b/mw/1e6:5.0f} GB/s")
         mk = tg(lambda: kvcache.mx_quantize_keys(k, "fp8_e4m3", 32)); mv = tg(lambda: kvcache.mx_quantize_values(k, "fp8_e4m3", 32))
         print(f"{str(dt)[6:]:8s} MX-FP8: keys (blocks along tokens) {mk*1e3:6.1f} us | values (blocks along head_dim) {mv*1e3:6.1f} us")
+        mk = tg(lambda: kvcache.mx_quantize_keys(k, "fp4_e2m1", 32)); mv = tg(lambda: kvcache.mx_quantize_values(k, "fp4_e2m1", 32))
+        print(f"{str(dt)[6:]:8s} MX-FP4: keys (blocks along tokens) {mk*1e3:6.1f} us | values (blocks along head_dim) {mv*1e3:6.1f} us")
+        keep, quant.CHECK_NAN = quant.CHECK_NAN, False                 # (the status read-back is a host sync: not inside a graph)
+        mk = tg(lambda: kvcache.mx_quantize_keys(k, "fp4_e2m1", 32, outlier_format="fp8_e4m3")); mv = tg(lambda: kvcache.mx_quantize_values(k, "fp4_e2m1", 32, outlier_format="fp8_e4m3"))
+        quant.CHECK_NAN = keep
+        print(f"{str(dt)[6:]:8s} MicroScopiQ fp4 + fp8 outliers (computed in float32): keys {mk*1e3:6.1f} us | values {mv*1e3:6.1f} us")
 
 
 def sec_vec():

@@ -813,25 +813,26 @@ def test_bench_shape_gemms_against_dense_reference(msq):
         assert bool(((y8d - r8).abs() <= 2.0 ** -11 * (xq.abs() @ W8.double().abs().t()) + 1e-6).all()), Md
 
 
-def test_fakequant_bf16_native_equals_upcast(msq):
-    """bf16 tensors through the fused fake-quant computed in fp32 (compute_dtype="float32": dtype 2 of msq_outlier_fakequant,
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
+def test_fakequant_bf16_native_equals_upcast(msq, dt16):
+    """bf16 / fp16 tensors through the fused fake-quant computed in fp32 (compute_dtype="float32": dtype 2 / 1 of msq_outlier_fakequant,
     no cast passes; the default for half tensors is the reference's compute-in-dtype arithmetic, tested elsewhere): the same
     bits as computing on the upcast tensor and rounding the result to bf16 once; both block layouts, ragged tails,
     hardware-convert and arithmetic codecs, posit outliers; masks identical."""
     g = torch.Generator(device=dev()).manual_seed(15)
     W = (torch.randn(300, 520, generator=g, device=dev()) * 0.02)
     W[torch.rand(300, 520, generator=g, device=dev()) < 0.01] *= 16
-    Wb = W.to(torch.bfloat16)
+    Wb = W.to(dt16)
     for axis, bs, fi, fo in ((-1, 32, "fp4_e2m1", "fp8_e4m3"), (0, 16, "int2", "fp4"), (-1, 32, "fp4_e2m1", "posit8_es1"),
                              (-1, 64, "fp6_e3m2", "fp8_e5m2"), (0, 32, "int4", "int8"), (-1, 8, "fp4_e2m1", "fp8_e4m3")):
         a = msq.quant.outlier_fakequant(Wb, 8, 8, fi, fo, 2, axis, bs, want_mask=True, compute_dtype="float32")
         b = msq.quant.outlier_fakequant(Wb.float(), 8, 8, fi, fo, 2, axis, bs, want_mask=True)
-        assert a["out"].dtype == torch.bfloat16
-        assert torch.equal(a["out"], b["out"].to(torch.bfloat16)), (axis, bs, fi, fo)
+        assert a["out"].dtype == dt16
+        assert torch.equal(a["out"], b["out"].to(dt16)), (axis, bs, fi, fo)
         assert torch.equal(a["mask"], b["mask"])
-    big = (torch.randn(512, 4096, generator=g, device=dev()) * 0.02).to(torch.bfloat16)     # full 64-block waves: coalesced path
+    big = (torch.randn(512, 4096, generator=g, device=dev()) * 0.02).to(dt16)     # full 64-block waves: coalesced path
     a = msq.quant.outlier_fakequant(big, 8, 8, "fp4_e2m1", "posit8_es1", 2, -1, 32, compute_dtype="float32")["out"]
-    assert torch.equal(a, msq.quant.outlier_fakequant(big.float(), 8, 8, "fp4_e2m1", "posit8_es1", 2, -1, 32)["out"].to(torch.bfloat16))
+    assert torch.equal(a, msq.quant.outlier_fakequant(big.float(), 8, 8, "fp4_e2m1", "posit8_es1", 2, -1, 32)["out"].to(dt16))
 
 
 def test_mx_pack_act_bf16_input(msq):
