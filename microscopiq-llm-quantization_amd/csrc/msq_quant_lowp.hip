@@ -699,6 +699,23 @@ template <int DT> MSQ_D uint32_t mx_e4m3_hw_pair(uint32_t w, float sc, float bou
     c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c, x0, x1, sc, false);
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(__builtin_bit_cast(uint32_t, c), sc, false));
 }
+// MX-FP4 (e2m1), same contract.  The grid is four binades wide, so the excepted magnitude (pred_T of half the smallest step = a quarter of
+// 2^se) sits in the bulk of every block: it is lifted over the tie (pk_lift: q = its T bits or 0xFFFF) instead of sending the wave away.
+// The e2m1 converts saturate by themselves.
+MSQ_D uint32_t pk_add_u16(uint32_t a, uint32_t b);                       // (defined with the packed fake-quant below)
+MSQ_D uint32_t pk_lift(uint32_t a, uint32_t q);
+template <int DT> MSQ_D uint32_t mx_e2m1_hw_pair(uint32_t w, float sc, uint32_t q) {
+    if (DT == 1) {
+        const lp_h2_t z = {(_Float16)0.f, (_Float16)0.f};
+        const uint32_t x = __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, w) + z));      // -0 -> +0
+        const uint32_t y = pk_lift(x & 0x7FFF7FFFu, q) | (x & 0x80008000u);                                    // lifted, sticky bit set, sign back
+        return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(__builtin_amdgcn_cvt_scalef32_pk_fp4_f16(y, __builtin_bit_cast(lp_h2_t, y), sc, 0), sc, 0));
+    }
+    const uint32_t a = w & 0x7FFF7FFFu;
+    const uint32_t sg = (pk_add_u16(a, 0x7FFF7FFFu) & w) & 0x80008000u;                                        // the sign of the non-zero values: -0 -> +0
+    const uint32_t y = pk_lift(a, q) | sg;
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(__builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(y, __builtin_bit_cast(lp_b2_t, y), sc, 0), sc, 0));
+}
 // largest magnitude of the two T values of a dword as T bits (non-negative T values order like their bit patterns; a NaN is > Inf's)
 typedef unsigned short lp_us2_t __attribute__((ext_vector_type(2)));
 template <int DT> MSQ_D uint32_t pk_absmax(uint32_t acc, uint32_t w) {    // v_and + v_pk_max_u16
@@ -709,6 +726,9 @@ template <int DT> MSQ_D float absmax_to_float(uint32_t bits16) {          // T m
     return u2f(bits16 << 16);
 }
 MSQ_D bool fmt_is_e4m3(const Fmt& f) { return f.kind == 0 && f.ebits == 4 && f.mbits == 5; }
+// element formats the convert path of the MX kernels takes: 1 = e4m3, 3 = e2m1 (MX-FP4: round 6), 0 = none
+MSQ_D int mx_hw_kind(const Fmt& f) { return fmt_is_e4m3(f) ? 1 : ((f.kind == 0 && f.ebits == 2 && f.mbits == 3) ? 3 : 0); }
+template <int DT> MSQ_D uint32_t pk_excepted(int k);                     // (defined with the packed fake-quant below)
 // The ONE magnitude on which the reference's in-dtype arithmetic differs from exact half-away rounding inside the fast path's bounds:
 // the largest T value under the tie between zero and the smallest e4m3 subnormal, |x| = pred_T(2^(se - 10)).  There m = |x| 2^(9 - se)
 // = 1/2 - ulp, and `floor(m + 0.5)` (elemwise_ops.py:59-62) computes m + 0.5 IN T: 1 - ulp/2 is a tie of T's grid under 1 and rounds
@@ -731,17 +751,19 @@ template <int DT> MSQ_D uint32_t pk_min_xor(uint32_t acc, uint32_t w, uint32_t c
 //   sc = 2^se exact in T and normal in float32; den = R(sc + 1e-6) == sc (evaluated, not assumed); the three range bounds of
 //   MxBlk::fast with e4m3's min_exp = -6, mbits = 5, emax = 8: se - 9 >= TMINE, se + 10 <= TMAXE, se - 1 >= TMINE + 11; mx finite, != 0.
 // flush_fp32_subnorms never applies (se0 > -127 inside these bounds).  A wave in which any lane says no runs the general set-up.
+// (e2m1, round 6: the same with its min_exp = 0, mbits = 3, emax = 2 -- the bounds below are written on the format's parameters)
 template <int DT> MSQ_D bool mx_setup_e4m3_lean(uint32_t mb, const MxLowpArgs& A, const uint8_t* tab, float& sc, float& bound, int& sei) {
     constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;
     constexpr uint32_t INFB = (DT == 1) ? 0x7C00u : 0x7F80u;
     const float mx = absmax_to_float<DT>(mb);
     const int se = (tab ? floor_log2_tab<DT>(mx, tab) : floor_log2_fast<DT>(mx)) - A.f.emax;
     const int semax = (1 << (A.scale_bits - 1)) - 1;
-    int lo = TMINE + 12; lo = lo < -semax ? -semax : lo; lo = lo < -126 ? -126 : lo;
-    int hi = TMAXE - 10; hi = hi > semax ? semax : hi;
+    const int min_exp = 2 - (1 << (A.f.ebits - 1));
+    int lo = TMINE + 12; lo = lo < TMINE - min_exp - 2 + A.f.mbits ? TMINE - min_exp - 2 + A.f.mbits : lo; lo = lo < -semax ? -semax : lo; lo = lo < -126 ? -126 : lo;
+    int hi = TMAXE - A.f.emax - 2; hi = hi > semax ? semax : hi;
     const int sc_e = se < lo ? lo : (se > hi ? hi : se);                 // (keeps the bit pattern below a normal power of two whatever se is)
     sc = u2f((uint32_t)(sc_e + 127) << 23);
-    bound = 448.f * sc;
+    bound = A.f.max_norm * sc;
     sei = sc_e;
     const float den = Rr<DT>(sc + 1e-6f);                                // mx_ops.py:444
     return mb != 0u && mb < INFB && se >= lo && se <= hi && den == sc;
@@ -786,9 +808,10 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
     union { uint4 u; uint16_t h[8]; } v;
     v.u = live ? *reinterpret_cast<const uint4*>(in + t * 8) : make_uint4(0, 0, 0, 0);
     // e4m3, round to nearest (kernel-uniform): one exponent look-up per lane -- computed, no table, no barrier in front of the data
-    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0;
-    const uint8_t* tab = e4 ? nullptr : s_tab;
-    if (!e4) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
+    const int hk = (A.rmode == 0) ? mx_hw_kind(A.f) : 0;
+    const bool e4 = hk == 1, e2 = hk == 3;
+    const uint8_t* tab = hk ? nullptr : s_tab;
+    if (!hk) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
     // block maximum on the T bit patterns (non-negative T values order like their bits; a NaN's magnitude bits exceed Inf's, so a NaN
     // element IS the maximum and stays one): four packed ops per lane instead of eight converts + compares
     uint32_t am = pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(0u, v.u.x), v.u.y), v.u.z), v.u.w);
@@ -807,6 +830,17 @@ k_mx_lowp_vec(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLow
         if (__builtin_amdgcn_ballot_w64(!hw) == 0) {                     // the whole wave: the scaled converts
             v.u.x = mx_e4m3_hw_pair<DT>(v.u.x, sc, bound); v.u.y = mx_e4m3_hw_pair<DT>(v.u.y, sc, bound);
             v.u.z = mx_e4m3_hw_pair<DT>(v.u.z, sc, bound); v.u.w = mx_e4m3_hw_pair<DT>(v.u.w, sc, bound);
+            if (live) *reinterpret_cast<uint4*>(out + t * 8) = v.u;
+            return;
+        }
+    }
+    if (e2) {                                                            // MX-FP4: the excepted magnitude (first tie 2^(se - 2)) is lifted, not looked for
+        float sc, bound; int sei;
+        const bool hw = mx_setup_e4m3_lean<DT>(mb, A, tab, sc, bound, sei);
+        const uint32_t q = pk_excepted<DT>(sei - 2);
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
+            v.u.x = mx_e2m1_hw_pair<DT>(v.u.x, sc, q); v.u.y = mx_e2m1_hw_pair<DT>(v.u.y, sc, q);
+            v.u.z = mx_e2m1_hw_pair<DT>(v.u.z, sc, q); v.u.w = mx_e2m1_hw_pair<DT>(v.u.w, sc, q);
             if (live) *reinterpret_cast<uint4*>(out + t * 8) = v.u;
             return;
         }
@@ -831,9 +865,10 @@ template <int BS, int DT>
 __global__ void __launch_bounds__(256)
 k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLowpArgs A) {
     __shared__ uint8_t s_tab[256];
-    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0 && (BS % 2) == 0 && (A.axis_len % BS) == 0;      // kernel-uniform
-    const uint8_t* tab = e4 ? nullptr : s_tab;
-    if (!e4) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
+    const int hk = (A.rmode == 0 && (BS % 2) == 0 && (A.axis_len % BS) == 0) ? mx_hw_kind(A.f) : 0;      // kernel-uniform
+    const bool e4 = hk == 1, e2 = hk == 3;
+    const uint8_t* tab = hk ? nullptr : s_tab;
+    if (!hk) { floor_log2_tab_init<DT>(s_tab); __syncthreads(); }
     const int64_t hp = A.post / 2;
     const int64_t total = A.pre * A.nblk * hp;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -865,6 +900,22 @@ k_mx_lowp_pair(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxLo
             for (int b = 0; b < BS; b += 2) {
                 const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
                 const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, sc0, bd0), q1 = mx_e4m3_hw_pair<DT>(p1, sc1, bd1);
+                *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
+                *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+            }
+            return;
+        }
+    }
+    if (e2) {
+        float sc0, sc1, bd0, bd1; int se0, se1;
+        bool hw = mx_setup_e4m3_lean<DT>(am & 0xFFFFu, A, tab, sc0, bd0, se0);
+        hw = mx_setup_e4m3_lean<DT>(am >> 16, A, tab, sc1, bd1, se1) && hw;
+        const uint32_t x0 = pk_excepted<DT>(se0 - 2), x1 = pk_excepted<DT>(se1 - 2);
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
+#pragma unroll
+            for (int b = 0; b < BS; b += 2) {
+                const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
+                const uint32_t q0 = mx_e2m1_hw_pair<DT>(p0, sc0, x0), q1 = mx_e2m1_hw_pair<DT>(p1, sc1, x1);
                 *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
                 *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
             }
@@ -929,9 +980,10 @@ k_mx_lowp_pair4(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxL
         raw[b] = *reinterpret_cast<const uint32_t*>(in + base + (int64_t)b * A.post);
         am = pk_absmax<DT>(am, raw[b]);
     }
-    const bool e4 = fmt_is_e4m3(A.f) && A.rmode == 0;                                     // kernel-uniform
-    const uint8_t* tab = e4 ? nullptr : s_tab;
-    if (!e4) floor_log2_tab_init<DT>(s_tab);
+    const int hk = (A.rmode == 0) ? mx_hw_kind(A.f) : 0;                                  // kernel-uniform
+    const bool e4 = hk == 1, e2 = hk == 3;
+    const uint8_t* tab = hk ? nullptr : s_tab;
+    if (!hk) floor_log2_tab_init<DT>(s_tab);
     s_am[w][lane] = am;
     __syncthreads();
     am = pk_absmax<DT>(pk_absmax<DT>(pk_absmax<DT>(s_am[0][lane], s_am[1][lane]), s_am[2][lane]), s_am[3][lane]);
@@ -949,6 +1001,24 @@ k_mx_lowp_pair4(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, MxL
             for (int b = 0; b < TW; b += 2) {
                 const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
                 const uint32_t q0 = mx_e4m3_hw_pair<DT>(p0, sc0, bd0), q1 = mx_e4m3_hw_pair<DT>(p1, sc1, bd1);
+                if (live) {
+                    *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
+                    *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+                }
+            }
+            return;
+        }
+    }
+    if (e2) {
+        float sc0, sc1, bd0, bd1; int se0, se1;
+        bool hw = mx_setup_e4m3_lean<DT>(am & 0xFFFFu, A, tab, sc0, bd0, se0);
+        hw = (mx_setup_e4m3_lean<DT>(am >> 16, A, tab, sc1, bd1, se1) && hw) || !live;
+        const uint32_t x0 = pk_excepted<DT>(se0 - 2), x1 = pk_excepted<DT>(se1 - 2);
+        if (__builtin_amdgcn_ballot_w64(!hw) == 0) {
+#pragma unroll
+            for (int b = 0; b < TW; b += 2) {
+                const uint32_t p0 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x05040100u), p1 = __builtin_amdgcn_perm(raw[b + 1], raw[b], 0x07060302u);
+                const uint32_t q0 = mx_e2m1_hw_pair<DT>(p0, sc0, x0), q1 = mx_e2m1_hw_pair<DT>(p1, sc1, x1);
                 if (live) {
                     *reinterpret_cast<uint32_t*>(out + base + (int64_t)b * A.post) = __builtin_amdgcn_perm(q1, q0, 0x05040100u);
                     *reinterpret_cast<uint32_t*>(out + base + (int64_t)(b + 1) * A.post) = __builtin_amdgcn_perm(q1, q0, 0x07060302u);

@@ -327,13 +327,16 @@ def _eq_bits(a, b):
     return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
 
 
+@pytest.mark.parametrize("FMT", ["fp8_e4m3", "fp4_e2m1"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype):
+def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype, FMT):
     """The e4m3 convert path of the KV-cache MX quantiser decides per block, from the T bits of the block maximum, whether the converts
     apply (msq_quant_lowp.hip mx_setup_e4m3_lean) -- scales at either end of T's range, the range in which `scale + 1e-6` is no longer the
     scale, the floor(log2) bump just under powers of two, zero / Inf / NaN blocks must all come out as the reference's in-dtype arithmetic
     (oracle: msq_oracle_quantize_mx_lowp).  One block maximum per binade of T (plus its bump neighbours), values spread below it; keys
-    layout (blocks along tokens, two channels per lane) and values layout (blocks along the contiguous axis, 8 values per lane)."""
+    layout (blocks along tokens, two channels per lane) and values layout (blocks along the contiguous axis, 8 values per lane).
+    Round 6: the same for the e2m1 convert path (MX-FP4), whose zero tie sits a factor 16 under the maximum, not 2^-6 of it."""
+    DEEP = 2.0 ** -6 if FMT == "fp8_e4m3" else 2.0 ** -3
     from msq import kvcache
     dn = "f16" if dtype == torch.float16 else "bf16"
     g = torch.Generator().manual_seed(77)
@@ -347,12 +350,12 @@ def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype):
     # values layout: [1, 1, nb, 128] = 4 blocks of 32 per row, each row under one maximum
     frac = torch.rand(nb, 128, generator=g, dtype=torch.float64) * 2 - 1
     frac[:, ::32] = 1.0
-    frac[torch.rand(nb, 128, generator=g) < 0.2] *= 2.0 ** -6              # elements deep in the e4m3 subnormal range / under the zero tie
+    frac[torch.rand(nb, 128, generator=g) < 0.2] *= DEEP                   # elements deep in the subnormal range / under the zero tie
     V_ = (frac * tops.double()[:, None]).to(dtype)
     V_[V_ != V_] = 0                                                       # inf * 0 of the overflowed maxima
     V_ = V_.reshape(1, 1, nb, 128)
-    vq = kvcache.mx_quantize_values(V_.to(dev()), "fp8_e4m3", 32)
-    vo = O.quantize_mx_lowp(V_.float().numpy(), dn, 8, "fp8_e4m3", 3, 32)
+    vq = kvcache.mx_quantize_values(V_.to(dev()), FMT, 32)
+    vo = O.quantize_mx_lowp(V_.float().numpy(), dn, 8, FMT, 3, 32)
     assert _eq_bits(vq.float().cpu().numpy(), vo), dn
     # keys layout: [1, 1, 32 * nbk, 128]: channel c of token block b sits under maximum tops[(b * 128 + c) % nb]
     nbk = (nb + 127) // 128 + 1
@@ -360,19 +363,19 @@ def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype):
     top_k = tops.double()[idx]                                              # [nbk, 128]
     fk = torch.rand(nbk, 32, 128, generator=g, dtype=torch.float64) * 2 - 1
     fk[:, 5, :] = -1.0
-    fk[torch.rand(nbk, 32, 128, generator=g) < 0.2] *= 2.0 ** -6
+    fk[torch.rand(nbk, 32, 128, generator=g) < 0.2] *= DEEP
     K_ = (fk * top_k[:, None, :]).to(dtype)
     K_[K_ != K_] = 0
     K_ = K_.reshape(1, 1, nbk * 32, 128)
-    ko = O.quantize_mx_lowp(K_.float().numpy(), dn, 8, "fp8_e4m3", 2, 32)
+    ko = O.quantize_mx_lowp(K_.float().numpy(), dn, 8, FMT, 2, 32)
     from msq._lib import lib
     try:
         for pair4 in (1, 0):                    # k_mx_lowp_pair4 (a block row over four waves, the default) and k_mx_lowp_pair
             assert lib().msq_set_tuning(b"MSQ_MX_LOWP_PAIR4", pair4) == 0
-            kq = kvcache.mx_quantize_keys(K_.to(dev()), "fp8_e4m3", 32)
+            kq = kvcache.mx_quantize_keys(K_.to(dev()), FMT, 32)
             assert _eq_bits(kq.float().cpu().numpy(), ko), (dn, pair4)
             # head dims that leave dead lanes (80: 40 channel pairs) and need two 64-pair chunks (160), other element formats
-            for hd, fmt in ((80, "fp8_e4m3"), (160, "fp8_e4m3"), (128, "fp4_e2m1"), (160, "fp6_e3m2"), (80, "int8")):
+            for hd, fmt in ((80, "fp8_e4m3"), (160, "fp8_e4m3"), (128, "fp4_e2m1"), (80, "fp4_e2m1"), (160, "fp4_e2m1"), (160, "fp6_e3m2"), (80, "int8")):
                 Kh = (torch.randn(2, 3, 64, hd, generator=g) * 3).to(dtype)
                 Kh[0, 0, :32, 1] *= 2.0 ** -12
                 got = kvcache.mx_quantize_keys(Kh.to(dev()), fmt, 32)
@@ -384,12 +387,54 @@ def test_kv_mx_e4m3_block_setup_every_binade(msq, O, dtype):
     Z = V_.clone().reshape(nb, 128)
     Z[0, :32] = 0; Z[1, 3] = float("inf"); Z[2, 40] = float("nan"); Z[3, 70] = -float("inf")
     Z = Z.reshape(1, 1, nb, 128)
-    zq = kvcache.mx_quantize_values(Z.to(dev()), "fp8_e4m3", 32)
-    zo = O.quantize_mx_lowp(Z.float().numpy(), dn, 8, "fp8_e4m3", 3, 32)
+    zq = kvcache.mx_quantize_values(Z.to(dev()), FMT, 32)
+    zo = O.quantize_mx_lowp(Z.float().numpy(), dn, 8, FMT, 3, 32)
     assert _eq_bits(zq.float().cpu().numpy(), zo), dn
-    zk = kvcache.mx_quantize_keys(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().to(dev()), "fp8_e4m3", 32)
-    zko = O.quantize_mx_lowp(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().float().numpy(), dn, 8, "fp8_e4m3", 2, 32)
+    zk = kvcache.mx_quantize_keys(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().to(dev()), FMT, 32)
+    zko = O.quantize_mx_lowp(Z.reshape(1, 1, nb * 4, 32).repeat(1, 1, 1, 4)[:, :, :(nb * 4 // 32) * 32].contiguous().float().numpy(), dn, 8, FMT, 2, 32)
     assert _eq_bits(zk.float().cpu().numpy(), zko), dn
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_kv_mx_fp4_every_tie_and_the_excepted_magnitude(msq, O, dtype):
+    """MX-FP4 through the e2m1 converts (round 6): every grid point and every tie of the format at every scale, two ulps of T either side -- the
+    excepted magnitude pred_T(2^(se - 2)) among them, which the kernel lifts over the tie on its way into the convert --, both signs, against the
+    oracle's op-by-op in-dtype arithmetic; values layout (k_mx_lowp_vec), keys layout through both strided kernels."""
+    from msq import kvcache
+    from msq._lib import lib
+    dn = "f16" if dtype == torch.float16 else "bf16"
+    g = torch.Generator().manual_seed(5)
+    exps = list(range(-22, 13)) if dtype == torch.float16 else list(range(-120, 121, 7))
+    rows = []
+    for e in exps:
+        k = torch.randint(0, 49, (4, 128), generator=g).double()             # k / 8: 0 ... 6 in steps of 1/8 (grid points: 0, .5, 1, 1.5, 2, 3, 4, 6; ties between)
+        k[:, ::32] = 48                                                       # the block maximum 6 x 2^e: se = e
+        k[:, 1::32] = 2                                                       # 0.25 x 2^e: the first tie; bumped below: the excepted magnitude
+        v = (k / 8.0) * 2.0 ** e * (torch.randint(0, 2, (4, 128), generator=g).double() * 2 - 1)
+        rows.append(v)
+    X = torch.cat(rows).to(dtype)
+    bits = X.view(torch.int16)
+    bump = torch.randint(-2, 3, bits.shape, generator=g).to(torch.int16)
+    bump[:, ::32] = 0                                                          # (the maxima stay: the scale is what the row is about)
+    bump[:, 1::32] = -1                                                        # pred_T(first tie) in every block
+    keep = (bits & 0x7FFF) < 4
+    X = torch.where(keep, bits, bits + bump).view(dtype)
+    nrow = X.shape[0]
+    V_ = X.reshape(1, 1, nrow, 128)
+    vq = kvcache.mx_quantize_values(V_.to(dev()), "fp4_e2m1", 32)
+    vo = O.quantize_mx_lowp(V_.float().numpy(), dn, 8, "fp4_e2m1", 3, 32)
+    assert _eq_bits(vq.float().cpu().numpy(), vo), dn
+    # keys: the 32 values of a block along tokens -- transpose the 32-wide blocks of X into [tokens, channels]
+    nbk = (nrow * 4) // 128
+    K_ = X.reshape(nrow * 4, 32)[:nbk * 128].reshape(nbk, 128, 32).permute(0, 2, 1).contiguous().reshape(1, 1, nbk * 32, 128)
+    ko = O.quantize_mx_lowp(K_.float().numpy(), dn, 8, "fp4_e2m1", 2, 32)
+    try:
+        for pair4 in (1, 0):
+            assert lib().msq_set_tuning(b"MSQ_MX_LOWP_PAIR4", pair4) == 0
+            kq = kvcache.mx_quantize_keys(K_.to(dev()), "fp4_e2m1", 32)
+            assert _eq_bits(kq.float().cpu().numpy(), ko), (dn, pair4)
+    finally:
+        lib().msq_set_tuning(b"MSQ_MX_LOWP_PAIR4", 1)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

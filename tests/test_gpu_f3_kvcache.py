@@ -18,6 +18,7 @@ from legacy_gpu_round3 import (  # noqa: F401
 )
 from legacy_gpu_round5 import (  # noqa: F401
     test_kv_mx_e4m3_block_setup_every_binade,
+    test_kv_mx_fp4_every_tie_and_the_excepted_magnitude,
 )
 
 pytestmark = pytest.mark.gpu
