@@ -1342,11 +1342,14 @@ MSQ_D bool outlier_block_pk(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2
     return ok;
 }
 
+template <int BS, int DT>
+MSQ_D bool outlier_block_pk32(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2], uint32_t (&mk)[BS / 2], float& se_in_o, float& se_out_o,
+                              const OutlierArgs& A, int order, int kin, int kout);      // float32 semantics: below the kernels
 // Blocks along the contiguous axis (post == 1, whole blocks, 16-byte aligned): one lane per block; the 64 blocks of a wave are one
 // contiguous run that crosses to the lanes through the wave's LDS slice, as in k_outlier_lowp.  A wave with a block outside the packed
 // form's bounds writes nothing and puts itself on the list for k_outlier_lowp_list (keeping that path's ~250 registers out of this kernel:
 // inlined as a branch it halved the occupancy and cost a factor of three).
-template <int BS, int DT>
+template <int BS, int DT, bool F32SEM = false>
 __global__ void __launch_bounds__(256)
 k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
     __shared__ uint8_t l2tab[256];
@@ -1385,7 +1388,9 @@ k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, O
     }
     uint32_t res[BS / 2], mk[BS / 2];
     float se_in, se_out;
-    const bool ok = outlier_block_pk<BS, DT>(pw, res, mk, se_in, se_out, A, 1, l2tab, kin, kout) || !live;
+    bool ok;
+    if constexpr (F32SEM) ok = outlier_block_pk32<BS, DT>(pw, res, mk, se_in, se_out, A, 1, kin, kout) || !live;
+    else ok = outlier_block_pk<BS, DT>(pw, res, mk, se_in, se_out, A, 1, l2tab, kin, kout) || !live;
     if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
         if (lane == 0) ws[8 + atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull)] = wave_t0;
         return;
@@ -1420,7 +1425,7 @@ k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, O
 
 // Blocks along a strided axis (post even, whole blocks, 4-byte aligned): one lane per PAIR of neighbouring columns -- a wave moves
 // 256 contiguous bytes per row --, the rows b, b + 1 of each column paired into one dword (v_perm) for the packed arithmetic.
-template <int BS, int DT>
+template <int BS, int DT, bool F32SEM = false>
 __global__ void __launch_bounds__(256)
 k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
     __shared__ uint8_t l2tab[256];
@@ -1453,8 +1458,14 @@ k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, 
     const int order = (q < lim) ? 0 : 2;
     uint32_t r0[BS / 2], r1[BS / 2], m0[BS / 2], m1[BS / 2];
     float si0, so0, si1, so1;
-    const bool ok0 = outlier_block_pk<BS, DT>(p0, r0, m0, si0, so0, A, order, l2tab, kin, kout);
-    const bool ok1 = outlier_block_pk<BS, DT>(p1, r1, m1, si1, so1, A, order, l2tab, kin, kout);
+    bool ok0, ok1;
+    if constexpr (F32SEM) {
+        ok0 = outlier_block_pk32<BS, DT>(p0, r0, m0, si0, so0, A, order, kin, kout);
+        ok1 = outlier_block_pk32<BS, DT>(p1, r1, m1, si1, so1, A, order, kin, kout);
+    } else {
+        ok0 = outlier_block_pk<BS, DT>(p0, r0, m0, si0, so0, A, order, l2tab, kin, kout);
+        ok1 = outlier_block_pk<BS, DT>(p1, r1, m1, si1, so1, A, order, l2tab, kin, kout);
+    }
     if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1)) != 0ull) {
         // this wave's columns are the lanes 2 (t - lane) ... + 127 of k_outlier_lowp's numbering: two of its waves
         if (lane == 0) {
@@ -1481,6 +1492,216 @@ k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, 
     const int64_t eidx = (p * A.nblk + nb) * A.post + q;
     if (A.e_in) { A.e_in[eidx] = si0; A.e_in[eidx + 1] = si1; }
     if (A.e_out) { A.e_out[eidx] = so0; A.e_out[eidx + 1] = so1; }
+}
+
+
+// ===========================================================================================================================
+// The same packed machinery for FLOAT32 semantics on 16-bit tensors (dtype 1 / 2 of msq_outlier_fakequant: an fp16 / bf16 tensor
+// read as float32 values, utils/quant.py:147-266 computed in float32, ONE rounding to the tensor dtype on the way out -- what the
+// MicroScopiQ KV cache runs, kvcache.py).  The float32 kernels (msq_outlier_kernels.h) spend ~45 instructions per element on it and one
+// lane walks a whole block; here the block's values stay packed as they were loaded.  What differs from the in-dtype form above:
+//  * mean, k std, lo, hi are float32 values; the mask compares T values with them, so the bounds are moved to the nearest T value
+//    inside (x < lo <=> x < ceil_T(lo), x > hi <=> x > floor_T(hi)).  The std must be ATen's to the last float32 bit for the
+//    reference's bounds -- but the mask only needs the two T values: both ends of sd' -+ its error bound give the same pair in all
+//    but one block in a few hundred, and those take the double-precision std in a rare branch;
+//  * exponents: floor(log2) of a T-valued float is its exponent field (torch.log2's float32 quirk needs a value within 2^-22 of a
+//    power of two); 2^e scalings are exact in float32, so x goes to either grid with ONE scale and no intermediate rounding;
+//  * no excepted magnitude: float32's `floor(|x| + 0.5)` errs only on pred_f32(half a step), which no 16-bit value is;
+//  * the results are grid values times a power of two: at most four significant bits, exact in T inside the exponent bounds that
+//    are checked per block -- outside, the block's wave goes on the list and the float32 routine redoes it.
+// ===========================================================================================================================
+template <int DT> MSQ_D float t_from_bits(uint32_t b) {
+    if (DT == 1) return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
+    return u2f(b << 16);
+}
+template <int DT> MSQ_D float t_ceil(float v) {                          // smallest T value >= v (v not NaN)
+    const float r = Rr<DT>(v);
+    if (!(r < v)) return r;
+    uint32_t b = t_bits<DT>(r);
+    b = ((b & 0x7FFFu) == 0u) ? 1u : ((b & 0x8000u) ? b - 1u : b + 1u);
+    return t_from_bits<DT>(b);
+}
+template <int DT> MSQ_D float t_floor(float v) {                         // largest T value <= v
+    const float r = Rr<DT>(v);
+    if (!(r > v)) return r;
+    uint32_t b = t_bits<DT>(r);
+    b = ((b & 0x7FFFu) == 0u) ? 0x8001u : ((b & 0x8000u) ? b + 1u : b - 1u);
+    return t_from_bits<DT>(b);
+}
+// x < lo or x > hi on two packed T values -> 0xFFFF per outlier (lo, hi: T values; see outlier_block_pk for the zero bounds)
+struct PkBounds { uint32_t lob, hib, lok, hik; };
+template <int DT> MSQ_D PkBounds pk_bounds(float lo, float hi) {
+    PkBounds B;
+    B.lob = dup16((lo == 0.f) ? 0x8000u : t_bits<DT>(lo)); B.hib = dup16((hi == 0.f) ? 0u : t_bits<DT>(hi));
+    B.lok = B.lob ^ (pk_sign_fill(B.lob) & 0x7FFF7FFFu); B.hik = B.hib ^ (pk_sign_fill(B.hib) & 0x7FFF7FFFu);
+    return B;
+}
+template <int DT> MSQ_D uint32_t pk_mask(uint32_t w, const PkBounds& B) {
+    uint32_t sg;
+    if (DT == 1) {
+        const lp_h2_t x = __builtin_bit_cast(lp_h2_t, w);
+        sg = __builtin_bit_cast(uint32_t, (lp_h2_t)(x - __builtin_bit_cast(lp_h2_t, B.lob))) | __builtin_bit_cast(uint32_t, (lp_h2_t)(__builtin_bit_cast(lp_h2_t, B.hib) - x));
+    } else {
+        const uint32_t key = w ^ (pk_sign_fill(w) & 0x7FFF7FFFu);
+        sg = pk_subsat_i16(key, B.lok) | pk_subsat_i16(B.hik, key);
+    }
+    return pk_sign_fill(sg);
+}
+template <int BS, int DT, int KI, int KO>
+MSQ_D void pk_codec_loop32(const uint32_t (&pw)[BS / 2], const uint32_t (&mk)[BS / 2], uint32_t (&res)[BS / 2], const OutlierArgs& A, int ei, int eoi) {
+    const float s_in = pow2f(ei), s_out = pow2f(eoi);
+    const uint32_t b_in = (KI == 4) ? 0u : dup16(t_bits<DT>(A.fi.max_norm * s_in)), b_out = dup16(t_bits<DT>(A.fo.max_norm * s_out));
+    const uint32_t h_in = (KI == 4) ? dup16(pow2_bits<DT>(ei - 1)) - 0x00010001u : 0u, st_in = (KI == 4) ? dup16(pow2_bits<DT>(ei)) : 0u;
+#pragma unroll
+    for (int j = 0; j < BS / 2; ++j) {
+        const uint32_t w = pw[j], a = w & 0x7FFF7FFFu, m = mk[j], in = a | 0x00010001u;
+        uint32_t ri;
+        if (KI == 4) ri = pk_mul_u16(pk_min_u16(pk_subsat_u16(a, h_in), 0x00010001u), st_in);
+        else ri = hw_mag_pair<DT, KI>(in, s_in, s_in, b_in);
+        const uint32_t ro = hw_mag_pair<DT, KO>(in, s_out, s_out, b_out);
+        const uint32_t rm = (ro & m) | (ri & ~m);
+        if (DT == 1) {
+            const lp_h2_t z = {(_Float16)0.f, (_Float16)0.f};
+            res[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(lp_h2_t, rm), __builtin_bit_cast(lp_h2_t, (w & 0x80008000u) | 0x3C003C00u), z));
+        } else {
+            res[j] = ((pk_add_u16(rm, 0x7FFF7FFFu) & w) & 0x80008000u) | rm;
+        }
+    }
+}
+// exponent of the block maximum minus emax, clamped as utils/quant.py:207-211 (float32 route: shared_exp_of_max + clamp_scale_exp)
+MSQ_D bool scale_exp_f32(float mx, int emax, int sb, int& se) {
+    const int lim = (1 << (sb - 1)) - 1, neg = (-lim < -20) ? -20 : -lim;
+    const int e = ((mx == 0.f) ? -126 : (int)((f2u(mx) >> 23) & 0xFFu) - 127) - emax;       // + FP32_MIN_NORMAL * (max == 0)
+    se = (e < -lim) ? neg : e;
+    return e <= lim;
+}
+template <int BS, int DT>
+MSQ_D bool outlier_block_pk32(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS / 2], uint32_t (&mk)[BS / 2], float& se_in_o, float& se_out_o,
+                              const OutlierArgs& A, int order, int kin, int kout) {
+    bool ok = true, exact;
+    float lo, hi, c;
+    {
+        float ab[BS];
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j) {
+            const uint32_t a = pw[j] & 0x7FFF7FFFu;
+            if (DT == 1) { const lp_h2_t h = __builtin_bit_cast(lp_h2_t, a); ab[2 * j] = (float)h[0]; ab[2 * j + 1] = (float)h[1]; }
+            else { ab[2 * j] = u2f(a << 16); ab[2 * j + 1] = u2f(a & 0xFFFF0000u); }
+        }
+        float s;
+        if (order == 1) s = sum_inner8<BS>(ab);
+        else if (order == 2) s = sum_ilp4<BS>(ab);
+        else s = sum_cascade<BS>(ab);
+        c = s / (float)BS;                                              // the reference's float32 mean (:477)
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+        for (int b = 0; b < BS; b += 4) {
+            const float d0 = ab[b] - c, d1 = ab[b + 1] - c, d2 = ab[b + 2] - c, d3 = ab[b + 3] - c;
+            q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1); q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
+        }
+        const float sdp = __builtin_amdgcn_sqrtf(((q0 + q1) + (q2 + q3)) * (1.0f / (float)BS));
+        constexpr uint32_t EULP = BS / 8 + 5;                            // (the bound derived in outlier_block_pk)
+        exact = !(sdp >= 8.8817841970012523e-16f && sdp <= 1.125899906842624e15f && sdp >= (float)BS * 0.000244140625f * c && A.k > 0.f);
+        const float ks_a = A.k * u2f(f2u(sdp) - EULP), ks_b = A.k * u2f(f2u(sdp) + EULP);
+        lo = t_ceil<DT>(c - ks_b); hi = t_floor<DT>(c + ks_b);          // :489-490 with the larger std ...
+        const float lo2 = t_ceil<DT>(c - ks_a), hi2 = t_floor<DT>(c + ks_a);   // ... and with the smaller one: the same T values, or the exact std decides
+        exact = exact || !(lo == lo2 && hi == hi2);
+    }
+    if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
+        if (exact) {
+            float ab[BS];
+#pragma unroll
+            for (int j = 0; j < BS / 2; ++j) {
+                const uint32_t a = pw[j] & 0x7FFF7FFFu;
+                if (DT == 1) { const lp_h2_t h = __builtin_bit_cast(lp_h2_t, a); ab[2 * j] = (float)h[0]; ab[2 * j + 1] = (float)h[1]; }
+                else { ab[2 * j] = u2f(a << 16); ab[2 * j + 1] = u2f(a & 0xFFFF0000u); }
+            }
+            const float ks = A.k * std_twopass_checked<BS>(ab, 0);      // :478
+            const float lof = c - ks, hif = c + ks;
+            ok = ok && lof == lof && hif == hif;
+            lo = t_ceil<DT>(lof); hi = t_floor<DT>(hif);
+        }
+    }
+    uint32_t mi = 0u, mo = 0u;
+    {
+        const PkBounds Bn = pk_bounds<DT>(lo, hi);
+#pragma unroll
+        for (int j = 0; j < BS / 2; ++j) {
+            const uint32_t w = pw[j];
+            const uint32_t m = pk_mask<DT>(w, Bn);                      // :492
+            mk[j] = m;
+            mo = pk_max_u16(mo, w & 0x7FFF7FFFu & m);
+            mi = pk_max_u16(mi, w & 0x7FFF7FFFu & ~m);
+        }
+    }
+    const uint32_t mib = (mi & 0xFFFFu) > (mi >> 16) ? (mi & 0xFFFFu) : (mi >> 16), mob = (mo & 0xFFFFu) > (mo >> 16) ? (mo & 0xFFFFu) : (mo >> 16);
+    constexpr uint32_t INFB = (DT == 1) ? 0x7C00u : 0x7F80u;
+    ok = ok && mib < INFB && mob < INFB;
+    int ei, eo;
+    ok = scale_exp_f32(absmax_to_float<DT>(mib), A.fi.emax, A.in_sb, ei) && ok;
+    se_in_o = (float)ei;
+    ok = ok && ei >= -60 && ei <= 60;
+    ei = ok ? ei : 0;
+    const bool no_out = mob == 0u;
+    const float mxo = absmax_to_float<DT>(mob);
+    const float mx_out = mxo * pow2f(ei);                               // max |o 2^e_in| (:216): exact in float32 inside the bound below
+    ok = ok && (no_out || mx_out >= 1.1754943508222875e-38f);
+    const bool eo_ok = scale_exp_f32(mx_out, A.fo.emax, A.out_sb, eo);
+    se_out_o = (float)eo;
+    ok = ok && eo_ok && (no_out || (eo >= -60 && eo <= 60));
+    const int eoi = (ok && !no_out) ? eo - ei : 0;                      // one scale takes x to the outlier grid and back
+    // the results q 2^e (q on the grid: at most four significant bits) and the clamp bounds must be T values, and T's own spacing four
+    // times finer than the first tie (the sticky bit is the half's lowest)
+    const int mine_i = A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0, mine_o = A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0;
+    constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;
+    ok = ok && ei + mine_i - A.fi.mbits + 1 >= TMINE + 2 && ei + A.fi.emax + 1 <= TMAXE && ei + A.fi.emax >= TMINE + 2
+            && (no_out || (eoi + mine_o - A.fo.mbits + 1 >= TMINE + 2 && eoi + A.fo.emax + 1 <= TMAXE && eoi + A.fo.emax >= TMINE + 2 && eoi >= -126 && eoi <= 126));
+    const int eoc = ok ? eoi : 0;
+    const int combo = kin * 4 + kout;
+    if (combo == 4 * 4 + 3) pk_codec_loop32<BS, DT, 4, 3>(pw, mk, res, A, ei, eoc);
+    else if (combo == 3 * 4 + 1) pk_codec_loop32<BS, DT, 3, 1>(pw, mk, res, A, ei, eoc);
+    else if (combo == 3 * 4 + 3) pk_codec_loop32<BS, DT, 3, 3>(pw, mk, res, A, ei, eoc);
+    else if (combo == 3 * 4 + 2) pk_codec_loop32<BS, DT, 3, 2>(pw, mk, res, A, ei, eoc);
+    else pk_codec_loop32<BS, DT, 1, 1>(pw, mk, res, A, ei, eoc);
+    return ok;
+}
+
+
+// the waves the float32-semantics packed kernels hand back: one block per lane through the float32 routine (outlier_block_fast with the
+// hardware codecs: the route of k_outlier_contig / _strided for these tensors), written with one rounding to T
+template <int BS, int DT>
+__global__ void __launch_bounds__(256)
+k_outlier_f32sem_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws) {
+    const int64_t count = ws[0];
+    if (count == 0) return;
+    const int64_t total = A.pre * A.nblk * A.post;
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += nw) {
+        const int64_t t = ws[8 + i] + lane;
+        if (t >= total) continue;
+        const int64_t q = t % A.post, nb = (t / A.post) % A.nblk, p = t / (A.post * A.nblk);
+        const int64_t base = (p * A.axis_len + nb * BS) * A.post + q;
+        float a[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) a[b] = ld16<DT>(in, base + (int64_t)b * A.post);
+        int order = 1;
+        if (A.post > 1) {
+            const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
+            order = (q < lim) ? 0 : 2;
+        }
+        uint32_t mkw[(BS + 31) / 32];
+        float se_in, se_out;
+        const int status = outlier_block_fast<BS, 0, false, 1>(a, mkw, se_in, se_out, A, order, nullptr, nullptr, 1);
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+            st16<DT>(out, base + (int64_t)b * A.post, Rr<DT>(a[b]));
+            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+        }
+        if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
+        if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
+        if (status && A.status) atomicOr(A.status, status);
+    }
 }
 
 extern "C" void msq_set_error_(const char* msg);
@@ -1546,6 +1767,8 @@ __global__ void __launch_bounds__(256) k_floor_log2_lowp(const float* __restrict
 }
 
 // called from msq_outlier_fakequant (msq_quant.hip) for dtype MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE
+// clears the head of the list (hipMemsetAsync goes through a generic fill kernel that takes 4.5 us for these 8 bytes; this one ~2)
+__global__ void k_lowp_list_clear(int64_t* __restrict__ ws) { if (threadIdx.x < 8) ws[threadIdx.x] = 0; }
 // bytes of the list of handed-back waves: a 64-byte head (the count) + one 8-byte entry per wave of k_outlier_lowp's lane numbering
 extern "C" int64_t msq_outlier_lowp_ws_bytes_(int64_t pre, int64_t axis_len, int64_t post, int block) {
     if (block != 8 && block != 16 && block != 32 && block != 64) return 0;
@@ -1570,9 +1793,9 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
         if (contig || strided) {
             const int64_t lanes = contig ? A.pre * A.nblk : A.pre * A.nblk * (A.post / 2);
             const dim3 gp((unsigned)((lanes + 255) / 256));
-            int64_t gl = (n + 255) / 256; if (gl > 512) gl = 512;
+            int64_t gl = (n + 1023) / 1024; if (gl > 512) gl = 512; if (gl < 1) gl = 1;
             const dim3 glist((unsigned)gl);
-            if (hipMemsetAsync(ws, 0, 64, st) != hipSuccess) return 1;
+            hipLaunchKernelGGL(k_lowp_list_clear, dim3(1), dim3(64), 0, st, (int64_t*)ws);
 #define MSQ_LPK(BS, DTV)                                                                                               \
             if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
             else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
@@ -1592,6 +1815,37 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
         return 1;
     switch (block) { MSQ_LP(8) MSQ_LP(16) MSQ_LP(32) MSQ_LP(64) MSQ_LP(128) default: return 0; }
 #undef MSQ_LP
+}
+
+// dtype 1 / 2 of msq_outlier_fakequant (fp16 / bf16 tensors computed in float32) on the packed kernels; 0 = not this call (the float32
+// kernels of msq_outlier_kernels.h take it): other formats / rounding modes / blocks, no workspace, odd strides
+extern "C" int msq_launch_outlier_f32sem_(const void* in, void* out, const void* args, int block, int dt, void* ws, int64_t ws_bytes, void* stream) {
+    const OutlierArgs& A = *(const OutlierArgs*)args;
+    const int kin = hw_codec_kind(A.fi), kout = hw_codec_kind(A.fo), combo = kin * 4 + kout;
+    const bool pk_fmt = A.rmode == 0 && !A.flush && A.variant == 0 && !A.n_out &&
+                        (combo == 4 * 4 + 3 || combo == 3 * 4 + 1 || combo == 3 * 4 + 3 || combo == 3 * 4 + 2 || combo == 1 * 4 + 1);
+    if (!pk_fmt || (block != 8 && block != 16 && block != 32) || (A.axis_len % block) != 0 || g_outlier_pk.load(std::memory_order_relaxed) == 0) return 0;
+    if (!ws || ws_bytes < msq_outlier_lowp_ws_bytes_(A.pre, A.axis_len, A.post, block) || ((uintptr_t)ws & 7) != 0) return 0;
+    const uintptr_t al = (uintptr_t)in | (uintptr_t)out | (uintptr_t)A.mask;
+    const bool contig = A.post == 1 && (al & 15) == 0;
+    const bool strided = A.post >= 2 && (A.post % 2) == 0 && (al & 3) == 0;
+    if (!contig && !strided) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = A.pre * A.nblk * A.post;
+    const int64_t lanes = contig ? A.pre * A.nblk : A.pre * A.nblk * (A.post / 2);
+    const dim3 gp((unsigned)((lanes + 255) / 256)), blk(256);
+    int64_t gl = (n + 1023) / 1024; if (gl > 512) gl = 512; if (gl < 1) gl = 1;
+    const dim3 glist((unsigned)gl);
+    hipLaunchKernelGGL(k_lowp_list_clear, dim3(1), dim3(64), 0, st, (int64_t*)ws);
+#define MSQ_LPK32(BS, DTV)                                                                                             \
+    if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
+    else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
+    hipLaunchKernelGGL((k_outlier_f32sem_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws);
+    if (block == 8) { if (dt == 1) { MSQ_LPK32(8, 1) } else { MSQ_LPK32(8, 2) } }
+    else if (block == 16) { if (dt == 1) { MSQ_LPK32(16, 1) } else { MSQ_LPK32(16, 2) } }
+    else { if (dt == 1) { MSQ_LPK32(32, 1) } else { MSQ_LPK32(32, 2) } }
+#undef MSQ_LPK32
+    return 1;
 }
 
 extern "C" int msq_floor_log2_lowp(const float* v, float* out, int64_t n, int dtype, void* stream) {

@@ -25,9 +25,10 @@ COMBOS = [("int2", "fp4"), ("fp4_e2m1", "fp8_e4m3"), ("fp4_e2m1", "fp4_e2m1"), (
 HANDED = {}
 
 
-def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None):
+def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None, native=True):
     """msq_outlier_fakequant in the tensor's dtype through the C ABI with a workspace of our own: its head is the number of waves the packed
-    kernels handed back to the op-by-op kernel (counted per kind of input: a fuzz that never stays on the packed path proves nothing)"""
+    kernels handed back to the op-by-op kernel (counted per kind of input: a fuzz that never stays on the packed path proves nothing).
+    native=False: the tensor computed in FLOAT32 (dtype 1 / 2): the float32-semantics packed kernels against the float32 kernels"""
     from msq._lib import ptr, check, current_stream
     from msq.formats import format_id
     assert L.msq_set_tuning(b"MSQ_OUTLIER_LOWP_PK", pk) == 0
@@ -45,7 +46,7 @@ def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None):
         st = torch.zeros(1, dtype=torch.int32, device=dev)
         wsb = L.msq_outlier_workspace_bytes(pre, al, post, bs, 0)
         ws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
-        check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), None, ptr(st), ptr(ws), wsb, 0x11 if x.dtype == torch.float16 else 0x12,
+        check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), None, ptr(st), ptr(ws), wsb, ((0x11 if x.dtype == torch.float16 else 0x12) if native else (1 if x.dtype == torch.float16 else 2)),
                                       pre, al, post, bs, format_id(fi), format_id(fo), sb, sb, float(sd), 0, 0, 0, current_stream(dev)), "msq_outlier_fakequant")
         if pk and tag is not None:
             h = HANDED.setdefault(tag, [0, 0])
@@ -132,23 +133,25 @@ def main():
                         for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16), (0, 8), (-1, 8), (0, 64), (-1, 64)):
                             if W.shape[axis] % bs:
                                 continue
-                            for sd, sb in ((2.0, 8), (3.0, 8), (1.0, 4)):
-                                a = run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:], kind))
-                                b = run(W, fi, fo, sd, axis, bs, sb, 0)
+                            for sd, sb, native in ((2.0, 8, True), (3.0, 8, True), (1.0, 4, True), (2.0, 8, False), (3.0, 8, False), (1.0, 4, False)):
+                                if not native and bs == 64:
+                                    continue
+                                a = run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:] + ("" if native else " (float32 semantics)"), kind), native)
+                                b = run(W, fi, fo, sd, axis, bs, sb, 0, None, native)
                                 ok = same(a["out"], b["out"]) and torch.equal(a["mask"], b["mask"]) and same(a["e_in"], b["e_in"]) and same(a["e_out"], b["e_out"]) and a["status"] == b["status"]
                                 n += 1
                                 if not ok:
                                     bad += 1
                                     dv = int(((a["out"].view(torch.int16) != b["out"].view(torch.int16)) & ~(torch.isnan(a["out"]) & torch.isnan(b["out"]))).sum())
                                     dm = int((a["mask"] != b["mask"]).sum())
-                                    print("MISMATCH", str(dt)[6:], kind, shape, fi, fo, "axis", axis, "bs", bs, "k", sd, "sb", sb, "values", dv, "masks", dm, flush=True)
+                                    print("MISMATCH", "native" if native else "float32-semantics", str(dt)[6:], kind, shape, fi, fo, "axis", axis, "bs", bs, "k", sd, "sb", sb, "values", dv, "masks", dm, flush=True)
                                     if bad <= 6:
                                         idx = ((a["out"].view(torch.int16) != b["out"].view(torch.int16)) & ~(torch.isnan(a["out"]) & torch.isnan(b["out"]))).nonzero()[:4]
                                         for i in idx.tolist():
                                             print("   at", i, "x", float(W[i[0], i[1]]), hex(int(W.view(torch.int16)[i[0], i[1]]) & 0xFFFF), "packed", float(a["out"][i[0], i[1]]),
                                                   "op-by-op", float(b["out"][i[0], i[1]]), "mask", int(a["mask"][i[0], i[1]]), int(b["mask"][i[0], i[1]]))
     for (dn, kind), (h, w) in sorted(HANDED.items()):
-        print("%-9s %-10s waves handed back to the op-by-op kernel: %8d of %9d (%.2f %%)" % (dn, kind, h, w, 100.0 * h / max(w, 1)))
+        print("%-30s %-10s waves handed back to the op-by-op kernel: %8d of %9d (%.2f %%)" % (dn, kind, h, w, 100.0 * h / max(w, 1)))
     print("cases %d, mismatching %d, %.0f s" % (n, bad, time.time() - t0))
     return 1 if bad else 0
 

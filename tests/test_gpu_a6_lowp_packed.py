@@ -156,3 +156,40 @@ def _nd_cases(msq, F, g):
                             msq._lib.lib().msq_set_tuning(b"MSQ_OUTLIER_LOWP_PK", 1)
                         assert F.same(a["out"], b["out"]) and torch.equal(a["mask"], b["mask"]), (dt, shape, axis, bs, fi)
                         assert F.same(a["e_in"], b["e_in"]) and F.same(a["e_out"], b["e_out"]), (dt, shape, axis, bs, fi)
+
+
+def test_float32_semantics_on_the_packed_kernels(msq):
+    """fp16 / bf16 tensors computed in FLOAT32 (dtype 1 / 2 of msq_outlier_fakequant: what the MicroScopiQ KV cache runs) on the packed kernels
+    (outlier_block_pk32) against the float32 kernels (MSQ_OUTLIER_LOWP_PK = 0 -> k_outlier_contig / _strided with 16-bit loads and stores), bit
+    for bit: values, masks, exponents, status -- on the adversarial generator, and on a KV-cache-like tensor where (almost) every wave must stay
+    on the packed path."""
+    F = _fuzz()
+    F.HANDED.clear()
+    g = torch.Generator(device=dev()).manual_seed(123)
+    kinds = ["weights", "scales", "ties", "tiesc", "negative", "positive", "sparse", "constant", "subnormal", "special"]
+    for dt in (torch.float16, torch.bfloat16):
+        for kind in kinds:
+            W = F.make(kind, (256, 512), dt, g)
+            for fi, fo in F.COMBOS:
+                for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16), (0, 8), (-1, 8)):
+                    for sd, sb in ((2.0, 8), (1.0, 4)):
+                        a = F.run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:], kind), native=False)
+                        b = F.run(W, fi, fo, sd, axis, bs, sb, 0, None, native=False)
+                        assert F.same(a["out"], b["out"]), (dt, kind, fi, fo, axis, bs, sd, sb)
+                        assert torch.equal(a["mask"], b["mask"]) and F.same(a["e_in"], b["e_in"]) and F.same(a["e_out"], b["e_out"]), (dt, kind, fi, fo, axis, bs)
+                        assert a["status"] == b["status"], (dt, kind, fi, fo, axis, bs, sd, sb)
+    for (dn, kind), (h, w) in F.HANDED.items():
+        if kind not in ("scales", "special"):
+            assert h < w, (dn, kind, h, w)
+    # a layer cache [1, 8, 1024, 128], keys (blocks along tokens) and values (blocks along head_dim): the method of kvcache.mx_quantize_*
+    for dt in (torch.float16, torch.bfloat16):
+        kv = torch.randn(1, 8, 1024, 128, generator=g, device=dev()).to(dt)
+        for axis in (2, 3):
+            F.HANDED.clear()
+            a = F.run(kv, "fp4_e2m1", "fp8_e4m3", 2.0, axis, 32, 8, 1, ("kv", "kv"), native=False)
+            b = F.run(kv, "fp4_e2m1", "fp8_e4m3", 2.0, axis, 32, 8, 0, None, native=False)
+            h, w = F.HANDED[("kv", "kv")]
+            assert h <= 0.01 * w, (dt, axis, h, w)
+            assert F.same(a["out"], b["out"]) and torch.equal(a["mask"], b["mask"]) and F.same(a["e_in"], b["e_in"]) and F.same(a["e_out"], b["e_out"])
+            ref = msq.quant.outlier_fakequant(kv.float(), 8, 8, "fp4_e2m1", "fp8_e4m3", 2, axis, 32)["out"].to(dt)      # upcast, float32 kernel, downcast
+            assert torch.equal(a["out"].view(torch.int16), ref.view(torch.int16))
