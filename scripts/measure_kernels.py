@@ -88,8 +88,10 @@ def sec_fakequant():
         ms = t(call)
         # the same tensor in bf16 ("same W in fp32 and bf16"): dtype 2, 2 B read + 2 B written per element
         Ab = A.to(torch.bfloat16); outb = torch.empty_like(Ab)
+        wsb = L.msq_outlier_workspace_bytes(pre, al, post, bs, 0)           # (round 6: with it the packed kernels take the 16-bit tensor)
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=dev)
         def callb():
-            pkg.check(L.msq_outlier_fakequant(pkg.ptr(Ab), pkg.ptr(outb), None, None, None, None, None, None, 0, 2, pre, al, post, bs,
+            pkg.check(L.msq_outlier_fakequant(pkg.ptr(Ab), pkg.ptr(outb), None, None, None, None, None, pkg.ptr(ws), wsb, 2, pre, al, post, bs,
                                               pkg.format_id(fi), pkg.format_id(fo), 8, 8, 2.0, 0, 0, 0, pkg.current_stream()))
         mb = t(callb)
         print(f"fakequant axis {axis:2d} bs {bs:2d} {fi:9s} {fo:11s}: {ms*1e3:7.1f} us  {2*A.numel()*4/ms/1e6:6.0f} GB/s | bf16 in/out {mb*1e3:7.1f} us  {2*A.numel()*2/mb/1e6:6.0f} GB/s")
