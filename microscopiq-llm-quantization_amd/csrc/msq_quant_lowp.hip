@@ -17,6 +17,12 @@
 // bound, ~200 instructions per element), read once / written once.  Offline step of the harness, not a GEMM-path
 // kernel: 6.5 G weights of Llama-2-7B take well under a second.
 // Compiled with -ffp-contract=off (no fused multiply-adds: every op rounds on its own).
+//
+// Round 6: the kernels above are the FALL-BACK now.  Weight-like tensors (round to nearest, the format pairs with a hardware codec, whole
+// blocks of 8 ... 64) run k_outlier_lowp_pk / _pk2 further down -- two values per dword from load to store, ~30 instructions per element,
+// 3-4 x faster, same bits -- and only the waves outside their exponent bounds come back here through a list (k_outlier_lowp_list).  The same
+// packed machinery with FLOAT32 semantics (outlier_block_pk32) serves dtype 1 / 2 of msq_outlier_fakequant (the MicroScopiQ KV cache), and the
+// MX quantiser (k_mx_lowp_*) takes e2m1 through the scaled converts next to e4m3.  DESIGN.md 5.005.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
