@@ -19,10 +19,12 @@ import msq  # noqa: E402
 
 L = msq._lib.lib()
 dev = torch.device("cuda:0")
+POSIT = []          # (posit outliers on the packed float32-semantics path were tried and dropped: scripts/experiments/README.md)
 COMBOS = [("int2", "fp4"), ("fp4_e2m1", "fp8_e4m3"), ("fp4_e2m1", "fp4_e2m1"), ("fp4_e2m1", "fp8_e5m2"), ("fp8_e4m3", "fp8_e4m3")]
 
 
 HANDED = {}
+DECLINED = {}
 
 
 def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None, native=True):
@@ -45,12 +47,16 @@ def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None, native=True):
         e_out = torch.empty((pre, nblk, post), dtype=torch.float32, device=dev)
         st = torch.zeros(1, dtype=torch.int32, device=dev)
         wsb = L.msq_outlier_workspace_bytes(pre, al, post, bs, 0)
-        ws = torch.zeros(wsb // 8 + 1, dtype=torch.int64, device=dev)
+        ws = torch.full((wsb // 8 + 1,), -7, dtype=torch.int64, device=dev)          # (the packed kernels clear the head: -7 left = the launcher declined)
         check(L.msq_outlier_fakequant(ptr(x), ptr(out), ptr(mask), ptr(e_in), ptr(e_out), None, ptr(st), ptr(ws), wsb, ((0x11 if x.dtype == torch.float16 else 0x12) if native else (1 if x.dtype == torch.float16 else 2)),
                                       pre, al, post, bs, format_id(fi), format_id(fo), sb, sb, float(sd), 0, 0, 0, current_stream(dev)), "msq_outlier_fakequant")
         if pk and tag is not None:
             h = HANDED.setdefault(tag, [0, 0])
-            h[0] += int(ws[0].item()); h[1] += (pre * nblk * post + 63) // 64
+            c = int(ws[0].item())
+            nwv = (pre * nblk * post + 63) // 64
+            h[0] += nwv if c == -7 else c; h[1] += nwv                             # declined = every wave on the old kernels
+            if c == -7:
+                DECLINED[(fi, fo, bs, native)] = DECLINED.get((fi, fo, bs, native), 0) + 1
         return {"out": out, "mask": mask, "e_in": e_in, "e_out": e_out, "status": int(st.item())}
     finally:
         L.msq_set_tuning(b"MSQ_OUTLIER_LOWP_PK", 1)
@@ -129,13 +135,13 @@ def main():
                     if shape[0] == 2048 and r > 0:
                         continue
                     W = make(kind, shape, dt, g)
-                    for fi, fo in COMBOS:
+                    for fi, fo in COMBOS + POSIT:
                         for axis, bs in ((0, 16), (-1, 32), (0, 32), (-1, 16), (0, 8), (-1, 8), (0, 64), (-1, 64)):
                             if W.shape[axis] % bs:
                                 continue
                             for sd, sb, native in ((2.0, 8, True), (3.0, 8, True), (1.0, 4, True), (2.0, 8, False), (3.0, 8, False), (1.0, 4, False)):
-                                if not native and bs == 64:
-                                    continue
+                                if (not native and bs == 64) or (native and (fi, fo) in POSIT):
+                                    continue                 # (in-dtype arithmetic has no posit codec: the reference's harness upcasts there too)
                                 a = run(W, fi, fo, sd, axis, bs, sb, 1, (str(dt)[6:] + ("" if native else " (float32 semantics)"), kind), native)
                                 b = run(W, fi, fo, sd, axis, bs, sb, 0, None, native)
                                 ok = same(a["out"], b["out"]) and torch.equal(a["mask"], b["mask"]) and same(a["e_in"], b["e_in"]) and same(a["e_out"], b["e_out"]) and a["status"] == b["status"]
@@ -152,6 +158,8 @@ def main():
                                                   "op-by-op", float(b["out"][i[0], i[1]]), "mask", int(a["mask"][i[0], i[1]]), int(b["mask"][i[0], i[1]]))
     for (dn, kind), (h, w) in sorted(HANDED.items()):
         print("%-30s %-10s waves handed back to the op-by-op kernel: %8d of %9d (%.2f %%)" % (dn, kind, h, w, 100.0 * h / max(w, 1)))
+    for k, v in sorted(DECLINED.items(), key=str):
+        print("launcher declined (ragged axis / odd stride / not a packed format pair):", k, v, "calls")
     print("cases %d, mismatching %d, %.0f s" % (n, bad, time.time() - t0))
     return 1 if bad else 0
 
