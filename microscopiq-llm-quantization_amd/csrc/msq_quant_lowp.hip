@@ -498,13 +498,13 @@ MSQ_D float outlier_elem_lowp(const float (&blk)[BS], float x, bool& mask, float
 // k_outlier_lowp would have: the redundant statistics of the first form cost throughput, the second costs latency.
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
-k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws) {
+k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws, const uint8_t* __restrict__ marks, int64_t cap) {
     __shared__ uint8_t l2tab[256];
     __shared__ __attribute__((aligned(16))) char xsm[4 * 64 * (BS * 2 + 16)];
     const int64_t count = ws[0];
     if (count == 0) return;
     const int64_t total = A.pre * A.nblk * A.post;
-    if (count * 16 <= (total + 63) / 64) {
+    if (count < cap) {
         constexpr int BPT = 256 / BS, TRIPS = 64 / BPT;                 // blocks per trip; trips per entry
         uint16_t* const sx = reinterpret_cast<uint16_t*>(xsm);
         const int lb = threadIdx.x / BS, i = threadIdx.x % BS;
@@ -541,10 +541,11 @@ k_outlier_lowp_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
     }
     floor_log2_tab_init<DT>(l2tab);
     __syncthreads();
+    // the list stopped growing at `cap`: the marks say which waves (a tensor mostly outside the bounds; every wave has written its own)
     const int lane = threadIdx.x & 63;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += nw)
-        outlier_lowp_lane<BS, DT>(in, out, A, ws[8 + i] + lane, l2tab, xsm);
+    const int64_t nwaves = (total + 63) / 64, step = (int64_t)gridDim.x * 4;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwaves; w += step)
+        if (marks[w]) outlier_lowp_lane<BS, DT>(in, out, A, w * 64 + lane, l2tab, xsm);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1357,7 +1358,7 @@ MSQ_D bool outlier_block_pk32(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS /
 // inlined as a branch it halved the occupancy and cost a factor of three).
 template <int BS, int DT, bool F32SEM = false>
 __global__ void __launch_bounds__(256)
-k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
+k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws, uint8_t* __restrict__ marks, int64_t cap) {
     __shared__ uint8_t l2tab[256];
     constexpr int CH = BS / 8, ROWB = BS * 2 + 16;
     __shared__ __attribute__((aligned(16))) char xsm[4 * 64 * ROWB];
@@ -1397,10 +1398,14 @@ k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, O
     bool ok;
     if constexpr (F32SEM) ok = outlier_block_pk32<BS, DT>(pw, res, mk, se_in, se_out, A, 1, kin, kout) || !live;
     else ok = outlier_block_pk<BS, DT>(pw, res, mk, se_in, se_out, A, 1, l2tab, kin, kout) || !live;
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
-        if (lane == 0) ws[8 + atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull)] = wave_t0;
-        return;
+    // handed back: every wave leaves its mark; the list takes entries only while it is short (one counter for 32 768 waves that all fail
+    // serialises on its cache line: 0.5 ms -- a tensor outside the bounds altogether is found through the marks instead)
+    const bool back = __builtin_amdgcn_ballot_w64(!ok) != 0ull;
+    if (lane == 0) {
+        marks[wave_t0 >> 6] = back ? 1 : 0;
+        if (back && *reinterpret_cast<volatile int64_t*>(ws) < cap) ws[8 + atomicAdd(reinterpret_cast<unsigned long long*>(ws), 1ull)] = wave_t0;
     }
+    if (back) return;
     if (full) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -1433,7 +1438,7 @@ k_outlier_lowp_pk(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, O
 // 256 contiguous bytes per row --, the rows b, b + 1 of each column paired into one dword (v_perm) for the packed arithmetic.
 template <int BS, int DT, bool F32SEM = false>
 __global__ void __launch_bounds__(256)
-k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws) {
+k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, int kin, int kout, int64_t* __restrict__ ws, uint8_t* __restrict__ marks, int64_t cap) {
     __shared__ uint8_t l2tab[256];
     floor_log2_tab_init<DT>(l2tab);
     __syncthreads();
@@ -1472,14 +1477,16 @@ k_outlier_lowp_pk2(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, 
         ok0 = outlier_block_pk<BS, DT>(p0, r0, m0, si0, so0, A, order, l2tab, kin, kout);
         ok1 = outlier_block_pk<BS, DT>(p1, r1, m1, si1, so1, A, order, l2tab, kin, kout);
     }
-    if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1)) != 0ull) {
-        // this wave's columns are the lanes 2 (t - lane) ... + 127 of k_outlier_lowp's numbering: two of its waves
-        if (lane == 0) {
+    // this wave's columns are the lanes 2 (t - lane) ... + 127 of k_outlier_lowp's numbering: two of its waves (marks and list: see k_outlier_lowp_pk)
+    const bool back = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) != 0ull;
+    if (lane == 0) {
+        marks[(t - lane) >> 5] = back ? 1 : 0; marks[((t - lane) >> 5) + 1] = back ? 1 : 0;
+        if (back && *reinterpret_cast<volatile int64_t*>(ws) < cap) {
             const unsigned long long i = atomicAdd(reinterpret_cast<unsigned long long*>(ws), 2ull);
             ws[8 + i] = 2 * (t - lane); ws[8 + i + 1] = 2 * (t - lane) + 64;
         }
-        return;
     }
+    if (back) return;
     if (!live) return;
     uint16_t* dst = out + base;
 #pragma unroll
@@ -1561,10 +1568,14 @@ MSQ_D void pk_codec_loop32(const uint32_t (&pw)[BS / 2], const uint32_t (&mk)[BS
 #pragma unroll
     for (int j = 0; j < BS / 2; ++j) {
         const uint32_t w = pw[j], a = w & 0x7FFF7FFFu, m = mk[j], in = a | 0x00010001u;
-        uint32_t ri;
+        // fp16, e4m3 / e5m2 grids: their small binades reach under 2^-22, where the half's lowest bit is no sticky bit any more (see
+        // hw_mag_pair_f32src): those pairs go through the float32-source convert; e2m1 (four binades) stays on the half-source one
+        uint32_t ri, ro;
         if (KI == 4) ri = pk_mul_u16(pk_min_u16(pk_subsat_u16(a, h_in), 0x00010001u), st_in);
+        else if (DT == 1 && KI != 3) ri = hw_mag_pair_f32src<KI>(pk_min_u16(a, b_in), s_in);
         else ri = hw_mag_pair<DT, KI>(in, s_in, s_in, b_in);
-        const uint32_t ro = hw_mag_pair<DT, KO>(in, s_out, s_out, b_out);
+        if (DT == 1 && KO != 3) ro = hw_mag_pair_f32src<KO>(pk_min_u16(a, b_out), s_out);
+        else ro = hw_mag_pair<DT, KO>(in, s_out, s_out, b_out);
         const uint32_t rm = (ro & m) | (ri & ~m);
         if (DT == 1) {
             const lp_h2_t z = {(_Float16)0.f, (_Float16)0.f};
@@ -1660,8 +1671,11 @@ MSQ_D bool outlier_block_pk32(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS /
     // times finer than the first tie (the sticky bit is the half's lowest)
     const int mine_i = A.fi.ebits ? 2 - (1 << (A.fi.ebits - 1)) : 0, mine_o = A.fo.ebits ? 2 - (1 << (A.fo.ebits - 1)) : 0;
     constexpr int TMINE = (DT == 1) ? -24 : -133, TMAXE = (DT == 1) ? 15 : 127;
-    ok = ok && ei + mine_i - A.fi.mbits + 1 >= TMINE + 2 && ei + A.fi.emax + 1 <= TMAXE && ei + A.fi.emax >= TMINE + 2
-            && (no_out || (eoi + mine_o - A.fo.mbits + 1 >= TMINE + 2 && eoi + A.fo.emax + 1 <= TMAXE && eoi + A.fo.emax >= TMINE + 2 && eoi >= -126 && eoi <= 126));
+    // (first tie at 2^(TMINE + 2) or above where the values enter a convert as halves / bf16; the smallest step a T value where they enter
+    //  as float32: fp16 with the e4m3 / e5m2 grids, see pk_codec_loop32)
+    const int slack_i = (DT == 1 && kin != 3 && kin != 4) ? -1 : 2, slack_o = (DT == 1 && kout != 3) ? -1 : 2;
+    ok = ok && ei + mine_i - A.fi.mbits + 1 >= TMINE + slack_i && ei + A.fi.emax + 1 <= TMAXE && ei + A.fi.emax >= TMINE + 2
+            && (no_out || (eoi + mine_o - A.fo.mbits + 1 >= TMINE + slack_o && eoi + A.fo.emax + 1 <= TMAXE && eoi + A.fo.emax >= TMINE + 2 && eoi >= -126 && eoi <= 126));
     const int eoc = ok ? eoi : 0;
     const int combo = kin * 4 + kout;
     if (combo == 4 * 4 + 3) pk_codec_loop32<BS, DT, 4, 3>(pw, mk, res, A, ei, eoc);
@@ -1677,20 +1691,33 @@ MSQ_D bool outlier_block_pk32(const uint32_t (&pw)[BS / 2], uint32_t (&res)[BS /
 // hardware codecs: the route of k_outlier_contig / _strided for these tensors), written with one rounding to T
 template <int BS, int DT>
 __global__ void __launch_bounds__(256)
-k_outlier_f32sem_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws) {
+k_outlier_f32sem_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, OutlierArgs A, const int64_t* __restrict__ ws, const uint8_t* __restrict__ marks, int64_t cap) {
     const int64_t count = ws[0];
     if (count == 0) return;
     const int64_t total = A.pre * A.nblk * A.post;
     const int lane = threadIdx.x & 63;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += nw) {
-        const int64_t t = ws[8 + i] + lane;
+    const bool by_marks = count >= cap;                                  // (the list stopped growing there: see k_outlier_lowp_pk)
+    const int64_t items = by_marks ? (total + 63) / 64 : count, step = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < items; i += step) {
+        if (by_marks && !marks[i]) continue;
+        const int64_t t = (by_marks ? i * 64 : ws[8 + i]) + lane;
         if (t >= total) continue;
         const int64_t q = t % A.post, nb = (t / A.post) % A.nblk, p = t / (A.post * A.nblk);
         const int64_t base = (p * A.axis_len + nb * BS) * A.post + q;
         float a[BS];
+        const bool vec = A.post == 1 && (BS % 8) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+        if (vec) {
 #pragma unroll
-        for (int b = 0; b < BS; ++b) a[b] = ld16<DT>(in, base + (int64_t)b * A.post);
+            for (int c = 0; c < BS / 8; ++c) {
+                union { uint4 u; uint16_t h[8]; } v;
+                v.u = *reinterpret_cast<const uint4*>(in + base + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[c * 8 + j] = ld16<DT>(v.h, j);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < BS; ++b) a[b] = ld16<DT>(in, base + (int64_t)b * A.post);
+        }
         int order = 1;
         if (A.post > 1) {
             const int64_t lim = (A.post >= 8) ? (A.post / 32) * 32 : (A.post / 4) * 4;
@@ -1699,10 +1726,21 @@ k_outlier_f32sem_list(const uint16_t* __restrict__ in, uint16_t* __restrict__ ou
         uint32_t mkw[(BS + 31) / 32];
         float se_in, se_out;
         const int status = outlier_block_fast<BS, 0, false, 1>(a, mkw, se_in, se_out, A, order, nullptr, nullptr, 1);
+        if (vec) {
 #pragma unroll
-        for (int b = 0; b < BS; ++b) {
-            st16<DT>(out, base + (int64_t)b * A.post, Rr<DT>(a[b]));
-            if (A.mask) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
+            for (int c = 0; c < BS / 8; ++c) {
+                union { uint4 u; uint16_t h[8]; } v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st16<DT>(v.h, j, Rr<DT>(a[c * 8 + j]));
+                *reinterpret_cast<uint4*>(out + base + c * 8) = v.u;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < BS; ++b) st16<DT>(out, base + (int64_t)b * A.post, Rr<DT>(a[b]));
+        }
+        if (A.mask) {
+#pragma unroll
+            for (int b = 0; b < BS; ++b) A.mask[base + (int64_t)b * A.post] = (uint8_t)((mkw[b >> 5] >> (b & 31)) & 1u);
         }
         if (A.e_in) A.e_in[(p * A.nblk + nb) * A.post + q] = se_in;
         if (A.e_out) A.e_out[(p * A.nblk + nb) * A.post + q] = se_out;
@@ -1775,11 +1813,12 @@ __global__ void __launch_bounds__(256) k_floor_log2_lowp(const float* __restrict
 // called from msq_outlier_fakequant (msq_quant.hip) for dtype MSQ_DTYPE_F16_NATIVE / _BF16_NATIVE
 // clears the head of the list (hipMemsetAsync goes through a generic fill kernel that takes 4.5 us for these 8 bytes; this one ~2)
 __global__ void k_lowp_list_clear(int64_t* __restrict__ ws) { if (threadIdx.x < 8) ws[threadIdx.x] = 0; }
-// bytes of the list of handed-back waves: a 64-byte head (the count) + one 8-byte entry per wave of k_outlier_lowp's lane numbering
+// bytes of the list of handed-back waves: a 64-byte head (the count) + one 8-byte entry per wave of k_outlier_lowp's lane numbering + one
+// mark byte per wave (the list stops taking entries at 1 / 16 of the waves: beyond that the marks are read)
 extern "C" int64_t msq_outlier_lowp_ws_bytes_(int64_t pre, int64_t axis_len, int64_t post, int block) {
     if (block != 8 && block != 16 && block != 32 && block != 64) return 0;
-    const int64_t lanes = pre * ((axis_len + block - 1) / block) * post;
-    return 64 + 8 * ((lanes + 63) / 64 + 2);
+    const int64_t lanes = pre * ((axis_len + block - 1) / block) * post, nwv = (lanes + 63) / 64;
+    return 64 + 8 * (nwv + 2) + (nwv + 2 + 63) / 64 * 64;               // head + list entries + one mark byte per wave
 }
 extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* args, int block, int dt, void* ws, int64_t ws_bytes, void* stream) {
     const OutlierArgs& A = *(const OutlierArgs*)args;
@@ -1801,11 +1840,13 @@ extern "C" int msq_launch_outlier_lowp_(const void* in, void* out, const void* a
             const dim3 gp((unsigned)((lanes + 255) / 256));
             int64_t gl = (n + 1023) / 1024; if (gl > 512) gl = 512; if (gl < 1) gl = 1;
             const dim3 glist((unsigned)gl);
+            const int64_t nwv = (n + 63) / 64, cap = nwv / 16 + 1;           // list entries while fewer than 1 / 16 of the waves; marks beyond
+            uint8_t* marks = (uint8_t*)ws + 64 + 8 * (nwv + 2);
             hipLaunchKernelGGL(k_lowp_list_clear, dim3(1), dim3(64), 0, st, (int64_t*)ws);
 #define MSQ_LPK(BS, DTV)                                                                                               \
-            if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
-            else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
-            hipLaunchKernelGGL((k_outlier_lowp_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws);
+            if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws, marks, cap); \
+            else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws, marks, cap); \
+            hipLaunchKernelGGL((k_outlier_lowp_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws, (const uint8_t*)marks, cap);
             if (block == 8) { if (dt == 1) { MSQ_LPK(8, 1) } else { MSQ_LPK(8, 2) } }
             else if (block == 16) { if (dt == 1) { MSQ_LPK(16, 1) } else { MSQ_LPK(16, 2) } }
             else if (block == 32) { if (dt == 1) { MSQ_LPK(32, 1) } else { MSQ_LPK(32, 2) } }
@@ -1842,11 +1883,13 @@ extern "C" int msq_launch_outlier_f32sem_(const void* in, void* out, const void*
     const dim3 gp((unsigned)((lanes + 255) / 256)), blk(256);
     int64_t gl = (n + 1023) / 1024; if (gl > 512) gl = 512; if (gl < 1) gl = 1;
     const dim3 glist((unsigned)gl);
+    const int64_t nwv = (n + 63) / 64, cap = nwv / 16 + 1;
+    uint8_t* marks = (uint8_t*)ws + 64 + 8 * (nwv + 2);
     hipLaunchKernelGGL(k_lowp_list_clear, dim3(1), dim3(64), 0, st, (int64_t*)ws);
 #define MSQ_LPK32(BS, DTV)                                                                                             \
-    if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
-    else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws); \
-    hipLaunchKernelGGL((k_outlier_f32sem_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws);
+    if (contig) hipLaunchKernelGGL((k_outlier_lowp_pk<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws, marks, cap); \
+    else hipLaunchKernelGGL((k_outlier_lowp_pk2<BS, DTV, true>), gp, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, kin, kout, (int64_t*)ws, marks, cap); \
+    hipLaunchKernelGGL((k_outlier_f32sem_list<BS, DTV>), glist, blk, 0, st, (const uint16_t*)in, (uint16_t*)out, A, (const int64_t*)ws, (const uint8_t*)marks, cap);
     if (block == 8) { if (dt == 1) { MSQ_LPK32(8, 1) } else { MSQ_LPK32(8, 2) } }
     else if (block == 16) { if (dt == 1) { MSQ_LPK32(16, 1) } else { MSQ_LPK32(16, 2) } }
     else { if (dt == 1) { MSQ_LPK32(32, 1) } else { MSQ_LPK32(32, 2) } }

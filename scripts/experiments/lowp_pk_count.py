@@ -22,6 +22,6 @@ for dt, code in ((torch.float16, 0x11), (torch.bfloat16, 0x12)):
         ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=dev)
         check(L.msq_outlier_fakequant(ptr(x), ptr(out), None, None, None, None, ptr(st), ptr(ws), wsb, code, pre, al, post, bs, format_id(fi), format_id(fo), 8, 8, 2.0, 0, 0, 0,
                                       current_stream(dev)), "fq")
-        v = int(ws[0].item())
+        v = int(ws[0].item())                       # (the list; it stops at 1 / 16 of the waves -- the marks behind it are complete)
         waves = (pre * (al // bs) * post + 63) // 64
         print(str(dt)[6:], fi, fo, "axis", axis, "bs", bs, ": handed back %d of %d waves (%.3f %%), status bits %d" % (v, waves, 100.0 * v / waves, int(st.item())))

@@ -54,7 +54,8 @@ def run(W, fi, fo, sd, axis, bs, sb, pk, tag=None, native=True):
             h = HANDED.setdefault(tag, [0, 0])
             c = int(ws[0].item())
             nwv = (pre * nblk * post + 63) // 64
-            h[0] += nwv if c == -7 else c; h[1] += nwv                             # declined = every wave on the old kernels
+            mk = ws.view(torch.uint8)[64 + 8 * (nwv + 2): 64 + 8 * (nwv + 2) + nwv]         # one mark per wave (the list itself stops at 1 / 16 of them)
+            h[0] += nwv if c == -7 else int(mk.sum().item()); h[1] += nwv          # declined = every wave on the old kernels
             if c == -7:
                 DECLINED[(fi, fo, bs, native)] = DECLINED.get((fi, fo, bs, native), 0) + 1
         return {"out": out, "mask": mask, "e_in": e_in, "e_out": e_out, "status": int(st.item())}
